@@ -1,0 +1,135 @@
+"""Deterministic synthetic weights / inputs and the named model configurations.
+
+No real EDTR / SD-2.1 checkpoints exist offline, so every parity
+fixture and every bench run uses parameters produced by a closed-form integer hash
+keyed by ``(state-dict key, flat index)``.  The hash is pure int64 arithmetic, so
+the reference side (tools/make_goldens.py), the oracle and the HIP engine all
+regenerate bit-identical fp32 values without relying on any torch RNG stream.
+
+The reference initialises 69 tensors to zero (``zero_module``: reference
+model/unet.py:177,260,678, model/controlnet.py:261, model/attention.py:274,280),
+which makes every control tensor and eps exactly 0; the generator therefore
+overwrites *all* parameters, including those.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+import torch
+
+_M32 = (1 << 32) - 1
+
+
+def _hash_u32(idx: torch.Tensor, seed: int) -> torch.Tensor:
+    """murmur3-style finaliser over (index, seed); int64 in, values in [0, 2^32)."""
+    x = (idx * 2654435761 + seed) & _M32
+    x = x ^ (x >> 16)
+    x = (x * 2246822519) & _M32
+    x = x ^ (x >> 13)
+    x = (x * 3266489917) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def hashed_uniform(key: str, numel: int, chunk: int = 1 << 24) -> torch.Tensor:
+    """fp32 tensor of ``numel`` values, uniform in [-1, 1), fully determined by ``key``."""
+    seed = zlib.crc32(key.encode("utf-8")) & _M32
+    out = torch.empty(numel, dtype=torch.float32)
+    for s in range(0, numel, chunk):
+        e = min(numel, s + chunk)
+        idx = torch.arange(s, e, dtype=torch.int64)
+        h = _hash_u32(idx, seed)
+        # 24 random bits -> exactly representable fp32 in [-1, 1)
+        out[s:e] = ((h >> 8).to(torch.float32) * (2.0 / (1 << 24))) - 1.0
+    return out
+
+
+def synth_param(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
+    """Synthetic value for one state-dict entry.
+
+    * norm scales (GroupNorm / LayerNorm ``weight``, 1-D, not a bias):  1 + 0.1 u
+    * biases (1-D ``bias``):                                            0.05 u
+    * conv / linear weights (>= 2-D):  u * sqrt(3 / fan_in)  (unit-variance preserving)
+    """
+    shape = tuple(int(s) for s in shape)
+    numel = int(np.prod(shape)) if len(shape) else 1
+    u = hashed_uniform(key, numel).reshape(shape)
+    if len(shape) <= 1:
+        if key.endswith("bias"):
+            return 0.05 * u
+        return 1.0 + 0.1 * u
+    fan_in = int(np.prod(shape[1:]))
+    return u * float(np.sqrt(3.0 / fan_in))
+
+
+def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], prefix: str = "") -> Dict[str, torch.Tensor]:
+    """``spec`` yields (key, shape); the hash key is ``prefix + key`` so that the unet and
+    the controlnet (which share key names) get different values."""
+    return {k: synth_param(prefix + k, shp) for k, shp in spec}
+
+
+def synth_input(name: str, shape: Tuple[int, ...], lo: float = -1.0, hi: float = 1.0) -> torch.Tensor:
+    shape = tuple(int(s) for s in shape)
+    u = hashed_uniform("input:" + name, int(np.prod(shape))).reshape(shape)
+    return (u + 1.0) * (0.5 * (hi - lo)) + lo
+
+
+def synth_normal(name: str, shape: Tuple[int, ...]) -> torch.Tensor:
+    """Approximately N(0,1) (sum of 4 uniforms, variance-normalised): the explicit noise
+    tensors injected into q_sample / p_sample so CPU and GPU runs see the same stream."""
+    shape = tuple(int(s) for s in shape)
+    n = int(np.prod(shape))
+    acc = torch.zeros(n, dtype=torch.float32)
+    for j in range(4):
+        acc += hashed_uniform(f"noise:{name}:{j}", n)
+    return (acc * float(np.sqrt(3.0 / 4.0))).reshape(shape)
+
+
+# ----------------------------------------------------------------------------------------------
+# Named configurations (constructor kwargs of ControlLDM; reference configs/det/demo.yaml:20-86)
+# ----------------------------------------------------------------------------------------------
+
+def sd21_config() -> dict:
+    """The SD-2.1 / EDTR configuration every shipped YAML uses (configs/det/demo.yaml:24-86)."""
+    unet = dict(
+        use_checkpoint=True, image_size=32, in_channels=4, out_channels=4, model_channels=320,
+        attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4],
+        num_head_channels=64, use_spatial_transformer=True, use_linear_in_transformer=True,
+        transformer_depth=1, context_dim=1024, legacy=False,
+    )
+    cnet = dict(unet)
+    cnet.pop("out_channels")
+    cnet["hint_channels"] = 4
+    vae = dict(
+        train_decoder=True, embed_dim=4,
+        ddconfig=dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                      ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0),
+    )
+    clip = dict(
+        embed_dim=1024,
+        vision_cfg=dict(image_size=224, layers=32, width=1280, head_width=80, patch_size=14),
+        text_cfg=dict(context_length=77, vocab_size=49408, width=1024, heads=16, layers=24),
+        layer="penultimate",
+    )
+    return dict(unet_cfg=unet, vae_cfg=vae, clip_cfg=clip, controlnet_cfg=cnet, latent_scale_factor=0.18215)
+
+
+def tiny_config() -> dict:
+    """Reduced configuration for end-to-end goldens: same topology (4 levels, 2 res blocks,
+    transformers at the first three levels, head width 64), 1/5 of the channels."""
+    cfg = sd21_config()
+    for k in ("unet_cfg", "controlnet_cfg"):
+        cfg[k] = dict(cfg[k], model_channels=64, context_dim=64)
+    cfg["vae_cfg"] = dict(cfg["vae_cfg"], ddconfig=dict(cfg["vae_cfg"]["ddconfig"], ch=32, resolution=64))
+    cfg["clip_cfg"] = dict(
+        embed_dim=64,
+        vision_cfg=dict(image_size=32, layers=1, width=64, head_width=32, patch_size=16),
+        text_cfg=dict(context_length=77, vocab_size=49408, width=64, heads=2, layers=2),
+        layer="penultimate",
+    )
+    return cfg
+
+
+CONFIGS = {"sd21": sd21_config, "tiny": tiny_config}

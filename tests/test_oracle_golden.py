@@ -1,0 +1,169 @@
+"""Pin the oracle (oracle/edtr_oracle.py) to the reference: every fixture here was produced by
+tools/make_goldens.py running /root/reference on CPU fp32 with edtr_amd.synth weights/inputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from edtr_amd import synth
+from oracle import edtr_oracle as O
+
+USED = [50, 100, 150, 200]
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def synth_sd(manifest_path, parts=("unet", "controlnet", "vae")):
+    with open(manifest_path) as f:
+        man = json.load(f)
+    sd = {}
+    for part in parts:
+        for key, shape in man[part]:
+            full = f"{part}.{key}"
+            sd[full] = synth.synth_param(full, tuple(shape))
+    return sd
+
+
+def test_schedule_known_answers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    betas = O.make_betas()
+    np.testing.assert_array_equal(betas, g["betas"])
+    t4 = O.schedule_tables(betas, USED)
+    t50 = O.schedule_tables(betas, O.space_timesteps(1000, "50"))
+    for name in ["sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                 "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]:
+        np.testing.assert_array_equal(t4[name], g["s4_" + name])
+        np.testing.assert_array_equal(t50[name], g["s50_" + name])
+    np.testing.assert_array_equal(t4["timesteps"], g["s4_timesteps"])
+    np.testing.assert_array_equal(t50["timesteps"], g["s50_timesteps"])
+    # values quoted in SURVEY.md §8(a) row a1
+    np.testing.assert_allclose(t4["sqrt_recip_alphas_cumprod"], [1.0251279, 1.0574917, 1.0990925, 1.1518688], rtol=1e-6)
+    np.testing.assert_allclose(t4["posterior_mean_coef2"], [0, 0.44377658, 0.59105539, 0.6670472], rtol=1e-6)
+    sa, sb = O.q_sample_coefs(betas)
+    np.testing.assert_array_equal(sa, g["q_sqrt_ac"])
+    np.testing.assert_array_equal(sb, g["q_sqrt_1mac"])
+    np.testing.assert_allclose([sa[200], sb[200]], [0.86815441, 0.49629423], rtol=1e-6)
+
+
+def test_space_timesteps(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    np.testing.assert_array_equal(O.space_timesteps(1000, "50"), g["space_1000_50"])
+    np.testing.assert_array_equal(O.space_timesteps(300, [10, 15, 20]), g["space_1000_10_15_20"])
+    np.testing.assert_array_equal(O.space_timesteps(1000, "ddim25"), g["space_ddim25"])
+    with pytest.raises(ValueError):
+        O.space_timesteps(10, [20])
+    with pytest.raises(ValueError):
+        O.space_timesteps(1000, "ddim999")
+
+
+def test_timestep_embedding_and_updates(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    t = torch.tensor([50, 100, 150, 200, 999])
+    assert rel_err(O.timestep_embedding(t, 320), g["temb_320"]) < 1e-6
+    assert rel_err(O.timestep_embedding(t, 64), g["temb_64"]) < 1e-6
+    x = synth.synth_normal("sched_x", (4, 4, 8, 8))
+    eps = synth.synth_normal("sched_eps", (4, 4, 8, 8))
+    noise = synth.synth_normal("sched_noise", (4, 4, 8, 8))
+    tabs = O.schedule_tables(O.make_betas(), USED)
+    x_prev, pred_x0 = O.p_sample_update(tabs, x, eps, noise, torch.tensor([0, 1, 2, 3]))
+    np.testing.assert_allclose(x_prev.numpy(), g["p_sample_x_prev"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(pred_x0.numpy(), g["p_sample_pred_x0"], rtol=1e-6, atol=1e-6)
+    q = O.q_sample(O.make_betas(), x, torch.full((4,), 200), noise)
+    np.testing.assert_allclose(q.numpy(), g["q_sample_200"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,tag,B,H,W", [("tiny_pipeline.npz", "tiny", 2, 128, 128),
+                                            ("tiny_pipeline_rect.npz", "tinyrect", 1, 192, 128)])
+def test_tiny_pipeline(golden_dir, name, tag, B, H, W):
+    g = np.load(os.path.join(golden_dir, name))
+    cfg = synth.tiny_config()
+    sd = synth_sd(os.path.join(golden_dir, "manifest_tiny.json"))
+    pre_res = synth.synth_input(f"{tag}:pre_res", (B, 3, H, W), 0.0, 1.0)
+    c_txt = synth.synth_input(f"{tag}:c_txt", (B, 77, 64), -1.0, 1.0)
+    noises = [synth.synth_normal(f"{tag}:noise{i}", (B, 4, H // 8, W // 8)) for i in range(5)]
+    with torch.no_grad():
+        img, tr = O.restore(sd, cfg, O.make_betas(), pre_res, c_txt, noises, USED, 200, return_trace=True)
+        res = O.wavelet_reconstruction((img + 1) / 2, pre_res)
+    assert rel_err(tr["z_pre"], g["z_pre"]) < 1e-5
+    assert rel_err(tr["x_T"], g["x_T"]) < 1e-5
+    for i in range(4):
+        assert rel_err(tr["eps"][i], g[f"eps{i}"]) < 2e-5, i
+        assert rel_err(tr["pred_x0"][i], g[f"pred_x0_{i}"]) < 2e-5, i
+    assert rel_err(tr["z"], g["z"]) < 2e-5
+    assert rel_err(img, g["img"]) < 2e-5
+    assert rel_err(res, g["res_wavelet"]) < 2e-5
+
+
+def test_tiny_controls(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))
+    cfg = synth.tiny_config()
+    sd = synth_sd(os.path.join(golden_dir, "manifest_tiny.json"), parts=("controlnet",))
+    x_T = torch.from_numpy(g["x_T"])
+    z_pre = torch.from_numpy(g["z_pre"])
+    c_txt = synth.synth_input("tiny:c_txt", (2, 77, 64), -1.0, 1.0)
+    with torch.no_grad():
+        ctrl = O.controlnet_forward(sd, cfg["controlnet_cfg"], x_T, z_pre, torch.full((2,), 200), c_txt, p="controlnet.")
+    assert len(ctrl) == 13
+    stats = np.array([[float(c.mean()), float(c.abs().mean()), float(c.abs().max())] for c in ctrl])
+    np.testing.assert_allclose(stats, g["ctrl_stats"], rtol=2e-4, atol=1e-5)
+    for i in (0, 3, 6, 12):
+        assert rel_err(ctrl[i], g[f"ctrl{i}"].astype(np.float32)) < 2e-3  # stored as fp16
+
+
+def test_tiled_paths(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiled.npz"))
+    np.testing.assert_allclose(O.gaussian_weights(64, 64), g["gauss_64"], rtol=1e-12)
+    np.testing.assert_allclose(O.gaussian_weights(8, 8), g["gauss_8x8"], rtol=1e-12)
+    np.testing.assert_array_equal(np.array(O.sliding_windows(128, 128, 64, 32)), g["win_128_128_64_32"])
+    np.testing.assert_array_equal(np.array(O.sliding_windows(72, 96, 64, 32)), g["win_72_96_64_32"])
+    np.testing.assert_array_equal(np.array(O.sliding_windows(16, 24, 8, 4)), g["win_16_24_8_4"])
+    cfg = synth.tiny_config()
+    sd = synth_sd(os.path.join(golden_dir, "manifest_tiny.json"), parts=("unet", "controlnet"))
+    B, h, w = 1, 16, 24
+    x_T = synth.synth_normal("tiled:x_T", (B, 4, h, w))
+    c_img = synth.synth_normal("tiled:c_img", (B, 4, h, w))
+    c_txt = synth.synth_input("tiled:c_txt", (B, 77, 64), -1.0, 1.0)
+    noises = [synth.synth_normal(f"tiled:noise{i}", (B, 4, h, w)) for i in range(4)]
+    with torch.no_grad():
+        z = O.sample(sd, cfg, O.make_betas(), x_T, USED, {"c_txt": c_txt, "c_img": c_img}, noises,
+                     tiled=True, tile_size=8, tile_stride=4)
+    assert rel_err(z, g["z_tiled"]) < 2e-5
+
+
+def test_wavelet(golden_dir):
+    g = np.load(os.path.join(golden_dir, "wavelet.npz"))
+    a = synth.synth_input("wav:content", (2, 3, 96, 80), 0.0, 1.0)
+    b = synth.synth_input("wav:style", (2, 3, 96, 80), 0.0, 1.0)
+    assert rel_err(O.wavelet_reconstruction(a, b), g["recon"]) < 1e-6
+    hi, lo = O.wavelet_decomposition(a)
+    assert rel_err(hi, g["high"]) < 1e-5
+    assert rel_err(lo, g["low"]) < 1e-6
+
+
+@pytest.mark.slow
+def test_sd21_blocks(golden_dir):
+    """Full SD-2.1-width networks at the true hot shape (latent 64x64): pins every real channel count."""
+    g = np.load(os.path.join(golden_dir, "sd21_blocks.npz"))
+    cfg = synth.sd21_config()
+    sd = synth_sd(os.path.join(golden_dir, "manifest_sd21.json"))
+    x = synth.synth_normal("sd21:x", (1, 4, 64, 64))
+    c_img = synth.synth_normal("sd21:c_img", (1, 4, 64, 64))
+    c_txt = synth.synth_input("sd21:c_txt", (1, 77, 1024), -1.0, 1.0)
+    t = torch.tensor([200])
+    with torch.no_grad():
+        ctrl = O.controlnet_forward(sd, cfg["controlnet_cfg"], x, c_img, t, c_txt, p="controlnet.")
+        stats = np.array([[float(c.mean()), float(c.abs().mean()), float(c.abs().max())] for c in ctrl])
+        np.testing.assert_allclose(stats, g["ctrl_stats"], rtol=5e-4, atol=2e-5)
+        assert rel_err(ctrl[12], g["ctrl12"]) < 5e-5
+        eps = O.unet_forward(sd, cfg["unet_cfg"], x, t, c_txt, ctrl, p="unet.")
+        assert rel_err(eps, g["eps"]) < 5e-5
+        img = synth.synth_input("sd21:img", (1, 3, 256, 256), -1.0, 1.0)
+        assert rel_err(O.vae_encode(sd, cfg, img), g["vae_z"]) < 5e-5
+        zin = synth.synth_normal("sd21:zdec", (1, 4, 32, 32))
+        assert rel_err(O.vae_decode(sd, cfg, zin), g["vae_dec"]) < 5e-5

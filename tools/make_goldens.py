@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ by running the *reference*
+(/root/reference, imported on CPU via tools/ref_import.py) on synthetic weights and inputs.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,wavelet]
+
+Fixtures are data (inputs are regenerated from edtr_amd.synth formulas, expected outputs
+are stored); nothing from the reference's source travels.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from edtr_amd import synth  # noqa: E402
+import ref_import  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+USED_TIMESTEPS = [50, 100, 150, 200]
+
+
+def build_reference_cldm(cfg_name: str):
+    ControlLDM, _, _, _ = ref_import.import_reference()
+    cfg = synth.CONFIGS[cfg_name]()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cldm = ControlLDM(**cfg)
+    cldm.eval()
+    with torch.no_grad():
+        for key, val in cldm.state_dict().items():
+            if key.startswith("clip."):
+                continue
+            val.copy_(synth.synth_param(key, tuple(val.shape)))
+    return cldm, cfg
+
+
+def manifest(cldm) -> dict:
+    out = {}
+    for part in ("unet", "controlnet", "vae"):
+        sd = getattr(cldm, part).state_dict()
+        out[part] = [[k, list(v.shape)] for k, v in sd.items()]
+    return out
+
+
+@contextlib.contextmanager
+def injected_noise(noises):
+    """The reference draws torch.randn_like once per p_sample (utils/sampler.py:199); feed it a
+    fixed list instead so CPU/GPU runs can replay the same stream."""
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: next(it).to(x)
+    try:
+        yield
+    finally:
+        torch.randn_like = orig
+
+
+def gen_schedule():
+    _, Diffusion, SpacedSampler, _ = ref_import.import_reference()
+    from model.util import timestep_embedding
+    from utils.sampler import space_timesteps
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    sampler = SpacedSampler(diffusion.betas)
+    out = {"betas": diffusion.betas,
+           "q_sqrt_ac": diffusion.sqrt_alphas_cumprod.numpy(),
+           "q_sqrt_1mac": diffusion.sqrt_one_minus_alphas_cumprod.numpy()}
+    names = ["sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+             "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]
+    sampler.make_schedule(4, USED_TIMESTEPS)
+    for n in names:
+        out["s4_" + n] = getattr(sampler, n).numpy().copy()
+    out["s4_timesteps"] = sampler.timesteps.copy()
+    sampler.make_schedule(50)
+    for n in names:
+        out["s50_" + n] = getattr(sampler, n).numpy().copy()
+    out["s50_timesteps"] = sampler.timesteps.copy()
+    out["space_1000_50"] = np.array(sorted(space_timesteps(1000, "50")), dtype=np.int32)
+    out["space_1000_10_15_20"] = np.array(sorted(space_timesteps(300, [10, 15, 20])), dtype=np.int32)
+    out["space_ddim25"] = np.array(sorted(space_timesteps(1000, "ddim25")), dtype=np.int32)
+    t = torch.tensor([50, 100, 150, 200, 999], dtype=torch.int64)
+    out["temb_320"] = timestep_embedding(t, 320).numpy()
+    out["temb_64"] = timestep_embedding(t, 64).numpy()
+    # elementwise sampler algebra on a small tensor, all 4 indices
+    x = synth.synth_normal("sched_x", (4, 4, 8, 8))
+    eps = synth.synth_normal("sched_eps", (4, 4, 8, 8))
+    noise = synth.synth_normal("sched_noise", (4, 4, 8, 8))
+    sampler.make_schedule(4, USED_TIMESTEPS)
+    index = torch.tensor([0, 1, 2, 3], dtype=torch.int64)
+
+    class _Fixed(torch.nn.Module):
+        def forward(self, x_, t_, cond_):
+            return eps
+
+    with injected_noise([noise]):
+        x_prev, pred_x0 = sampler.p_sample(_Fixed(), x, torch.tensor([50, 100, 150, 200]), index, None, None, 1.0)
+    out["p_sample_x_prev"] = x_prev.numpy()
+    out["p_sample_pred_x0"] = pred_x0.numpy()
+    out["q_sample_200"] = diffusion.q_sample(x, torch.full((4,), 200, dtype=torch.int64), noise).numpy()
+    np.savez_compressed(os.path.join(GOLD, "schedule.npz"), **out)
+    print("schedule.npz written")
+
+
+def run_pipeline(cldm, cfg, B, H, W, tag, Diffusion, SpacedSampler, ref_common, store_controls=True):
+    ctx_dim = cfg["unet_cfg"]["context_dim"]
+    pre_res = synth.synth_input(f"{tag}:pre_res", (B, 3, H, W), 0.0, 1.0)
+    c_txt = synth.synth_input(f"{tag}:c_txt", (B, 77, ctx_dim), -1.0, 1.0)
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    sampler = SpacedSampler(diffusion.betas)
+    out = {}
+    eps_list, ctrl_list = [], []
+    h1 = cldm.register_forward_hook(lambda m, i, o: eps_list.append(o.detach().clone()))
+    h2 = cldm.controlnet.register_forward_hook(lambda m, i, o: ctrl_list.append([c.detach().clone() for c in o]))
+    with torch.no_grad():
+        t0 = time.time()
+        z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
+        t_enc = time.time() - t0
+        noises = [synth.synth_normal(f"{tag}:noise{i}", tuple(z_pre.shape)) for i in range(5)]
+        x_T = diffusion.q_sample(z_pre, torch.full((B,), 200, dtype=torch.int64), noises[0])
+        cond = {"c_txt": c_txt, "c_img": z_pre}
+        t0 = time.time()
+        with injected_noise(noises[1:]):
+            z, inter = sampler.manual_sample_with_timesteps(
+                model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=B,
+                cond=cond, uncond=None, cfg_scale=1.0, progress=False, return_intermediates=True)
+        t_smp = time.time() - t0
+        t0 = time.time()
+        img = cldm.vae_decode(z)
+        t_dec = time.time() - t0
+        res = ref_common.wavelet_reconstruction((img + 1) / 2, pre_res)
+    h1.remove()
+    h2.remove()
+    out["z_pre"] = z_pre.numpy()
+    out["x_T"] = x_T.numpy()
+    for i, e in enumerate(eps_list):
+        out[f"eps{i}"] = e.numpy()
+    for i, p in enumerate(inter):
+        out[f"pred_x0_{i}"] = p.numpy()
+    out["z"] = z.numpy()
+    out["img"] = img.numpy()
+    out["res_wavelet"] = res.numpy()
+    ctrl0 = ctrl_list[0]
+    out["ctrl_stats"] = np.array([[float(c.mean()), float(c.abs().mean()), float(c.abs().max())] for c in ctrl0],
+                                 dtype=np.float64)
+    if store_controls:
+        for i in (0, 3, 6, 12):
+            out[f"ctrl{i}"] = ctrl0[i].numpy().astype(np.float16)
+    out["timing_s"] = np.array([t_enc, t_smp, t_dec])
+    return out
+
+
+def gen_tiny():
+    ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
+    cldm, cfg = build_reference_cldm("tiny")
+    with open(os.path.join(GOLD, "manifest_tiny.json"), "w") as f:
+        json.dump(manifest(cldm), f)
+    out = run_pipeline(cldm, cfg, 2, 128, 128, "tiny", Diffusion, SpacedSampler, ref_common)
+    np.savez_compressed(os.path.join(GOLD, "tiny_pipeline.npz"), **out)
+    print("tiny_pipeline.npz written; timings", out["timing_s"])
+    # non-square, B=1 (seg-style 72x96-like latent in miniature: 192x128 image -> 24x16 latent)
+    out = run_pipeline(cldm, cfg, 1, 192, 128, "tinyrect", Diffusion, SpacedSampler, ref_common, store_controls=False)
+    np.savez_compressed(os.path.join(GOLD, "tiny_pipeline_rect.npz"), **out)
+    print("tiny_pipeline_rect.npz written")
+
+
+def gen_sd21():
+    ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
+    t0 = time.time()
+    cldm, cfg = build_reference_cldm("sd21")
+    print(f"sd21 reference built + synthetic weights in {time.time() - t0:.1f}s")
+    with open(os.path.join(GOLD, "manifest_sd21.json"), "w") as f:
+        json.dump(manifest(cldm), f)
+    out = {}
+    with torch.no_grad():
+        # one ControlLDM.forward at the true hot shape (latent 64x64), B=1, t=200
+        x = synth.synth_normal("sd21:x", (1, 4, 64, 64))
+        c_img = synth.synth_normal("sd21:c_img", (1, 4, 64, 64))
+        c_txt = synth.synth_input("sd21:c_txt", (1, 77, 1024), -1.0, 1.0)
+        t = torch.tensor([200], dtype=torch.int64)
+        ctrl = cldm.controlnet(x=x, hint=c_img, timesteps=t, context=c_txt)
+        out["ctrl_stats"] = np.array([[float(c.mean()), float(c.abs().mean()), float(c.abs().max())] for c in ctrl],
+                                     dtype=np.float64)
+        out["ctrl12"] = ctrl[12].numpy()
+        out["ctrl0_f16"] = ctrl[0].numpy().astype(np.float16)
+        t0 = time.time()
+        eps = cldm(x, t, {"c_txt": c_txt, "c_img": c_img})
+        print(f"sd21 cldm forward {time.time() - t0:.1f}s")
+        out["eps"] = eps.numpy()
+        # VAE at full width on a 256x256 image (latent 32x32)
+        img = synth.synth_input("sd21:img", (1, 3, 256, 256), -1.0, 1.0)
+        z = cldm.vae_encode(img, sample=False)
+        out["vae_z"] = z.numpy()
+        zin = synth.synth_normal("sd21:zdec", (1, 4, 32, 32))
+        dec = cldm.vae_decode(zin)
+        out["vae_dec"] = dec.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "sd21_blocks.npz"), **out)
+    print("sd21_blocks.npz written")
+
+
+def gen_tiled():
+    """cfg-4 style paths on the tiny config: latent-tiled ControlLDM step (tile 8 / stride 4 latent px
+    on a 16x24 latent) and the tile geometry helpers."""
+    ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
+    out = {}
+    out["gauss_64"] = ref_common.gaussian_weights(64, 64)
+    out["gauss_8x8"] = ref_common.gaussian_weights(8, 8)
+    out["win_128_128_64_32"] = np.array(ref_common.sliding_windows(128, 128, 64, 32), dtype=np.int32)
+    out["win_72_96_64_32"] = np.array(ref_common.sliding_windows(72, 96, 64, 32), dtype=np.int32)
+    out["win_16_24_8_4"] = np.array(ref_common.sliding_windows(16, 24, 8, 4), dtype=np.int32)
+    cldm, cfg = build_reference_cldm("tiny")
+    B, h, w = 1, 16, 24
+    ctx_dim = cfg["unet_cfg"]["context_dim"]
+    x_T = synth.synth_normal("tiled:x_T", (B, 4, h, w))
+    c_img = synth.synth_normal("tiled:c_img", (B, 4, h, w))
+    c_txt = synth.synth_input("tiled:c_txt", (B, 77, ctx_dim), -1.0, 1.0)
+    noises = [synth.synth_normal(f"tiled:noise{i}", (B, 4, h, w)) for i in range(4)]
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    sampler = SpacedSampler(diffusion.betas)
+    with torch.no_grad(), injected_noise(noises):
+        z = sampler.manual_sample_with_timesteps(
+            model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=B,
+            cond={"c_txt": c_txt, "c_img": c_img}, uncond=None, cfg_scale=1.0,
+            tiled=True, tile_size=8, tile_stride=4, progress=False)
+    out["z_tiled"] = z.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiled.npz"), **out)
+    print("tiled.npz written")
+
+
+def gen_wavelet():
+    _, _, _, ref_common = ref_import.import_reference()
+    a = synth.synth_input("wav:content", (2, 3, 96, 80), 0.0, 1.0)
+    b = synth.synth_input("wav:style", (2, 3, 96, 80), 0.0, 1.0)
+    out = {"recon": ref_common.wavelet_reconstruction(a, b).numpy()}
+    hf, lf = ref_common.wavelet_decomposition(a)
+    out["high"] = hf.numpy()
+    out["low"] = lf.numpy()
+    np.savez_compressed(os.path.join(GOLD, "wavelet.npz"), **out)
+    print("wavelet.npz written")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,wavelet")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    todo = args.only.split(",")
+    for name in todo:
+        {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled,
+         "wavelet": gen_wavelet}[name]()
+
+
+if __name__ == "__main__":
+    main()
