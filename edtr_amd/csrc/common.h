@@ -1,0 +1,83 @@
+// Shared device-side helpers for libedtr_hip (gfx950 / CDNA4 only: wave64, MFMA 32x32x16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/edtr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+// 16-bit storage traits: conversions + the matching MFMA.
+struct BF16 {
+    using vec8 = bf16x8_t;
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) {
+        __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+        return __builtin_bit_cast(uint16_t, b);
+    }
+    static __device__ __forceinline__ f32x16 mfma(const U4& a, const U4& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+struct F16 {
+    using vec8 = f16x8_t;
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) {
+        _Float16 h = (_Float16)f;
+        return __builtin_bit_cast(uint16_t, h);
+    }
+    static __device__ __forceinline__ f32x16 mfma(const U4& a, const U4& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void unpack8(const U4& v, float (&f)[8]) {
+    f[0] = T::to_f32((uint16_t)(v.x & 0xffff)); f[1] = T::to_f32((uint16_t)(v.x >> 16));
+    f[2] = T::to_f32((uint16_t)(v.y & 0xffff)); f[3] = T::to_f32((uint16_t)(v.y >> 16));
+    f[4] = T::to_f32((uint16_t)(v.z & 0xffff)); f[5] = T::to_f32((uint16_t)(v.z >> 16));
+    f[6] = T::to_f32((uint16_t)(v.w & 0xffff)); f[7] = T::to_f32((uint16_t)(v.w >> 16));
+}
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+}
+template <typename T>
+__device__ __forceinline__ U4 pack8(const float (&f)[8]) {
+    U4 v;
+    v.x = pack2<T>(f[0], f[1]); v.y = pack2<T>(f[2], f[3]);
+    v.z = pack2<T>(f[4], f[5]); v.w = pack2<T>(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ U4 ldg16(const void* p) { return *reinterpret_cast<const U4*>(p); }
+__device__ __forceinline__ void stg16(void* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
+__device__ __forceinline__ U4 zero16() { U4 v; v.x = v.y = v.z = v.w = 0u; return v; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Byte offset of 16-byte chunk `c` of row `r` in a [rows][64 x 16-bit] LDS tile (128-byte rows).
+// XOR swizzle so that the 16 lanes of every ds_read_b128 lane group (rows r..r+15 pattern of the
+// MFMA operand read, chunk fixed) hit 16 distinct 16-byte bank slots of the 256-byte bank row.
+__device__ __forceinline__ int tile_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define EDTR_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

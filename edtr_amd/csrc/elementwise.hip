@@ -1,0 +1,298 @@
+// Layout conversion and small elementwise kernels (HBM-bound or negligible) + runtime helpers.
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+// NCHW fp32 -> NHWC 16-bit through an LDS transpose tile: reads are contiguous along pixels,
+// writes are contiguous along channels.  grid (ceil(HW/64), B), 256 threads.
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* src, int C, int64_t HW, uint16_t* dst, int ld,
+                                                          int coff, int cpad, float scale, float shift) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < cpad; c0 += 64) {
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc;
+            float v = 0.0f;
+            if (c < C && p0 + tx < HW) v = src[((int64_t)b * C + c) * HW + p0 + tx] * scale + shift;
+            tile[cc][tx] = v;
+        }
+        __syncthreads();
+        for (int pp = ty; pp < 64; pp += 4) {
+            const int c = c0 + tx;
+            if (c < cpad && p0 + pp < HW) dst[((int64_t)b * HW + p0 + pp) * ld + coff + c] = T::from_f32(tile[tx][pp]);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const void* src, int src_f32, int C, int64_t HW, int ld,
+                                                          float* dst, float scale) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        for (int pp = ty; pp < 64; pp += 4) {
+            const int c = c0 + tx;
+            float v = 0.0f;
+            if (c < C && p0 + pp < HW) {
+                const int64_t idx = ((int64_t)b * HW + p0 + pp) * ld + c;
+                v = src_f32 ? static_cast<const float*>(src)[idx] : T::to_f32(static_cast<const uint16_t*>(src)[idx]);
+            }
+            tile[pp][tx] = v;
+        }
+        __syncthreads();
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc;
+            if (c < C && p0 + tx < HW) dst[((int64_t)b * C + c) * HW + p0 + tx] = tile[tx][cc] * scale;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) add_kernel(const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* out,
+                                                 int ldo, int64_t rows, int CV) {
+    const int64_t total = rows * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / CV;
+        const int cv = (int)(i - r * CV);
+        U4 va = ldg16(a + r * lda + cv * 8);
+        if (b) {
+            float fa[8], fb[8];
+            unpack8<T>(va, fa);
+            unpack8<T>(ldg16(b + r * ldb + cv * 8), fb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+            va = pack8<T>(fa);
+        }
+        stg16(out + r * ldo + cv * 8, va);
+    }
+}
+
+template <typename T>
+__global__ void temb_kernel(const int64_t* t, int dim, uint16_t* out, int ld) {
+    const int b = blockIdx.x, half = dim >> 1;
+    const float tv = (float)t[b];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        // exp(-ln(10000) * i / half), fp32 like the reference
+        const float freq = expf(-9.210340371976184f * (float)i / (float)half);
+        const float arg = tv * freq;
+        out[(int64_t)b * ld + i] = T::from_f32(cosf(arg));
+        out[(int64_t)b * ld + half + i] = T::from_f32(sinf(arg));
+    }
+}
+
+__global__ void __launch_bounds__(256) sampler_update_kernel(const float* x, const float* eps, const float* noise,
+                                                            float c_recip, float c_recipm1, float coef1, float coef2,
+                                                            float sigma, float* x_prev, float* pred_x0, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float xv = x[i];
+        const float p0 = c_recip * xv - c_recipm1 * eps[i];
+        const float mean = coef1 * p0 + coef2 * xv;
+        if (pred_x0) pred_x0[i] = p0;
+        x_prev[i] = mean + sigma * noise[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) axpby_kernel(const float* x, const float* y, float a, float b, float* out,
+                                                   int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = a * x[i] + b * y[i];
+}
+
+__global__ void __launch_bounds__(256) divide_kernel(const float* num, const float* den, float* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = num[i] / den[i];
+}
+
+__global__ void __launch_bounds__(256) tile_acc_kernel(const float* tile, const float* wts, float* out, float* count,
+                                                      int BC, int H, int W, int th, int tw, int hi, int wi) {
+    const int64_t n = (int64_t)BC * th * tw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % tw), y = (int)((i / tw) % th);
+        const int64_t bc = i / ((int64_t)tw * th);
+        const float w = wts[y * tw + x];
+        const int64_t o = (bc * H + hi + y) * W + wi + x;
+        out[o] += tile[i] * w;
+        count[o] += w;
+    }
+}
+
+inline unsigned blocks_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" int edtr_abi_version(void) { return EDTR_ABI_VERSION; }
+
+extern "C" const char* edtr_error_string(int code) {
+    switch (code) {
+        case EDTR_OK: return "ok";
+        case EDTR_E_NULL: return "EDTR_E_NULL: required pointer is NULL";
+        case EDTR_E_SHAPE: return "EDTR_E_SHAPE: non-positive or inconsistent extent";
+        case EDTR_E_ALIGN: return "EDTR_E_ALIGN: pointer / leading dimension violates the 16-byte rule";
+        case EDTR_E_DTYPE: return "EDTR_E_DTYPE: unknown dtype or flag value";
+        case EDTR_E_UNSUPPORTED: return "EDTR_E_UNSUPPORTED: configuration not supported by this kernel";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "unknown edtr error";
+}
+
+extern "C" int edtr_device_info(int* compute_units, int64_t* hbm_bytes, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return 1;
+}
+
+extern "C" int edtr_nchw_to_nhwc(int dtype, const float* src, int B, int C, int64_t HW, void* dst, int ld, int coff,
+                                 int zero_pad_to, float scale, float shift, edtr_stream_t stream) {
+    if (!src || !dst) return EDTR_E_NULL;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (B <= 0 || C <= 0 || HW <= 0 || ld <= 0 || coff < 0) return EDTR_E_SHAPE;
+    const int cpad = zero_pad_to > C ? zero_pad_to : C;
+    if (coff + cpad > ld) return EDTR_E_SHAPE;
+    dim3 grid((unsigned)((HW + 63) / 64), B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == EDTR_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<BF16>, grid, dim3(256), 0, s, src, C, HW, static_cast<uint16_t*>(dst), ld,
+                           coff, cpad, scale, shift);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<F16>, grid, dim3(256), 0, s, src, C, HW, static_cast<uint16_t*>(dst), ld,
+                           coff, cpad, scale, shift);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_nhwc_to_nchw(int dtype, const void* src, int src_f32, int B, int C, int64_t HW, int ld, float* dst,
+                                 float scale, edtr_stream_t stream) {
+    if (!src || !dst) return EDTR_E_NULL;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (B <= 0 || C <= 0 || HW <= 0 || ld < C) return EDTR_E_SHAPE;
+    dim3 grid((unsigned)((HW + 63) / 64), B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == EDTR_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<BF16>, grid, dim3(256), 0, s, src, src_f32, C, HW, ld, dst, scale);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<F16>, grid, dim3(256), 0, s, src, src_f32, C, HW, ld, dst, scale);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_add(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,
+                        int C, edtr_stream_t stream) {
+    if (!a || !out) return EDTR_E_NULL;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (rows <= 0 || C <= 0) return EDTR_E_SHAPE;
+    if ((C & 7) || (lda & 7) || (ldo & 7) || (b && (ldb & 7)) || !aligned16(a) || (b && !aligned16(b)) || !aligned16(out))
+        return EDTR_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int CV = C >> 3;
+    const unsigned blocks = blocks_for(rows * CV);
+    if (dtype == EDTR_BF16)
+        hipLaunchKernelGGL(add_kernel<BF16>, dim3(blocks), dim3(256), 0, s, static_cast<const uint16_t*>(a), lda,
+                           static_cast<const uint16_t*>(b), ldb, static_cast<uint16_t*>(out), ldo, rows, CV);
+    else
+        hipLaunchKernelGGL(add_kernel<F16>, dim3(blocks), dim3(256), 0, s, static_cast<const uint16_t*>(a), lda,
+                           static_cast<const uint16_t*>(b), ldb, static_cast<uint16_t*>(out), ldo, rows, CV);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_timestep_embedding(int dtype, const int64_t* t, int B, int dim, void* out, int ld,
+                                       edtr_stream_t stream) {
+    if (!t || !out) return EDTR_E_NULL;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (B <= 0 || dim <= 0 || (dim & 1) || ld < dim) return EDTR_E_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == EDTR_BF16)
+        hipLaunchKernelGGL(temb_kernel<BF16>, dim3(B), dim3(256), 0, s, t, dim, static_cast<uint16_t*>(out), ld);
+    else
+        hipLaunchKernelGGL(temb_kernel<F16>, dim3(B), dim3(256), 0, s, t, dim, static_cast<uint16_t*>(out), ld);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_sampler_update(const float* x, const float* eps, const float* noise, float c_recip, float c_recipm1,
+                                   float coef1, float coef2, float sigma, float* x_prev, float* pred_x0, int64_t n,
+                                   edtr_stream_t stream) {
+    if (!x || !eps || !noise || !x_prev) return EDTR_E_NULL;
+    if (n <= 0) return EDTR_E_SHAPE;
+    hipLaunchKernelGGL(sampler_update_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, eps,
+                       noise, c_recip, c_recipm1, coef1, coef2, sigma, x_prev, pred_x0, n);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, edtr_stream_t stream) {
+    if (!x || !y || !out) return EDTR_E_NULL;
+    if (n <= 0) return EDTR_E_SHAPE;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, a, b, out,
+                       n);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_divide(const float* num, const float* den, float* out, int64_t n, edtr_stream_t stream) {
+    if (!num || !den || !out) return EDTR_E_NULL;
+    if (n <= 0) return EDTR_E_SHAPE;
+    hipLaunchKernelGGL(divide_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), num, den, out,
+                       n);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_tile_accumulate(const float* tile, const float* wts, float* out, float* count, int B, int C, int H,
+                                    int W, int th, int tw, int hi, int wi, edtr_stream_t stream) {
+    if (!tile || !wts || !out || !count) return EDTR_E_NULL;
+    if (B <= 0 || C <= 0 || th <= 0 || tw <= 0 || hi < 0 || wi < 0 || hi + th > H || wi + tw > W) return EDTR_E_SHAPE;
+    const int64_t n = (int64_t)B * C * th * tw;
+    hipLaunchKernelGGL(tile_acc_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), tile, wts, out,
+                       count, B * C, H, W, th, tw, hi, wi);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+// ---- hipGraph helpers -------------------------------------------------------------------------
+extern "C" int edtr_graph_begin(edtr_stream_t stream) {
+    return (int)hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal);
+}
+
+extern "C" int edtr_graph_end(edtr_stream_t stream, void** graph_exec_out) {
+    if (!graph_exec_out) return EDTR_E_NULL;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(static_cast<hipStream_t>(stream), &graph);
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return (int)e;
+    *graph_exec_out = exec;
+    return EDTR_OK;
+}
+
+extern "C" int edtr_graph_launch(void* graph_exec, edtr_stream_t stream) {
+    if (!graph_exec) return EDTR_E_NULL;
+    return (int)hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream));
+}
+
+extern "C" int edtr_graph_destroy(void* graph_exec) {
+    if (!graph_exec) return EDTR_E_NULL;
+    return (int)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec));
+}

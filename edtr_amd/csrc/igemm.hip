@@ -1,0 +1,321 @@
+// Implicit-GEMM convolution / linear / batched GEMM for gfx950 (see include/edtr_hip.h).
+//
+// Block tile (64*MI) x (64*NI) x 64, 256 threads = 4 waves in a 2x2 arrangement, each wave owning
+// a (32*MI) x (32*NI) sub-tile as MI x NI accumulators of v_mfma_f32_32x32x16_{bf16,f16}.
+// Operands are staged global -> registers -> LDS (the A gather needs per-chunk predication for the
+// conv halo / concat / upsample, so the staging is register-based, not LDS-DMA), LDS is double
+// buffered with ONE barrier per K-tile: the loads of tile t+2 are issued right after the registers
+// holding tile t+1 have been written to LDS, so their latency hides under the MFMAs of tile t+1.
+// LDS tiles are [rows][64 x 16-bit] with the XOR swizzle of common.h (conflict-free ds_read_b128).
+// The epilogue stages the fp32 accumulators through LDS so that bias / time-embedding row vector /
+// residual / activation are applied on 8-wide row vectors and stored with 16-byte writes.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BK = 64;
+
+template <typename T, int MI, int NI, bool SPATIAL>
+__global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_params p) {
+    constexpr int BM = 64 * MI, BN = 64 * NI;
+    constexpr int RA = BM / 32, RW = BN / 32;  // 16-byte chunks per thread per K-tile
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- block -> tile, XCD-aware (blocks b and b+8 share an XCD/L2: give each XCD a contiguous run)
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- batch (grid.z) offsets
+    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
+    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
+    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
+    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
+
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
+    const uint16_t* a2 = p.a2 ? static_cast<const uint16_t*>(p.a2) + a_zoff : nullptr;
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
+
+    // ---- per-thread load geometry: chunk column kc, rows (tid>>3) + 32*i
+    const int kc = tid & 7, r0 = tid >> 3;
+    const int Cin = p.C1 + p.C2;
+    const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
+
+    int a_iy0[RA], a_ix0[RA], a_pix[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < p.M;
+        if (SPATIAL) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_iy0[i] = oy * p.stride - p.pad_t;
+            a_ix0[i] = ox * p.stride - p.pad_l;
+            a_pix[i] = b * p.IH * p.IW;
+        } else {
+            a_iy0[i] = 0; a_ix0[i] = 0; a_pix[i] = m;
+        }
+    }
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    bool w_ok[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) w_ok[i] = (n0 + r0 + 32 * i) < nvalid;
+
+    U4 ra[RA], rw[RW];
+
+    auto load_tile = [&](int kt) {
+        const int kg = kt * BK + kc * 8;
+        const bool kvalid = kg < p.K;
+        int c = kg, ky = 0, kx = 0;
+        if (SPATIAL && p.taps == 9) {
+            const int tap = kg / Cin;
+            c = kg - tap * Cin;
+            ky = tap / 3;
+            kx = tap - 3 * ky;
+        }
+        const bool second = c >= p.C1;
+        const uint16_t* base = second ? a2 : a1;
+        const int ld = second ? p.ld2 : p.ld1;
+        const int cc = second ? c - p.C1 : c;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            bool ok = a_ok[i] && kvalid;
+            int64_t pix;
+            if (SPATIAL) {
+                int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                ok = ok && iy >= 0 && iy < LH && ix >= 0 && ix < LW;
+                if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+                pix = (int64_t)a_pix[i] + iy * p.IW + ix;
+            } else {
+                pix = a_pix[i];
+            }
+            ra[i] = zero16();
+            if (ok) ra[i] = ldg16(base + pix * ld + cc);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            rw[i] = zero16();
+            if (w_ok[i] && kvalid) rw[i] = ldg16(wp + (int64_t)(n0 + r0 + 32 * i) * p.ldw + kg);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<U4*>(sa + tile_off(r0 + 32 * i, kc)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) *reinterpret_cast<U4*>(sw + tile_off(r0 + 32 * i, kc)) = rw[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const int nkt = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    if (nkt > 1) load_tile(1);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const char* sa = smem + cur * STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int c = 2 * ks + lh;
+            U4 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const U4*>(sa + tile_off(wm * 32 * MI + mi * 32 + l31, c));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                bf[ni] = *reinterpret_cast<const U4*>(sw + tile_off(wn * 32 * NI + ni * 32 + l31, c));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma(af[mi], bf[ni], acc[mi][ni]);
+        }
+        if (kt + 1 < nkt) {
+            store_tile(cur ^ 1);               // registers hold tile kt+1 (loaded one iteration ago)
+            if (kt + 2 < nkt) load_tile(kt + 2);  // in flight during the next iteration's MFMAs
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32) -> row vectors of 8
+    const bool geglu = (p.act == EDTR_ACT_GEGLU);
+    const int BNO = geglu ? BN / 2 : BN;      // output columns of this block
+    float* stage = reinterpret_cast<float*>(smem);
+    if (geglu) {
+        if constexpr (NI == 2) {
+            const int nv = n0 + wn * 64 + l31;  // packed column of the value half; gate = +32
+            const float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
+            const float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float val = acc[mi][0][r] * p.alpha + bv;
+                    const float gate = acc[mi][1][r] * p.alpha + bg;
+                    stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
+                }
+    }
+    __syncthreads();
+
+    const int n_out = geglu ? p.N / 2 : p.N;
+    const int no0 = geglu ? n0 / 2 : n0;
+    const int vec_per_row = BNO / 8;
+    char* outp = static_cast<char*>(p.out);
+    for (int v = tid; v < BM * vec_per_row; v += kThreads) {
+        const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
+        const int m = m0 + ml, n = no0 + n8 * 8;
+        if (m >= p.M || n >= n_out) continue;
+        float f[8];
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+        f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
+        f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
+        if (!geglu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= p.alpha;
+            if (p.bias_n) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] += p.bias_n[n + j];
+            }
+        }
+        if (p.bias_m) {
+            const float bm = p.bias_m[m];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += bm;
+        }
+        if (p.rowvec) {
+            const float* rv = p.rowvec + (int64_t)(m / p.rows_per_image) * p.rowvec_ld + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += rv[j];
+        }
+        if (p.act == EDTR_ACT_SILU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+        }
+        if (p.residual) {
+            const U4 rv = ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n);
+            float rf[8];
+            unpack8<T>(rv, rf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += rf[j];
+        }
+        const int64_t oidx = o_zoff + (int64_t)m * p.ldc + n;
+        if (p.out_f32) {
+            float* o = reinterpret_cast<float*>(outp) + oidx;
+            f32x4 o0, o1;
+            o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2]; o0[3] = f[3];
+            o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
+            *reinterpret_cast<f32x4*>(o) = o0;
+            *reinterpret_cast<f32x4*>(o + 4) = o1;
+        } else {
+            stg16(reinterpret_cast<uint16_t*>(outp) + oidx, pack8<T>(f));
+        }
+    }
+}
+
+template <typename T, int MI, int NI, bool SPATIAL>
+int launch(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int BM = 64 * MI, BN = 64 * NI;
+    constexpr int lds = 2 * (BM + BN) * BK * 2;
+    static_assert(lds >= BM * BN * 4, "epilogue staging must fit the main-loop LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, MI, NI, SPATIAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    dim3 grid(nbm * nbn, 1, p.Z);
+    hipLaunchKernelGGL((igemm_kernel<T, MI, NI, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+template <typename T>
+int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
+    if (tile == 1) return spatial ? launch<T, 2, 2, true>(p, s) : launch<T, 2, 2, false>(p, s);
+    return spatial ? launch<T, 1, 1, true>(p, s) : launch<T, 1, 1, false>(p, s);
+}
+
+}  // namespace
+
+extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
+    if (!pp) return EDTR_E_NULL;
+    edtr_igemm_params p = *pp;
+    if (!p.a1 || !p.w || !p.out) return EDTR_E_NULL;
+    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (p.taps != 1 && p.taps != 9) return EDTR_E_UNSUPPORTED;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.Z <= 0) return EDTR_E_SHAPE;
+    if (p.zdiv <= 0) p.zdiv = 1;
+    if (p.C2 > 0 && !p.a2) return EDTR_E_NULL;
+    if (p.C2 < 0 || p.C1 <= 0) return EDTR_E_SHAPE;
+    if (p.K != p.taps * (p.C1 + p.C2)) return EDTR_E_SHAPE;
+    const bool spatial = p.OH > 0;
+    if (p.taps == 9 && !spatial) return EDTR_E_SHAPE;
+    if (spatial) {
+        if (p.OW <= 0 || p.IH <= 0 || p.IW <= 0 || p.stride <= 0) return EDTR_E_SHAPE;
+        if (p.M % (p.OH * p.OW) != 0) return EDTR_E_SHAPE;
+    }
+    if (p.act < EDTR_ACT_NONE || p.act > EDTR_ACT_SILU) return EDTR_E_DTYPE;
+    if (p.rowvec && p.rows_per_image <= 0) return EDTR_E_SHAPE;
+    // 16-byte rule
+    if ((p.K & 7) || (p.N & 7) || (p.C1 & 7) || (p.C2 & 7) || (p.ld1 & 7) || (p.C2 && (p.ld2 & 7)) || (p.ldw & 7))
+        return EDTR_E_ALIGN;
+    const int n_out = p.act == EDTR_ACT_GEGLU ? p.N / 2 : p.N;
+    if (p.act == EDTR_ACT_GEGLU && (p.N & 63)) return EDTR_E_ALIGN;
+    if ((n_out & 7) || (p.ldc & (p.out_f32 ? 3 : 7)) || (p.residual && (p.ldr & 7))) return EDTR_E_ALIGN;
+    if (!aligned16(p.a1) || !aligned16(p.w) || !aligned16(p.out) || (p.a2 && !aligned16(p.a2)) ||
+        (p.residual && !aligned16(p.residual)))
+        return EDTR_E_ALIGN;
+    if ((p.a_zs_outer & 7) || (p.a_zs_inner & 7) || (p.w_zs_outer & 7) || (p.w_zs_inner & 7) ||
+        (p.o_zs_outer & 3) || (p.o_zs_inner & 3))
+        return EDTR_E_ALIGN;
+    if (p.n_valid < 0 || p.n_valid > p.N) return EDTR_E_SHAPE;
+    if (p.residual && p.Z != 1) return EDTR_E_UNSUPPORTED;  // residual / rowvec are not z-batched
+    if (p.rowvec && p.Z != 1) return EDTR_E_UNSUPPORTED;
+
+    int tile = p.tile;
+    if (tile == 0) {
+        const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.Z;
+        tile = big >= 200 ? 1 : 2;
+    }
+    if (p.act == EDTR_ACT_GEGLU) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
+    if (tile != 1 && tile != 2) return EDTR_E_DTYPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
+}

@@ -1,0 +1,117 @@
+"""ctypes binding of libedtr_hip.so (include/edtr_hip.h).  The product path has NO fallback: if the
+library is missing or a launch fails, a RuntimeError is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
+
+BF16, F16 = 0, 1
+ACT_NONE, ACT_GEGLU, ACT_SILU = 0, 1, 2
+
+DECLARED_SYMBOLS = [
+    "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
+    "edtr_gn_stats", "edtr_gn_apply", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
+    "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
+    "edtr_tile_accumulate", "edtr_divide", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
+    "edtr_graph_destroy",
+]
+
+
+class IgemmParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("taps", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("n_valid", C.c_int32), ("Z", C.c_int32), ("zdiv", C.c_int32),
+        ("a1", C.c_void_p), ("a2", C.c_void_p),
+        ("C1", C.c_int32), ("C2", C.c_int32), ("ld1", C.c_int32), ("ld2", C.c_int32),
+        ("a_zs_outer", C.c_int64), ("a_zs_inner", C.c_int64),
+        ("IH", C.c_int32), ("IW", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("upsample2x", C.c_int32),
+        ("w", C.c_void_p), ("ldw", C.c_int32),
+        ("w_zs_outer", C.c_int64), ("w_zs_inner", C.c_int64),
+        ("alpha", C.c_float),
+        ("bias_n", C.c_void_p), ("bias_m", C.c_void_p),
+        ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_image", C.c_int32),
+        ("act", C.c_int32),
+        ("residual", C.c_void_p), ("ldr", C.c_int32),
+        ("out", C.c_void_p), ("ldc", C.c_int32), ("out_f32", C.c_int32),
+        ("o_zs_outer", C.c_int64), ("o_zs_inner", C.c_int64),
+        ("tile", C.c_int32),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32),
+        ("q", C.c_void_p), ("q_bs", C.c_int64), ("q_ld", C.c_int32),
+        ("k", C.c_void_p), ("k_bs", C.c_int64), ("k_ld", C.c_int32),
+        ("vt", C.c_void_p), ("vt_bs", C.c_int64), ("vt_ld", C.c_int32),
+        ("out", C.c_void_p), ("o_bs", C.c_int64), ("o_ld", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
+class GnParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("groups", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("sums", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("eps", C.c_float), ("silu", C.c_int32),
+        ("y", C.c_void_p), ("ldy", C.c_int32),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (building nothing: see edtr_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the EDTR MI355X path has no CPU/PyTorch fallback. "
+            "Build it with `python -m edtr_amd.build` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.edtr_abi_version.restype = i32
+    lib.edtr_error_string.restype = C.c_char_p
+    lib.edtr_error_string.argtypes = [i32]
+    lib.edtr_device_info.argtypes = [C.POINTER(i32), C.POINTER(i64), C.c_char_p, i32]
+    lib.edtr_igemm.argtypes = [C.POINTER(IgemmParams), vp]
+    lib.edtr_flash_attn64.argtypes = [C.POINTER(AttnParams), vp]
+    lib.edtr_gn_stats.argtypes = [C.POINTER(GnParams), vp]
+    lib.edtr_gn_apply.argtypes = [C.POINTER(GnParams), vp]
+    lib.edtr_layernorm.argtypes = [i32, vp, i64, i32, i32, vp, vp, f32, vp, i32, vp]
+    lib.edtr_softmax_rows.argtypes = [i32, vp, i64, i32, i64, vp, i64, vp]
+    lib.edtr_nchw_to_nhwc.argtypes = [i32, vp, i32, i32, i64, vp, i32, i32, i32, f32, f32, vp]
+    lib.edtr_nhwc_to_nchw.argtypes = [i32, vp, i32, i32, i32, i64, i32, vp, f32, vp]
+    lib.edtr_add.argtypes = [i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]
+    lib.edtr_timestep_embedding.argtypes = [i32, vp, i32, i32, vp, i32, vp]
+    lib.edtr_sampler_update.argtypes = [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]
+    lib.edtr_axpby.argtypes = [vp, vp, f32, f32, vp, i64, vp]
+    lib.edtr_tile_accumulate.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.edtr_divide.argtypes = [vp, vp, vp, i64, vp]
+    lib.edtr_graph_begin.argtypes = [vp]
+    lib.edtr_graph_end.argtypes = [vp, C.POINTER(vp)]
+    lib.edtr_graph_launch.argtypes = [vp, vp]
+    lib.edtr_graph_destroy.argtypes = [vp]
+    for name in DECLARED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("edtr_error_string",):
+            fn.restype = i32
+    if lib.edtr_abi_version() != 1:
+        raise RuntimeError("libedtr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().edtr_error_string(code).decode()
+        raise RuntimeError(f"libedtr_hip {what} failed with code {code}: {msg}")

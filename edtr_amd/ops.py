@@ -1,0 +1,208 @@
+"""Thin torch-tensor front end over the C ABI (edtr_amd/lib.py).  torch is plumbing here: it owns the
+device buffers and the stream; every computation is a libedtr_hip launch on torch's current stream.
+
+Launch records: each ``make_*`` returns a ``(c_function, params_struct, keepalive)`` tuple that can
+be replayed any number of times with ``launch(rec)`` — the engine (edtr_amd/engine.py) pre-builds
+them once per shape so the steady-state host cost per kernel is one ctypes call.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"libedtr_hip stores activations as bfloat16 or float16, got {dtype}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Rec:
+    """One pre-built kernel launch."""
+    __slots__ = ("fn", "args", "keep", "name", "flops", "bytes")
+
+    def __init__(self, fn, args, keep, name, flops=0.0, nbytes=0.0):
+        self.fn, self.args, self.keep, self.name, self.flops, self.bytes = fn, args, keep, name, flops, nbytes
+
+    def launch(self, stream: int) -> None:
+        code = self.fn(*self.args, stream)
+        if code != 0:
+            L.check(code, self.name)
+
+
+def launch(rec: Rec) -> None:
+    rec.launch(stream_ptr())
+
+
+# --------------------------------------------------------------------------------------------
+# igemm
+# --------------------------------------------------------------------------------------------
+def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, N: int,
+               C1: int, ld1: int, ldw: int, ldc: int, taps: int = 1, a2: Optional[torch.Tensor] = None, C2: int = 0,
+               ld2: int = 0, spatial: Optional[Tuple[int, int, int, int, int, int, int, int]] = None, Z: int = 1,
+               zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0), alpha: float = 1.0,
+               bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
+               rowvec: Optional[torch.Tensor] = None, rowvec_ld: int = 0, rows_per_image: int = 0, act: int = 0,
+               residual: Optional[torch.Tensor] = None, ldr: int = 0, out_f32: bool = False, n_valid: int = 0,
+               tile: int = 0, name: str = "igemm") -> Rec:
+    p = L.IgemmParams()
+    p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
+    p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
+    p.a1, p.a2, p.C1, p.C2, p.ld1, p.ld2 = ptr(a1), ptr(a2), C1, C2, ld1, ld2
+    p.a_zs_outer, p.a_zs_inner = a_zs
+    if spatial is not None:
+        p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l, p.upsample2x = spatial
+    p.w, p.ldw = ptr(w), ldw
+    p.w_zs_outer, p.w_zs_inner = w_zs
+    p.alpha = alpha
+    p.bias_n, p.bias_m, p.rowvec = ptr(bias_n), ptr(bias_m), ptr(rowvec)
+    p.rowvec_ld, p.rows_per_image, p.act = rowvec_ld, rows_per_image, act
+    p.residual, p.ldr = ptr(residual), ldr
+    p.out, p.ldc, p.out_f32 = ptr(out), ldc, int(out_f32)
+    p.o_zs_outer, p.o_zs_inner = o_zs
+    p.tile = tile
+    flops = 2.0 * M * N * p.K * Z
+    return Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual), name, flops)
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld,
+                    scale: float, name: str = "flash_attn64") -> Rec:
+    p = L.AttnParams()
+    p.dtype, p.B, p.H, p.Nq, p.Nk = dt_code(dtype), B, H, Nq, Nk
+    p.q, p.q_bs, p.q_ld = ptr(q), q_bs, q_ld
+    p.k, p.k_bs, p.k_ld = ptr(k), k_bs, k_ld
+    p.vt, p.vt_bs, p.vt_ld = ptr(vt), vt_bs, vt_ld
+    p.out, p.o_bs, p.o_ld = ptr(out), o_bs, o_ld
+    p.scale = scale
+    flops = 4.0 * B * H * Nq * Nk * 64
+    return Rec(L.load().edtr_flash_attn64, (ct.byref(p),), (p, q, k, vt, out), name, flops)
+
+
+# --------------------------------------------------------------------------------------------
+# norms
+# --------------------------------------------------------------------------------------------
+def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, groups: int = 32, name="gn"):
+    """Returns (stats_rec, apply_rec)."""
+    p = L.GnParams()
+    p.dtype, p.B, p.HW, p.C, p.groups = dt_code(dtype), B, HW, C, groups
+    p.x, p.ldx, p.sums = ptr(x), ldx, ptr(sums)
+    p.gamma, p.beta, p.eps, p.silu = ptr(gamma), ptr(beta), eps, int(silu)
+    p.y, p.ldy = ptr(y), ldy
+    keep = (p, x, sums, gamma, beta, y)
+    lib = L.load()
+    nb = 2.0 * B * HW * C
+    return (Rec(lib.edtr_gn_stats, (ct.byref(p),), keep, name + ".stats", 0.0, nb),
+            Rec(lib.edtr_gn_apply, (ct.byref(p),), keep, name + ".apply", 0.0, 2 * nb))
+
+
+def make_layernorm(*, dtype, x, rows, C, ldx, gamma, beta, eps, y, ldy, name="layernorm") -> Rec:
+    args = (dt_code(dtype), ptr(x), rows, C, ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy)
+    return Rec(L.load().edtr_layernorm, args, (x, gamma, beta, y), name, 0.0, 4.0 * rows * C)
+
+
+def make_softmax_rows(*, dtype, s, rows, cols, ld_s, p, ld_p, name="softmax_rows") -> Rec:
+    args = (dt_code(dtype), ptr(s), rows, cols, ld_s, ptr(p), ld_p)
+    return Rec(L.load().edtr_softmax_rows, args, (s, p), name, 0.0, 10.0 * rows * cols)
+
+
+# --------------------------------------------------------------------------------------------
+# layout / elementwise
+# --------------------------------------------------------------------------------------------
+def make_nchw_to_nhwc(*, dtype, src, B, C, HW, dst, ld, coff=0, zero_pad_to=0, scale=1.0, shift=0.0,
+                      name="nchw_to_nhwc") -> Rec:
+    args = (dt_code(dtype), ptr(src), B, C, HW, ptr(dst), ld, coff, zero_pad_to, scale, shift)
+    return Rec(L.load().edtr_nchw_to_nhwc, args, (src, dst), name, 0.0, 6.0 * B * C * HW)
+
+
+def make_nhwc_to_nchw(*, dtype, src, src_f32, B, C, HW, ld, dst, scale=1.0, name="nhwc_to_nchw") -> Rec:
+    args = (dt_code(dtype), ptr(src), int(src_f32), B, C, HW, ld, ptr(dst), scale)
+    return Rec(L.load().edtr_nhwc_to_nchw, args, (src, dst), name, 0.0, 6.0 * B * C * HW)
+
+
+def make_add(*, dtype, a, lda, b, ldb, out, ldo, rows, C, name="add") -> Rec:
+    args = (dt_code(dtype), ptr(a), lda, ptr(b), ldb, ptr(out), ldo, rows, C)
+    return Rec(L.load().edtr_add, args, (a, b, out), name, 0.0, (6.0 if b is not None else 4.0) * rows * C)
+
+
+def make_timestep_embedding(*, dtype, t, B, dim, out, ld, name="timestep_embedding") -> Rec:
+    return Rec(L.load().edtr_timestep_embedding, (dt_code(dtype), ptr(t), B, dim, ptr(out), ld), (t, out), name)
+
+
+def make_sampler_update(*, x, eps, noise, coefs: Sequence[float], x_prev, pred_x0, n, name="sampler_update") -> Rec:
+    a, b, c1, c2, sigma = (float(v) for v in coefs)
+    args = (ptr(x), ptr(eps), ptr(noise), a, b, c1, c2, sigma, ptr(x_prev), ptr(pred_x0), n)
+    return Rec(L.load().edtr_sampler_update, args, (x, eps, noise, x_prev, pred_x0), name, 0.0, 20.0 * n)
+
+
+def make_axpby(*, x, y, a, b, out, n, name="axpby") -> Rec:
+    return Rec(L.load().edtr_axpby, (ptr(x), ptr(y), float(a), float(b), ptr(out), n), (x, y, out), name, 0.0, 12.0 * n)
+
+
+def make_tile_accumulate(*, tile, wts, out, count, B, C, H, W, th, tw, hi, wi, name="tile_accumulate") -> Rec:
+    args = (ptr(tile), ptr(wts), ptr(out), ptr(count), B, C, H, W, th, tw, hi, wi)
+    return Rec(L.load().edtr_tile_accumulate, args, (tile, wts, out, count), name)
+
+
+def make_divide(*, num, den, out, n, name="divide") -> Rec:
+    return Rec(L.load().edtr_divide, (ptr(num), ptr(den), ptr(out), n), (num, den, out), name)
+
+
+# --------------------------------------------------------------------------------------------
+# weight packing (host side, torch CPU or GPU tensors)
+# --------------------------------------------------------------------------------------------
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: Optional[int] = None,
+                     cout_pad: Optional[int] = None) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] fp32 -> [Cout_pad][kh][kw][Cin_pad] 16-bit, flattened to [N][K] (K contiguous)."""
+    co, ci, kh, kw = w.shape
+    cip = cin_pad or round_up(ci, 8)
+    cop = cout_pad or round_up(co, 8)
+    out = torch.zeros((cop, kh, kw, cip), dtype=torch.float32, device=w.device)
+    out[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+    return out.reshape(cop, kh * kw * cip).to(dtype).contiguous()
+
+
+def pack_linear_weight(w: torch.Tensor, dtype: torch.dtype, n_pad: Optional[int] = None) -> torch.Tensor:
+    n, k = w.shape
+    npad = n_pad or round_up(n, 8)
+    out = torch.zeros((npad, round_up(k, 8)), dtype=torch.float32, device=w.device)
+    out[:n, :k] = w
+    return out.to(dtype).contiguous()
+
+
+def geglu_perm(inner: int) -> torch.Tensor:
+    """Row permutation that interleaves 32-row value / gate blocks (see edtr_hip.h, GEGLU epilogue)."""
+    assert inner % 32 == 0
+    j = torch.arange(inner // 32)
+    val = (j[:, None] * 32 + torch.arange(32)[None, :])            # [J, 32]
+    gate = val + inner
+    return torch.cat([val, gate], dim=1).reshape(-1)               # [J * 64]
+
+
+def pad_bias(b: Optional[torch.Tensor], n_pad: int) -> Optional[torch.Tensor]:
+    if b is None:
+        return None
+    out = torch.zeros(n_pad, dtype=torch.float32, device=b.device)
+    out[: b.numel()] = b.float()
+    return out

@@ -1,0 +1,215 @@
+/*
+ * edtr_hip.h — C ABI of libedtr_hip.so, the MI355X (gfx950) kernel library underneath the
+ * EDTR ControlLDM restoration path.
+ *
+ * The reference (JaehaKim97/EDTR) has no native code: every device op on its hot path is an
+ * ATen call made from torch.nn modules.  Each entry point below therefore names the reference
+ * call site(s) (file:line under the reference tree) whose ATen op it replaces.  The Python
+ * host (edtr_amd/) binds these with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD parameter structs; no torch / HIP types in signatures
+ *     (a stream is passed as void* = hipStream_t; NULL = the default stream).
+ *   - the caller owns every buffer (device memory unless stated); the library allocates
+ *     nothing on the device and keeps no global mutable state; every launch is asynchronous
+ *     on the given stream and is legal inside hipStreamBeginCapture (hipGraph capture).
+ *   - activations are NHWC ("pixel-major") 16-bit (bf16 or fp16, chosen by `dtype`) with
+ *     fp32 accumulation inside kernels; boundary tensors of the reference API (latents,
+ *     images, eps) are NCHW fp32 and are converted by edtr_nchw_to_nhwc / edtr_nhwc_to_nchw.
+ *   - 16-bit rows must be 16-byte aligned: channel counts, leading dimensions and column
+ *     offsets are multiples of 8 elements.
+ *   - return value: 0 = success; negative = EDTR_E* argument error (nothing was launched);
+ *     positive = hipError_t from the launch.  Never throws, never exits.
+ */
+#ifndef EDTR_HIP_H
+#define EDTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDTR_ABI_VERSION 1
+
+enum edtr_dtype { EDTR_BF16 = 0, EDTR_F16 = 1 };
+
+enum edtr_error {
+    EDTR_OK = 0,
+    EDTR_E_NULL = -1,      /* required pointer is NULL */
+    EDTR_E_SHAPE = -2,     /* non-positive or inconsistent extent */
+    EDTR_E_ALIGN = -3,     /* pointer / leading dimension violates the 16-byte rule */
+    EDTR_E_DTYPE = -4,     /* unknown dtype / flag value */
+    EDTR_E_UNSUPPORTED = -5
+};
+
+enum edtr_act { EDTR_ACT_NONE = 0, EDTR_ACT_GEGLU = 1, EDTR_ACT_SILU = 2 };
+
+typedef void* edtr_stream_t; /* hipStream_t */
+
+int edtr_abi_version(void);
+const char* edtr_error_string(int code);
+/* number of compute units / HBM bytes of the current device (0 on failure) */
+int edtr_device_info(int* compute_units, int64_t* hbm_bytes, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear / batched GEMM on the matrix cores (MFMA 32x32x16).
+ *
+ *   out[z][m][n] = epilogue( alpha * sum_k A(z, m, k) * W[z][n][k] )
+ *
+ * replaces: F.conv2d 3x3 / 1x1 (reference model/unet.py:152,178,99-101,76-78,189;
+ *           model/controlnet.py:138,261; model/vae.py:35-39,54-61,74-101), nn.Linear
+ *           (model/attention.py:23,43,170-174,266,280; model/unet.py:168,476-480), the
+ *           torch.cat feeding a conv (model/controlnet.py:35,37,266), F.interpolate(nearest,x2)
+ *           feeding a conv (model/unet.py:76; model/vae.py:36), F.pad(0,1,0,1) (model/vae.py:57),
+ *           and the bmm pair of the single-head VAE attention (model/vae.py:298).
+ *
+ * A operand ("im2col on the fly"): k = tap * (C1 + C2) + c, tap = ky * 3 + kx for taps == 9.
+ *   pixel (b, oy, ox) = unflatten(m; OH, OW);  iy = oy*stride + ky - pad_t;  ix likewise;
+ *   out-of-range taps read 0;  upsample2x != 0 reads source pixel (iy>>1, ix>>1) of an
+ *   (IH, IW) source (logical input is 2IH x 2IW);  channels c < C1 come from a1 (pixel stride
+ *   ld1), the rest from a2 (pixel stride ld2) — the fused channel concat.
+ *   taps == 1 and OH == 0: plain row-major matrix, A(z, m, k) = a1[z][m*ld1 + k] (concat too).
+ * W operand: row-major [N][K] (K contiguous, i.e. conv weights packed [Cout][ky][kx][Cin]).
+ *   Rows n >= n_valid read as zero.
+ * z (grid.z) offsets: operand_offset = (z / zdiv) * zs_outer + (z % zdiv) * zs_inner (elements).
+ * Epilogue order: *alpha, +bias_n[n], +bias_m[m], GEGLU (value/gate column blocks of 32
+ *   interleaved by the weight packer; output has N/2 columns), +rowvec[(m / rows_per_image)][n],
+ *   SiLU, +residual[m][n], then store as 16-bit or fp32 at out[m*ldc + n].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct edtr_igemm_params {
+    int32_t dtype;          /* edtr_dtype of a1/a2/w/residual and of a 16-bit output */
+    int32_t taps;           /* 1 or 9 */
+    int32_t M, N, K;        /* K = taps * (C1 + C2), multiple of 8; N multiple of 8 */
+    int32_t n_valid;        /* W rows >= n_valid are zero (0 means N) */
+    int32_t Z, zdiv;        /* batch count (grid.z) and its split (zdiv >= 1) */
+    /* A */
+    const void* a1; const void* a2;
+    int32_t C1, C2, ld1, ld2;
+    int64_t a_zs_outer, a_zs_inner;
+    int32_t IH, IW, OH, OW; /* spatial mode when OH > 0 */
+    int32_t stride, pad_t, pad_l, upsample2x;
+    /* W */
+    const void* w; int32_t ldw;
+    int64_t w_zs_outer, w_zs_inner;
+    /* epilogue */
+    float alpha;
+    const float* bias_n; const float* bias_m;
+    const float* rowvec; int32_t rowvec_ld; int32_t rows_per_image;
+    int32_t act;            /* edtr_act */
+    const void* residual; int32_t ldr;
+    /* out */
+    void* out; int32_t ldc; int32_t out_f32;
+    int64_t o_zs_outer, o_zs_inner;
+    int32_t tile;           /* 0 = auto, 1 = 128x128, 2 = 64x64 block tile */
+} edtr_igemm_params;
+
+int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-head attention, head width 64: out = softmax(q k^T * scale) v per (batch, head),
+ * online softmax, scores never leave the CU.
+ * replaces: F.scaled_dot_product_attention, reference model/attention.py:193 (46 calls/step).
+ *   q   : [B][Nq][q_ld]  head h occupies columns h*64 .. h*64+63
+ *   k   : [B][Nk][k_ld]  same column convention
+ *   vt  : [B][H*64][vt_ld]  V transposed ("key-major"): row h*64+d holds v[:, h*64+d] over the
+ *         keys; vt_ld >= roundup8(Nk) and the padding keys must be zero
+ *   out : [B][Nq][o_ld]
+ * ---------------------------------------------------------------------------------------- */
+typedef struct edtr_attn_params {
+    int32_t dtype;
+    int32_t B, H, Nq, Nk;
+    const void* q; int64_t q_bs; int32_t q_ld;
+    const void* k; int64_t k_bs; int32_t k_ld;
+    const void* vt; int64_t vt_bs; int32_t vt_ld;
+    void* out; int64_t o_bs; int32_t o_ld;
+    float scale;
+} edtr_attn_params;
+
+int edtr_flash_attn64(const edtr_attn_params* p, edtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (32 groups in the reference; `groups` here) over NHWC 16-bit activations, fp32 math.
+ * replaces: GroupNorm32 (model/util.py:146-163, eps 1e-5), Normalize (model/attention.py:50-51,
+ *           model/vae.py:22-23, eps 1e-6) and the SiLU / x*sigmoid(x) that follows
+ *           (model/unet.py:150,175,677; model/vae.py:17-19,104-113,443-444,555-556).
+ * Two launches: edtr_gn_stats accumulates per-(image, group) sum / sum of squares in fp64
+ * (sums[B][groups][2], zeroed by the call itself); edtr_gn_apply normalises, applies the affine
+ * and optionally SiLU.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct edtr_gn_params {
+    int32_t dtype;
+    int32_t B, HW, C, groups;
+    const void* x; int32_t ldx;     /* pixel stride of x (>= C) */
+    double* sums;                   /* [B][groups][2] workspace */
+    const float* gamma; const float* beta; /* [C] */
+    float eps;
+    int32_t silu;                   /* 0 / 1 */
+    void* y; int32_t ldy;
+} edtr_gn_params;
+
+int edtr_gn_stats(const edtr_gn_params* p, edtr_stream_t stream);
+int edtr_gn_apply(const edtr_gn_params* p, edtr_stream_t stream);
+
+/* LayerNorm over the last dimension, rows x C (C <= 2048), fp32 math, 16-bit in/out.
+ * replaces: nn.LayerNorm, reference model/attention.py:222-224. */
+int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int ldx, const float* gamma,
+                   const float* beta, float eps, void* y, int ldy, edtr_stream_t stream);
+
+/* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p).
+ * replaces: the softmax inside F.scaled_dot_product_attention of the d=512 single-head VAE
+ *           attention, reference model/vae.py:298. */
+int edtr_softmax_rows(int dtype, const float* s, int64_t rows, int cols, int64_t ld_s, void* p,
+                      int64_t ld_p, edtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / elementwise helpers.
+ * ---------------------------------------------------------------------------------------- */
+/* NCHW fp32 [B][C][HW] -> NHWC 16-bit: dst[(b*HW+p)*ld + coff + c] = scale*src + shift; when
+ * zero_pad_to > C the channels C..zero_pad_to-1 (relative to coff) are written as 0.
+ * replaces: `.type(self.dtype)` + rearranges (model/controlnet.py:266-269; model/attention.py:292)
+ * and the `*2-1` / `/scale_factor` scalings at the callers (demo.py:102; model/cldm.py:156). */
+int edtr_nchw_to_nhwc(int dtype, const float* src, int B, int C, int64_t HW, void* dst, int ld,
+                      int coff, int zero_pad_to, float scale, float shift, edtr_stream_t stream);
+/* NHWC (16-bit, or fp32 when src_f32) -> NCHW fp32, first C channels, times scale. */
+int edtr_nhwc_to_nchw(int dtype, const void* src, int src_f32, int B, int C, int64_t HW, int ld,
+                      float* dst, float scale, edtr_stream_t stream);
+/* out[r][c] = a[r][c] + b[r][c] over rows x C 16-bit elements with row strides lda/ldb/ldo (b == NULL: strided copy).
+ * Writing straight into a column slice of a wider buffer is how the channel concat is made for free.
+ * replaces: `hs.pop() + control.pop()`, `h += control.pop()` and the torch.cat of model/controlnet.py:31,35,37. */
+int edtr_add(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C,
+             edtr_stream_t stream);
+/* Sinusoidal timestep embedding [cos | sin] written as 16-bit rows of `dim` (even).
+ * replaces: timestep_embedding, reference model/util.py:98-118. */
+int edtr_timestep_embedding(int dtype, const int64_t* t, int B, int dim, void* out, int ld,
+                            edtr_stream_t stream);
+/* Spaced-sampler update on fp32 NCHW latents, n elements:
+ *   pred_x0 = c_recip*x - c_recipm1*eps;  x_prev = coef1*pred_x0 + coef2*x + sigma*noise
+ * replaces: utils/sampler.py:160-164,150-153,199-203 (sigma = sqrt(var) * [index != 0]). */
+int edtr_sampler_update(const float* x, const float* eps, const float* noise, float c_recip,
+                        float c_recipm1, float coef1, float coef2, float sigma, float* x_prev,
+                        float* pred_x0, int64_t n, edtr_stream_t stream);
+/* out = a*x + b*y (fp32).  replaces: Diffusion.q_sample, model/gaussian_diffusion.py:80-84. */
+int edtr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n,
+               edtr_stream_t stream);
+/* Gaussian-weighted overlap-add of one latent tile (fp32 NCHW):
+ *   out[b][c][hi+y][wi+x] += tile[b][c][y][x] * wts[y][x];  count[...] += wts[y][x]
+ * replaces: utils/common.py:415-424 (make_tiled_fn accumulation). */
+int edtr_tile_accumulate(const float* tile, const float* wts, float* out, float* count, int B,
+                         int C, int H, int W, int th, int tw, int hi, int wi, edtr_stream_t stream);
+/* out = num / den elementwise (fp32).  replaces: utils/common.py:425. */
+int edtr_divide(const float* num, const float* den, float* out, int64_t n, edtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hipGraph capture of a launch sequence issued on `stream` (one denoise step, or a whole batch).
+ * ---------------------------------------------------------------------------------------- */
+int edtr_graph_begin(edtr_stream_t stream);
+int edtr_graph_end(edtr_stream_t stream, void** graph_exec_out);
+int edtr_graph_launch(void* graph_exec, edtr_stream_t stream);
+int edtr_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDTR_HIP_H */

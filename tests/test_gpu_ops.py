@@ -1,0 +1,397 @@
+"""Per-kernel parity tests (run on the MI355X box: pytest -m gpu).  Every HIP kernel is called through the
+C ABI (edtr_amd.ops -> libedtr_hip.so) and compared with a plain torch fp32 CPU computation of the same op
+on the same 16-bit-rounded inputs.  Stated tolerances (relative L2 error of the output tensor):
+  bf16 storage: 6e-3 (one output rounding is 2^-9 = 2e-3 max)     fp16 storage: 1e-3."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+TOL = {torch.bfloat16: 6e-3, torch.float16: 1e-3}
+
+
+def _ops():
+    from edtr_amd import ops
+    return ops
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def nhwc16(x, dtype, pad_to=None):
+    """NCHW fp32 cpu -> NHWC 16-bit cuda (optionally zero-padded channels); also returns the rounded fp32 NCHW."""
+    xr = x.to(dtype).float()
+    t = xr.permute(0, 2, 3, 1).contiguous()
+    if pad_to and pad_to > t.shape[-1]:
+        t = F.pad(t, (0, pad_to - t.shape[-1]))
+    return t.to(dtype).to(dev()).contiguous(), xr
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,tile", [(256, 128, 64, 1), (300, 72, 200, 2), (4096, 320, 320, 0), (77, 640, 1024, 0),
+                                        (8, 1280, 320, 2), (130, 136, 72, 1)])
+def test_gemm_bias_residual(dtype, M, N, K, tile):
+    ops = _ops()
+    a = rnd((M, K), 1).to(dtype)
+    w = rnd((N, K), 2, 1 / math.sqrt(K)).to(dtype)
+    bias = rnd((N,), 3)
+    res = rnd((M, N), 4).to(dtype)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    d = dev()
+    ad, wd, bd, rd = a.to(d), w.to(d), bias.to(d), res.to(d)
+    out = torch.empty((M, N), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=ad, w=wd, out=out, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N, bias_n=bd,
+                              residual=rd, ldr=N, tile=tile))
+    torch.cuda.synchronize()
+    assert rel(out.float(), ref) < TOL[dtype]
+    # fp32 output, alpha, SiLU epilogue, no residual
+    out32 = torch.empty((M, N), dtype=torch.float32, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=ad, w=wd, out=out32, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N, bias_n=bd,
+                              alpha=0.5, act=2, out_f32=True, tile=tile))
+    torch.cuda.synchronize()
+    ref2 = F.silu(0.5 * (a.float() @ w.float().t()) + bias)
+    assert rel(out32, ref2) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_geglu_and_concat(dtype):
+    ops = _ops()
+    M, d_model, inner = 200, 128, 512
+    x = rnd((M, d_model), 5).to(dtype)
+    w = rnd((2 * inner, d_model), 6, 1 / math.sqrt(d_model))
+    b = rnd((2 * inner,), 7, 0.1)
+    perm = ops.geglu_perm(inner)
+    wp = w[perm].to(dtype)
+    bp = b[perm].contiguous()
+    h = x.float() @ w.to(dtype).float().t() + b
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    d = dev()
+    out = torch.empty((M, inner), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=x.to(d), w=wp.to(d), out=out, M=M, N=2 * inner, C1=d_model, ld1=d_model,
+                              ldw=d_model, ldc=inner, bias_n=bp.to(d), act=1))
+    torch.cuda.synchronize()
+    assert rel(out.float(), ref) < TOL[dtype]
+    # K-concat of two sources (1x1 conv over cat([h, skip]))
+    x2 = rnd((M, 64), 8).to(dtype)
+    wc = rnd((72, d_model + 64), 9, 0.1).to(dtype)
+    refc = torch.cat([x.float(), x2.float()], dim=1) @ wc.float().t()
+    outc = torch.empty((M, 72), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=x.to(d), a2=x2.to(d), w=wc.to(d), out=outc, M=M, N=72, C1=d_model, C2=64,
+                              ld1=d_model, ld2=64, ldw=d_model + 64, ldc=72))
+    torch.cuda.synchronize()
+    assert rel(outc.float(), refc) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_strided(dtype):
+    """z-batched forms used by the VAE attention: S = alpha Q K^T (fp32 out), V^T = Wv X^T + bias_m, O = P V."""
+    ops = _ops()
+    B, Ntok, Cc = 2, 136, 64
+    d = dev()
+    q = rnd((B, Ntok, Cc), 10).to(dtype)
+    k = rnd((B, Ntok, Cc), 11).to(dtype)
+    s = torch.empty((B, Ntok, Ntok), dtype=torch.float32, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=q.to(d), w=k.to(d), out=s, M=Ntok, N=Ntok, C1=Cc, ld1=Cc, ldw=Cc, ldc=Ntok,
+                              Z=B, a_zs=(Ntok * Cc, 0), w_zs=(Ntok * Cc, 0), o_zs=(Ntok * Ntok, 0), alpha=0.125,
+                              out_f32=True))
+    torch.cuda.synchronize()
+    assert rel(s, 0.125 * q.float() @ k.float().transpose(1, 2)) < 2e-5
+    # V^T with a shared weight (zero z-stride on A) and per-row bias; Ntok not a multiple of 8 -> n_valid
+    Nt2 = 77
+    x = rnd((B, Nt2, Cc), 12).to(dtype)
+    wv = rnd((96, Cc), 13, 0.2).to(dtype)
+    bm = rnd((96,), 14)
+    ldv = 80
+    vt = torch.full((B, 96, ldv), 7.0, dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=wv.to(d), w=x.to(d), out=vt, M=96, N=ldv, n_valid=Nt2, C1=Cc, ld1=Cc, ldw=Cc,
+                              ldc=ldv, Z=B, a_zs=(0, 0), w_zs=(Nt2 * Cc, 0), o_zs=(96 * ldv, 0), bias_m=bm.to(d)))
+    torch.cuda.synchronize()
+    refv = wv.float() @ x.float().transpose(1, 2) + bm[None, :, None]
+    assert rel(vt[:, :, :Nt2].float(), refv) < TOL[dtype]
+    assert float((vt[:, :, Nt2:].float() - bm.to(d)[None, :, None]).abs().max()) < 2e-2  # zero rows + bias only
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["s1", "s2", "vae_down", "up", "concat", "small_cin", "small_cout"])
+def test_conv3x3(dtype, case):
+    ops = _ops()
+    d = dev()
+    B, H, W = 2, 12, 20
+    cin, cout = 64, 72
+    stride, pad, ups, pad_tl = 1, 1, False, 1
+    if case == "small_cin":
+        cin = 4
+    if case == "small_cout":
+        cout = 3
+    x = rnd((B, cin, H, W), 20)
+    w = rnd((cout, cin, 3, 3), 21, 1 / math.sqrt(9 * cin))
+    bias = rnd((cout,), 22)
+    xr16, xr = nhwc16(x, dtype, pad_to=ops.round_up(cin, 8))
+    wr = w.to(dtype).float()
+    x2 = None
+    if case == "s1" or case.startswith("small"):
+        ref = F.conv2d(xr, wr, bias, padding=1)
+    elif case == "s2":
+        stride = 2
+        ref = F.conv2d(xr, wr, bias, stride=2, padding=1)
+    elif case == "vae_down":   # pad (0,1,0,1) then stride 2, pad 0
+        stride, pad_tl = 2, 0
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, bias, stride=2, padding=0)
+    elif case == "up":
+        ups = True
+        ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wr, bias, padding=1)
+    elif case == "concat":
+        x2 = rnd((B, 40, H, W), 23)
+        w = rnd((cout, cin + 40, 3, 3), 24, 1 / math.sqrt(9 * (cin + 40)))
+        wr = w.to(dtype).float()
+        x216, x2r = nhwc16(x2, dtype)
+        ref = F.conv2d(torch.cat([xr, x2r], dim=1), wr, bias, padding=1)
+    OH, OW = ref.shape[2], ref.shape[3]
+    cinp = ops.round_up(cin, 8)
+    c2 = 40 if case == "concat" else 0
+    if case == "concat":
+        wp = ops.pack_conv_weight(w, dtype).to(d)
+    else:
+        wp = ops.pack_conv_weight(w, dtype, cin_pad=cinp).to(d)
+    N = wp.shape[0]
+    bp = ops.pad_bias(bias, N).to(d)
+    emb = rnd((B, N), 25).to(d)
+    res = rnd((B, OH, OW, N), 26).to(dtype).to(d)
+    out = torch.empty((B, OH, OW, N), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=xr16, a2=(x216 if case == "concat" else None), w=wp, out=out, taps=9,
+                              M=B * OH * OW, N=N, C1=cinp, C2=c2, ld1=cinp, ld2=c2, ldw=wp.shape[1], ldc=N,
+                              spatial=(H, W, OH, OW, stride, pad_tl, pad_tl, int(ups)), bias_n=bp, rowvec=emb,
+                              rowvec_ld=N, rows_per_image=OH * OW, residual=res, ldr=N))
+    torch.cuda.synchronize()
+    got = out.float().cpu()[..., :cout].permute(0, 3, 1, 2)
+    full_ref = ref + emb.cpu()[:, :cout, None, None] + res.float().cpu()[..., :cout].permute(0, 3, 1, 2)
+    assert rel(got, full_ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 5, 256, 256), (1, 2, 1024, 77), (2, 1, 64, 64), (1, 3, 4, 4), (1, 1, 200, 333)])
+def test_flash_attn64(dtype, B, H, Nq, Nk):
+    ops = _ops()
+    d = dev()
+    Cc = H * 64
+    q = rnd((B, Nq, Cc), 30).to(dtype)
+    k = rnd((B, Nk, Cc), 31).to(dtype)
+    v = rnd((B, Nk, Cc), 32).to(dtype)
+    ldv = ops.round_up(Nk, 8)
+    vt = torch.zeros((B, Cc, ldv), dtype=dtype)
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    out = torch.empty((B, Nq, Cc), dtype=dtype, device=d)
+    scale = 0.125
+    ops.launch(ops.make_flash_attn(dtype=dtype, q=q.to(d), k=k.to(d), vt=vt.to(d), out=out, B=B, H=H, Nq=Nq, Nk=Nk,
+                                   q_bs=Nq * Cc, q_ld=Cc, k_bs=Nk * Cc, k_ld=Cc, vt_bs=Cc * ldv, vt_ld=ldv, o_bs=Nq * Cc,
+                                   o_ld=Cc, scale=scale))
+    torch.cuda.synchronize()
+
+    def heads(t):
+        return t.float().reshape(B, -1, H, 64).transpose(1, 2)
+
+    p = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * scale, dim=-1)
+    ref = (p @ heads(v)).transpose(1, 2).reshape(B, Nq, Cc)
+    assert rel(out.float(), ref) < TOL[dtype] * 1.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_flash_attn64_forced_rescale(dtype):
+    """Online-softmax rescale branch: a late key dominates one query row (max jumps in the last tile)."""
+    ops = _ops()
+    d = dev()
+    B, H, Nq, Nk, Cc = 1, 1, 128, 256, 64
+    q = rnd((B, Nq, Cc), 33).to(dtype)
+    k = rnd((B, Nk, Cc), 34).to(dtype)
+    v = rnd((B, Nk, Cc), 35).to(dtype)
+    k[0, 250] = (q[0, 17].float() * 4).to(dtype)   # spike for query 17 in the 4th tile
+    k[0, 3] = (q[0, 90].float() * 4).to(dtype)     # and one in the 1st tile
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty((B, Nq, Cc), dtype=dtype, device=d)
+    ops.launch(ops.make_flash_attn(dtype=dtype, q=q.to(d), k=k.to(d), vt=vt.to(d), out=out, B=B, H=H, Nq=Nq, Nk=Nk,
+                                   q_bs=Nq * Cc, q_ld=Cc, k_bs=Nk * Cc, k_ld=Cc, vt_bs=Cc * Nk, vt_ld=Nk, o_bs=Nq * Cc,
+                                   o_ld=Cc, scale=0.125))
+    torch.cuda.synchronize()
+    p = torch.softmax(q.float() @ k.float().transpose(1, 2) * 0.125, dim=-1)
+    ref = p @ v.float()
+    assert rel(out.float(), ref) < TOL[dtype] * 1.5
+    assert (out.float().cpu()[0, 17] - ref[0, 17]).abs().max() < 0.05
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,HW,eps,silu", [(320, 1024, 1e-5, True), (32, 300, 1e-6, True), (128, 4096, 1e-6, False),
+                                          (2560, 64, 1e-5, True), (1920, 256, 1e-5, True), (64, 4, 1e-5, True)])
+def test_groupnorm(dtype, C, HW, eps, silu):
+    ops = _ops()
+    d = dev()
+    B = 2
+    x = rnd((B, C, HW, 1), 40) * 2 + 0.7
+    gamma, beta = 1 + 0.1 * rnd((C,), 41), 0.1 * rnd((C,), 42)
+    x16, xr = nhwc16(x, dtype)
+    sums = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    y = torch.empty_like(x16)
+    st, ap = ops.make_gn(dtype=dtype, x=x16, ldx=C, B=B, HW=HW, C=C, sums=sums, gamma=gamma.to(d), beta=beta.to(d),
+                         eps=eps, silu=silu, y=y, ldy=C)
+    ops.launch(st)
+    ops.launch(ap)
+    torch.cuda.synchronize()
+    ref = F.group_norm(xr, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel(got, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (5, 64), (300, 640)])
+def test_layernorm(dtype, rows, C):
+    ops = _ops()
+    d = dev()
+    x = (rnd((rows, C), 50) * 1.5 + 0.3).to(dtype)
+    gamma, beta = 1 + 0.1 * rnd((C,), 51), 0.1 * rnd((C,), 52)
+    y = torch.empty((rows, C), dtype=dtype, device=d)
+    ops.launch(ops.make_layernorm(dtype=dtype, x=x.to(d), rows=rows, C=C, ldx=C, gamma=gamma.to(d), beta=beta.to(d),
+                                  eps=1e-5, y=y, ldy=C))
+    torch.cuda.synchronize()
+    assert rel(y.float(), F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(64, 4096), (10, 136), (3, 16384)])
+def test_softmax_rows(dtype, rows, cols):
+    ops = _ops()
+    d = dev()
+    s = rnd((rows, cols), 60) * 3
+    p = torch.empty((rows, cols), dtype=dtype, device=d)
+    ops.launch(ops.make_softmax_rows(dtype=dtype, s=s.to(d), rows=rows, cols=cols, ld_s=cols, p=p, ld_p=cols))
+    torch.cuda.synchronize()
+    assert rel(p.float(), torch.softmax(s, dim=-1)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_and_elementwise(dtype):
+    ops = _ops()
+    d = dev()
+    B, Cc, H, W = 2, 4, 10, 13
+    x = rnd((B, Cc, H, W), 70)
+    dst = torch.full((B, H * W, 16), 9.0, dtype=dtype, device=d)
+    ops.launch(ops.make_nchw_to_nhwc(dtype=dtype, src=x.to(d), B=B, C=Cc, HW=H * W, dst=dst, ld=16, coff=8,
+                                     zero_pad_to=8, scale=2.0, shift=-1.0))
+    torch.cuda.synchronize()
+    ref = (x * 2 - 1).permute(0, 2, 3, 1).reshape(B, H * W, Cc)
+    assert rel(dst[:, :, 8:12].float(), ref) < TOL[dtype]
+    assert float(dst[:, :, 12:16].float().abs().max()) == 0.0
+    assert float((dst[:, :, :8].float() - 9.0).abs().max()) == 0.0
+    back = torch.empty((B, Cc, H * W), dtype=torch.float32, device=d)
+    ops.launch(ops.make_nhwc_to_nchw(dtype=dtype, src=dst[:, :, 8:], src_f32=False, B=B, C=Cc, HW=H * W, ld=16, dst=back,
+                                     scale=0.5))
+    torch.cuda.synchronize()
+    assert rel(back.reshape(B, Cc, H, W), 0.5 * (x * 2 - 1)) < TOL[dtype]
+    # fp32 NHWC source
+    src32 = rnd((B, H * W, 8), 71).to(d)
+    back2 = torch.empty((B, 3, H * W), dtype=torch.float32, device=d)
+    ops.launch(ops.make_nhwc_to_nchw(dtype=dtype, src=src32, src_f32=True, B=B, C=3, HW=H * W, ld=8, dst=back2))
+    torch.cuda.synchronize()
+    assert rel(back2, src32[:, :, :3].permute(0, 2, 1)) < 1e-7
+    # add / strided copy into a column slice
+    a, b = rnd((1000, 24), 72).to(dtype), rnd((1000, 24), 73).to(dtype)
+    o = torch.zeros((1000, 40), dtype=dtype, device=d)
+    ops.launch(ops.make_add(dtype=dtype, a=a.to(d), lda=24, b=b.to(d), ldb=24, out=o[:, 16:], ldo=40, rows=1000, C=24))
+    ops.launch(ops.make_add(dtype=dtype, a=a.to(d)[:, 8:], lda=24, b=None, ldb=0, out=o, ldo=40, rows=1000, C=16))
+    torch.cuda.synchronize()
+    assert rel(o[:, 16:].float(), a.float() + b.float()) < TOL[dtype]
+    assert rel(o[:, :16].float(), a[:, 8:].float()) == 0.0
+    # timestep embedding
+    t = torch.tensor([50, 100, 150, 200, 999], dtype=torch.int64)
+    e = torch.empty((5, 320), dtype=dtype, device=d)
+    ops.launch(ops.make_timestep_embedding(dtype=dtype, t=t.to(d), B=5, dim=320, out=e, ld=320))
+    torch.cuda.synchronize()
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(160, dtype=torch.float32) / 160)
+    args = t[:, None].float() * freqs[None]
+    assert rel(e.float(), torch.cat([torch.cos(args), torch.sin(args)], dim=-1)) < TOL[dtype]
+
+
+def test_sampler_kernels():
+    ops = _ops()
+    d = dev()
+    n = 2 * 4 * 16 * 16
+    x, eps, noise = rnd((n,), 80), rnd((n,), 81), rnd((n,), 82)
+    xp = torch.empty(n, device=d)
+    p0 = torch.empty(n, device=d)
+    coefs = (1.0990925, 0.45607486, 0.40786713, 0.59105539, math.sqrt(0.045623116))
+    ops.launch(ops.make_sampler_update(x=x.to(d), eps=eps.to(d), noise=noise.to(d), coefs=coefs, x_prev=xp, pred_x0=p0, n=n))
+    o = torch.empty(n, device=d)
+    ops.launch(ops.make_axpby(x=x.to(d), y=noise.to(d), a=0.86815441, b=0.49629423, out=o, n=n))
+    torch.cuda.synchronize()
+    rp0 = coefs[0] * x - coefs[1] * eps
+    assert rel(p0, rp0) < 1e-6
+    assert rel(xp, coefs[2] * rp0 + coefs[3] * x + coefs[4] * noise) < 1e-6
+    assert rel(o, 0.86815441 * x + 0.49629423 * noise) < 1e-6
+    # tile accumulate + divide
+    out = torch.zeros((1, 4, 16, 24), device=d)
+    cnt = torch.zeros_like(out)
+    tile = rnd((1, 4, 8, 8), 83)
+    wts = rnd((8, 8), 84).abs() + 0.1
+    ops.launch(ops.make_tile_accumulate(tile=tile.to(d), wts=wts.to(d), out=out, count=cnt, B=1, C=4, H=16, W=24, th=8, tw=8,
+                                        hi=4, wi=16))
+    torch.cuda.synchronize()
+    ref = torch.zeros(1, 4, 16, 24)
+    ref[..., 4:12, 16:24] = tile * wts
+    assert rel(out, ref) < 1e-6
+    assert rel(cnt[0, 0, 4:12, 16:24], wts) < 1e-6
+
+
+def test_error_codes():
+    ops = _ops()
+    from edtr_amd import lib as L
+    d = dev()
+    a = torch.zeros((16, 12), dtype=torch.bfloat16, device=d)
+    with pytest.raises(RuntimeError, match="EDTR_E_ALIGN"):
+        ops.launch(ops.make_igemm(dtype=torch.bfloat16, a1=a, w=a, out=a, M=16, N=16, C1=12, ld1=12, ldw=12, ldc=16))
+    with pytest.raises(RuntimeError, match="EDTR_E_NULL"):
+        L.check(L.load().edtr_igemm(None, None), "igemm")
+
+
+def test_graph_capture_replay():
+    """A launch sequence captured into a hipGraph replays with the same result."""
+    ops = _ops()
+    from edtr_amd import lib as L
+    import ctypes as C
+    d = dev()
+    n = 4096
+    x = torch.ones(n, device=d)
+    y = torch.full((n,), 2.0, device=d)
+    o1 = torch.empty(n, device=d)
+    o2 = torch.empty(n, device=d)
+    r1 = ops.make_axpby(x=x, y=y, a=1.0, b=1.0, out=o1, n=n)
+    r2 = ops.make_axpby(x=o1, y=y, a=2.0, b=1.0, out=o2, n=n)
+    s = torch.cuda.Stream()
+    lib = L.load()
+    with torch.cuda.stream(s):
+        L.check(lib.edtr_graph_begin(s.cuda_stream), "graph_begin")
+        r1.launch(s.cuda_stream)
+        r2.launch(s.cuda_stream)
+        g = C.c_void_p()
+        L.check(lib.edtr_graph_end(s.cuda_stream, C.byref(g)), "graph_end")
+        x.fill_(3.0)
+        L.check(lib.edtr_graph_launch(g, s.cuda_stream), "graph_launch")
+    s.synchronize()
+    assert float(o2[0]) == (3.0 + 2.0) * 2 + 2.0
+    L.check(lib.edtr_graph_destroy(g), "graph_destroy")
