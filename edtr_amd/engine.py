@@ -1,0 +1,353 @@
+"""Kernel-program machinery: device arena, packed-weight store, program (pre-built launch list with
+hipGraph capture and per-launch timing) and the primitive emitters used by edtr_amd/nets.py.
+
+Design (MI355X-first): a network evaluation at a fixed shape is compiled ONCE into a flat
+list of libedtr_hip launch records whose buffers live at fixed addresses inside an arena (288 GB of HBM
+makes a generous, rarely-freed arena the simplest correct allocator).  Steady state = a loop of ctypes
+calls on one HIP stream, or one hipGraphLaunch when captured.  There is no tracing compiler and no
+PyTorch operator on the data path.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+from .ops import Rec, round_up
+
+
+# ----------------------------------------------------------------------------------------------
+# arena
+# ----------------------------------------------------------------------------------------------
+class Arena:
+    """First-fit allocator over large device chunks.  Build-time only: a Program's launch order equals its
+    build order on one stream, so a buffer released at build time may be handed to a later op safely."""
+
+    ALIGN = 256
+
+    def __init__(self, device: torch.device, chunk_bytes: int = 1 << 28):
+        self.device = device
+        self.chunk_bytes = chunk_bytes
+        self.chunks: List[torch.Tensor] = []
+        self.free_lists: List[List[List[int]]] = []   # per chunk: sorted [offset, size]
+        self.live: Dict[int, Tuple[int, int, int, int]] = {}
+        self.peak = 0
+        self.in_use = 0
+
+    def alloc(self, shape: Sequence[int], dtype: torch.dtype) -> torch.Tensor:
+        numel = 1
+        for s in shape:
+            numel *= int(s)
+        item = torch.empty((), dtype=dtype).element_size()
+        nbytes = max(self.ALIGN, round_up(numel * item, self.ALIGN))
+        for ci, fl in enumerate(self.free_lists):
+            for fi, (off, size) in enumerate(fl):
+                if size >= nbytes:
+                    if size == nbytes:
+                        fl.pop(fi)
+                    else:
+                        fl[fi] = [off + nbytes, size - nbytes]
+                    return self._view(ci, off, nbytes, numel, shape, dtype)
+        size = max(nbytes, self.chunk_bytes)
+        self.chunks.append(torch.empty(size, dtype=torch.uint8, device=self.device))
+        self.free_lists.append([[nbytes, size - nbytes]] if size > nbytes else [])
+        return self._view(len(self.chunks) - 1, 0, nbytes, numel, shape, dtype)
+
+    def _view(self, ci, off, nbytes, numel, shape, dtype):
+        t = self.chunks[ci][off:off + nbytes].view(dtype)[:numel].view(*shape)
+        self.live[t.data_ptr()] = (ci, off, nbytes, numel)
+        self.in_use += nbytes
+        self.peak = max(self.peak, self.in_use)
+        return t
+
+    def free(self, t: Optional[torch.Tensor]) -> None:
+        if t is None:
+            return
+        key = t.data_ptr()
+        if key not in self.live or self.live[key][3] != t.numel() or not t.is_contiguous():
+            return  # a column-slice view / foreign tensor: the owner frees it
+        ci, off, nbytes, _ = self.live.pop(key)
+        self.in_use -= nbytes
+        fl = self.free_lists[ci]
+        fl.append([off, nbytes])
+        fl.sort()
+        merged: List[List[int]] = []
+        for o, s in fl:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1][1] += s
+            else:
+                merged.append([o, s])
+        self.free_lists[ci] = merged
+
+    def total_bytes(self) -> int:
+        return sum(c.numel() for c in self.chunks)
+
+
+# ----------------------------------------------------------------------------------------------
+# packed weights
+# ----------------------------------------------------------------------------------------------
+class WeightStore:
+    """fp32 parameters (reference names/shapes) -> device-resident packed 16-bit matrices + fp32 vectors.
+    Packs lazily, caches per (kind, names); ``invalidate()`` after the parameters change."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], dtype: torch.dtype, device: torch.device):
+        self.params, self.dtype, self.device = params, dtype, device
+        self.cache: Dict[tuple, object] = {}
+
+    def invalidate(self):
+        self.cache.clear()
+
+    def _p(self, name: str) -> torch.Tensor:
+        return self.params[name].detach().to(self.device, torch.float32)
+
+    def vec(self, name: str, n_pad: Optional[int] = None) -> torch.Tensor:
+        key = ("vec", name, n_pad)
+        if key not in self.cache:
+            v = self._p(name).reshape(-1)
+            self.cache[key] = ops.pad_bias(v, n_pad or v.numel()).contiguous()
+        return self.cache[key]
+
+    def conv(self, prefix: str, cin_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(w16 [Np, taps*Cinp], bias f32 [Np]) for ``prefix + 'weight'/'bias'`` (3x3 or 1x1 conv)."""
+        key = ("conv", prefix, cin_pad)
+        if key not in self.cache:
+            w = self._p(prefix + "weight")
+            wp = ops.pack_conv_weight(w, self.dtype, cin_pad=cin_pad)
+            self.cache[key] = (wp, self.vec(prefix + "bias", wp.shape[0]))
+        return self.cache[key]
+
+    def linear(self, names: Sequence[str], biases: Optional[Sequence[Optional[str]]] = None):
+        """Row-concatenation of several [out, in] matrices (fused projections) + matching fp32 bias (or None)."""
+        key = ("linear", tuple(names), tuple(biases) if biases else None)
+        if key not in self.cache:
+            ws = [self._p(n).reshape(self.params[n].shape[0], -1) for n in names]
+            w = torch.cat(ws, dim=0)
+            wp = ops.pack_linear_weight(w, self.dtype)
+            b = None
+            if biases:
+                parts = [self._p(bn).reshape(-1) if bn else torch.zeros(ws[i].shape[0], device=self.device)
+                         for i, bn in enumerate(biases)]
+                b = ops.pad_bias(torch.cat(parts), wp.shape[0])
+            self.cache[key] = (wp, b)
+        return self.cache[key]
+
+    def geglu(self, wname: str, bname: str):
+        key = ("geglu", wname)
+        if key not in self.cache:
+            w, b = self._p(wname), self._p(bname)
+            perm = ops.geglu_perm(w.shape[0] // 2).to(self.device)
+            self.cache[key] = (ops.pack_linear_weight(w[perm], self.dtype), b[perm].contiguous())
+        return self.cache[key]
+
+
+# ----------------------------------------------------------------------------------------------
+# program
+# ----------------------------------------------------------------------------------------------
+class Program:
+    """A flat launch list.  ``run()`` replays it on torch's current stream; ``capture()`` turns it into a
+    hipGraph; ``run_timed()`` brackets every launch with events on the same stream."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.recs: List[Rec] = []
+        self.graph = None
+
+    def add(self, rec: Rec) -> Rec:
+        self.recs.append(rec)
+        return rec
+
+    def extend(self, other: "Program") -> None:
+        self.recs.extend(other.recs)
+
+    def run(self) -> None:
+        s = ops.stream_ptr()
+        if self.graph is not None:
+            L.check(L.load().edtr_graph_launch(self.graph, s), "graph_launch")
+            return
+        for r in self.recs:
+            r.launch(s)
+
+    def capture(self) -> None:
+        """Capture on a side stream (hipGraph), then replay with one launch per run()."""
+        lib = L.load()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sp = side.cuda_stream
+            L.check(lib.edtr_graph_begin(sp), "graph_begin")
+            try:
+                for r in self.recs:
+                    r.launch(sp)
+            finally:
+                g = ct.c_void_p()
+                code = lib.edtr_graph_end(sp, ct.byref(g))
+            L.check(code, "graph_end")
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = g
+
+    def release_graph(self) -> None:
+        if self.graph is not None:
+            L.load().edtr_graph_destroy(self.graph)
+            self.graph = None
+
+    def run_timed(self) -> List[Tuple[str, float, float, float]]:
+        """[(name, ms, flops, bytes)] per launch, HIP events on the launch stream."""
+        s = ops.stream_ptr()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(self.recs) + 1)]
+        evs[0].record()
+        for i, r in enumerate(self.recs):
+            r.launch(s)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        return [(r.name, evs[i].elapsed_time(evs[i + 1]), r.flops, r.bytes) for i, r in enumerate(self.recs)]
+
+    def total_flops(self) -> float:
+        return sum(r.flops for r in self.recs)
+
+
+# ----------------------------------------------------------------------------------------------
+# activations + primitive emitters
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class Act:
+    """NHWC activation: ``t`` is a 2-D view [B*H*W, C] (row stride ``ld`` >= C) of 16-bit storage."""
+    t: torch.Tensor
+    B: int
+    H: int
+    W: int
+    C: int
+
+    @property
+    def ld(self) -> int:
+        return self.t.stride(0)
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.H * self.W
+
+
+class Emitter:
+    def __init__(self, prog: Program, arena: Arena, store: WeightStore, dtype: torch.dtype):
+        self.prog, self.arena, self.store, self.dtype = prog, arena, store, dtype
+
+    # -- memory
+    def new(self, rows: int, cols: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        return self.arena.alloc((rows, cols), dtype or self.dtype)
+
+    def free(self, *ts) -> None:
+        for t in ts:
+            if isinstance(t, Act):
+                t = t.t
+            self.arena.free(t)
+
+    # -- GEMM family ------------------------------------------------------------------------
+    def gemm(self, a: torch.Tensor, w: torch.Tensor, M: int, N: int, K: int, *, bias=None, out=None, act=0,
+             residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", **kw) -> torch.Tensor:
+        """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld)."""
+        n_out = N // 2 if act == L.ACT_GEGLU else N
+        if out is None:
+            out = self.new(M, n_out, torch.float32 if out_f32 else None)
+        self.prog.add(ops.make_igemm(
+            dtype=self.dtype, a1=a, w=w, out=out, M=M, N=N, C1=K, ld1=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
+            bias_n=bias, act=act, residual=residual, ldr=residual.stride(0) if residual is not None else 0,
+            rowvec=rowvec, rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=rows_per_image,
+            out_f32=out_f32, alpha=alpha, name=name, **kw))
+        return out
+
+    def conv(self, x: Act, prefix: str, *, taps=9, stride=1, pad_tl=1, ups=False, rowvec=None, residual=None,
+             out=None, out_f32=False, alpha=1.0, name=None) -> Act:
+        """3x3 (or 1x1) convolution of an NHWC activation with the packed weight ``prefix``."""
+        w, bias = self.store.conv(prefix, cin_pad=x.C)
+        N = w.shape[0]
+        if taps == 9:
+            LH, LW = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
+            pad_br = 1  # bottom/right halo always exists (zero); only the top/left pad differs (VAE downsample)
+            OH = (LH + pad_tl + pad_br - 3) // stride + 1
+            OW = (LW + pad_tl + pad_br - 3) // stride + 1
+            spatial = (x.H, x.W, OH, OW, stride, pad_tl, pad_tl, int(ups))
+        else:
+            OH, OW, spatial = x.H, x.W, None
+        M = x.B * OH * OW
+        if out is None:
+            out = self.new(M, N, torch.float32 if out_f32 else None)
+        if alpha != 1.0:
+            bias = bias * alpha  # epilogue applies alpha before the bias
+        self.prog.add(ops.make_igemm(
+            dtype=self.dtype, a1=x.t, w=w, out=out, taps=taps, M=M, N=N, C1=x.C, ld1=x.ld, ldw=w.stride(0),
+            ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
+            rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
+            ldr=residual.stride(0) if residual is not None else 0, out_f32=out_f32, alpha=alpha,
+            name=name or ("conv3x3" if taps == 9 else "conv1x1")))
+        return Act(out, x.B, OH, OW, N)
+
+    # -- norms --------------------------------------------------------------------------------
+    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None) -> Act:
+        gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
+        c_real = self.store.params[prefix + "weight"].numel()
+        if c_real != x.C:
+            raise ValueError(f"GroupNorm {prefix}: activation has {x.C} channels, parameter has {c_real}")
+        sums = self.arena.alloc((x.B, 32, 2), torch.float64)
+        y = out if out is not None else self.new(x.rows, x.C)
+        st, ap = ops.make_gn(dtype=self.dtype, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C, sums=sums, gamma=gamma,
+                             beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0))
+        self.prog.add(st)
+        self.prog.add(ap)
+        self.arena.free(sums)
+        return Act(y, x.B, x.H, x.W, x.C)
+
+    def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str) -> torch.Tensor:
+        y = self.new(rows, C)
+        self.prog.add(ops.make_layernorm(dtype=self.dtype, x=x, rows=rows, C=C, ldx=x.stride(0),
+                                         gamma=self.store.vec(prefix + "weight"), beta=self.store.vec(prefix + "bias"),
+                                         eps=1e-5, y=y, ldy=C))
+        return y
+
+    # -- elementwise --------------------------------------------------------------------------
+    def add(self, a: torch.Tensor, b: Optional[torch.Tensor], rows: int, C: int, out=None) -> torch.Tensor:
+        if out is None:
+            out = self.new(rows, C)
+        self.prog.add(ops.make_add(dtype=self.dtype, a=a, lda=a.stride(0), b=b, ldb=b.stride(0) if b is not None else 0,
+                                   out=out, ldo=out.stride(0), rows=rows, C=C))
+        return out
+
+    def to_nhwc(self, src: torch.Tensor, B: int, C: int, HW: int, dst: torch.Tensor, coff=0, pad_to=0, scale=1.0,
+                shift=0.0) -> None:
+        self.prog.add(ops.make_nchw_to_nhwc(dtype=self.dtype, src=src, B=B, C=C, HW=HW, dst=dst, ld=dst.stride(0),
+                                            coff=coff, zero_pad_to=pad_to, scale=scale, shift=shift))
+
+    def to_nchw(self, src: torch.Tensor, B: int, C: int, HW: int, dst: torch.Tensor, scale=1.0) -> None:
+        self.prog.add(ops.make_nhwc_to_nchw(dtype=self.dtype, src=src, src_f32=(src.dtype == torch.float32), B=B, C=C,
+                                            HW=HW, ld=src.stride(0), dst=dst, scale=scale))
+
+    def cast_flat(self, src_f32: torch.Tensor, n: int) -> torch.Tensor:
+        """fp32 -> 16-bit cast of n contiguous elements (inputs such as c_txt)."""
+        dst = self.new(n, 1)
+        self.prog.add(ops.make_nchw_to_nhwc(dtype=self.dtype, src=src_f32, B=1, C=1, HW=n, dst=dst, ld=1, name="cast16"))
+        return dst
+
+    # -- attention ------------------------------------------------------------------------------
+    def flash(self, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B, H, Nq, Nk, k_bs, vt_bs, vt_ld,
+              out=None) -> torch.Tensor:
+        C = H * 64
+        if out is None:
+            out = self.new(B * Nq, C)
+        self.prog.add(ops.make_flash_attn(dtype=self.dtype, q=q, k=k, vt=vt, out=out, B=B, H=H, Nq=Nq, Nk=Nk,
+                                          q_bs=Nq * q.stride(0), q_ld=q.stride(0), k_bs=k_bs, k_ld=k.stride(0),
+                                          vt_bs=vt_bs, vt_ld=vt_ld, o_bs=Nq * out.stride(0), o_ld=out.stride(0),
+                                          scale=1.0 / math.sqrt(64.0)))
+        return out
+
+    def vt_gemm(self, wv: torch.Tensor, x: torch.Tensor, *, B, Ntok, Cin, bias_m=None, name="v_transposed") -> Tuple[torch.Tensor, int]:
+        """V^T[b] = Wv @ x[b]^T  ->  [B, Cout, roundup8(Ntok)] (padding keys exactly zero when bias_m is None)."""
+        Cout = wv.shape[0]
+        ldv = round_up(Ntok, 8)
+        vt = self.arena.alloc((B * Cout, ldv), self.dtype)
+        self.prog.add(ops.make_igemm(dtype=self.dtype, a1=wv, w=x, out=vt, M=Cout, N=ldv, n_valid=Ntok, C1=Cin,
+                                     ld1=wv.stride(0), ldw=x.stride(0), ldc=ldv, Z=B, a_zs=(0, 0),
+                                     w_zs=(Ntok * x.stride(0), 0), o_zs=(Cout * ldv, 0), bias_m=bias_m, name=name))
+        return vt, ldv

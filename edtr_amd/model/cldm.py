@@ -1,0 +1,363 @@
+"""Host-side mirror of the reference's `model.cldm.ControlLDM` (reference model/cldm.py:17-194) and of the
+modules it owns, with the SAME constructor arguments, attribute names, method signatures and state-dict keys —
+but every forward is a pre-built program of libedtr_hip launches (edtr_amd/engine.py, nets.py).
+
+There is no CPU / PyTorch-operator fallback: calling a forward on a CPU-resident module raises.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Set, Tuple
+
+import torch
+from torch import nn
+
+from .. import arch, nets
+from ..engine import Act, Arena, Emitter, Program, WeightStore
+from .params import ParamTree, params_fingerprint
+
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16}
+
+
+def default_compute_dtype() -> torch.dtype:
+    return _DTYPES[os.environ.get("EDTR_AMD_DTYPE", "bf16").lower()]
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{what}: the EDTR MI355X path runs only on a ROCm GPU (tensor is on {t.device}); "
+                           "there is no CPU fallback. Move the module and inputs to 'cuda'.")
+
+
+def disabled_train(self: nn.Module, mode: bool = True) -> nn.Module:
+    return self
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter-holding modules (reference class names; forward() of the parts is not on the hot path)
+# ----------------------------------------------------------------------------------------------
+class ControlledUnetModel(ParamTree):
+    """Parameters of reference model/controlnet.py:18 (ControlledUnetModel = UNetModel, model/unet.py:361)."""
+
+    def __init__(self, **cfg):
+        self.cfg = dict(cfg)
+        self.arch = arch.unet_arch(self.cfg, controlnet=False)
+        super().__init__(arch.unet_param_spec(self.arch), unet_like=True)
+        self.model_channels = self.arch.model_channels
+        self.dtype = torch.float32
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("call ControlLDM.forward: ControlNet + UNet run as one fused kernel program")
+
+
+class ControlNet(ParamTree):
+    """Parameters of reference model/controlnet.py:44 (ControlNet)."""
+
+    def __init__(self, **cfg):
+        self.cfg = dict(cfg)
+        self.arch = arch.unet_arch(self.cfg, controlnet=True)
+        super().__init__(arch.unet_param_spec(self.arch), unet_like=True)
+        self.model_channels = self.arch.model_channels
+        self.dtype = torch.float32
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("call ControlLDM.forward: ControlNet + UNet run as one fused kernel program")
+
+
+class AutoencoderKL(ParamTree):
+    """Parameters of reference model/vae.py:681 (AutoencoderKL: encoder, decoder, quant_conv, post_quant_conv)."""
+
+    def __init__(self, ddconfig, embed_dim, train_encoder=False, train_decoder=False):
+        self.cfg = dict(ddconfig=dict(ddconfig), embed_dim=embed_dim)
+        assert ddconfig["double_z"]
+        super().__init__(arch.vae_param_spec(self.cfg), unet_like=False)
+        self.embed_dim = embed_dim
+        self.train_encoder, self.train_decoder = train_encoder, train_decoder
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("use ControlLDM.vae_encode / vae_decode")
+
+
+class PromptEncoder(nn.Module):
+    """Placeholder for FrozenOpenCLIPEmbedder (reference model/clip.py:12-65), which is OUT of the accelerated
+    path: EDTR always encodes the fixed prompt "" once per run.  Supply that constant with
+    ``set_embedding`` (e.g. computed once by the reference CLIP on the host) and ``encode`` broadcasts it."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.register_buffer("embedding", None, persistent=False)
+
+    def set_embedding(self, emb: torch.Tensor) -> None:
+        self.embedding = emb
+
+    def encode(self, text) -> torch.Tensor:
+        if self.embedding is None:
+            raise RuntimeError("PromptEncoder.encode: no prompt embedding set; the CLIP text tower is outside the "
+                               "accelerated path. Call cldm.clip.set_embedding(c_txt[1,77,ctx_dim]) first.")
+        n = len(text) if isinstance(text, (list, tuple)) else 1
+        return self.embedding.expand(n, -1, -1).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# engines: one pre-built program set per input shape
+# ----------------------------------------------------------------------------------------------
+class CldmEngine:
+    """ControlNet + ControlledUNet for a fixed (B, h, w): static input/output buffers, a context program
+    (cross-attention K / V^T, run only when c_txt changes) and the per-step program."""
+
+    def __init__(self, owner: "ControlLDM", B: int, h: int, w: int, nctx: int):
+        dev = owner._device()
+        dt = owner.compute_dtype
+        self.B, self.h, self.w, self.nctx = B, h, w, nctx
+        self.arena = Arena(dev)
+        store = owner._store()
+        ua, ca = owner.unet.arch, owner.controlnet.arch
+        f32 = torch.float32
+        self.x_in = torch.zeros((B, ua.in_channels, h, w), dtype=f32, device=dev)
+        self.hint_in = torch.zeros((B, ca.hint_channels, h, w), dtype=f32, device=dev)
+        self.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        self.ctx_in = torch.zeros((B, nctx, ua.context_dim), dtype=f32, device=dev)
+        self.eps_out = torch.zeros((B, ua.out_channels, h, w), dtype=f32, device=dev)
+        self.ctx_key = None
+
+        # ---- context program
+        self.ctx_prog = Program("cldm.context")
+        em = Emitter(self.ctx_prog, self.arena, store, dt)
+        ctx16 = em.cast_flat(self.ctx_in, B * nctx * ua.context_dim).view(B * nctx, ua.context_dim)
+        self.kv_c = nets.emit_context_kv(em, "controlnet.", ca, ctx16, B, nctx)
+        self.kv_u = nets.emit_context_kv(em, "unet.", ua, ctx16, B, nctx)
+
+        # ---- step program
+        self.step_prog = Program("cldm.step")
+        em = Emitter(self.step_prog, self.arena, store, dt)
+        hw = h * w
+        cin_c = ca.in_channels + ca.hint_channels
+        x8c = em.new(B * hw, arch_round8(cin_c))
+        em.to_nhwc(self.x_in, B, ca.in_channels, hw, x8c, coff=0)
+        em.to_nhwc(self.hint_in, B, ca.hint_channels, hw, x8c, coff=ca.in_channels,
+                   pad_to=arch_round8(cin_c) - ca.in_channels)
+        x8u = em.new(B * hw, arch_round8(ua.in_channels))
+        em.to_nhwc(self.x_in, B, ua.in_channels, hw, x8u, coff=0, pad_to=arch_round8(ua.in_channels))
+        tab_c, offs_c = nets.emit_time_rows(em, "controlnet.", ca, self.t_in, B)
+        tab_u, offs_u = nets.emit_time_rows(em, "unet.", ua, self.t_in, B)
+        ctrl = nets.emit_controlnet(em, "controlnet.", ca, Act(x8c, B, h, w, x8c.shape[1]), tab_c, offs_c, self.kv_c,
+                                    list(owner.control_scales))
+        eps = nets.emit_unet(em, "unet.", ua, Act(x8u, B, h, w, x8u.shape[1]), tab_u, offs_u, self.kv_u, ctrl)
+        em.to_nchw(eps, B, ua.out_channels, hw, self.eps_out)
+
+    def set_context(self, c_txt: torch.Tensor) -> None:
+        key = (c_txt.data_ptr(), c_txt._version, tuple(c_txt.shape))
+        if key == self.ctx_key:
+            return
+        if c_txt.shape[0] == 1 and self.B > 1:
+            c_txt = c_txt.expand(self.B, -1, -1)
+        self.ctx_in.copy_(c_txt)
+        self.ctx_prog.run()
+        self.ctx_key = key
+
+    def step(self, x: torch.Tensor, t: torch.Tensor, c_txt: torch.Tensor, c_img: torch.Tensor) -> torch.Tensor:
+        self.set_context(c_txt)
+        self.x_in.copy_(x)
+        self.hint_in.copy_(c_img)
+        self.t_in.copy_(t)
+        self.step_prog.run()
+        return self.eps_out
+
+
+def arch_round8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+class VaeEngine:
+    """Encoder (+quant_conv, mode, scale) or decoder (scale^-1, post_quant_conv, decoder) for a fixed shape."""
+
+    def __init__(self, owner: "ControlLDM", kind: str, B: int, H: int, W: int):
+        dev = owner._device()
+        dt = owner.compute_dtype
+        self.arena = Arena(dev)
+        store = owner._store()
+        dd = owner.vae.cfg["ddconfig"]
+        f32 = torch.float32
+        self.prog = Program(f"vae.{kind}")
+        em = Emitter(self.prog, self.arena, store, dt)
+        sf = owner.scale_factor
+        nlev = len(dd["ch_mult"])
+        if kind == "encode":
+            self.inp = torch.zeros((B, dd["in_channels"], H, W), dtype=f32, device=dev)
+            h, w = H >> (nlev - 1), W >> (nlev - 1)
+            self.out = torch.zeros((B, owner.vae.embed_dim, h, w), dtype=f32, device=dev)
+            cp = arch_round8(dd["in_channels"])
+            x = em.new(B * H * W, cp)
+            em.to_nhwc(self.inp, B, dd["in_channels"], H * W, x, pad_to=cp)
+            y = nets.emit_vae_net(em, "vae.encoder.", arch.vae_encoder_arch(dd), Act(x, B, H, W, cp), final_f32=False)
+            # quant_conv 1x1 (model/vae.py:727) then DiagonalGaussianDistribution.mode() = first half (distributions.py:30,64)
+            m = em.conv(y, "vae.quant_conv.", taps=1, out_f32=True, name="vae.quant_conv")
+            em.free(y)
+            em.to_nchw(m.t, B, owner.vae.embed_dim, h * w, self.out, scale=sf)
+        else:
+            zc = dd["z_channels"]
+            self.inp = torch.zeros((B, zc, H, W), dtype=f32, device=dev)
+            up = 1 << (nlev - 1)
+            self.out = torch.zeros((B, dd["out_ch"], H * up, W * up), dtype=f32, device=dev)
+            cp = arch_round8(zc)
+            z = em.new(B * H * W, cp)
+            em.to_nhwc(self.inp, B, zc, H * W, z, pad_to=cp, scale=1.0 / sf)           # z / scale_factor (cldm.py:156)
+            z2 = em.conv(Act(z, B, H, W, cp), "vae.post_quant_conv.", taps=1, name="vae.post_quant_conv")
+            y = nets.emit_vae_net(em, "vae.decoder.", arch.vae_decoder_arch(dd), z2, final_f32=True)
+            em.to_nchw(y.t, B, dd["out_ch"], y.H * y.W, self.out)
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        self.inp.copy_(x)
+        self.prog.run()
+        return self.out
+
+
+# ----------------------------------------------------------------------------------------------
+# ControlLDM
+# ----------------------------------------------------------------------------------------------
+class ControlLDM(nn.Module):
+    """Drop-in for reference model/cldm.py:17 — same constructor, attributes and methods."""
+
+    def __init__(self, unet_cfg, vae_cfg, clip_cfg, controlnet_cfg, latent_scale_factor, tail_block=False):
+        super().__init__()
+        if tail_block:
+            raise NotImplementedError("tail_block / woSD is dead code in the reference (no caller) and is not built")
+        self.unet = ControlledUnetModel(**unet_cfg)
+        self.vae = AutoencoderKL(**vae_cfg)
+        self.clip = PromptEncoder(**clip_cfg)
+        self.controlnet = ControlNet(**controlnet_cfg)
+        self.scale_factor = latent_scale_factor
+        self.control_scales = [1.0] * 13
+        self.compute_dtype = default_compute_dtype()
+        self._weights = None
+        self._fingerprint = None
+        self._cldm_engines: Dict[tuple, CldmEngine] = {}
+        self._vae_engines: Dict[tuple, VaeEngine] = {}
+
+    # -- engine plumbing ---------------------------------------------------------------------
+    def _device(self) -> torch.device:
+        return next(self.unet.parameters()).device
+
+    def _check_fresh(self) -> None:
+        fp = (params_fingerprint(self.unet), params_fingerprint(self.controlnet), params_fingerprint(self.vae),
+              self.compute_dtype, tuple(self.control_scales))
+        if fp != self._fingerprint:
+            self.release_engines()
+            self._fingerprint = fp
+
+    def release_engines(self) -> None:
+        for e in list(self._cldm_engines.values()):
+            e.step_prog.release_graph()
+            e.ctx_prog.release_graph()
+        for e in list(self._vae_engines.values()):
+            e.prog.release_graph()
+        self._cldm_engines.clear()
+        self._vae_engines.clear()
+        self._weights = None
+
+    def _store(self) -> WeightStore:
+        if self._weights is None:
+            params: Dict[str, torch.Tensor] = {}
+            params.update(self.unet.flat_params("unet."))
+            params.update(self.controlnet.flat_params("controlnet."))
+            params.update(self.vae.flat_params("vae."))
+            self._weights = WeightStore(params, self.compute_dtype, self._device())
+        return self._weights
+
+    def cldm_engine(self, B: int, h: int, w: int, nctx: int = 77) -> CldmEngine:
+        self._check_fresh()
+        key = (B, h, w, nctx)
+        if key not in self._cldm_engines:
+            self._cldm_engines[key] = CldmEngine(self, B, h, w, nctx)
+        return self._cldm_engines[key]
+
+    def vae_engine(self, kind: str, B: int, H: int, W: int) -> VaeEngine:
+        self._check_fresh()
+        key = (kind, B, H, W)
+        if key not in self._vae_engines:
+            self._vae_engines[key] = VaeEngine(self, kind, B, H, W)
+        return self._vae_engines[key]
+
+    # -- checkpoint ingestion (reference model/cldm.py:46-105) -----------------------------------
+    @torch.no_grad()
+    def load_pretrained_sd(self, sd: Dict[str, torch.Tensor], is_turbo: bool = False) -> Set[str]:
+        """Strict key-for-key copy of the SD checkpoint's `model.diffusion_model.*` / `first_stage_model.*` entries.
+        The CLIP text tower (`cond_stage_model.*`) is outside the accelerated path and is left in `unused`."""
+        module_map = {"unet": "model.diffusion_model", "vae": "first_stage_model"}
+        used: Set[str] = set()
+        for name, module in (("unet", self.unet), ("vae", self.vae)):
+            init_sd = {}
+            for key in module.state_dict():
+                target = f"{module_map[name]}.{key}"
+                init_sd[key] = sd[target].clone()
+                used.add(target)
+            module.load_state_dict(init_sd, strict=True)
+        for module in (self.unet,):
+            module.eval()
+            module.train = disabled_train.__get__(module)
+            for p in module.parameters():
+                p.requires_grad = False
+        return set(sd.keys()) - used
+
+    @torch.no_grad()
+    def load_controlnet_from_ckpt(self, sd: Dict[str, torch.Tensor]) -> None:
+        self.controlnet.load_state_dict(sd, strict=True)
+
+    @torch.no_grad()
+    def load_controlnet_from_unet(self) -> Tuple[Set[str], Set[str]]:
+        unet_sd = self.unet.state_dict()
+        scratch = self.controlnet.state_dict()
+        init_sd, with_zero, with_scratch = {}, set(), set()
+        for key, this in scratch.items():
+            if key in unet_sd:
+                target = unet_sd[key]
+                if this.size() == target.size():
+                    init_sd[key] = target.clone()
+                else:   # the 8-channel input conv: UNet weights for the latent half, zeros for the hint half
+                    extra = this.size(1) - target.size(1)
+                    oc, _, kh, kw = this.size()
+                    init_sd[key] = torch.cat((target, torch.zeros((oc, extra, kh, kw), dtype=target.dtype,
+                                                                  device=target.device)), dim=1)
+                    with_zero.add(key)
+            else:
+                init_sd[key] = this.clone()
+                with_scratch.add(key)
+        self.controlnet.load_state_dict(init_sd, strict=True)
+        return with_zero, with_scratch
+
+    # -- VAE (reference model/cldm.py:107-156) ------------------------------------------------------
+    @torch.no_grad()
+    def vae_encode(self, image: torch.Tensor, sample: bool = True, tiled: bool = False, tile_size: int = -1) -> torch.Tensor:
+        _require_gpu(image, "vae_encode")
+        if tiled:
+            raise NotImplementedError("tiled VAE encode (utils/tilevae) is not built yet; see DESIGN.md scope table")
+        if sample:
+            raise NotImplementedError("vae_encode(sample=True) is a training-time path; the restoration path uses "
+                                      "sample=False (posterior mode)")
+        B, _, H, W = image.shape
+        return self.vae_engine("encode", B, H, W).run(image).clone()
+
+    @torch.no_grad()
+    def vae_decode(self, z: torch.Tensor, tiled: bool = False, tile_size: int = -1) -> torch.Tensor:
+        _require_gpu(z, "vae_decode")
+        if tiled:
+            raise NotImplementedError("tiled VAE decode (utils/tilevae) is not built yet; see DESIGN.md scope table")
+        B, _, h, w = z.shape
+        return self.vae_engine("decode", B, h, w).run(z).clone()
+
+    def prepare_condition(self, clean: torch.Tensor, prompt: List[str]) -> Dict[str, torch.Tensor]:
+        if prompt is None:
+            prompt = [""] * clean.size(0)
+        return dict(c_txt=self.clip.encode(prompt), c_img=self.vae_encode(clean * 2 - 1, sample=False))
+
+    # -- the denoiser (reference model/cldm.py:166-194) -------------------------------------------
+    @torch.no_grad()
+    def forward(self, x_noisy: torch.Tensor, t: torch.Tensor, cond: Dict[str, torch.Tensor], woSD: bool = False) -> torch.Tensor:
+        if woSD:
+            raise NotImplementedError("woSD/tail_block is dead code in the reference and is not built")
+        _require_gpu(x_noisy, "ControlLDM.forward")
+        c_txt, c_img = cond["c_txt"], cond["c_img"]
+        B, _, h, w = x_noisy.shape
+        eng = self.cldm_engine(B, h, w, c_txt.shape[1])
+        return eng.step(x_noisy, t, c_txt, c_img).clone()

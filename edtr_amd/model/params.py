@@ -1,0 +1,61 @@
+"""Parameter trees with the reference's exact state-dict key names / shapes / order, built from the flat specs
+of edtr_amd/arch.py (so `load_state_dict(strict=True)` of SD-2.1 / EDTR checkpoints works)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, Tuple
+
+import torch
+from torch import nn
+
+# parameters the reference zero-initialises (zero_module: model/unet.py:177,678; model/controlnet.py:261;
+# model/attention.py:280)
+_ZERO_INIT_SUFFIXES = ("out_layers.3.weight", "out_layers.3.bias", "proj_out.weight", "proj_out.bias")
+_ZERO_INIT_PREFIXES = ("zero_convs.", "middle_block_out.", "out.2.")
+
+
+class _Node(nn.Module):
+    pass
+
+
+def _is_zero_init(key: str, is_unet_like: bool) -> bool:
+    if not is_unet_like:
+        return False
+    return key.endswith(_ZERO_INIT_SUFFIXES) or key.startswith(_ZERO_INIT_PREFIXES)
+
+
+class ParamTree(nn.Module):
+    def __init__(self, spec: Iterable[Tuple[str, Tuple[int, ...]]], unet_like: bool = False):
+        super().__init__()
+        gen = torch.Generator().manual_seed(0)
+        for key, shape in spec:
+            parts = key.split(".")
+            node: nn.Module = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            if _is_zero_init(key, unet_like):
+                val = torch.zeros(shape)
+            elif len(shape) >= 2:
+                fan_in = int(math.prod(shape[1:]))
+                bound = 1.0 / math.sqrt(fan_in)
+                val = (torch.rand(shape, generator=gen) * 2 - 1) * bound
+            elif parts[-1] == "weight":
+                val = torch.ones(shape)
+            else:
+                val = torch.zeros(shape)
+            node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
+
+    def flat_params(self, prefix: str = "") -> Dict[str, torch.Tensor]:
+        return {prefix + k: v for k, v in self.named_parameters()}
+
+
+def params_fingerprint(module: nn.Module) -> Tuple:
+    """Changes whenever any parameter is rewritten in place (load_state_dict copy_) or moved."""
+    ver = 0
+    dev = None
+    for p in module.parameters():
+        ver += p._version
+        dev = p.device
+    return (str(dev), ver)

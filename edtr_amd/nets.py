@@ -1,0 +1,331 @@
+"""Kernel-program emitters for the networks on the hot path.  Each function appends libedtr_hip launches to
+the emitter's Program; no arithmetic happens here.  Structure follows edtr_amd/arch.py (derived from the
+reference constructors); per-function citations give the reference forward being restated.
+
+Fusions relative to the reference's op-by-op execution:
+  * NHWC 16-bit activations end to end: no `b c h w <-> b (h w) c` rearranges (model/attention.py:292,299)
+  * bias, time-embedding add, residual add, GEGLU gate, SiLU are GEMM/conv epilogues
+  * nearest-2x upsample, the VAE's asymmetric pad and stride-2 are folded into the conv's gather
+  * torch.cat([h, skip + control]) is never materialised: producers write column slices of one buffer
+  * all ResBlock emb_layers of a net are ONE GEMM; all cross-attention K / V^T projections of a net are
+    two GEMMs, computed once per prompt instead of once per denoise step
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+from .arch import Layer, UNetArch, VaeLayer
+from .engine import Act, Emitter
+from .ops import round_up
+
+
+# ----------------------------------------------------------------------------------------------
+# conditioning that does not depend on the latent: time embedding rows, cross-attention K / V^T
+# ----------------------------------------------------------------------------------------------
+def emit_time_rows(em: Emitter, P: str, a: UNetArch, t_dev: torch.Tensor, B: int) -> Tuple[torch.Tensor, Dict[str, int]]:
+    """timestep_embedding -> time_embed MLP -> SiLU -> every ResBlock's emb_layers Linear, as 4 launches.
+    Returns the fp32 [B, sum(Cout)] table and the column offset of each ResBlock prefix.
+    Reference: model/util.py:98-118, model/unet.py:475-480 / model/controlnet.py:128-133, model/unet.py:212."""
+    mc, ted = a.model_channels, a.model_channels * 4
+    temb = em.new(B, mc)
+    em.prog.add(ops.make_timestep_embedding(dtype=em.dtype, t=t_dev, B=B, dim=mc, out=temb, ld=mc))
+    w0, b0 = em.store.linear([P + "time_embed.0.weight"], [P + "time_embed.0.bias"])
+    h = em.gemm(temb, w0, B, ted, mc, bias=b0, act=L.ACT_SILU, name="time_embed.0")
+    w2, b2 = em.store.linear([P + "time_embed.2.weight"], [P + "time_embed.2.bias"])
+    semb = em.gemm(h, w2, B, ted, ted, bias=b2, act=L.ACT_SILU, name="time_embed.2")   # SiLU(emb): all consumers want it
+    res = a.res_layers()
+    wall, ball = em.store.linear([P + l.prefix + "emb_layers.1.weight" for l in res],
+                                 [P + l.prefix + "emb_layers.1.bias" for l in res])
+    total = wall.shape[0]
+    table = em.gemm(semb, wall, B, total, ted, bias=ball, out_f32=True, name="emb_layers(all)")
+    em.free(temb, h, semb)
+    offs, o = {}, 0
+    for l in res:
+        offs[l.prefix] = o
+        o += l.cout
+    return table, offs
+
+
+class ContextKV:
+    """Per-net cross-attention keys / transposed values for every transformer layer, from c_txt."""
+
+    def __init__(self):
+        self.k_all = None      # [B*Nctx, sumC]
+        self.vt_all = None     # [B*sumC, ldv]
+        self.sumC = 0
+        self.ldv = 0
+        self.Nctx = 0
+        self.offs: Dict[str, int] = {}
+
+
+def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: int, Nctx: int) -> ContextKV:
+    """k = to_k(context), v = to_v(context) of every attn2 (model/attention.py:171-174), batched over layers."""
+    layers = a.attn_layers()
+    kv = ContextKV()
+    t = "transformer_blocks.0.attn2."
+    wk, _ = em.store.linear([P + l.prefix + t + "to_k.weight" for l in layers])
+    wv, _ = em.store.linear([P + l.prefix + t + "to_v.weight" for l in layers])
+    kv.sumC, kv.Nctx = wk.shape[0], Nctx
+    kv.k_all = em.gemm(ctx16, wk, B * Nctx, kv.sumC, a.context_dim, name="ctx_k(all)")
+    kv.vt_all, kv.ldv = em.vt_gemm(wv, ctx16, B=B, Ntok=Nctx, Cin=a.context_dim, name="ctx_vT(all)")
+    o = 0
+    for l in layers:
+        kv.offs[l.prefix] = o
+        o += l.cout
+    return kv
+
+
+# ----------------------------------------------------------------------------------------------
+# UNet / ControlNet blocks
+# ----------------------------------------------------------------------------------------------
+def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, offs: Dict[str, int], out=None) -> Act:
+    """model/unet.py:203-223: GN-SiLU-conv (+bias +emb row) ; GN-SiLU-conv (+bias) + skip(x)."""
+    p = P + l.prefix
+    n1 = em.group_norm(x, p + "in_layers.0.", 1e-5, True)
+    h = em.conv(n1, p + "in_layers.2.", rowvec=table[:, offs[l.prefix]:], name="res.conv1")
+    em.free(n1)
+    n2 = em.group_norm(h, p + "out_layers.0.", 1e-5, True)
+    em.free(h)
+    if l.cin != l.cout:
+        skip = em.conv(x, p + "skip_connection.", taps=1, name="res.skip1x1").t
+    else:
+        skip = x.t
+    y = em.conv(n2, p + "out_layers.3.", residual=skip, out=out, name="res.conv2")
+    em.free(n2)
+    if l.cin != l.cout:
+        em.free(skip)
+    return y
+
+
+def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C: int, heads: int,
+                        ctx: Optional[Tuple[torch.Tensor, torch.Tensor, int, int, int, int]], residual: torch.Tensor) -> torch.Tensor:
+    """One attention layer on tokens x [B*N, C] (already layer-normed): projections, fused attention, output
+    projection with bias and residual.  model/attention.py:176-203."""
+    if ctx is None:   # self attention: fused [Wq;Wk] projection, V^T via the operand-swapped GEMM
+        wqk, _ = em.store.linear([p + "to_q.weight", p + "to_k.weight"])
+        qk = em.gemm(x, wqk, B * N, 2 * C, C, name="attn1.qk")
+        wv, _ = em.store.linear([p + "to_v.weight"])
+        vt, ldv = em.vt_gemm(wv, x, B=B, Ntok=N, Cin=C, name="attn1.vT")
+        o = em.flash(qk[:, :C], qk[:, C:], vt, B=B, H=heads, Nq=N, Nk=N, k_bs=N * qk.stride(0), vt_bs=C * ldv, vt_ld=ldv)
+        em.free(qk, vt)
+    else:
+        k, vt, k_bs, vt_bs, ldv, nctx = ctx
+        wq, _ = em.store.linear([p + "to_q.weight"])
+        q = em.gemm(x, wq, B * N, C, C, name="attn2.q")
+        o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv)
+        em.free(q)
+    wo, bo = em.store.linear([p + "to_out.0.weight"], [p + "to_out.0.bias"])
+    y = em.gemm(o, wo, B * N, C, C, bias=bo, residual=residual, name="attn.out")
+    em.free(o)
+    return y
+
+
+def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextKV, out=None) -> Act:
+    """model/attention.py:283-302 + :230-234 + :20-47 (use_linear, depth 1, gated FF)."""
+    p = P + l.prefix
+    B, N, C = x.B, x.H * x.W, x.C
+    rows = B * N
+    n = em.group_norm(x, p + "norm.", 1e-6, False)
+    wi, bi = em.store.linear([p + "proj_in.weight"], [p + "proj_in.bias"])
+    t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in")
+    em.free(n)
+    tb = p + "transformer_blocks.0."
+    l1 = em.layer_norm(t, rows, C, tb + "norm1.")
+    t1 = emit_attention_core(em, tb + "attn1.", l1, B, N, C, l.heads, None, t)
+    em.free(l1, t)
+    l2 = em.layer_norm(t1, rows, C, tb + "norm2.")
+    off = kv.offs[l.prefix]
+    k_view = kv.k_all[:, off:off + C]
+    vt_view = kv.vt_all.view(B, kv.sumC, kv.ldv)[:, off:off + C, :]
+    ctx = (k_view, vt_view, kv.Nctx * kv.sumC, kv.sumC * kv.ldv, kv.ldv, kv.Nctx)
+    t2 = emit_attention_core(em, tb + "attn2.", l2, B, N, C, l.heads, ctx, t1)
+    em.free(l2, t1)
+    l3 = em.layer_norm(t2, rows, C, tb + "norm3.")
+    wg, bg = em.store.geglu(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias")
+    g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu")
+    em.free(l3)
+    wf, bf = em.store.linear([tb + "ff.net.2.weight"], [tb + "ff.net.2.bias"])
+    t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out")
+    em.free(g, t2)
+    wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
+    y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out")
+    em.free(t3)
+    return Act(y, x.B, x.H, x.W, C)
+
+
+def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv, out=None, keep_input=True) -> Act:
+    """TimestepEmbedSequential dispatch (model/unet.py:40-48).  ``out`` (a 2-D view) receives the LAST layer's
+    result; the block input is freed unless ``keep_input``."""
+    h = x
+    for i, l in enumerate(layers):
+        tgt = out if i == len(layers) - 1 else None
+        if l.kind == "conv":
+            y = em.conv(h, P + l.prefix, out=tgt, name="conv_in")
+        elif l.kind == "res":
+            y = emit_resblock(em, P, l, h, table, offs, out=tgt)
+        elif l.kind == "attn":
+            y = emit_spatial_transformer(em, P, l, h, kv, out=tgt)
+        elif l.kind == "down":
+            y = em.conv(h, P + l.prefix + "op.", stride=2, out=tgt, name="downsample")      # model/unet.py:99-108
+        elif l.kind == "up":
+            y = em.conv(h, P + l.prefix + "conv.", ups=True, out=tgt, name="upsample.conv")  # model/unet.py:70-79
+        else:
+            raise ValueError(l.kind)
+        if h is not x or not keep_input:
+            em.free(h)
+        h = y
+    return h
+
+
+def emit_controlnet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, scales: List[float]) -> List[Act]:
+    """model/controlnet.py:263-277: 12 encoder blocks + middle block, each tapped by a 1x1 conv.  ``x8`` is
+    cat(x, hint) already in NHWC.  The control scale (model/cldm.py:189) is the tap's alpha."""
+    outs: List[Act] = []
+    h = x8
+    for i, layers in enumerate(a.input_blocks):
+        y = emit_block(em, P, layers, h, table, offs, kv, keep_input=(i == 0))
+        outs.append(em.conv(y, P + a.zero_convs[i][0], taps=1, alpha=scales[i], name="zero_conv"))
+        h = y
+    y = emit_block(em, P, a.middle, h, table, offs, kv, keep_input=False)
+    outs.append(em.conv(y, P + a.zero_convs[-1][0], taps=1, alpha=scales[12], name="zero_conv"))
+    em.free(y)
+    return outs
+
+
+def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, control: Optional[List[Act]]) -> torch.Tensor:
+    """model/controlnet.py:20-41 (ControlledUnetModel.forward) + output head model/unet.py:675-679.
+    Returns the fp32 NHWC eps [B*h*w, 8] (first out_channels columns valid)."""
+    control = list(control) if control is not None else None
+    hs: List[Act] = []
+    h = x8
+    for i, layers in enumerate(a.input_blocks):
+        h = emit_block(em, P, layers, h, table, offs, kv, keep_input=True)
+        hs.append(h)
+    mid = emit_block(em, P, a.middle, h, table, offs, kv, keep_input=True)
+
+    # first decoder input: cat([mid + control_mid, hs[-1] + control[-2]])
+    skip = hs.pop()
+    cat = em.new(skip.rows, mid.C + skip.C)
+    if control is not None:
+        c = control.pop()
+        em.add(mid.t, c.t, mid.rows, mid.C, out=cat[:, :mid.C])
+        em.free(c)
+    else:
+        em.add(mid.t, None, mid.rows, mid.C, out=cat[:, :mid.C])
+    em.free(mid)
+    cur_C = mid.C
+    B, H, W = skip.B, skip.H, skip.W
+    nblk = len(a.output_blocks)
+    for j, layers in enumerate(a.output_blocks):
+        # right half of the concat: skip (+ control)
+        if control is not None:
+            c = control.pop()
+            em.add(skip.t, c.t, skip.rows, skip.C, out=cat[:, cur_C:])
+            em.free(c)
+        else:
+            em.add(skip.t, None, skip.rows, skip.C, out=cat[:, cur_C:])
+        em.free(skip)
+        xin = Act(cat, B, H, W, cur_C + skip.C)
+        if j + 1 < nblk:
+            nskip = hs.pop()
+            out_C = layers[-1].cout
+            ncat = em.new(nskip.rows, out_C + nskip.C)
+            y = emit_block(em, P, layers, xin, table, offs, kv, out=ncat[:, :out_C], keep_input=True)
+            em.free(cat)
+            cat, skip, cur_C = ncat, nskip, out_C
+            B, H, W = nskip.B, nskip.H, nskip.W
+        else:
+            y = emit_block(em, P, layers, xin, table, offs, kv, keep_input=True)
+            em.free(cat)
+    n = em.group_norm(y, P + "out.0.", 1e-5, True)
+    em.free(y)
+    eps = em.conv(n, P + "out.2.", out_f32=True, name="unet.out_conv")
+    em.free(n)
+    return eps.t
+
+
+# ----------------------------------------------------------------------------------------------
+# VAE
+# ----------------------------------------------------------------------------------------------
+def emit_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act) -> Act:
+    """model/vae.py:103-124."""
+    n1 = em.group_norm(x, p + "norm1.", 1e-6, True)
+    h = em.conv(n1, p + "conv1.", name="vae.conv1")
+    em.free(n1)
+    n2 = em.group_norm(h, p + "norm2.", 1e-6, True)
+    em.free(h)
+    if l.cin != l.cout:
+        skip = em.conv(x, p + "nin_shortcut.", taps=1, name="vae.nin_shortcut").t
+    else:
+        skip = x.t
+    y = em.conv(n2, p + "conv2.", residual=skip, name="vae.conv2")
+    em.free(n2)
+    if l.cin != l.cout:
+        em.free(skip)
+    return y
+
+
+def emit_vae_attn(em: Emitter, p: str, x: Act) -> Act:
+    """model/vae.py:279-308: single-head attention with d = C (512): too wide for the fused kernel's register
+    budget, and only 2 calls per image, so it runs as QK^T GEMM (fp32 scores) -> row softmax -> PV GEMM."""
+    B, N, C = x.B, x.H * x.W, x.C
+    rows = B * N
+    if N % 8:
+        raise ValueError("VAE attention needs h*w to be a multiple of 8")
+    n = em.group_norm(x, p + "norm.", 1e-6, False)
+    wqk, bqk = em.store.linear([p + "q.weight", p + "k.weight"], [p + "q.bias", p + "k.bias"])
+    qk = em.gemm(n.t, wqk, rows, 2 * C, C, bias=bqk, name="vae.attn.qk")
+    wv, _ = em.store.linear([p + "v.weight"])
+    vt, ldv = em.vt_gemm(wv, n.t, B=B, Ntok=N, Cin=C, bias_m=em.store.vec(p + "v.bias"), name="vae.attn.vT")
+    em.free(n)
+    lds = round_up(N, 8)
+    s = em.new(rows, lds, torch.float32)
+    em.prog.add(ops.make_igemm(dtype=em.dtype, a1=qk[:, :C], w=qk[:, C:], out=s, M=N, N=lds, n_valid=N, C1=C,
+                               ld1=qk.stride(0), ldw=qk.stride(0), ldc=lds, Z=B, a_zs=(N * qk.stride(0), 0),
+                               w_zs=(N * qk.stride(0), 0), o_zs=(N * lds, 0), alpha=1.0 / math.sqrt(C), out_f32=True,
+                               name="vae.attn.scores"))
+    em.free(qk)
+    pr = em.new(rows, lds)
+    em.prog.add(ops.make_softmax_rows(dtype=em.dtype, s=s, rows=rows, cols=N, ld_s=lds, p=pr, ld_p=lds))
+    em.free(s)
+    o = em.new(rows, C)
+    em.prog.add(ops.make_igemm(dtype=em.dtype, a1=pr, w=vt, out=o, M=N, N=C, C1=N, ld1=lds, ldw=ldv, ldc=C, Z=B,
+                               a_zs=(N * lds, 0), w_zs=(C * ldv, 0), o_zs=(N * C, 0), name="vae.attn.pv"))
+    em.free(pr, vt)
+    wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
+    y = em.gemm(o, wo, rows, C, C, bias=bo, residual=x.t, name="vae.attn.proj_out")
+    em.free(o)
+    return Act(y, x.B, x.H, x.W, C)
+
+
+def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool) -> Act:
+    """Encoder.forward (model/vae.py:421-446) / Decoder.forward (:527-560) over the flat layer list."""
+    h = x
+    first = True
+    for l in layers:
+        p = P + l.prefix
+        last = l is layers[-1]
+        if l.kind == "conv":
+            y = em.conv(h, p, out_f32=(final_f32 and last), name="vae.conv_in" if first else "vae.conv_out")
+        elif l.kind == "res":
+            y = emit_vae_resblock(em, p, l, h)
+        elif l.kind == "attn":
+            y = emit_vae_attn(em, p, h)
+        elif l.kind == "down":
+            y = em.conv(h, p, stride=2, pad_tl=0, name="vae.downsample")     # pad (0,1,0,1) + stride 2: vae.py:54-61
+        elif l.kind == "up":
+            y = em.conv(h, p, ups=True, name="vae.upsample.conv")           # nearest x2 + conv: vae.py:35-39
+        elif l.kind == "norm_out":
+            y = em.group_norm(h, p, 1e-6, True)
+        else:
+            raise ValueError(l.kind)
+        if not first:
+            em.free(h)
+        first = False
+        h = y
+    return h
