@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): restored 512x512 images/s at 4 denoise steps.
+
+One "step" = one pass of the whole hot path over one batch of synthetic degraded images that are already resident
+in HBM:  vae_encode -> q_sample(t=200) -> 4 x (ControlNet + ControlledUNet + sampler update) -> vae_decode,
+through the reference-shaped API (ControlLDM / Diffusion / SpacedSampler of edtr_amd) on hand-written HIP kernels.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          # one rank per GPU; batch axis sharded, no collective in the loop
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel = the MFMA implicit-GEMM, timed per launch
+with HIP events on the launch stream) and, at N=1, "cpu_baseline" (the CPU oracle timed on the host cores on a
+bounded sample of the same workload) plus "parity" (GPU vs oracle on that sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+USED_TIMESTEPS = [50, 100, 150, 200]
+PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md chip table
+FLOP_PER_IMAGE = 7.925e12  # VAE-enc 1.1167 + 4 x 1.0734 + VAE-dec 2.5145 TFLOP per 512x512 image
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE config 2: 8)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
+    ap.add_argument("--no-graph", action="store_true", help="replay launch lists eagerly instead of hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-name time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the EDTR MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    cpu_handle = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_handle = start_cpu_baseline(args.config, args.size)
+
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.model import ControlLDM
+    from edtr_amd.model.params import skip_init
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import flat_oracle_sd, injected_noise, rel_err, synthetic_state_dicts
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    cfg = synth.CONFIGS[args.config]()
+    B, S = args.batch, args.size
+    h = S // 8
+    ctx_dim = cfg["unet_cfg"]["context_dim"]
+
+    # ---- model: rank 0 materialises the synthetic checkpoint, the other ranks receive it by ONE bucketed RCCL
+    #      broadcast over xGMI (start-up only; the denoise loop has no collective)
+    t0 = time.time()
+    with skip_init():
+        cldm = ControlLDM(**cfg)
+    cldm.compute_dtype = dtype
+    sds = None
+    if rank == 0:
+        sds = synthetic_state_dicts(cfg)
+        cldm.unet.load_state_dict(sds["unet"], strict=True)
+        cldm.load_controlnet_from_ckpt(sds["controlnet"])
+        cldm.vae.load_state_dict(sds["vae"], strict=True)
+    cldm = cldm.eval().to(dev)
+    if world > 1:
+        params = [p for p in cldm.parameters()]
+        bucket, size = [], 0
+        def flush():
+            if not bucket:
+                return
+            flat = torch.cat([p.data.reshape(-1) for p in bucket])
+            dist.broadcast(flat, src=0)
+            o = 0
+            for p in bucket:
+                n = p.numel()
+                p.data.copy_(flat[o:o + n].view_as(p.data))
+                o += n
+        for p in params:
+            bucket.append(p)
+            size += p.numel() * 4
+            if size >= (1 << 29):   # 512 MiB buckets: few, large messages (ring broadcast is per-link bound)
+                flush()
+                bucket, size = [], 0
+        flush()
+    log(f"[rank {rank}] model ready in {time.time() - t0:.1f}s")
+
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
+    sampler = SpacedSampler(diffusion.betas)
+
+    # ---- synthetic inputs for the GLOBAL batch, sliced per rank (results independent of the GPU count)
+    GB = B * world
+    sl = slice(rank * B, (rank + 1) * B)
+    pre_res_g = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)
+    c_txt1 = synth.synth_normal("bench:c_txt", (1, 77, ctx_dim))
+    noises_g = [synth.synth_normal(f"bench:noise{i}", (GB, 4, h, h)) for i in range(5)]
+    pre_res = pre_res_g[sl].to(dev)
+    c_txt = c_txt1.expand(B, -1, -1).contiguous().to(dev)
+    noises = [n[sl].to(dev) for n in noises_g]
+    t200 = torch.full((B,), 200, dtype=torch.int64, device=dev)
+
+    def one_pass():
+        z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
+        x_T = diffusion.q_sample(z_pre, t200, noises[0])
+        with injected_noise(noises[1:]):
+            z = sampler.manual_sample_with_timesteps(
+                model=cldm, device=dev, x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=B,
+                cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+        return cldm.vae_decode(z), z
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (builds the kernel programs on the first pass), optional hipGraph capture
+    t0 = time.time()
+    img, z = one_pass()
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] first pass (program build + weight packing) {time.time() - t0:.1f}s")
+    if not args.no_graph:
+        for e in cldm._cldm_engines.values():
+            e.step_prog.capture()
+        for e in cldm._vae_engines.values():
+            e.prog.capture()
+    for _ in range(max(0, args.warmup - 1) + (0 if args.no_graph else 1)):
+        img, z = one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img, z = one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = GB * args.steps / elapsed
+
+    result = {
+        "metric": "restored 512x512 images/sec @ 4 denoise steps",
+        "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"EDTR-det s4 ({args.config}): vae_encode + q_sample(t=200) + 4 x (ControlNet+UNet) + "
+                               f"vae_decode, batch {B}/GPU of {S}x{S}", "global_batch": GB, "image_size": S,
+                   "denoise_steps": 4, "parallelism": f"batch-sharded x{world}", "graphs": not args.no_graph},
+        "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE / (world * PEAK_TFLOPS * 1e12), 4) if S == 512 and args.config == "sd21" else None,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        result.update(roofline_pass(cldm, args))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result.update(finish_cpu_baseline(cpu_handle, pre_res_g, c_txt1, noises_g, img.cpu(), z.cpu(), S, rel_err))
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_pass(cldm, args) -> dict:
+    """Per-launch HIP-event timing of every program once (eager replay on the launch stream), aggregated by kernel."""
+    agg = {}
+    progs = []
+    for e in cldm._cldm_engines.values():
+        progs.append((e.step_prog, 4))
+    for e in cldm._vae_engines.values():
+        progs.append((e.prog, 1))
+    for prog, mult in progs:
+        g, prog.graph = prog.graph, None
+        prog.run_timed()                      # warm
+        rows = prog.run_timed()
+        prog.graph = g
+        for name, ms, flops, nbytes in rows:
+            kind = kernel_of(name)
+            a = agg.setdefault(kind, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "by_name": {}})
+            a["ms"] += ms * mult
+            a["flops"] += flops * mult
+            a["bytes"] += nbytes * mult
+            a["n"] += mult
+            bn = a["by_name"].setdefault(name, [0.0, 0.0, 0])
+            bn[0] += ms * mult
+            bn[1] += flops * mult
+            bn[2] += mult
+    total_ms = sum(a["ms"] for a in agg.values())
+    if args.breakdown:
+        log(f"--- per-kernel breakdown of one pass (sum of launch durations {total_ms:.2f} ms) ---")
+        for kind, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+            log(f"{kind:28s} {a['ms']:9.3f} ms  {100 * a['ms'] / total_ms:5.1f}%  n={a['n']:5d}  {tf:8.1f} TFLOP/s")
+            for name, (ms, fl, n) in sorted(a["by_name"].items(), key=lambda kv: -kv[1][0])[:12]:
+                tfn = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                log(f"    {name:28s} {ms:9.3f} ms  n={n:5d}  {tfn:8.1f} TFLOP/s")
+    ig = agg.get("igemm_kernel")
+    at = agg.get("flash_attn64_kernel")
+    out = {}
+    if ig:
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "igemm_kernel (implicit-GEMM conv / linear, MFMA 32x32x16)", "bound": "mfma",
+                           "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_pass": ig["n"], "avg_launch_ms": round(ig["ms"] / ig["n"], 4),
+                           "share_of_pass": round(ig["ms"] / total_ms, 3)}
+    if at:
+        ach = at["flops"] / (at["ms"] * 1e-3) / 1e12
+        out["roofline_attention"] = {"kernel": "flash_attn64_kernel", "bound": "mfma", "achieved": round(ach, 2),
+                                     "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
+                                     "launches_per_pass": at["n"], "share_of_pass": round(at["ms"] / total_ms, 3)}
+    out["kernel_time_ms_per_pass"] = {k: round(a["ms"], 3) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    return out
+
+
+def kernel_of(name: str) -> str:
+    if name.startswith("flash"):
+        return "flash_attn64_kernel"
+    if name.endswith(".stats"):
+        return "gn_stats_kernel"
+    if name.endswith(".apply"):
+        return "gn_apply_kernel"
+    for k in ("layernorm", "softmax_rows", "nchw_to_nhwc", "nhwc_to_nchw", "add", "timestep_embedding", "cast16",
+              "sampler_update", "axpby"):
+        if name.startswith(k):
+            return k + "_kernel"
+    return "igemm_kernel"
+
+
+def _cpu_worker(q_in, q_out, cfg_name, S, threads):
+    """Child process: the oracle (CPU fp32 restatement pinned to the reference) on image 0 of the bench batch."""
+    import torch as th
+    th.set_num_threads(threads)
+    from edtr_amd import synth as sy
+    from edtr_amd.testing import flat_oracle_sd, synthetic_state_dicts
+    from oracle import edtr_oracle as O
+    cfg = sy.CONFIGS[cfg_name]()
+    sd = flat_oracle_sd(synthetic_state_dicts(cfg))
+    q_out.put(("ready", None))
+    pre_res, c_txt, noises = q_in.get()          # numpy arrays (pickled by value, no shared-memory handles)
+    pre_res, c_txt, noises = th.from_numpy(pre_res), th.from_numpy(c_txt), [th.from_numpy(n) for n in noises]
+    with th.no_grad():
+        t0 = time.perf_counter()
+        img, tr = O.restore(sd, cfg, O.make_betas(), pre_res, c_txt, noises, USED_TIMESTEPS, 200, return_trace=True)
+        dt = time.perf_counter() - t0
+    q_out.put(("done", (dt, img.numpy(), tr["z"].numpy())))
+
+
+def start_cpu_baseline(cfg_name, S):
+    """Spawn the oracle process early: it builds its fp32 weights while the GPU side builds its own, then idles
+    until the timed GPU region is over (so neither measurement perturbs the other)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    threads = int(os.environ.get("EDTR_CPU_THREADS", str(min(cores, 32))))
+    ctx = mp.get_context("spawn")
+    q_in, q_out = ctx.Queue(), ctx.Queue()
+    proc = ctx.Process(target=_cpu_worker, args=(q_in, q_out, cfg_name, S, threads), daemon=True)
+    proc.start()
+    return proc, q_in, q_out, threads, cores
+
+
+def finish_cpu_baseline(handle, pre_res_g, c_txt1, noises_g, img, z, S, rel_err, budget_s=420.0) -> dict:
+    proc, q_in, q_out, threads, cores = handle
+    res = None
+    try:
+        q_out.get(timeout=budget_s)                       # "ready"
+        q_in.put((pre_res_g[:1].numpy().copy(), c_txt1.numpy().copy(), [n[:1].numpy().copy() for n in noises_g]))
+        _, res = q_out.get(timeout=budget_s)
+    except Exception:
+        res = None
+    finally:
+        if proc.is_alive():
+            proc.kill()
+        proc.join(timeout=10)
+    if res is None:
+        return {"cpu_baseline": {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
+                                 "sample": f"1 image {S}x{S}, 4 steps: exceeded the {budget_s:.0f}s budget"}}
+    dt, ref_img, ref_z = res
+    return {
+        "cpu_baseline": {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": threads, "kind": "port",
+                         "sample": f"1 image {S}x{S}, 4 steps, fp32 oracle on torch CPU kernels, {threads} threads "
+                                   f"of {cores} host cores ({dt:.1f} s)"},
+        "parity": {"rel_err_latent_vs_oracle": float(f"{rel_err(z[:1], ref_z):.3e}"),
+                   "rel_err_image_vs_oracle": float(f"{rel_err(img[:1], ref_img):.3e}"), "sample": "image 0 of the batch"},
+    }
+
+
+if __name__ == "__main__":
+    main()

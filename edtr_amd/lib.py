@@ -73,6 +73,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; import it FIRST so that libedtr_hip.so binds to the same (already
+    # loaded) HIP runtime instead of pulling a second one from /opt/rocm ("no ROCm-capable device" otherwise).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the EDTR MI355X path has no CPU/PyTorch fallback. "

@@ -18,6 +18,21 @@ class _Node(nn.Module):
     pass
 
 
+_SKIP_INIT = False
+
+
+class skip_init:
+    """Context manager: construct ParamTrees with uninitialised storage (the caller loads a checkpoint next)."""
+
+    def __enter__(self):
+        global _SKIP_INIT
+        self.prev, _SKIP_INIT = _SKIP_INIT, True
+
+    def __exit__(self, *exc):
+        global _SKIP_INIT
+        _SKIP_INIT = self.prev
+
+
 def _is_zero_init(key: str, is_unet_like: bool) -> bool:
     if not is_unet_like:
         return False
@@ -35,7 +50,9 @@ class ParamTree(nn.Module):
                 if p not in node._modules:
                     node.add_module(p, _Node())
                 node = node._modules[p]
-            if _is_zero_init(key, unet_like):
+            if _SKIP_INIT:
+                val = torch.empty(shape)
+            elif _is_zero_init(key, unet_like):
                 val = torch.zeros(shape)
             elif len(shape) >= 2:
                 fan_in = int(math.prod(shape[1:]))

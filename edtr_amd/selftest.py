@@ -1,0 +1,57 @@
+"""smoke(): one small restoration (tiny config, B=1, 64x64 image, 4 denoise steps) through the HIP path on cuda:0,
+checked against the CPU oracle on the same weights / inputs / noise."""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+
+
+def smoke(verbose: bool = True) -> dict:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, flat_oracle_sd, injected_noise, rel_err, synthetic_state_dicts
+    from oracle import edtr_oracle as O   # checker only
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("smoke() needs cuda:0 (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda:0")
+    cfg = synth.tiny_config()
+    sds = synthetic_state_dicts(cfg)
+    B, H, W = 1, 64, 64
+    used = [50, 100, 150, 200]
+    pre_res = synth.synth_input("smoke:pre_res", (B, 3, H, W), 0.0, 1.0)
+    c_txt = synth.synth_input("smoke:c_txt", (B, 77, 64), -1.0, 1.0)
+    noises = [synth.synth_normal(f"smoke:noise{i}", (B, 4, H // 8, W // 8)) for i in range(5)]
+    with torch.no_grad():
+        ref_img, tr = O.restore(flat_oracle_sd(sds), cfg, O.make_betas(), pre_res, c_txt, noises, used, 200,
+                                return_trace=True)
+    out = {}
+    for dtype, tol in ((torch.float16, 8e-3), (torch.bfloat16, 5e-2)):
+        cldm = build_synthetic_cldm(cfg, dev, dtype, sds)
+        diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
+        sampler = SpacedSampler(diffusion.betas)
+        z_pre = cldm.vae_encode(pre_res.to(dev) * 2 - 1, sample=False)
+        x_T = diffusion.q_sample(z_pre, torch.full((B,), 200, dtype=torch.int64, device=dev), noises[0].to(dev))
+        with injected_noise(noises[1:]):
+            z = sampler.manual_sample_with_timesteps(
+                model=cldm, device=dev, x_T=x_T, steps=4, used_timesteps=used, batch_size=B,
+                cond={"c_txt": c_txt.to(dev), "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+        img = cldm.vae_decode(z)
+        torch.cuda.synchronize()
+        e_z, e_img = rel_err(z, tr["z"]), rel_err(img, ref_img)
+        out[str(dtype)] = (e_z, e_img)
+        if verbose:
+            print(f"smoke[{dtype}]: rel err latent {e_z:.2e}, image {e_img:.2e} (tolerance {tol:.0e})")
+        if not (e_img < tol and e_z < tol):
+            raise AssertionError(f"smoke parity failed for {dtype}: latent {e_z:.3e}, image {e_img:.3e}")
+    return out
+
+
+if __name__ == "__main__":
+    smoke()

@@ -26,7 +26,9 @@ def flat_oracle_sd(sds: Dict[str, Dict[str, torch.Tensor]]) -> Dict[str, torch.T
 
 
 def build_synthetic_cldm(cfg: dict, device, dtype=None, sds=None) -> ControlLDM:
-    model = ControlLDM(**cfg)
+    from .model.params import skip_init
+    with skip_init():
+        model = ControlLDM(**cfg)
     sds = sds or synthetic_state_dicts(cfg)
     model.unet.load_state_dict(sds["unet"], strict=True)
     model.load_controlnet_from_ckpt(sds["controlnet"])
