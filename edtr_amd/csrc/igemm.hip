@@ -16,6 +16,75 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int BK = 64;
 
+
+// Row-vector epilogue shared by the main kernel and the split-K reducer: 8 consecutive output columns of row m.
+template <typename T>
+__device__ __forceinline__ void finish_vector(const edtr_igemm_params& p, float (&f)[8], int m, int n, bool scale_bias,
+                                              int64_t o_zoff) {
+    if (scale_bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= p.alpha;
+        if (p.bias_n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += p.bias_n[n + j];
+        }
+    }
+    if (p.bias_m) {
+        const float bm = p.bias_m[m];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += bm;
+    }
+    if (p.rowvec) {
+        const float* rv = p.rowvec + (int64_t)(m / p.rows_per_image) * p.rowvec_ld + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += rv[j];
+    }
+    if (p.act == EDTR_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+    }
+    if (p.residual) {
+        const U4 rv = ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n);
+        float rf[8];
+        unpack8<T>(rv, rf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += rf[j];
+    }
+    const int64_t oidx = o_zoff + (int64_t)m * p.ldc + n;
+    if (p.out_f32) {
+        float* o = static_cast<float*>(p.out) + oidx;
+        f32x4 o0, o1;
+        o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2]; o0[3] = f[3];
+        o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
+        *reinterpret_cast<f32x4*>(o) = o0;
+        *reinterpret_cast<f32x4*>(o + 4) = o1;
+    } else {
+        stg16(static_cast<uint16_t*>(p.out) + oidx, pack8<T>(f));
+    }
+}
+
+// Split-K second stage: out = epilogue(sum over splits of the fp32 partial slabs [S][M][N]).
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_params p) {
+    const int nv = p.N >> 3;
+    const int64_t total = (int64_t)p.M * nv;
+    const float* ws = static_cast<const float*>(p.workspace);
+    const int64_t slab = (int64_t)p.M * p.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nv), n = (int)(i - (int64_t)m * nv) * 8;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.0f;
+        for (int sidx = 0; sidx < p.splitk; ++sidx) {
+            const float* src = ws + sidx * slab + (int64_t)m * p.N + n;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+            f[0] += a[0]; f[1] += a[1]; f[2] += a[2]; f[3] += a[3];
+            f[4] += b[0]; f[5] += b[1]; f[6] += b[2]; f[7] += b[3];
+        }
+        finish_vector<T>(p, f, m, n, true, 0);
+    }
+}
+
 template <typename T, int MI, int NI, bool SPATIAL>
 __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_params p) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -128,10 +197,19 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    const int nkt = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    if (nkt > 1) load_tile(1);
+    const int nkt_all = (p.K + BK - 1) / BK;
+    int kt0 = 0, nkt = nkt_all;
+    if (p.splitk > 1) {   // blockIdx.y = K split: a contiguous run of K-tiles, partial sums go to the workspace
+        const int per = (nkt_all + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.y * per;
+        nkt = min(per, nkt_all - kt0);
+        if (nkt < 0) nkt = 0;
+    }
+    if (nkt > 0) {
+        load_tile(kt0);
+        store_tile(0);
+        if (nkt > 1) load_tile(kt0 + 1);
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -155,7 +233,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
         }
         if (kt + 1 < nkt) {
             store_tile(cur ^ 1);               // registers hold tile kt+1 (loaded one iteration ago)
-            if (kt + 2 < nkt) load_tile(kt + 2);  // in flight during the next iteration's MFMAs
+            if (kt + 2 < nkt) load_tile(kt0 + kt + 2);  // in flight during the next iteration's MFMAs
         }
         __syncthreads();
     }
@@ -195,7 +273,6 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
     const int n_out = geglu ? p.N / 2 : p.N;
     const int no0 = geglu ? n0 / 2 : n0;
     const int vec_per_row = BNO / 8;
-    char* outp = static_cast<char*>(p.out);
     for (int v = tid; v < BM * vec_per_row; v += kThreads) {
         const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
         const int m = m0 + ml, n = no0 + n8 * 8;
@@ -205,46 +282,13 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
         f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
         f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
-        if (!geglu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] *= p.alpha;
-            if (p.bias_n) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] += p.bias_n[n + j];
-            }
+        if (p.splitk > 1) {
+            float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
+            *reinterpret_cast<f32x4*>(o) = s0;
+            *reinterpret_cast<f32x4*>(o + 4) = s1;
+            continue;
         }
-        if (p.bias_m) {
-            const float bm = p.bias_m[m];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += bm;
-        }
-        if (p.rowvec) {
-            const float* rv = p.rowvec + (int64_t)(m / p.rows_per_image) * p.rowvec_ld + n;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += rv[j];
-        }
-        if (p.act == EDTR_ACT_SILU) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
-        }
-        if (p.residual) {
-            const U4 rv = ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n);
-            float rf[8];
-            unpack8<T>(rv, rf);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += rf[j];
-        }
-        const int64_t oidx = o_zoff + (int64_t)m * p.ldc + n;
-        if (p.out_f32) {
-            float* o = reinterpret_cast<float*>(outp) + oidx;
-            f32x4 o0, o1;
-            o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2]; o0[3] = f[3];
-            o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
-            *reinterpret_cast<f32x4*>(o) = o0;
-            *reinterpret_cast<f32x4*>(o + 4) = o1;
-        } else {
-            stg16(reinterpret_cast<uint16_t*>(outp) + oidx, pack8<T>(f));
-        }
+        finish_vector<T>(p, f, m, n, !geglu, o_zoff);
     }
 }
 
@@ -260,9 +304,16 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    dim3 grid(nbm * nbn, 1, p.Z);
+    dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
     hipLaunchKernelGGL((igemm_kernel<T, MI, NI, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
+        int64_t blocks = (nvec + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        EDTR_LAUNCH_CHECK();
+    }
     return EDTR_OK;
 }
 
@@ -308,6 +359,14 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (p.n_valid < 0 || p.n_valid > p.N) return EDTR_E_SHAPE;
     if (p.residual && p.Z != 1) return EDTR_E_UNSUPPORTED;  // residual / rowvec are not z-batched
     if (p.rowvec && p.Z != 1) return EDTR_E_UNSUPPORTED;
+    if (p.splitk < 0) return EDTR_E_SHAPE;
+    if (p.splitk <= 1) p.splitk = 1;
+    if (p.splitk > 1) {
+        if (p.Z != 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+        if (!p.workspace) return EDTR_E_NULL;
+        if (p.workspace_bytes < (int64_t)p.splitk * p.M * p.N * 4 || !aligned16(p.workspace)) return EDTR_E_SHAPE;
+        if (p.splitk > (p.K + 63) / 64) return EDTR_E_SHAPE;
+    }
 
     int tile = p.tile;
     if (tile == 0) {

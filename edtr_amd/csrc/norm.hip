@@ -5,99 +5,137 @@
 
 namespace {
 
-constexpr int GN_PIX = 256;  // pixels per workgroup (stats and apply)
-
 // ------------------------------------------------------------------------------------------
-// GroupNorm statistics.  grid (ceil(HW / GN_PIX), B); block = CV * R threads where CV = C/8 channel
-// vectors and R rows in flight; thread (row r, vector cv) accumulates 8 channel sums / squares over
-// its pixels in fp32, folds them into per-group LDS accumulators, then one fp64 atomic per group.
+// GroupNorm statistics.  grid (pixel chunks <= 64 per image, B); block = CV * R threads (CV = C/8 channel
+// vectors, R pixel rows in flight).  Each thread accumulates 8 channel sums / squares over its pixels in
+// fp32 (4 independent 16-byte loads in flight), rows are folded through LDS, channels are folded into
+// groups by 32 threads, and each workgroup issues ONE fp64 atomic pair per group (<= 64 arrivals per
+// address per image, so the atomics never become the bottleneck).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void gn_stats_kernel(const edtr_gn_params p, int CV, int R) {
-    __shared__ float g_sum[64], g_sq[64];
+__global__ void gn_stats_kernel(const edtr_gn_params p, int CV, int R, int ppb) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);   // [2][R][C]
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    if (tid < 64) { g_sum[tid] = 0.0f; g_sq[tid] = 0.0f; }
-    __syncthreads();
-    const int cpg = p.C / p.groups;
-    const int64_t pix0 = (int64_t)blockIdx.x * GN_PIX;
-    const int npix = (int)min((int64_t)GN_PIX, (int64_t)p.HW - pix0);
+    const int C = p.C;
+    const int cpg = C / p.groups;
+    const int64_t pix0 = (int64_t)blockIdx.x * ppb;
+    const int npix = (int)min((int64_t)ppb, (int64_t)p.HW - pix0);
     const uint16_t* xb = static_cast<const uint16_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx;
-    const int nslots = (CV + blockDim.x - 1) / blockDim.x;  // > 1 only when CV > blockDim (R == 1)
+    const int nslots = (CV + blockDim.x - 1) / blockDim.x;  // > 1 only when CV > blockDim (then R == 1)
     for (int slot = 0; slot < nslots; ++slot) {
-        const int cv = R > 1 ? tid % CV : tid + slot * blockDim.x;
+        const int cv = R > 1 ? tid % CV : tid + slot * (int)blockDim.x;
         const int r = R > 1 ? tid / CV : 0;
         if (cv >= CV || r >= R) continue;
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-        for (int pi = r; pi < npix; pi += R) {
+        const uint16_t* xp = xb + cv * 8;
+        int pi = r;
+        for (; pi + 3 * R < npix; pi += 4 * R) {
+            U4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ldg16(xp + (int64_t)(pi + u * R) * p.ldx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8<T>(v[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+            }
+        }
+        for (; pi < npix; pi += R) {
             float f[8];
-            unpack8<T>(ldg16(xb + (int64_t)pi * p.ldx + cv * 8), f);
+            unpack8<T>(ldg16(xp + (int64_t)pi * p.ldx), f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int g = (cv * 8 + j) / cpg;
-            atomicAdd(&g_sum[g], s[j]);
-            atomicAdd(&g_sq[g], q[j]);
+            red[r * C + cv * 8 + j] = s[j];
+            red[(R + r) * C + cv * 8 + j] = q[j];
         }
     }
     __syncthreads();
+    // fold rows: channel c -> red[c], red[R*C + c]
+    for (int c = tid; c < C; c += blockDim.x) {
+        float a = 0.0f, bq = 0.0f;
+        for (int r = 0; r < R; ++r) { a += red[r * C + c]; bq += red[(R + r) * C + c]; }
+        red[c] = a;
+        red[R * C + c] = bq;
+    }
+    __syncthreads();
     if (tid < p.groups) {
+        float a = 0.0f, bq = 0.0f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += red[c]; bq += red[R * C + c]; }
         double* dst = p.sums + ((int64_t)b * p.groups + tid) * 2;
-        atomicAdd(dst, (double)g_sum[tid]);
-        atomicAdd(dst + 1, (double)g_sq[tid]);
+        atomicAdd(dst, (double)a);
+        atomicAdd(dst + 1, (double)bq);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// GroupNorm apply (+SiLU).  grid (ceil(HW / GN_PIX), B), 256 threads.  Per-channel scale/shift
-// (rstd*gamma, beta - mean*rstd*gamma) are built once per workgroup in LDS, then the pixel chunk is
-// streamed as 16-byte vectors.
+// GroupNorm apply (+SiLU).  grid (pixel chunks, channel chunks of <= 256, B), 256 threads.  Per-channel
+// scale/shift (rstd*gamma, beta - mean*rstd*gamma) of the chunk are built once per workgroup in LDS, then
+// the [pixels x channels] slab is streamed as 16-byte vectors, 4 independent loads in flight per thread.
 // ------------------------------------------------------------------------------------------
+constexpr int GN_CC = 256;  // channels per workgroup in the apply kernel
+
 template <typename T>
-__global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sc = reinterpret_cast<float*>(smem_raw);
-    float* sh = sc + p.C;
-    const int tid = threadIdx.x, b = blockIdx.y;
+__global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, int ppb) {
+    __shared__ __attribute__((aligned(16))) float sc[GN_CC];
+    __shared__ __attribute__((aligned(16))) float sh[GN_CC];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int c0 = blockIdx.y * GN_CC;
+    const int cc = min(GN_CC, p.C - c0);
     const int cpg = p.C / p.groups;
     const double cnt = (double)p.HW * cpg;
-    for (int c = tid; c < p.C; c += 256) {
-        const double* src = p.sums + ((int64_t)b * p.groups + c / cpg) * 2;
+    for (int c = tid; c < cc; c += 256) {
+        const double* src = p.sums + ((int64_t)b * p.groups + (c0 + c) / cpg) * 2;
         const double mean = src[0] / cnt;
         double var = src[1] / cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-        const float g = p.gamma[c] * rstd;
+        const float g = p.gamma[c0 + c] * rstd;
         sc[c] = g;
-        sh[c] = p.beta[c] - (float)mean * g;
+        sh[c] = p.beta[c0 + c] - (float)mean * g;
     }
     __syncthreads();
-    const int CV = p.C >> 3;
-    const int64_t pix0 = (int64_t)blockIdx.x * GN_PIX;
-    const int npix = (int)min((int64_t)GN_PIX, (int64_t)p.HW - pix0);
-    const uint16_t* xb = static_cast<const uint16_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx;
-    uint16_t* yb = static_cast<uint16_t*>(p.y) + ((int64_t)b * p.HW + pix0) * p.ldy;
-    const int total = npix * CV;
-    for (int i = tid; i < total; i += 256) {
-        const int pi = i / CV, cv = i - pi * CV;
-        float f[8];
-        unpack8<T>(ldg16(xb + (int64_t)pi * p.ldx + cv * 8), f);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + cv * 8), a1 = *reinterpret_cast<const f32x4*>(sc + cv * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh + cv * 8), b1 = *reinterpret_cast<const f32x4*>(sh + cv * 8 + 4);
+    const int ncv = cc >> 3;
+    const int64_t pix0 = (int64_t)blockIdx.x * ppb;
+    const int npix = (int)min((int64_t)ppb, (int64_t)p.HW - pix0);
+    const uint16_t* xb = static_cast<const uint16_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx + c0;
+    uint16_t* yb = static_cast<uint16_t*>(p.y) + ((int64_t)b * p.HW + pix0) * p.ldy + c0;
+    const int total = npix * ncv;
+    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+        U4 v[4];
+        int pi[4], cv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f[j] = f[j] * a0[j] + b0[j];
-            f[j + 4] = f[j + 4] * a1[j] + b1[j];
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            pi[u] = i / ncv;
+            cv[u] = i - pi[u] * ncv;
+            if (i < total) v[u] = ldg16(xb + (int64_t)pi[u] * p.ldx + cv[u] * 8);
         }
-        if (p.silu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * 256 >= total) continue;
+            float f[8];
+            unpack8<T>(v[u], f);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + cv[u] * 8), a1 = *reinterpret_cast<const f32x4*>(sc + cv[u] * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh + cv[u] * 8), b1 = *reinterpret_cast<const f32x4*>(sh + cv[u] * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = f[j] * a0[j] + b0[j];
+                f[j + 4] = f[j + 4] * a1[j] + b1[j];
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+            }
+            stg16(yb + (int64_t)pi[u] * p.ldy + cv[u] * 8, pack8<T>(f));
         }
-        stg16(yb + (int64_t)pi * p.ldy + cv * 8, pack8<T>(f));
     }
 }
 
@@ -198,6 +236,15 @@ int check_gn(const edtr_gn_params& p, bool apply) {
 
 }  // namespace
 
+static int gn_pixels_per_block(int64_t HW, int B, int min_ppb, int max_chunks_per_image) {
+    // enough workgroups to fill 256 CUs, but never more than max_chunks_per_image per image
+    int64_t chunks = (1024 + B - 1) / B;
+    if (chunks > max_chunks_per_image) chunks = max_chunks_per_image;
+    int64_t ppb = (HW + chunks - 1) / chunks;
+    if (ppb < min_ppb) ppb = min_ppb;
+    return (int)ppb;
+}
+
 extern "C" int edtr_gn_stats(const edtr_gn_params* pp, edtr_stream_t stream) {
     if (!pp) return EDTR_E_NULL;
     const edtr_gn_params& p = *pp;
@@ -211,11 +258,13 @@ extern "C" int edtr_gn_stats(const edtr_gn_params* pp, edtr_stream_t stream) {
     int threads = CV >= 256 ? 256 : CV * R;
     threads = ((threads + 63) / 64) * 64;
     if (threads < 64) threads = 64;
-    dim3 grid((unsigned)((p.HW + GN_PIX - 1) / GN_PIX), p.B);
+    const int ppb = gn_pixels_per_block(p.HW, p.B, 16, 64);
+    dim3 grid((unsigned)((p.HW + ppb - 1) / ppb), p.B);
+    const size_t lds = sizeof(float) * 2 * R * p.C;
     if (p.dtype == EDTR_BF16)
-        hipLaunchKernelGGL(gn_stats_kernel<BF16>, grid, dim3(threads), 0, s, p, CV, R);
+        hipLaunchKernelGGL(gn_stats_kernel<BF16>, grid, dim3(threads), lds, s, p, CV, R, ppb);
     else
-        hipLaunchKernelGGL(gn_stats_kernel<F16>, grid, dim3(threads), 0, s, p, CV, R);
+        hipLaunchKernelGGL(gn_stats_kernel<F16>, grid, dim3(threads), lds, s, p, CV, R, ppb);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }
@@ -225,12 +274,18 @@ extern "C" int edtr_gn_apply(const edtr_gn_params* pp, edtr_stream_t stream) {
     const edtr_gn_params& p = *pp;
     if (int e = check_gn(p, true)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid((unsigned)((p.HW + GN_PIX - 1) / GN_PIX), p.B);
-    const size_t lds = sizeof(float) * 2 * p.C;
+    const int nchunk_c = (p.C + GN_CC - 1) / GN_CC;
+    // ~2048 workgroups when the tensor allows it, at least 8 pixels (>= 1 vector per thread at 256 channels) each
+    int64_t want = (2048 + (int64_t)p.B * nchunk_c - 1) / ((int64_t)p.B * nchunk_c);
+    if (want < 1) want = 1;
+    int64_t ppb = (p.HW + want - 1) / want;
+    if (ppb < 8) ppb = 8;
+    if (ppb > 256) ppb = 256;
+    dim3 grid((unsigned)((p.HW + ppb - 1) / ppb), nchunk_c, p.B);
     if (p.dtype == EDTR_BF16)
-        hipLaunchKernelGGL(gn_apply_kernel<BF16>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(gn_apply_kernel<BF16>, grid, dim3(256), 0, s, p, (int)ppb);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<F16>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(gn_apply_kernel<F16>, grid, dim3(256), 0, s, p, (int)ppb);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

@@ -252,11 +252,14 @@ class Emitter:
         n_out = N // 2 if act == L.ACT_GEGLU else N
         if out is None:
             out = self.new(M, n_out, torch.float32 if out_f32 else None)
+        tile, splitk = ops.choose_splitk(M, N, K, kw.get("Z", 1), act) if "tile" not in kw else (kw.pop("tile"), 1)
+        ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=a, w=w, out=out, M=M, N=N, C1=K, ld1=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
             bias_n=bias, act=act, residual=residual, ldr=residual.stride(0) if residual is not None else 0,
             rowvec=rowvec, rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=rows_per_image,
-            out_f32=out_f32, alpha=alpha, name=name, **kw))
+            out_f32=out_f32, alpha=alpha, name=name, tile=tile, splitk=splitk, workspace=ws, **kw))
+        self.arena.free(ws)
         return out
 
     def conv(self, x: Act, prefix: str, *, taps=9, stride=1, pad_tl=1, ups=False, rowvec=None, residual=None,
@@ -277,12 +280,15 @@ class Emitter:
             out = self.new(M, N, torch.float32 if out_f32 else None)
         if alpha != 1.0:
             bias = bias * alpha  # epilogue applies alpha before the bias
+        tile, splitk = ops.choose_splitk(M, N, taps * x.C)
+        ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=x.t, w=w, out=out, taps=taps, M=M, N=N, C1=x.C, ld1=x.ld, ldw=w.stride(0),
             ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
-            ldr=residual.stride(0) if residual is not None else 0, out_f32=out_f32, alpha=alpha,
-            name=name or ("conv3x3" if taps == 9 else "conv1x1")))
+            ldr=residual.stride(0) if residual is not None else 0, out_f32=out_f32, alpha=alpha, tile=tile, splitk=splitk,
+            workspace=ws, name=name or ("conv3x3" if taps == 9 else "conv1x1")))
+        self.arena.free(ws)
         return Act(out, x.B, OH, OW, N)
 
     # -- norms --------------------------------------------------------------------------------

@@ -39,7 +39,8 @@ class IgemmParams(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int32),
         ("out", C.c_void_p), ("ldc", C.c_int32), ("out_f32", C.c_int32),
         ("o_zs_outer", C.c_int64), ("o_zs_inner", C.c_int64),
-        ("tile", C.c_int32),
+        ("tile", C.c_int32), ("splitk", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

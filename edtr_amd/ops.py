@@ -59,7 +59,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
                rowvec: Optional[torch.Tensor] = None, rowvec_ld: int = 0, rows_per_image: int = 0, act: int = 0,
                residual: Optional[torch.Tensor] = None, ldr: int = 0, out_f32: bool = False, n_valid: int = 0,
-               tile: int = 0, name: str = "igemm") -> Rec:
+               tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -76,8 +76,25 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     p.out, p.ldc, p.out_f32 = ptr(out), ldc, int(out_f32)
     p.o_zs_outer, p.o_zs_inner = o_zs
     p.tile = tile
+    p.splitk = splitk
+    if splitk > 1:
+        p.workspace, p.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     flops = 2.0 * M * N * p.K * Z
-    return Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual), name, flops)
+    return Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace), name, flops)
+
+
+def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int, int]:
+    """(tile, splitk) heuristic for the 256-CU MI355X: when the 128x128 tile grid cannot fill the chip, cut K so
+    that ~512-1024 workgroups exist, keeping >= 6 K-tiles (of 64) per split."""
+    if Z != 1 or act == L.ACT_GEGLU:
+        return 0, 1
+    nkt = (K + 63) // 64
+    b128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if b128 >= 200 or nkt < 12:
+        return 0, 1
+    want = max(1, round(480 / b128))
+    s = max(1, min(want, nkt // 6, 8))
+    return 1, s
 
 
 # --------------------------------------------------------------------------------------------

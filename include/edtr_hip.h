@@ -103,6 +103,11 @@ typedef struct edtr_igemm_params {
     void* out; int32_t ldc; int32_t out_f32;
     int64_t o_zs_outer, o_zs_inner;
     int32_t tile;           /* 0 = auto, 1 = 128x128, 2 = 64x64 block tile */
+    /* split-K (small-M problems that cannot fill 256 CUs): K is cut into `splitk` runs of K-tiles, each
+     * workgroup row writes an fp32 partial slab into `workspace` ([splitk][M][N] floats, caller-owned), and a
+     * second launch sums the slabs and applies the epilogue.  splitk <= 1 disables it.  Needs Z == 1, no GEGLU. */
+    int32_t splitk;
+    void* workspace; int64_t workspace_bytes;
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);

@@ -71,6 +71,49 @@ def test_gemm_bias_residual(dtype, M, N, K, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,S,tile", [(512, 256, 1152, 4, 1), (100, 72, 640, 10, 2), (64, 1280, 2880, 7, 1)])
+def test_gemm_splitk(dtype, M, N, K, S, tile):
+    """Split-K: fp32 partial slabs + reducer with the full epilogue (bias, row vector, SiLU-free residual)."""
+    ops = _ops()
+    d = dev()
+    a = rnd((M, K), 1).to(dtype)
+    w = rnd((N, K), 2, 1 / math.sqrt(K)).to(dtype)
+    bias, res, rv = rnd((N,), 3), rnd((M, N), 4).to(dtype), rnd((2, N), 5)
+    ref = a.float() @ w.float().t() + bias + rv.repeat_interleave(M // 2, dim=0) + res.float()
+    out = torch.empty((M, N), dtype=dtype, device=d)
+    ws = torch.empty(S * M * N, dtype=torch.float32, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=a.to(d), w=w.to(d), out=out, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N,
+                              bias_n=bias.to(d), residual=res.to(d), ldr=N, rowvec=rv.to(d), rowvec_ld=N,
+                              rows_per_image=M // 2, tile=tile, splitk=S, workspace=ws))
+    torch.cuda.synchronize()
+    assert rel(out.float(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_splitk_matches_plain(dtype):
+    ops = _ops()
+    d = dev()
+    B, H, W, cin, cout = 2, 8, 8, 128, 136
+    x = rnd((B, cin, H, W), 20)
+    w = rnd((cout, cin, 3, 3), 21, 1 / math.sqrt(9 * cin))
+    x16, xr = nhwc16(x, dtype)
+    wp = ops.pack_conv_weight(w, dtype).to(d)
+    bias = rnd((cout,), 22).to(d)
+    ref = F.conv2d(xr, w.to(dtype).float(), bias.cpu(), padding=1)
+    outs = []
+    for S in (1, 6):
+        out = torch.empty((B, H, W, cout), dtype=dtype, device=d)
+        ws = torch.empty(S * B * H * W * cout, dtype=torch.float32, device=d) if S > 1 else None
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x16, w=wp, out=out, taps=9, M=B * H * W, N=cout, C1=cin, ld1=cin,
+                                  ldw=9 * cin, ldc=cout, spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, tile=1, splitk=S,
+                                  workspace=ws))
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu().permute(0, 3, 1, 2))
+    assert rel(outs[0], ref) < TOL[dtype]
+    assert rel(outs[1], ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_geglu_and_concat(dtype):
     ops = _ops()
     M, d_model, inner = 200, 128, 512
