@@ -85,6 +85,67 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
     }
 }
 
+// Tile epilogue shared by both main-loop variants: accumulators -> LDS (fp32) -> row vectors of 8 columns.
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16 (&acc)[MI][NI], char* smem, int m0, int n0,
+                                              int64_t o_zoff) {
+    constexpr int BM = 64 * MI, BN = 64 * NI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const bool geglu = (p.act == EDTR_ACT_GEGLU);
+    const int BNO = geglu ? BN / 2 : BN;      // output columns of this block
+    float* stage = reinterpret_cast<float*>(smem);
+    if (geglu) {
+        if constexpr (NI == 2) {
+            const int nv = n0 + wn * 64 + l31;  // packed column of the value half; gate = +32
+            const float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
+            const float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float val = acc[mi][0][r] * p.alpha + bv;
+                    const float gate = acc[mi][1][r] * p.alpha + bg;
+                    stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
+                }
+    }
+    __syncthreads();
+
+    const int n_out = geglu ? p.N / 2 : p.N;
+    const int no0 = geglu ? n0 / 2 : n0;
+    const int vec_per_row = BNO / 8;
+    for (int v = tid; v < BM * vec_per_row; v += kThreads) {
+        const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
+        const int m = m0 + ml, n = no0 + n8 * 8;
+        if (m >= p.M || n >= n_out) continue;
+        float f[8];
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+        f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
+        f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
+        if (p.splitk > 1) {
+            float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
+            *reinterpret_cast<f32x4*>(o) = s0;
+            *reinterpret_cast<f32x4*>(o + 4) = s1;
+            continue;
+        }
+        finish_vector<T>(p, f, m, n, !geglu, o_zoff);
+    }
+}
+
 template <typename T, int MI, int NI, bool SPATIAL>
 __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_params p) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -238,58 +299,201 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32) -> row vectors of 8
-    const bool geglu = (p.act == EDTR_ACT_GEGLU);
-    const int BNO = geglu ? BN / 2 : BN;      // output columns of this block
-    float* stage = reinterpret_cast<float*>(smem);
-    if (geglu) {
-        if constexpr (NI == 2) {
-            const int nv = n0 + wn * 64 + l31;  // packed column of the value half; gate = +32
-            const float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
-            const float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
+    tile_epilogue<T, MI, NI>(p, acc, smem, m0, n0, o_zoff);
+}
+
+
+// 16 bytes of zeros in device memory: the LDS-DMA source of every out-of-range chunk (conv halo, M / N tails).
+__device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4];
+
+// One global_load_lds_dwordx4: lane i's 16 bytes land at LDS byte address lds_addr + 16*i (lds_addr wave-uniform, in
+// M0).  Inline asm on purpose: hipcc neither counts it in its own vmcnt bookkeeping nor serialises later ds_reads
+// behind it with a vmcnt(0), so the prefetch can stay in flight across the barrier; completion is waited for by
+// the hand-placed counted s_waitcnt in the main loop.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
+    return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LDS-DMA main loop (128x128x64 tile): operands go global -> LDS directly (global_load_lds_dwordx4), no VGPR
+// staging and no ds_write traffic.  One wave instruction fills 1 KiB = 8 tile rows; the XOR swizzle is applied
+// on the SOURCE side (lane (row, slot) fetches logical chunk slot ^ f(row)) because the DMA destination is
+// lane-linear.  Out-of-range chunks fetch g_zero_chunk.  Two LDS buffers, tile t+1 in flight while tile t is
+// multiplied: counted s_waitcnt vmcnt(8) + raw s_barrier (a __syncthreads() would drain the prefetch).
+// Requires (C1 % 64 == 0, C2 == 0): every 64-wide K-tile lies inside one filter tap.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, bool SPATIAL>
+__global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm_params p) {
+    constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
+    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
+    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
+    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
+    const void* zsrc = g_zero_chunk;
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    // this lane's 4 A rows / 4 W rows: tile row = wave*32 + 8*j + (lane>>3); LDS slot = lane&7
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int Cin = p.C1;
+    const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
+    int a_iy0[4], a_ix0[4], a_pix[4], coff[4];
+    bool a_ok[4], w_ok[4];
+    int64_t w_row[4];
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + 8 * j + rsub;
+        coff[j] = (slot ^ ((row >> 1) & 7)) * 8;        // logical 8-element chunk held by this LDS slot
+        const int m = m0 + row;
+        a_ok[j] = m < p.M;
+        if (SPATIAL) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_iy0[j] = oy * p.stride - p.pad_t;
+            a_ix0[j] = ox * p.stride - p.pad_l;
+            a_pix[j] = b * p.IH * p.IW;
+        } else {
+            a_iy0[j] = 0; a_ix0[j] = 0; a_pix[j] = m;
+        }
+        const int n = n0 + row;
+        w_ok[j] = n < nvalid;
+        w_row[j] = (int64_t)n * p.ldw;
+    }
+
+    auto issue_tile = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        int c0 = k0, ky = 0, kx = 0;
+        if (SPATIAL && p.taps == 9) {
+            const int tap = k0 / Cin;
+            c0 = k0 - tap * Cin;
+            ky = tap / 3;
+            kx = tap - 3 * ky;
+        }
+        const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
+        const uint32_t sw = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ok = a_ok[j];
+            int64_t pix;
+            if (SPATIAL) {
+                int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                ok = ok && iy >= 0 && iy < LH && ix >= 0 && ix < LW;
+                if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+                pix = (int64_t)a_pix[j] + iy * p.IW + ix;
+            } else {
+                pix = a_pix[j];
+            }
+            const void* src = ok ? static_cast<const void*>(a1 + pix * p.ld1 + c0 + coff[j]) : zsrc;
+            dma16(src, sa + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const void* src = w_ok[j] ? static_cast<const void*>(wp + w_row[j] + k0 + coff[j]) : zsrc;
+            dma16(src, sw + j * 1024);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const int nkt_all = p.K / BK;
+    int kt0 = 0, nkt = nkt_all;
+    if (p.splitk > 1) {
+        const int per = (nkt_all + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.y * per;
+        nkt = min(per, nkt_all - kt0);
+        if (nkt < 0) nkt = 0;
+    }
+    if (nkt > 0) issue_tile(kt0, 0);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) {
+            issue_tile(kt0 + kt + 1, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMAs of tile kt have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                           // ... and every other wave's
+        asm volatile("" ::: "memory");
+        const char* sa = smem + cur * STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int c = 2 * ks + lh;
+            U4 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const U4*>(sa + tile_off(wm * 64 + mi * 32 + l31, c));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                bf[ni] = *reinterpret_cast<const U4*>(sw + tile_off(wn * 64 + ni * 32 + l31, c));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float val = acc[mi][0][r] * p.alpha + bv;
-                    const float gate = acc[mi][1][r] * p.alpha + bg;
-                    stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
-                }
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma(af[mi], bf[ni], acc[mi][ni]);
         }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
-                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // buffer `cur` may be refilled next iteration
+        asm volatile("" ::: "memory");
     }
-    __syncthreads();
+    if (nkt == 0) __syncthreads();
+    tile_epilogue<T, MI, NI>(p, acc, smem, m0, n0, o_zoff);
+}
 
-    const int n_out = geglu ? p.N / 2 : p.N;
-    const int no0 = geglu ? n0 / 2 : n0;
-    const int vec_per_row = BNO / 8;
-    for (int v = tid; v < BM * vec_per_row; v += kThreads) {
-        const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
-        const int m = m0 + ml, n = no0 + n8 * 8;
-        if (m >= p.M || n >= n_out) continue;
-        float f[8];
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
-        f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
-        f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
-        if (p.splitk > 1) {
-            float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
-            *reinterpret_cast<f32x4*>(o) = s0;
-            *reinterpret_cast<f32x4*>(o + 4) = s1;
-            continue;
-        }
-        finish_vector<T>(p, f, m, n, !geglu, o_zoff);
+template <typename T, bool SPATIAL>
+int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int lds = 2 * (128 + 128) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
     }
+    const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
+    dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
+    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
+        int64_t blocks = (nvec + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        EDTR_LAUNCH_CHECK();
+    }
+    return EDTR_OK;
 }
 
 template <typename T, int MI, int NI, bool SPATIAL>
@@ -319,6 +523,7 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
+    if (tile == 3) return spatial ? launch_dma<T, true>(p, s) : launch_dma<T, false>(p, s);
     if (tile == 1) return spatial ? launch<T, 2, 2, true>(p, s) : launch<T, 2, 2, false>(p, s);
     return spatial ? launch<T, 1, 1, true>(p, s) : launch<T, 1, 1, false>(p, s);
 }
@@ -373,8 +578,12 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.Z;
         tile = big >= 200 ? 1 : 2;
     }
-    if (p.act == EDTR_ACT_GEGLU) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
-    if (tile != 1 && tile != 2) return EDTR_E_DTYPE;
+    if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
+    // the LDS-DMA main loop needs every 64-wide K-tile inside one tap of one source
+    const bool dma_ok = p.C2 == 0 && (p.C1 & 63) == 0;
+    if (tile == 1 && dma_ok && !p.tile) tile = 3;
+    if (tile == 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
+    if (tile < 1 || tile > 3) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

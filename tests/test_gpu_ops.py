@@ -46,7 +46,10 @@ def nhwc16(x, dtype, pad_to=None):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,tile", [(256, 128, 64, 1), (300, 72, 200, 2), (4096, 320, 320, 0), (77, 640, 1024, 0),
-                                        (8, 1280, 320, 2), (130, 136, 72, 1)])
+                                        (8, 1280, 320, 2), (130, 136, 72, 1),
+                                        # tile 3 = LDS-DMA main loop (K % 64 == 0)
+                                        (256, 128, 64, 3), (300, 72, 192, 3), (4096, 320, 320, 3), (130, 136, 128, 3),
+                                        (77, 640, 1024, 3), (8, 1280, 320, 3)])
 def test_gemm_bias_residual(dtype, M, N, K, tile):
     ops = _ops()
     a = rnd((M, K), 1).to(dtype)
@@ -71,7 +74,8 @@ def test_gemm_bias_residual(dtype, M, N, K, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,S,tile", [(512, 256, 1152, 4, 1), (100, 72, 640, 10, 2), (64, 1280, 2880, 7, 1)])
+@pytest.mark.parametrize("M,N,K,S,tile", [(512, 256, 1152, 4, 1), (100, 72, 640, 10, 2), (64, 1280, 2880, 7, 1),
+                                          (512, 256, 1152, 4, 3), (100, 72, 640, 10, 3), (64, 1280, 2880, 45, 3)])
 def test_gemm_splitk(dtype, M, N, K, S, tile):
     """Split-K: fp32 partial slabs + reducer with the full epilogue (bias, row vector, SiLU-free residual)."""
     ops = _ops()
@@ -172,8 +176,12 @@ def test_gemm_batched_strided(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", ["s1", "s2", "vae_down", "up", "concat", "small_cin", "small_cout"])
+@pytest.mark.parametrize("case", ["s1", "s2", "vae_down", "up", "concat", "small_cin", "small_cout",
+                                  "s1_dma", "s2_dma", "vae_down_dma", "up_dma", "small_cout_dma"])
 def test_conv3x3(dtype, case):
+    tile = 0
+    if case.endswith("_dma"):
+        case, tile = case[:-4], 3
     ops = _ops()
     d = dev()
     B, H, W = 2, 12, 20
@@ -221,7 +229,7 @@ def test_conv3x3(dtype, case):
     ops.launch(ops.make_igemm(dtype=dtype, a1=xr16, a2=(x216 if case == "concat" else None), w=wp, out=out, taps=9,
                               M=B * OH * OW, N=N, C1=cinp, C2=c2, ld1=cinp, ld2=c2, ldw=wp.shape[1], ldc=N,
                               spatial=(H, W, OH, OW, stride, pad_tl, pad_tl, int(ups)), bias_n=bp, rowvec=emb,
-                              rowvec_ld=N, rows_per_image=OH * OW, residual=res, ldr=N))
+                              rowvec_ld=N, rows_per_image=OH * OW, residual=res, ldr=N, tile=tile))
     torch.cuda.synchronize()
     got = out.float().cpu()[..., :cout].permute(0, 3, 1, 2)
     full_ref = ref + emb.cpu()[:, :cout, None, None] + res.float().cpu()[..., :cout].permute(0, 3, 1, 2)

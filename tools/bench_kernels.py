@@ -67,7 +67,7 @@ def bench_gemm(M, N, K, tile=0, act=0, residual=False):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     B = int(os.environ.get("B", "8"))
-    tiles = [int(t) for t in os.environ.get("TILES", "1,2").split(",")]
+    tiles = [int(t) for t in os.environ.get("TILES", "1,2,3").split(",")]
     if what in ("conv", "all"):
         print(f"--- conv3x3 (B={B}) ---")
         shapes = [(64, 320, 320), (64, 640, 320), (64, 960, 320), (64, 640, 640), (32, 320, 640), (32, 640, 640),
@@ -92,7 +92,7 @@ def main():
         print(f"--- conv3x3 split-K sweep (B={B}) ---")
         for H, ci, co in [(8, 1280, 1280), (8, 2560, 1280), (16, 1280, 1280), (16, 2560, 1280), (16, 640, 1280), (32, 640, 640)]:
             row = f"H={H:4d} {ci:5d}->{co:5d}"
-            for t in (1, 2):
+            for t in (1, 3):
                 for S in (1, 2, 4, 8, 16):
                     ms, tf = bench_conv(B, H, ci, co, tile=t, extra={"splitk": S})
                     row += f" | t{t}s{S}: {ms:6.3f} {tf:5.0f}"
