@@ -75,6 +75,7 @@ def main() -> None:
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.model import ControlLDM
     from edtr_amd.model.params import skip_init
+    from edtr_amd.parallel import broadcast_parameters, shard_slice
     from edtr_amd.sampler import SpacedSampler
     from edtr_amd.testing import flat_oracle_sd, injected_noise, rel_err, synthetic_state_dicts
 
@@ -98,25 +99,8 @@ def main() -> None:
         cldm.vae.load_state_dict(sds["vae"], strict=True)
     cldm = cldm.eval().to(dev)
     if world > 1:
-        params = [p for p in cldm.parameters()]
-        bucket, size = [], 0
-        def flush():
-            if not bucket:
-                return
-            flat = torch.cat([p.data.reshape(-1) for p in bucket])
-            dist.broadcast(flat, src=0)
-            o = 0
-            for p in bucket:
-                n = p.numel()
-                p.data.copy_(flat[o:o + n].view_as(p.data))
-                o += n
-        for p in params:
-            bucket.append(p)
-            size += p.numel() * 4
-            if size >= (1 << 29):   # 512 MiB buckets: few, large messages (ring broadcast is per-link bound)
-                flush()
-                bucket, size = [], 0
-        flush()
+        calls, nbytes = broadcast_parameters(cldm, src=0)
+        log(f"[rank {rank}] weights broadcast over RCCL: {calls} collectives, {nbytes / 2**30:.2f} GiB")
     log(f"[rank {rank}] model ready in {time.time() - t0:.1f}s")
 
     diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
@@ -124,7 +108,7 @@ def main() -> None:
 
     # ---- synthetic inputs for the GLOBAL batch, sliced per rank (results independent of the GPU count)
     GB = B * world
-    sl = slice(rank * B, (rank + 1) * B)
+    sl = shard_slice(rank, world, GB)
     pre_res_g = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)
     c_txt1 = synth.synth_normal("bench:c_txt", (1, 77, ctx_dim))
     noises_g = [synth.synth_normal(f"bench:noise{i}", (GB, 4, h, h)) for i in range(5)]

@@ -1,0 +1,160 @@
+"""Host-side logic that needs no GPU: schedules, respacing, tile geometry, state-dict compatibility with the
+reference manifests, weight packing, arena, split-K heuristic, error behaviour."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from edtr_amd import arch, ops, synth
+from edtr_amd.diffusion import Diffusion, make_beta_schedule
+from edtr_amd.engine import Arena
+from edtr_amd.model import ControlLDM
+from edtr_amd.model.params import skip_init
+from edtr_amd.parallel import bucketize, shard_slice
+from edtr_amd.sampler import SpacedSampler, space_timesteps
+from edtr_amd.tiling import gaussian_weights, sliding_windows
+
+TABLES = ["sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+          "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]
+
+
+def test_diffusion_and_sampler_tables_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    d = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    np.testing.assert_array_equal(d.betas, g["betas"])
+    np.testing.assert_array_equal(d.sqrt_alphas_cumprod.numpy(), g["q_sqrt_ac"])
+    np.testing.assert_array_equal(d.sqrt_one_minus_alphas_cumprod.numpy(), g["q_sqrt_1mac"])
+    s = SpacedSampler(d.betas)
+    s.make_schedule(4, [50, 100, 150, 200])
+    for n in TABLES:
+        np.testing.assert_array_equal(getattr(s, n).numpy(), g["s4_" + n])
+    np.testing.assert_array_equal(s.timesteps, g["s4_timesteps"])
+    a, b, c1, c2, sigma = s._coefs(0)
+    assert sigma == 0.0 and c1 == 1.0 and c2 == 0.0           # last step: x_prev = pred_x0, noise masked
+    s.make_schedule(50)
+    for n in TABLES:
+        np.testing.assert_array_equal(getattr(s, n).numpy(), g["s50_" + n])
+    np.testing.assert_array_equal(s.timesteps, g["s50_timesteps"])
+    s.make_schedule(1, [200])
+    assert float(s.posterior_log_variance_clipped[0]) == -10.0
+
+
+def test_space_timesteps_and_errors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    np.testing.assert_array_equal(sorted(space_timesteps(1000, "50")), g["space_1000_50"])
+    np.testing.assert_array_equal(sorted(space_timesteps(300, [10, 15, 20])), g["space_1000_10_15_20"])
+    np.testing.assert_array_equal(sorted(space_timesteps(1000, "ddim25")), g["space_ddim25"])
+    with pytest.raises(ValueError):
+        space_timesteps(10, [20])
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim999")
+    with pytest.raises(ValueError):
+        make_beta_schedule("nope", 10)
+
+
+def test_tiling_geometry(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiled.npz"))
+    np.testing.assert_allclose(gaussian_weights(64, 64), g["gauss_64"], rtol=1e-12)
+    np.testing.assert_array_equal(np.array(sliding_windows(128, 128, 64, 32)), g["win_128_128_64_32"])
+    np.testing.assert_array_equal(np.array(sliding_windows(72, 96, 64, 32)), g["win_72_96_64_32"])
+    np.testing.assert_array_equal(np.array(sliding_windows(16, 24, 8, 4)), g["win_16_24_8_4"])
+    assert sliding_windows(64, 64, 64, 32) == [(0, 64, 0, 64)]          # single window when the tile covers the latent
+
+
+@pytest.mark.parametrize("name", ["tiny", "sd21"])
+def test_state_dict_spec_equals_reference_manifest(golden_dir, name):
+    man = json.load(open(os.path.join(golden_dir, f"manifest_{name}.json")))
+    cfg = synth.CONFIGS[name]()
+    specs = {"unet": arch.unet_param_spec(arch.unet_arch(cfg["unet_cfg"])),
+             "controlnet": arch.unet_param_spec(arch.unet_arch(cfg["controlnet_cfg"], controlnet=True)),
+             "vae": arch.vae_param_spec(cfg["vae_cfg"])}
+    for part, spec in specs.items():
+        assert [[k, list(s)] for k, s in spec] == man[part], part       # names, shapes AND order
+
+
+def test_strict_checkpoint_loading_tiny():
+    cfg = synth.tiny_config()
+    with skip_init():
+        m = ControlLDM(**cfg)
+    from edtr_amd.testing import synthetic_state_dicts
+    sds = synthetic_state_dicts(cfg)
+    sd_ckpt = {f"model.diffusion_model.{k}": v for k, v in sds["unet"].items()}
+    sd_ckpt.update({f"first_stage_model.{k}": v for k, v in sds["vae"].items()})
+    sd_ckpt["cond_stage_model.model.positional_embedding"] = torch.zeros(77, 64)
+    unused = m.load_pretrained_sd(sd_ckpt)
+    assert unused == {"cond_stage_model.model.positional_embedding"}
+    assert torch.equal(m.unet.state_dict()["out.2.weight"], sds["unet"]["out.2.weight"])
+    m.load_controlnet_from_ckpt(sds["controlnet"])
+    bad = dict(sds["controlnet"])
+    bad.pop("zero_convs.0.0.weight")
+    with pytest.raises(RuntimeError):
+        m.load_controlnet_from_ckpt(bad)                                # strict=True, as the reference
+    zero_keys, scratch_keys = m.load_controlnet_from_unet()
+    assert zero_keys == {"input_blocks.0.0.weight"}
+    w = m.controlnet.state_dict()["input_blocks.0.0.weight"]
+    assert w.shape[1] == 8 and float(w[:, 4:].abs().max()) == 0.0       # hint half zero-initialised
+    assert all(k.startswith(("zero_convs.", "middle_block_out.")) for k in scratch_keys)
+    m.vae.decoder.load_state_dict({k[len("decoder."):]: v for k, v in sds["vae"].items() if k.startswith("decoder.")},
+                                  strict=True)                          # demo.py:53 call shape
+
+
+def test_unsupported_configs_and_cpu_inputs_raise():
+    cfg = synth.tiny_config()
+    with pytest.raises(NotImplementedError):
+        arch.unet_arch(dict(cfg["unet_cfg"], num_head_channels=32))
+    with pytest.raises(NotImplementedError):
+        ControlLDM(**cfg, tail_block=True)
+    with skip_init():
+        m = ControlLDM(**cfg)
+    x = torch.zeros(1, 4, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, torch.zeros(1, dtype=torch.long), {"c_txt": torch.zeros(1, 77, 64), "c_img": x})
+    with pytest.raises(RuntimeError, match="set_embedding"):
+        m.clip.encode([""])
+    m.clip.set_embedding(torch.ones(1, 77, 64))
+    assert m.clip.encode(["", ""]).shape == (2, 77, 64)
+
+
+def test_weight_packing():
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = ops.pack_conv_weight(w, torch.float16, cin_pad=8)
+    assert p.shape == (8, 72)
+    assert float(p[1, (1 * 3 + 2) * 8 + 2]) == float(w[1, 2, 1, 2])      # [cout][ky][kx][cin]
+    assert float(p[:, 3:8].abs().max()) == 0.0 and float(p[2:].abs().max()) == 0.0
+    perm = ops.geglu_perm(64)
+    assert perm[:32].tolist() == list(range(32)) and perm[32:64].tolist() == list(range(64, 96))
+    assert perm[64:96].tolist() == list(range(32, 64)) and sorted(perm.tolist()) == list(range(128))
+
+
+def test_splitk_heuristic_and_arena():
+    assert ops.choose_splitk(32768, 320, 2880) == (0, 1)                 # fills the chip already
+    tile, s = ops.choose_splitk(512, 1280, 11520)
+    assert tile == 1 and 4 <= s <= 8
+    assert ops.choose_splitk(512, 1280, 11520, act=1) == (0, 1)          # GEGLU epilogue cannot be split
+    a = Arena(torch.device("cpu"), chunk_bytes=1 << 16)
+    t1 = a.alloc((100, 8), torch.float32)
+    t2 = a.alloc((64,), torch.float16)
+    p1 = t1.data_ptr()
+    a.free(t1[:, :4])            # a view never frees its owner
+    assert p1 in a.live
+    a.free(t1)
+    t3 = a.alloc((50, 8), torch.float32)
+    assert t3.data_ptr() == p1   # first fit reuses the hole
+    a.free(t2), a.free(t3)
+    assert a.in_use == 0 and len(a.free_lists[0]) == 1
+
+
+def test_batch_sharding_helpers():
+    cover = []
+    for r in range(8):
+        s = shard_slice(r, 8, 64)
+        cover += list(range(64))[s]
+    assert cover == list(range(64))
+    sizes = [len(range(10)[shard_slice(r, 4, 10)]) for r in range(4)]
+    assert sizes == [3, 3, 2, 2]
+    with pytest.raises(ValueError):
+        shard_slice(4, 4, 8)
+    ts = [torch.zeros(n) for n in (10, 20, 30, 40)]
+    assert [len(b) for b in bucketize(ts, 100)] == [2, 1, 1]      # 40+80 B, 120 B, 160 B
