@@ -330,7 +330,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
 // multiplied: counted s_waitcnt vmcnt(8) + raw s_barrier (a __syncthreads() would drain the prefetch).
 // Requires (C1 % 64 == 0, C2 == 0): every 64-wide K-tile lies inside one filter tap.
 // ------------------------------------------------------------------------------------------------------
-template <typename T, bool SPATIAL>
+template <typename T, bool SPATIAL, bool FAST>
 __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm_params p) {
     constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
@@ -386,8 +386,57 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         w_ok[j] = n < nvalid;
         w_row[j] = (int64_t)n * p.ldw;
     }
+    // FAST path (no upsample): per-row byte address of filter tap (0,0) + a 9-bit "tap in range" mask, computed once;
+    // a K-tile then costs one scalar delta, a 64-bit add and a select per row instead of the full coordinate math.
+    const char* a_base[4];
+    const char* w_base[4];
+    uint32_t a_mask[4];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t pix0;
+            uint32_t mask = 0;
+            if (SPATIAL) {
+                pix0 = (int64_t)a_pix[j] + (int64_t)a_iy0[j] * p.IW + a_ix0[j];
+                const int ntap = p.taps;
+                for (int t = 0; t < ntap; ++t) {
+                    const int ky = ntap == 9 ? (t * 11) >> 5 : 0, kx = ntap == 9 ? t - 3 * ky : 0;
+                    const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                    if (a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
+                }
+            } else {
+                pix0 = a_pix[j];
+                mask = a_ok[j] ? 1u : 0u;
+            }
+            a_mask[j] = mask;
+            a_base[j] = reinterpret_cast<const char*>(a1) + (pix0 * p.ld1 + coff[j]) * 2;
+            w_base[j] = reinterpret_cast<const char*>(wp) + (w_row[j] + coff[j]) * 2;
+        }
+    }
+    int run_tap = 0, run_c0 = 0;   // (tap, channel offset) of the NEXT tile to issue; tiles are issued in order
 
     auto issue_tile = [&](int kt, int buf) {
+        if constexpr (FAST) {
+            const int tap = run_tap, c0 = run_c0;
+            run_c0 += BK;
+            if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int64_t da = SPATIAL ? ((int64_t)(ky * p.IW + kx) * p.ld1 + c0) * 2 : (int64_t)kt * (BK * 2);
+            const int64_t dw = (int64_t)kt * (BK * 2);
+            const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
+            const uint32_t sw = sa + A_BYTES;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const void* src = ((a_mask[j] >> tap) & 1u) ? static_cast<const void*>(a_base[j] + da) : zsrc;
+                dma16(src, sa + j * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const void* src = w_ok[j] ? static_cast<const void*>(w_base[j] + dw) : zsrc;
+                dma16(src, sw + j * 1024);
+            }
+            return;
+        }
         const int k0 = kt * BK;
         int c0 = k0, ky = 0, kx = 0;
         if (SPATIAL && p.taps == 9) {
@@ -436,6 +485,10 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         nkt = min(per, nkt_all - kt0);
         if (nkt < 0) nkt = 0;
     }
+    if (SPATIAL && p.taps == 9) {
+        run_tap = (kt0 * BK) / Cin;
+        run_c0 = kt0 * BK - run_tap * Cin;
+    }
     if (nkt > 0) issue_tile(kt0, 0);
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -473,18 +526,18 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     tile_epilogue<T, MI, NI>(p, acc, smem, m0, n0, o_zoff);
 }
 
-template <typename T, bool SPATIAL>
+template <typename T, bool SPATIAL, bool FAST>
 int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int lds = 2 * (128 + 128) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
-    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
     if (p.splitk > 1) {
         const int64_t nvec = (int64_t)p.M * (p.N >> 3);
@@ -523,7 +576,10 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile == 3) return spatial ? launch_dma<T, true>(p, s) : launch_dma<T, false>(p, s);
+    if (tile == 3) {
+        if (!spatial) return launch_dma<T, false, true>(p, s);
+        return p.upsample2x ? launch_dma<T, true, false>(p, s) : launch_dma<T, true, true>(p, s);
+    }
     if (tile == 1) return spatial ? launch<T, 2, 2, true>(p, s) : launch<T, 2, 2, false>(p, s);
     return spatial ? launch<T, 1, 1, true>(p, s) : launch<T, 1, 1, false>(p, s);
 }
