@@ -318,6 +318,29 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr) {
                  : "memory");
 }
 
+// Buffer-addressed LDS-DMA: address = SRD base + voff (per lane) + soff (wave uniform); lanes whose voff fails the
+// descriptor's range check write zeros.
+constexpr uint32_t kOobOffset = 0xFFFFFF00u;     // >= num_records - 15 -> always out of range
+constexpr uint32_t kNumRecords = 0xFFFFFF00u;
+
+__device__ __forceinline__ u32x4 make_srd(const void* base) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    u32x4 srd;
+    srd.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    srd.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);   // stride 0 (raw buffer)
+    srd.z = kNumRecords;
+    srd.w = 0x00020000u;
+    return srd;
+}
+
+__device__ __forceinline__ void dma16_buf(uint32_t voff, const u32x4& srd, uint32_t soff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
+                 : "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
     return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
@@ -386,31 +409,34 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         w_ok[j] = n < nvalid;
         w_row[j] = (int64_t)n * p.ldw;
     }
-    // FAST path (no upsample): per-row byte address of filter tap (0,0) + a 9-bit "tap in range" mask, computed once;
-    // a K-tile then costs one scalar delta, a 64-bit add and a select per row instead of the full coordinate math.
-    const char* a_base[4];
-    const char* w_base[4];
-    uint32_t a_mask[4];
+    // FAST path (no upsample, tensors < 4 GiB): buffer-addressed LDS-DMA.  Each lane keeps ONE constant 32-bit byte
+    // offset per row (its pixel's centre tap / its weight row) and a 9-bit "tap in range" mask; a K-tile only moves the
+    // wave-uniform soffset (SALU).  Halo / tail lanes present an out-of-range offset and the buffer range check makes
+    // the DMA write zeros (verified on gfx950: tools/exp/buffer_lds_probe.hip) — no zero page, no 64-bit VALU address math.
+    uint32_t voff_a[4], voff_w[4], a_mask[4];
+    u32x4 srd_a, srd_w;
     if constexpr (FAST) {
+        const int64_t bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
+        srd_a = make_srd(reinterpret_cast<const char*>(a1) - bias);
+        srd_w = make_srd(wp);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int64_t pix0;
             uint32_t mask = 0;
             if (SPATIAL) {
-                pix0 = (int64_t)a_pix[j] + (int64_t)a_iy0[j] * p.IW + a_ix0[j];
+                const int64_t pc = (int64_t)a_pix[j] + (int64_t)(a_iy0[j] + p.pad_t) * p.IW + (a_ix0[j] + p.pad_l);
+                voff_a[j] = (uint32_t)((pc * p.ld1 + coff[j]) * 2);
                 const int ntap = p.taps;
                 for (int t = 0; t < ntap; ++t) {
-                    const int ky = ntap == 9 ? (t * 11) >> 5 : 0, kx = ntap == 9 ? t - 3 * ky : 0;
+                    const int ky = ntap == 9 ? (t * 11) >> 5 : p.pad_t, kx = ntap == 9 ? t - 3 * ky : p.pad_l;
                     const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
                     if (a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
                 }
             } else {
-                pix0 = a_pix[j];
-                mask = a_ok[j] ? 1u : 0u;
+                voff_a[j] = a_ok[j] ? (uint32_t)(((int64_t)a_pix[j] * p.ld1 + coff[j]) * 2) : kOobOffset;
+                mask = 1u;
             }
             a_mask[j] = mask;
-            a_base[j] = reinterpret_cast<const char*>(a1) + (pix0 * p.ld1 + coff[j]) * 2;
-            w_base[j] = reinterpret_cast<const char*>(wp) + (w_row[j] + coff[j]) * 2;
+            voff_w[j] = w_ok[j] ? (uint32_t)((w_row[j] + coff[j]) * 2) : kOobOffset;
         }
     }
     int run_tap = 0, run_c0 = 0;   // (tap, channel offset) of the NEXT tile to issue; tiles are issued in order
@@ -420,21 +446,24 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
             const int tap = run_tap, c0 = run_c0;
             run_c0 += BK;
             if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
-            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-            const int64_t da = SPATIAL ? ((int64_t)(ky * p.IW + kx) * p.ld1 + c0) * 2 : (int64_t)kt * (BK * 2);
-            const int64_t dw = (int64_t)kt * (BK * 2);
+            uint32_t soff_a, tapbit = 1u;
+            if (SPATIAL) {
+                int ky = p.pad_t, kx = p.pad_l;     // 1x1 conv in spatial mode: the centre tap
+                if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
+                soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + c0) * 2);
+            } else {
+                soff_a = (uint32_t)kt * (BK * 2);
+            }
+            const uint32_t soff_w = (uint32_t)kt * (BK * 2);
             const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
             const uint32_t sw = sa + A_BYTES;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const void* src = ((a_mask[j] >> tap) & 1u) ? static_cast<const void*>(a_base[j] + da) : zsrc;
-                dma16(src, sa + j * 1024);
+                const uint32_t vo = SPATIAL ? ((a_mask[j] & tapbit) ? voff_a[j] : kOobOffset) : voff_a[j];
+                dma16_buf(vo, srd_a, soff_a, sa + j * 1024);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const void* src = w_ok[j] ? static_cast<const void*>(w_base[j] + dw) : zsrc;
-                dma16(src, sw + j * 1024);
-            }
+            for (int j = 0; j < 4; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
             return;
         }
         const int k0 = kt * BK;
@@ -577,8 +606,13 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
     if (tile == 3) {
-        if (!spatial) return launch_dma<T, false, true>(p, s);
-        return p.upsample2x ? launch_dma<T, true, false>(p, s) : launch_dma<T, true, true>(p, s);
+        // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
+        const int64_t a_rows = spatial ? (int64_t)(p.M / (p.OH * p.OW)) * p.IH * p.IW : p.M;
+        const int64_t a_bytes = (a_rows + (spatial ? 3 * (int64_t)p.IW + 3 : 0)) * p.ld1 * 2 + (int64_t)p.K * 2;
+        const int64_t w_bytes = (int64_t)p.N * p.ldw * 2 + (int64_t)p.K * 2;
+        const bool fast = !p.upsample2x && a_bytes < 0xF0000000LL && w_bytes < 0xF0000000LL;
+        if (!spatial) return fast ? launch_dma<T, false, true>(p, s) : launch_dma<T, false, false>(p, s);
+        return fast ? launch_dma<T, true, true>(p, s) : launch_dma<T, true, false>(p, s);
     }
     if (tile == 1) return spatial ? launch<T, 2, 2, true>(p, s) : launch<T, 2, 2, false>(p, s);
     return spatial ? launch<T, 1, 1, true>(p, s) : launch<T, 1, 1, false>(p, s);

@@ -68,6 +68,13 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     B = int(os.environ.get("B", "8"))
     tiles = [int(t) for t in os.environ.get("TILES", "1,2,3").split(",")]
+    if what == "one":      # python tools/bench_kernels.py one H Cin Cout tile [stride] [ups]   (for rocprofv3 --pmc runs)
+        H, ci, co, t = (int(v) for v in sys.argv[2:6])
+        st = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+        up = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
+        ms, tf = bench_conv(B, H, ci, co, stride=st, ups=up, tile=t)
+        print(f"one: H={H} {ci}->{co} tile{t} s{st} up{int(up)}: {ms:.3f} ms {tf:.1f} TF")
+        return
     if what in ("conv", "all"):
         print(f"--- conv3x3 (B={B}) ---")
         shapes = [(64, 320, 320), (64, 640, 320), (64, 960, 320), (64, 640, 640), (32, 320, 640), (32, 640, 640),
