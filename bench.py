@@ -47,6 +47,7 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
     ap.add_argument("--no-graph", action="store_true", help="replay launch lists eagerly instead of hipGraphs")
+    ap.add_argument("--serial-lanes", action="store_true", help="capture ControlNet and the UNet encoder on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-name time table to stderr")
@@ -139,7 +140,7 @@ def main() -> None:
     log(f"[rank {rank}] first pass (program build + weight packing) {time.time() - t0:.1f}s")
     if not args.no_graph:
         for e in cldm._cldm_engines.values():
-            e.step_prog.capture()
+            e.step_prog.capture(parallel_lanes=not args.serial_lanes)
         for e in cldm._vae_engines.values():
             e.prog.capture()
     for _ in range(max(0, args.warmup - 1) + (0 if args.no_graph else 1)):

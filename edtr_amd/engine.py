@@ -150,19 +150,35 @@ class WeightStore:
 # ----------------------------------------------------------------------------------------------
 class Program:
     """A flat launch list.  ``run()`` replays it on torch's current stream; ``capture()`` turns it into a
-    hipGraph; ``run_timed()`` brackets every launch with events on the same stream."""
+    hipGraph; ``run_timed()`` brackets every launch with events on the same stream.
+
+    Launches may be tagged with a lane: between ``fork()`` and ``join()`` the lane-1 launches are independent of the
+    lane-0 launches that follow them in the list (e.g. ControlNet vs the UNet encoder).  Eager replay ignores lanes
+    (list order is a valid serial order); graph capture puts lane 1 on a second stream so the hipGraph gets two
+    parallel branches and small kernels of one branch fill the CUs the other leaves idle."""
 
     def __init__(self, name: str):
         self.name = name
         self.recs: List[Rec] = []
+        self.lanes: List[int] = []
+        self.marks: Dict[int, str] = {}     # index into recs -> "fork" / "join" placed BEFORE that launch
+        self.lane = 0
         self.graph = None
 
     def add(self, rec: Rec) -> Rec:
         self.recs.append(rec)
+        self.lanes.append(self.lane)
         return rec
 
-    def extend(self, other: "Program") -> None:
-        self.recs.extend(other.recs)
+    def fork(self) -> None:
+        self.marks[len(self.recs)] = "fork"
+
+    def join(self) -> None:
+        self.marks[len(self.recs)] = "join"
+        self.lane = 0
+
+    def set_lane(self, lane: int) -> None:
+        self.lane = lane
 
     def run(self) -> None:
         s = ops.stream_ptr()
@@ -172,17 +188,34 @@ class Program:
         for r in self.recs:
             r.launch(s)
 
-    def capture(self) -> None:
-        """Capture on a side stream (hipGraph), then replay with one launch per run()."""
+    def capture(self, parallel_lanes: bool = True) -> None:
+        """Capture on side streams (hipGraph), then replay with one launch per run()."""
         lib = L.load()
         side = torch.cuda.Stream()
+        side2 = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            sp = side.cuda_stream
+            sp, sp2 = side.cuda_stream, side2.cuda_stream
             L.check(lib.edtr_graph_begin(sp), "graph_begin")
+            forked = False
             try:
-                for r in self.recs:
-                    r.launch(sp)
+                for i, r in enumerate(self.recs):
+                    mark = self.marks.get(i)
+                    if mark == "fork" and parallel_lanes:
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        side2.wait_event(ev)          # side2 joins the capture
+                        forked = True
+                    elif mark == "join" and forked:
+                        ev = torch.cuda.Event()
+                        ev.record(side2)
+                        side.wait_event(ev)
+                        forked = False
+                    r.launch(sp2 if (forked and self.lanes[i] == 1) else sp)
+                if forked:
+                    ev = torch.cuda.Event()
+                    ev.record(side2)
+                    side.wait_event(ev)
             finally:
                 g = ct.c_void_p()
                 code = lib.edtr_graph_end(sp, ct.byref(g))

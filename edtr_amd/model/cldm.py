@@ -141,9 +141,16 @@ class CldmEngine:
         em.to_nhwc(self.x_in, B, ua.in_channels, hw, x8u, coff=0, pad_to=arch_round8(ua.in_channels))
         tab_c, offs_c = nets.emit_time_rows(em, "controlnet.", ca, self.t_in, B)
         tab_u, offs_u = nets.emit_time_rows(em, "unet.", ua, self.t_in, B)
-        ctrl = nets.emit_controlnet(em, "controlnet.", ca, Act(x8c, B, h, w, x8c.shape[1]), tab_c, offs_c, self.kv_c,
+        # ControlNet (lane 1, own arena) is independent of the UNet encoder + middle block (lane 0): two graph branches
+        self.arena_cn = Arena(dev)
+        em_cn = Emitter(self.step_prog, self.arena_cn, store, dt)
+        self.step_prog.fork()
+        self.step_prog.set_lane(1)
+        ctrl = nets.emit_controlnet(em_cn, "controlnet.", ca, Act(x8c, B, h, w, x8c.shape[1]), tab_c, offs_c, self.kv_c,
                                     list(owner.control_scales))
-        eps = nets.emit_unet(em, "unet.", ua, Act(x8u, B, h, w, x8u.shape[1]), tab_u, offs_u, self.kv_u, ctrl)
+        self.step_prog.set_lane(0)
+        eps = nets.emit_unet(em, "unet.", ua, Act(x8u, B, h, w, x8u.shape[1]), tab_u, offs_u, self.kv_u, ctrl,
+                             before_control=self.step_prog.join)
         em.to_nchw(eps, B, ua.out_channels, hw, self.eps_out)
 
     def set_context(self, c_txt: torch.Tensor) -> None:

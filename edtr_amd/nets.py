@@ -197,7 +197,8 @@ def emit_controlnet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, 
     return outs
 
 
-def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, control: Optional[List[Act]]) -> torch.Tensor:
+def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, control: Optional[List[Act]],
+              before_control=None) -> torch.Tensor:
     """model/controlnet.py:20-41 (ControlledUnetModel.forward) + output head model/unet.py:675-679.
     Returns the fp32 NHWC eps [B*h*w, 8] (first out_channels columns valid)."""
     control = list(control) if control is not None else None
@@ -207,6 +208,8 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
         h = emit_block(em, P, layers, h, table, offs, kv, keep_input=True)
         hs.append(h)
     mid = emit_block(em, P, a.middle, h, table, offs, kv, keep_input=True)
+    if before_control is not None:
+        before_control()      # e.g. Program.join(): everything above is independent of the ControlNet
 
     # first decoder input: cat([mid + control_mid, hs[-1] + control[-2]])
     skip = hs.pop()
