@@ -1,15 +1,19 @@
 // Fused attention, head width 64, for gfx950 (see include/edtr_hip.h: edtr_flash_attn64).
 //
 // One workgroup = 4 waves = 128 queries of one (image, head); each wave owns 32 queries.
-// Per 64-key tile a wave computes S^T = K Q^T (keys on the MFMA rows, queries on the lanes), so a
-// lane holds 32 of the 64 scores of ITS query in registers: the row max / row sum are in-lane
-// reductions plus one exchange with lane^32 (wavefront shuffle), never through LDS.
-// The probabilities are converted to 16-bit in registers and fed straight back as the B operand of
-// O^T += V^T P^T ("accumulator tile as the next MFMA's operand"): K rows are read from LDS in an
-// order with bits 2,3 of the row swapped, which makes registers 8s..8s+7 of a score accumulator
-// exactly keys 16s+8h..16s+8h+7 — the natural k order of the V^T fragment (one ds_read_b128).
-// V arrives key-major (V^T, written that way by the projection GEMM), so no transposed read is
-// needed.  K / V^T tiles are staged global -> registers -> LDS, double buffered, one barrier per tile.
+// Per 64-key tile a wave computes S^T = K Q^T (keys on the MFMA rows, queries on the lanes), so a lane holds 32 of
+// the 64 scores of ITS query in registers: the row max / row sum are in-lane reductions plus one exchange with
+// lane^32 (wavefront shuffle), never through LDS.  The probabilities are converted to 16-bit in registers (one
+// v_cvt_pk per pair) and fed straight back as the B operand of O^T += V^T P^T ("accumulator tile as the next MFMA's
+// operand"): K rows are read from LDS in an order with bits 2,3 of the row swapped, which makes registers 8s..8s+7
+// of a score accumulator exactly keys 16s+8h..16s+8h+7 — the natural k order of the V^T fragment (one ds_read_b128).
+// V arrives key-major (V^T, written that way by the projection GEMM), so no transposed read is needed.
+//
+// K / V^T tiles go global -> LDS by buffer-addressed LDS-DMA (no VGPR staging, no ds_write; keys >= Nk fail the
+// buffer range check and land as zeros), double buffered: tile t+1 is in flight while tile t is consumed
+// (counted s_waitcnt vmcnt + raw s_barrier).  The softmax is VALU-bound at d = 64, so the instruction count per
+// score is kept minimal: exp2 domain (one FMA + one v_exp per score), v_max3 reductions, and the running max is only
+// raised when it grows by more than 2^8 (deferred rescale: O and l are rescaled on <1 % of the tiles).
 #include "common.h"
 
 namespace {
@@ -17,14 +21,35 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int KV = 64;            // keys per tile
 constexpr int TILE_BYTES = 64 * 64 * 2;
+constexpr float kDeferLog2 = 8.0f;   // P <= 2^8 before a rescale is forced (exact in bf16/fp16: only the exponent grows)
+
+constexpr uint32_t kOob = 0xFFFFFF00u;
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+__device__ __forceinline__ u32x4 srd_of(const void* base) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    u32x4 srd;
+    srd.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    srd.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
+    srd.z = 0xFFFFFF00u;
+    srd.w = 0x00020000u;
+    return srd;
+}
+
+__device__ __forceinline__ void dma16(uint32_t voff, const u32x4& srd, uint32_t soff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
+                 : "memory");
+}
 
 template <typename T>
 __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_attn_params p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [2 buffers][K tile | V^T tile]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_row = blockIdx.x * 128 + wave * 32 + l31;
@@ -42,27 +67,30 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
         if (q_ok) qf[ks] = ldg16(qp + (int64_t)q_row * p.q_ld + ks * 16 + lh * 8);
     }
 
-    // tile staging: thread -> chunk column kc, rows (tid>>3) and (tid>>3)+32
-    const int kc = tid & 7, r0 = tid >> 3;
-    U4 rk[2], rv[2];
-    auto load_tile = [&](int t) {
+    // ---- tile staging by LDS-DMA: one instruction = 8 tile rows of 128 bytes; a wave owns rows wave*16 + 8j + (lane>>3)
+    const u32x4 srd_k = srd_of(kp), srd_v = srd_of(vp);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem));
+    const int rsub = lane >> 3, slot = lane & 7;
+    uint32_t koff[2], voff[2];     // constant per-lane byte offsets (tile 0); a tile step only moves the scalar offset
+    int vkey[2], krow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wave * 16 + 8 * j + rsub;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        krow[j] = row;                                      // key index inside the tile
+        koff[j] = (uint32_t)(((int64_t)row * p.k_ld + chunk * 8) * 2);
+        vkey[j] = chunk * 8;                                // first key of this chunk inside the tile
+        voff[j] = (uint32_t)(((int64_t)row * p.vt_ld + chunk * 8) * 2);
+    }
+    auto issue_tile = [&](int t, int buf) {
         const int kv0 = t * KV;
+        const uint32_t sk = smem_base + buf * 2 * TILE_BYTES + wave * (16 * 128);
+        const uint32_t sv = sk + TILE_BYTES;
+        const uint32_t soff_k = (uint32_t)kv0 * (uint32_t)p.k_ld * 2u, soff_v = (uint32_t)kv0 * 2u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = r0 + 32 * i;
-            rk[i] = zero16();
-            if (kv0 + row < p.Nk) rk[i] = ldg16(kp + (int64_t)(kv0 + row) * p.k_ld + kc * 8);
-            rv[i] = zero16();
-            if (kv0 + kc * 8 < p.Nk) rv[i] = ldg16(vp + (int64_t)row * p.vt_ld + kv0 + kc * 8);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* sk = smem + buf * 2 * TILE_BYTES;
-        char* sv = sk + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<U4*>(sk + tile_off(r0 + 32 * i, kc)) = rk[i];
-            *reinterpret_cast<U4*>(sv + tile_off(r0 + 32 * i, kc)) = rv[i];
+        for (int j = 0; j < 2; ++j) {
+            dma16(kv0 + krow[j] < p.Nk ? koff[j] : kOob, srd_k, soff_k, sk + j * 1024);
+            dma16(kv0 + vkey[j] < p.Nk ? voff[j] : kOob, srd_v, soff_v, sv + j * 1024);
         }
     };
 
@@ -70,18 +98,23 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
     float m_run = -1e30f, l_run = 0.0f;
-    const float c = p.scale * 1.4426950408889634f;  // scores are kept raw; exp2(c*s - c*m)
+    const float c = p.scale * 1.4426950408889634f;  // scores are kept raw; p = exp2(c*s - c*m)
+    float mc = m_run * c;
 
     const int nt = (p.Nk + KV - 1) / KV;
-    load_tile(0);
-    store_tile(0);
-    if (nt > 1) load_tile(1);
-    __syncthreads();
-
-    const int krow = swap23(l31);  // LDS row of the K tile feeding MFMA row l31
+    issue_tile(0, 0);
+    const int krd = swap23(l31);  // LDS row of the K tile feeding MFMA row l31
 
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
+        if (t + 1 < nt) {
+            issue_tile(t + 1, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's 4 DMAs of tile t have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         const char* sk = smem + cur * 2 * TILE_BYTES;
         const char* sv = sk + TILE_BYTES;
 
@@ -93,7 +126,7 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const U4 kf = *reinterpret_cast<const U4*>(sk + tile_off(kb * 32 + krow, 2 * ks + lh));
+                const U4 kf = *reinterpret_cast<const U4*>(sk + tile_off(kb * 32 + krd, 2 * ks + lh));
                 s[kb] = T::mfma(kf, qf[ks], s[kb]);
             }
         }
@@ -114,10 +147,16 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        // deferred rescale: keep the old running max unless some row's max grew by more than 2^kDeferLog2
+        if (!__all((mt - m_run) * c <= kDeferLog2)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            mc = m_new * c;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
         float psum = 0.0f;
         U4 pf[2][2];  // [key block][16-key step]: B operand fragments of P^T
 #pragma unroll
@@ -133,11 +172,7 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
             pf[kb][1].x = pack2<T>(pr[8], pr[9]);   pf[kb][1].y = pack2<T>(pr[10], pr[11]);
             pf[kb][1].z = pack2<T>(pr[12], pr[13]); pf[kb][1].w = pack2<T>(pr[14], pr[15]);
         }
-        l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.0f)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-        }
+        l_run += psum;
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -148,12 +183,9 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
                     const U4 vf = *reinterpret_cast<const U4*>(sv + tile_off(db * 32 + l31, kb * 4 + 2 * st + lh));
                     o[db] = T::mfma(vf, pf[kb][st], o[db]);
                 }
-
-        if (t + 1 < nt) {
-            store_tile(cur ^ 1);
-            if (t + 2 < nt) load_tile(t + 2);
-        }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // buffer `cur` is refilled by the next iteration's DMA
+        asm volatile("" ::: "memory");
     }
 
     // ---- normalise and store: lane (q, half) holds d = db*32 + 8g + 4*half + (0..3) in regs 4g..4g+3
@@ -186,6 +218,8 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
         return EDTR_E_ALIGN;
     if (p.vt_ld < ((p.Nk + 7) & ~7)) return EDTR_E_SHAPE;
     if (!aligned16(p.q) || !aligned16(p.k) || !aligned16(p.vt) || !aligned16(p.out)) return EDTR_E_ALIGN;
+    // 32-bit byte offsets inside one (image, head) slice of K and of V^T (buffer addressing)
+    if ((int64_t)(p.Nk + 64) * p.k_ld * 2 >= 0xF0000000LL || (int64_t)64 * p.vt_ld * 2 >= 0xF0000000LL) return EDTR_E_UNSUPPORTED;
     dim3 grid((p.Nq + 127) / 128, p.H, p.B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.dtype == EDTR_BF16)

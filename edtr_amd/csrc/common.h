@@ -7,8 +7,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 
@@ -20,6 +23,11 @@ struct BF16 {
         __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
         return __builtin_bit_cast(uint16_t, b);
     }
+    // two fp32 -> one dword of two bf16 (ONE v_cvt_pk_bf16_f32, RNE)
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    }
     static __device__ __forceinline__ f32x16 mfma(const U4& a, const U4& b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
@@ -30,6 +38,10 @@ struct F16 {
     static __device__ __forceinline__ uint16_t from_f32(float f) {
         _Float16 h = (_Float16)f;
         return __builtin_bit_cast(uint16_t, h);
+    }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // ONE v_cvt_pk_f16_f32 (RNE)
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
     }
     static __device__ __forceinline__ f32x16 mfma(const U4& a, const U4& b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -44,9 +56,7 @@ __device__ __forceinline__ void unpack8(const U4& v, float (&f)[8]) {
     f[6] = T::to_f32((uint16_t)(v.w & 0xffff)); f[7] = T::to_f32((uint16_t)(v.w >> 16));
 }
 template <typename T>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
-}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return T::pack2(lo, hi); }
 template <typename T>
 __device__ __forceinline__ U4 pack8(const float (&f)[8]) {
     U4 v;

@@ -75,6 +75,18 @@ def main():
         ms, tf = bench_conv(B, H, ci, co, stride=st, ups=up, tile=t)
         print(f"one: H={H} {ci}->{co} tile{t} s{st} up{int(up)}: {ms:.3f} ms {tf:.1f} TF")
         return
+    if what == "oneattn":   # python tools/bench_kernels.py oneattn HW C NK
+        hw, c, nk = (int(v) for v in sys.argv[2:5])
+        H = c // 64
+        q, k = rnd(B * hw, c), rnd(B * nk, c)
+        ldv = ops.round_up(nk, 8)
+        vt = rnd(B * c, ldv)
+        out = torch.empty((B * hw, c), dtype=DT, device=dev)
+        rec = ops.make_flash_attn(dtype=DT, q=q, k=k, vt=vt, out=out, B=B, H=H, Nq=hw, Nk=nk, q_bs=hw * c, q_ld=c,
+                                  k_bs=nk * c, k_ld=c, vt_bs=c * ldv, vt_ld=ldv, o_bs=hw * c, o_ld=c, scale=0.125)
+        ms = timeit(rec)
+        print(f"oneattn N={hw} Nk={nk} heads={H}: {ms:.3f} ms {rec.flops / ms / 1e9:.1f} TF")
+        return
     if what in ("conv", "all"):
         print(f"--- conv3x3 (B={B}) ---")
         shapes = [(64, 320, 320), (64, 640, 320), (64, 960, 320), (64, 640, 640), (32, 320, 640), (32, 640, 640),
