@@ -808,6 +808,233 @@ int launch_p3(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Large-tile variant: 256x128 block tile, K-tiles of 64, EIGHT waves (4 along M x 2 along N, 64x64 each), three
+// 48 KiB LDS stages (144 KiB, one workgroup per CU), tile t+2 in flight while tile t is multiplied, one barrier per
+// K-tile.  Per FLOP it pulls 25 % fewer operand bytes through L2 -> LDS than the 128x128 tile (the measured limiter
+// of that kernel on the large convolutions).  Buffer addressing only; the epilogue stages all 256x128 fp32 values.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, bool SPATIAL>
+__global__ void __launch_bounds__(512, 2) igemm_big_kernel(const edtr_igemm_params p) {
+    constexpr int MI = 2, NI = 2, BM = 256, BN = 128, NT = 512;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;   // 48 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
+    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
+    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
+    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    // DMA ownership: A rows wave*32 + 8j + (lane>>3), j < 4;  W rows wave*16 + 8j + (lane>>3), j < 2
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int Cin = p.C1;
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    const int64_t bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
+    const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - bias);
+    const u32x4 srd_w = make_srd(wp);
+    uint32_t voff_a[4], a_mask[4], voff_w[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + 8 * j + rsub;
+        const int coff = (slot ^ ((row >> 1) & 7)) * 8;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        uint32_t mask = 0;
+        if (SPATIAL) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            const int64_t pc = (int64_t)b * p.IH * p.IW + (int64_t)(oy * p.stride) * p.IW + ox * p.stride;
+            voff_a[j] = (uint32_t)((pc * p.ld1 + coff) * 2);
+            const int ntap = p.taps;
+            for (int t = 0; t < ntap; ++t) {
+                const int ky = ntap == 9 ? (t * 11) >> 5 : p.pad_t, kx = ntap == 9 ? t - 3 * ky : p.pad_l;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
+            }
+        } else {
+            voff_a[j] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
+            mask = 1u;
+        }
+        a_mask[j] = mask;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wave * 16 + 8 * j + rsub;
+        const int coff = (slot ^ ((row >> 1) & 7)) * 8;
+        const int n = n0 + row;
+        voff_w[j] = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
+    }
+
+    int run_tap = 0, run_c0 = 0;
+    auto issue_tile = [&](int kt, int buf) {
+        const int tap = run_tap, c0 = run_c0;
+        run_c0 += BK;
+        if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
+        uint32_t soff_a, tapbit = 1u;
+        if (SPATIAL) {
+            int ky = p.pad_t, kx = p.pad_l;
+            if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
+            soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + c0) * 2);
+        } else {
+            soff_a = (uint32_t)kt * (BK * 2);
+        }
+        const uint32_t soff_w = (uint32_t)kt * (BK * 2);
+        const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
+        const uint32_t sw = smem_base + buf * STAGE + A_BYTES + wave * (16 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t vo = SPATIAL ? ((a_mask[j] & tapbit) ? voff_a[j] : kOobOffset) : voff_a[j];
+            dma16_buf(vo, srd_a, soff_a, sa + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const int nkt_all = p.K / BK;
+    int kt0 = 0, nkt = nkt_all;
+    if (p.splitk > 1) {
+        const int per = (nkt_all + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.y * per;
+        nkt = min(per, nkt_all - kt0);
+        if (nkt < 0) nkt = 0;
+    }
+    if (SPATIAL && p.taps == 9) {
+        run_tap = (kt0 * BK) / Cin;
+        run_c0 = kt0 * BK - run_tap * Cin;
+    }
+    if (nkt > 0) issue_tile(kt0, 0);
+    if (nkt > 1) issue_tile(kt0 + 1, 1);
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed; tile kt+1 (6 DMAs) may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nkt) issue_tile(kt0 + kt + 2, cur == 0 ? 2 : cur - 1);
+        const char* sa = smem + cur * STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int c = 2 * ks + lh;
+            U4 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const U4*>(sa + tile_off(wm * 64 + mi * 32 + l31, c));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                bf[ni] = *reinterpret_cast<const U4*>(sw + tile_off(wn * 64 + ni * 32 + l31, c));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma(af[mi], bf[ni], acc[mi][ni]);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+
+    // ---- epilogue: the whole 256x128 fp32 tile through LDS (128 KiB), then 8-wide row vectors
+    const bool geglu = (p.act == EDTR_ACT_GEGLU);
+    const int BNO = geglu ? BN / 2 : BN;
+    float* stage = reinterpret_cast<float*>(smem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (geglu) {
+        const int nv = n0 + wn * 64 + l31;
+        const float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
+        const float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float val = acc[mi][0][r] * p.alpha + bv;
+                const float gate = acc[mi][1][r] * p.alpha + bg;
+                stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
+            }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    stage[ml * BNO + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
+                }
+    }
+    __syncthreads();
+    const int n_out = geglu ? p.N / 2 : p.N;
+    const int no0 = geglu ? n0 / 2 : n0;
+    const int vec_per_row = BNO / 8;
+    for (int v = tid; v < BM * vec_per_row; v += NT) {
+        const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
+        const int m = m0 + ml, n = no0 + n8 * 8;
+        if (m >= p.M || n >= n_out) continue;
+        float f[8];
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+        f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
+        f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
+        if (p.splitk > 1) {
+            float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
+            *reinterpret_cast<f32x4*>(o) = s0;
+            *reinterpret_cast<f32x4*>(o + 4) = s1;
+            continue;
+        }
+        finish_vector<T>(p, f, m, n, !geglu, o_zoff);
+    }
+}
+
+template <typename T, bool SPATIAL>
+int launch_big(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int lds = 3 * (256 + 128) * BK * 2;   // 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_big_kernel<T, SPATIAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
+    dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
+    hipLaunchKernelGGL((igemm_big_kernel<T, SPATIAL>), grid, dim3(512), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
+        int64_t blocks = (nvec + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        EDTR_LAUNCH_CHECK();
+    }
+    return EDTR_OK;
+}
+
 template <typename T, int MI, int NI, bool SPATIAL>
 int launch(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -835,7 +1062,7 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile == 3 || tile == 4) {
+    if (tile == 3 || tile == 4 || tile == 5) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const int64_t a_rows = spatial ? (int64_t)(p.M / (p.OH * p.OW)) * p.IH * p.IW : p.M;
         const int64_t a_bytes = (a_rows + (spatial ? 3 * (int64_t)p.IW + 3 : 0)) * p.ld1 * 2 + (int64_t)p.K * 2;
@@ -844,6 +1071,10 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
         if (tile == 4) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_p3<T, true>(p, s) : launch_p3<T, false>(p, s);
+        }
+        if (tile == 5) {
+            if (!fast) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_big<T, true>(p, s) : launch_big<T, false>(p, s);
         }
         if (!spatial) return fast ? launch_dma<T, false, true>(p, s) : launch_dma<T, false, false>(p, s);
         return fast ? launch_dma<T, true, true>(p, s) : launch_dma<T, true, false>(p, s);
@@ -906,8 +1137,8 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     // the LDS-DMA main loop needs every 64-wide K-tile inside one tap of one source
     const bool dma_ok = p.C2 == 0 && (p.C1 & 63) == 0;
     if (tile == 1 && dma_ok && !p.tile) tile = 3;
-    if ((tile == 3 || tile == 4) && !dma_ok) return EDTR_E_UNSUPPORTED;
-    if (tile < 1 || tile > 4) return EDTR_E_DTYPE;
+    if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
+    if (tile < 1 || tile > 5) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

@@ -52,7 +52,10 @@ def nhwc16(x, dtype, pad_to=None):
                                         (77, 640, 1024, 3), (8, 1280, 320, 3),
                                         # tile 4 = 3-stage LDS-DMA main loop (K-tiles of 32)
                                         (256, 128, 64, 4), (300, 72, 192, 4), (4096, 320, 320, 4), (130, 136, 128, 4),
-                                        (77, 640, 1024, 4), (8, 1280, 320, 4)])
+                                        (77, 640, 1024, 4), (8, 1280, 320, 4),
+                                        # tile 5 = 256x128 tile, 8 waves, 3 stages
+                                        (256, 128, 64, 5), (300, 72, 192, 5), (4096, 320, 320, 5), (130, 136, 128, 5),
+                                        (77, 640, 1024, 5), (520, 1280, 320, 5)])
 def test_gemm_bias_residual(dtype, M, N, K, tile):
     ops = _ops()
     a = rnd((M, K), 1).to(dtype)
@@ -79,7 +82,8 @@ def test_gemm_bias_residual(dtype, M, N, K, tile):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,S,tile", [(512, 256, 1152, 4, 1), (100, 72, 640, 10, 2), (64, 1280, 2880, 7, 1),
                                           (512, 256, 1152, 4, 3), (100, 72, 640, 10, 3), (64, 1280, 2880, 45, 3),
-                                          (512, 256, 1152, 4, 4), (100, 72, 640, 10, 4), (64, 1280, 2880, 45, 4)])
+                                          (512, 256, 1152, 4, 4), (100, 72, 640, 10, 4), (64, 1280, 2880, 45, 4),
+                                          (512, 256, 1152, 4, 5), (300, 72, 640, 10, 5)])
 def test_gemm_splitk(dtype, M, N, K, S, tile):
     """Split-K: fp32 partial slabs + reducer with the full epilogue (bias, row vector, SiLU-free residual)."""
     ops = _ops()
@@ -135,7 +139,7 @@ def test_gemm_geglu_and_concat(dtype):
     ref = h[:, :inner] * F.gelu(h[:, inner:])
     d = dev()
     out = torch.empty((M, inner), dtype=dtype, device=d)
-    for tile in (1, 3, 4):      # register-staged, 2-stage DMA, 3-stage DMA main loops
+    for tile in (1, 3, 4, 5):   # register-staged, 2-stage DMA, 3-stage DMA, 256x128 main loops
         out.zero_()
         ops.launch(ops.make_igemm(dtype=dtype, a1=x.to(d), w=wp.to(d), out=out, M=M, N=2 * inner, C1=d_model,
                                   ld1=d_model, ldw=d_model, ldc=inner, bias_n=bp.to(d), act=1, tile=tile))
@@ -184,13 +188,16 @@ def test_gemm_batched_strided(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["s1", "s2", "vae_down", "up", "concat", "small_cin", "small_cout",
                                   "s1_dma", "s2_dma", "vae_down_dma", "up_dma", "small_cout_dma",
-                                  "s1_p3", "s2_p3", "vae_down_p3", "small_cout_p3"])
+                                  "s1_p3", "s2_p3", "vae_down_p3", "small_cout_p3",
+                                  "s1_big", "s2_big", "vae_down_big", "small_cout_big"])
 def test_conv3x3(dtype, case):
     tile = 0
     if case.endswith("_dma"):
         case, tile = case[:-4], 3
     if case.endswith("_p3"):
         case, tile = case[:-3], 4
+    if case.endswith("_big"):
+        case, tile = case[:-4], 5
     ops = _ops()
     d = dev()
     B, H, W = 2, 12, 20
