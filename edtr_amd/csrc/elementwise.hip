@@ -296,3 +296,39 @@ extern "C" int edtr_graph_destroy(void* graph_exec) {
     if (!graph_exec) return EDTR_E_NULL;
     return (int)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec));
 }
+
+// ---- wavelet colour fix ------------------------------------------------------------------
+// One level of the "wavelet blur": depthwise 3x3 binomial kernel with dilation r and replicate padding on fp32 NCHW
+// planes (reference utils/common.py:99-118).  Optionally accumulates high += (in - low) in the same pass
+// (utils/common.py:127-131), so a 5-level decomposition is 5 launches per image batch.
+namespace {
+__global__ void __launch_bounds__(256) wavelet_level_kernel(const float* in, float* low, float* high, int planes, int H,
+                                                           int W, int r) {
+    const int64_t n = (int64_t)planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float* pl = in + (i - (int64_t)y * W - x);
+        const int ym = max(y - r, 0), yp = min(y + r, H - 1), xm = max(x - r, 0), xp = min(x + r, W - 1);
+        const float c = pl[(int64_t)y * W + x];
+        const float v = 0.0625f * (pl[(int64_t)ym * W + xm] + pl[(int64_t)ym * W + xp] + pl[(int64_t)yp * W + xm] +
+                                   pl[(int64_t)yp * W + xp]) +
+                        0.125f * (pl[(int64_t)ym * W + x] + pl[(int64_t)yp * W + x] + pl[(int64_t)y * W + xm] +
+                                  pl[(int64_t)y * W + xp]) +
+                        0.25f * c;
+        low[i] = v;
+        if (high) high[i] += c - v;
+    }
+}
+}  // namespace
+
+extern "C" int edtr_wavelet_level(const float* in, float* low, float* high_accum, int planes, int H, int W, int radius,
+                                  edtr_stream_t stream) {
+    if (!in || !low) return EDTR_E_NULL;
+    if (planes <= 0 || H <= 0 || W <= 0 || radius <= 0) return EDTR_E_SHAPE;
+    if (in == low) return EDTR_E_UNSUPPORTED;   // not in-place: neighbours are read after the centre is written
+    const int64_t n = (int64_t)planes * H * W;
+    hipLaunchKernelGGL(wavelet_level_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), in, low,
+                       high_accum, planes, H, W, radius);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}

@@ -16,7 +16,7 @@ DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
     "edtr_gn_stats", "edtr_gn_apply", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
-    "edtr_tile_accumulate", "edtr_divide", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
+    "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy",
 ]
 
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.edtr_axpby.argtypes = [vp, vp, f32, f32, vp, i64, vp]
     lib.edtr_tile_accumulate.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.edtr_divide.argtypes = [vp, vp, vp, i64, vp]
+    lib.edtr_wavelet_level.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.edtr_graph_begin.argtypes = [vp]
     lib.edtr_graph_end.argtypes = [vp, C.POINTER(vp)]
     lib.edtr_graph_launch.argtypes = [vp, vp]

@@ -182,6 +182,11 @@ def make_divide(*, num, den, out, n, name="divide") -> Rec:
     return Rec(L.load().edtr_divide, (ptr(num), ptr(den), ptr(out), n), (num, den, out), name)
 
 
+def make_wavelet_level(*, src, low, high, planes, H, W, radius, name="wavelet_level") -> Rec:
+    args = (ptr(src), ptr(low), ptr(high), planes, H, W, radius)
+    return Rec(L.load().edtr_wavelet_level, args, (src, low, high), name, 0.0, 12.0 * planes * H * W)
+
+
 # --------------------------------------------------------------------------------------------
 # weight packing (host side, torch CPU or GPU tensors)
 # --------------------------------------------------------------------------------------------

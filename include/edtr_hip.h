@@ -206,6 +206,12 @@ int edtr_tile_accumulate(const float* tile, const float* wts, float* out, float*
 /* out = num / den elementwise (fp32).  replaces: utils/common.py:425. */
 int edtr_divide(const float* num, const float* den, float* out, int64_t n, edtr_stream_t stream);
 
+/* One level of the wavelet colour fix on fp32 NCHW planes: low = blur3x3(in; dilation radius, replicate pad) and, when
+ * high_accum != NULL, high_accum += in - low.  `low` must not alias `in`.
+ * replaces: wavelet_blur / wavelet_decomposition, reference utils/common.py:99-133 (runs right after vae_decode). */
+int edtr_wavelet_level(const float* in, float* low, float* high_accum, int planes, int H, int W, int radius,
+                       edtr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * hipGraph capture of a launch sequence issued on `stream` (one denoise step, or a whole batch).
  * ---------------------------------------------------------------------------------------- */
