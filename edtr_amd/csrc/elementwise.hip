@@ -332,3 +332,28 @@ extern "C" int edtr_wavelet_level(const float* in, float* low, float* high_accum
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }
+
+// ---- strided fp32 block copy (tile extraction / valid-region placement of the tiled VAE) -------------------------
+namespace {
+__global__ void __launch_bounds__(256) copy3d_kernel(const float* src, int64_t s_plane, int64_t s_row, float* dst,
+                                                    int64_t d_plane, int64_t d_row, int planes, int rows, int cols) {
+    const int64_t n = (int64_t)planes * rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % cols), y = (int)((i / cols) % rows);
+        const int64_t pl = i / ((int64_t)cols * rows);
+        dst[pl * d_plane + (int64_t)y * d_row + x] = src[pl * s_plane + (int64_t)y * s_row + x];
+    }
+}
+}  // namespace
+
+extern "C" int edtr_copy3d_f32(const float* src, int64_t src_plane_stride, int64_t src_row_stride, float* dst,
+                               int64_t dst_plane_stride, int64_t dst_row_stride, int planes, int rows, int cols,
+                               edtr_stream_t stream) {
+    if (!src || !dst) return EDTR_E_NULL;
+    if (planes <= 0 || rows <= 0 || cols <= 0) return EDTR_E_SHAPE;
+    const int64_t n = (int64_t)planes * rows * cols;
+    hipLaunchKernelGGL(copy3d_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       src_plane_stride, src_row_stride, dst, dst_plane_stride, dst_row_stride, planes, rows, cols);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* x, int64
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* s, int cols, int64_t ld_s, uint16_t* pout,
-                                                          int64_t ld_p) {
+                                                          int64_t ld_p, int cols_pad) {
     __shared__ float red_m[4], red_l[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = s + (int64_t)blockIdx.x * ld_s;
@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* s, int c
         o.y = pack2<T>(__expf(v[2] - gm) * inv, __expf(v[3] - gm) * inv);
         *reinterpret_cast<uint2*>(orow + c) = o;
     }
+    for (int c = cols + tid * 4; c < cols_pad; c += 1024) *reinterpret_cast<uint2*>(orow + c) = make_uint2(0u, 0u);
 }
 
 int check_gn(const edtr_gn_params& p, bool apply) {
@@ -290,6 +291,41 @@ extern "C" int edtr_gn_apply(const edtr_gn_params* pp, edtr_stream_t stream) {
     return EDTR_OK;
 }
 
+// Tiled-VAE GroupNorm pooling: sums is [T][BG][2] fp64 (per tile: sum, sum of squares of each (image, group)).
+// Per tile mean / biased variance, weighted average over tiles (weights[t]), written back as the (sum, sumsq) pair
+// that makes edtr_gn_apply reproduce exactly (pooled mean, pooled variance) for that tile's element count.
+namespace {
+__global__ void gn_pool_kernel(double* sums, const float* weights, const float* counts, int T, int BG) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BG) return;
+    double mean = 0.0, var = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double* s = sums + ((int64_t)t * BG + i) * 2;
+        const double c = (double)counts[t];
+        const double m = s[0] / c;
+        double v = s[1] / c - m * m;
+        v = v < 0.0 ? 0.0 : v;
+        mean += (double)weights[t] * m;
+        var += (double)weights[t] * v;
+    }
+    for (int t = 0; t < T; ++t) {
+        double* s = sums + ((int64_t)t * BG + i) * 2;
+        const double c = (double)counts[t];
+        s[0] = mean * c;
+        s[1] = (var + mean * mean) * c;
+    }
+}
+}  // namespace
+
+extern "C" int edtr_gn_pool(double* sums, const float* weights, const float* counts, int T, int BG, edtr_stream_t stream) {
+    if (!sums || !weights || !counts) return EDTR_E_NULL;
+    if (T <= 0 || BG <= 0) return EDTR_E_SHAPE;
+    hipLaunchKernelGGL(gn_pool_kernel, dim3((BG + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sums, weights,
+                       counts, T, BG);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int ldx, const float* gamma,
                               const float* beta, float eps, void* y, int ldy, edtr_stream_t stream) {
     if (!x || !y || !gamma || !beta) return EDTR_E_NULL;
@@ -310,19 +346,21 @@ extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int
 }
 
 extern "C" int edtr_softmax_rows(int dtype, const float* sc, int64_t rows, int cols, int64_t ld_s, void* pr,
-                                 int64_t ld_p, edtr_stream_t stream) {
+                                 int64_t ld_p, int cols_pad, edtr_stream_t stream) {
     if (!sc || !pr) return EDTR_E_NULL;
     if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
     if (rows <= 0 || cols <= 0 || rows > 0x7fffffffLL) return EDTR_E_SHAPE;
-    if ((cols & 3) || (ld_s & 3) || (ld_p & 3) || !aligned16(sc) || (reinterpret_cast<uintptr_t>(pr) & 7))
+    if ((cols & 3) || (ld_s & 3) || (ld_p & 3) || (cols_pad & 3) || !aligned16(sc) || (reinterpret_cast<uintptr_t>(pr) & 7))
         return EDTR_E_ALIGN;
+    if (cols_pad < cols) cols_pad = cols;
+    if (cols_pad > ld_p) return EDTR_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == EDTR_BF16)
         hipLaunchKernelGGL(softmax_rows_kernel<BF16>, dim3((unsigned)rows), dim3(256), 0, s, sc, cols, ld_s,
-                           static_cast<uint16_t*>(pr), ld_p);
+                           static_cast<uint16_t*>(pr), ld_p, cols_pad);
     else
         hipLaunchKernelGGL(softmax_rows_kernel<F16>, dim3((unsigned)rows), dim3(256), 0, s, sc, cols, ld_s,
-                           static_cast<uint16_t*>(pr), ld_p);
+                           static_cast<uint16_t*>(pr), ld_p, cols_pad);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

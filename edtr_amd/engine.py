@@ -325,19 +325,34 @@ class Emitter:
         return Act(out, x.B, OH, OW, N)
 
     # -- norms --------------------------------------------------------------------------------
-    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None) -> Act:
+    def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, y: torch.Tensor):
         gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
         c_real = self.store.params[prefix + "weight"].numel()
         if c_real != x.C:
             raise ValueError(f"GroupNorm {prefix}: activation has {x.C} channels, parameter has {c_real}")
+        return ops.make_gn(dtype=self.dtype, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C, sums=sums, gamma=gamma,
+                           beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0))
+
+    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None) -> Act:
         sums = self.arena.alloc((x.B, 32, 2), torch.float64)
         y = out if out is not None else self.new(x.rows, x.C)
-        st, ap = ops.make_gn(dtype=self.dtype, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C, sums=sums, gamma=gamma,
-                             beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0))
+        st, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
         self.prog.add(st)
         self.prog.add(ap)
         self.arena.free(sums)
         return Act(y, x.B, x.H, x.W, x.C)
+
+    def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor):
+        """Statistics half only (tiled VAE: the caller pools `sums` across tiles before the apply half).
+        Returns a closure that emits the apply half and yields the normalised activation."""
+        y = self.new(x.rows, x.C)
+        st, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
+        self.prog.add(st)
+
+        def apply() -> Act:
+            self.prog.add(ap)
+            return Act(y, x.B, x.H, x.W, x.C)
+        return apply
 
     def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str) -> torch.Tensor:
         y = self.new(rows, C)

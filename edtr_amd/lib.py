@@ -16,7 +16,7 @@ DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
     "edtr_gn_stats", "edtr_gn_apply", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
-    "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
+    "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy",
 ]
 
@@ -92,7 +92,7 @@ def load() -> C.CDLL:
     lib.edtr_gn_stats.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_apply.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_layernorm.argtypes = [i32, vp, i64, i32, i32, vp, vp, f32, vp, i32, vp]
-    lib.edtr_softmax_rows.argtypes = [i32, vp, i64, i32, i64, vp, i64, vp]
+    lib.edtr_softmax_rows.argtypes = [i32, vp, i64, i32, i64, vp, i64, i32, vp]
     lib.edtr_nchw_to_nhwc.argtypes = [i32, vp, i32, i32, i64, vp, i32, i32, i32, f32, f32, vp]
     lib.edtr_nhwc_to_nchw.argtypes = [i32, vp, i32, i32, i32, i64, i32, vp, f32, vp]
     lib.edtr_add.argtypes = [i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]
@@ -102,6 +102,8 @@ def load() -> C.CDLL:
     lib.edtr_tile_accumulate.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.edtr_divide.argtypes = [vp, vp, vp, i64, vp]
     lib.edtr_wavelet_level.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.edtr_gn_pool.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.edtr_copy3d_f32.argtypes = [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp]
     lib.edtr_graph_begin.argtypes = [vp]
     lib.edtr_graph_end.argtypes = [vp, C.POINTER(vp)]
     lib.edtr_graph_launch.argtypes = [vp, vp]

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .. import arch, nets
+from .. import ops as ops_mod
 from ..engine import Act, Arena, Emitter, Program, WeightStore
 from .params import ParamTree, params_fingerprint
 
@@ -177,19 +178,24 @@ def arch_round8(c: int) -> int:
 
 
 class VaeEngine:
-    """Encoder (+quant_conv, mode, scale) or decoder (scale^-1, post_quant_conv, decoder) for a fixed shape."""
+    """Encoder (+quant_conv, mode, scale) or decoder (scale^-1, post_quant_conv, decoder) for a fixed shape.
+    ``tile_size`` > 0 builds the tiled form (reference utils/tilevae VAEHook, non-fast mode): padded tiles cut from the
+    full NHWC tensor, GroupNorm statistics pooled across tiles, valid regions written back."""
 
-    def __init__(self, owner: "ControlLDM", kind: str, B: int, H: int, W: int):
+    def __init__(self, owner: "ControlLDM", kind: str, B: int, H: int, W: int, tile_size: int = 0):
         dev = owner._device()
         dt = owner.compute_dtype
         self.arena = Arena(dev)
         store = owner._store()
         dd = owner.vae.cfg["ddconfig"]
         f32 = torch.float32
-        self.prog = Program(f"vae.{kind}")
+        self.prog = Program(f"vae.{kind}" + (".tiled" if tile_size else ""))
         em = Emitter(self.prog, self.arena, store, dt)
         sf = owner.scale_factor
         nlev = len(dd["ch_mult"])
+        is_dec = kind == "decode"
+        pad = 11 if is_dec else 32
+        tiled = tile_size > 0 and max(H, W) > 2 * pad + tile_size     # tiny inputs run untiled (tilevae.py:317-323)
         if kind == "encode":
             self.inp = torch.zeros((B, dd["in_channels"], H, W), dtype=f32, device=dev)
             h, w = H >> (nlev - 1), W >> (nlev - 1)
@@ -197,7 +203,11 @@ class VaeEngine:
             cp = arch_round8(dd["in_channels"])
             x = em.new(B * H * W, cp)
             em.to_nhwc(self.inp, B, dd["in_channels"], H * W, x, pad_to=cp)
-            y = nets.emit_vae_net(em, "vae.encoder.", arch.vae_encoder_arch(dd), Act(x, B, H, W, cp), final_f32=False)
+            layers = arch.vae_encoder_arch(dd)
+            if not tiled:
+                y = nets.emit_vae_net(em, "vae.encoder.", layers, Act(x, B, H, W, cp), final_f32=False)
+            else:
+                y = self._tiled(em, "vae.encoder.", layers, x, B, H, W, cp, tile_size, False, h, w)
             # quant_conv 1x1 (model/vae.py:727) then DiagonalGaussianDistribution.mode() = first half (distributions.py:30,64)
             m = em.conv(y, "vae.quant_conv.", taps=1, out_f32=True, name="vae.quant_conv")
             em.free(y)
@@ -211,8 +221,44 @@ class VaeEngine:
             z = em.new(B * H * W, cp)
             em.to_nhwc(self.inp, B, zc, H * W, z, pad_to=cp, scale=1.0 / sf)           # z / scale_factor (cldm.py:156)
             z2 = em.conv(Act(z, B, H, W, cp), "vae.post_quant_conv.", taps=1, name="vae.post_quant_conv")
-            y = nets.emit_vae_net(em, "vae.decoder.", arch.vae_decoder_arch(dd), z2, final_f32=True)
+            layers = arch.vae_decoder_arch(dd)
+            if not tiled:
+                y = nets.emit_vae_net(em, "vae.decoder.", layers, z2, final_f32=True)
+            else:
+                y = self._tiled(em, "vae.decoder.", layers, z2.t, B, H, W, z2.C, tile_size, True, H * up, W * up)
             em.to_nchw(y.t, B, dd["out_ch"], y.H * y.W, self.out)
+
+    @staticmethod
+    def _tiled(em: Emitter, P: str, layers, full: torch.Tensor, B: int, H: int, W: int, C: int, tile_size: int,
+               is_dec: bool, OH: int, OW: int) -> Act:
+        """Cut padded tiles out of the full NHWC tensor, run them in GroupNorm lock-step, assemble the valid regions."""
+        ins, outs = nets.split_tiles(H, W, tile_size, is_dec)
+        tiles = []
+        for x1, x2, y1, y2 in ins:
+            th, tw = y2 - y1, x2 - x1
+            t = em.new(B * th * tw, C)
+            for b in range(B):      # 2-D strided copy: th rows of tw*C contiguous elements
+                em.add(full[(b * H + y1) * W + x1:].reshape(-1)[: (th - 1) * W * C + tw * C].as_strided((th, tw * C), (W * C, 1)),
+                       None, th, tw * C, out=t[b * th * tw:(b + 1) * th * tw].reshape(th, tw * C))
+            tiles.append(Act(t, B, th, tw, C))
+        res = nets.emit_vae_net_tiled(em, P, layers, tiles, final_f32=is_dec)
+        Co = res[0].C
+        out = em.new(B * OH * OW, Co, torch.float32 if is_dec else None)
+        for r, ib, ob in zip(res, ins, outs):
+            pb = [v * 8 if is_dec else v // 8 for v in ib]
+            mx0, my0 = ob[0] - pb[0], ob[2] - pb[2]                 # crop_valid_region (tilevae.py:218-229)
+            cw, ch = ob[1] - ob[0], ob[3] - ob[2]
+            for b in range(B):
+                src = r.t[(b * r.H + my0) * r.W + mx0:]
+                dst = out[(b * OH + ob[2]) * OW + ob[0]:]
+                if is_dec:
+                    em.prog.add(ops_mod.make_copy3d(src=src, src_plane=0, src_row=r.W * Co, dst=dst, dst_plane=0,
+                                                    dst_row=OW * Co, planes=1, rows=ch, cols=cw * Co))
+                else:
+                    em.add(src.reshape(-1)[: (ch - 1) * r.W * Co + cw * Co].as_strided((ch, cw * Co), (r.W * Co, 1)), None, ch,
+                           cw * Co, out=dst.reshape(-1)[: (ch - 1) * OW * Co + cw * Co].as_strided((ch, cw * Co), (OW * Co, 1)))
+            em.free(r)
+        return Act(out, B, OH, OW, Co)
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
         self.inp.copy_(x)
@@ -279,11 +325,11 @@ class ControlLDM(nn.Module):
             self._cldm_engines[key] = CldmEngine(self, B, h, w, nctx)
         return self._cldm_engines[key]
 
-    def vae_engine(self, kind: str, B: int, H: int, W: int) -> VaeEngine:
+    def vae_engine(self, kind: str, B: int, H: int, W: int, tile_size: int = 0) -> VaeEngine:
         self._check_fresh()
-        key = (kind, B, H, W)
+        key = (kind, B, H, W, tile_size)
         if key not in self._vae_engines:
-            self._vae_engines[key] = VaeEngine(self, kind, B, H, W)
+            self._vae_engines[key] = VaeEngine(self, kind, B, H, W, tile_size)
         return self._vae_engines[key]
 
     # -- checkpoint ingestion (reference model/cldm.py:46-105) -----------------------------------
@@ -337,21 +383,21 @@ class ControlLDM(nn.Module):
     @torch.no_grad()
     def vae_encode(self, image: torch.Tensor, sample: bool = True, tiled: bool = False, tile_size: int = -1) -> torch.Tensor:
         _require_gpu(image, "vae_encode")
-        if tiled:
-            raise NotImplementedError("tiled VAE encode (utils/tilevae) is not built yet; see DESIGN.md scope table")
         if sample:
             raise NotImplementedError("vae_encode(sample=True) is a training-time path; the restoration path uses "
                                       "sample=False (posterior mode)")
         B, _, H, W = image.shape
-        return self.vae_engine("encode", B, H, W).run(image).clone()
+        if tiled and tile_size <= 0:
+            raise ValueError("vae_encode(tiled=True) needs a positive tile_size (image pixels)")
+        return self.vae_engine("encode", B, H, W, tile_size if tiled else 0).run(image).clone()
 
     @torch.no_grad()
     def vae_decode(self, z: torch.Tensor, tiled: bool = False, tile_size: int = -1) -> torch.Tensor:
         _require_gpu(z, "vae_decode")
-        if tiled:
-            raise NotImplementedError("tiled VAE decode (utils/tilevae) is not built yet; see DESIGN.md scope table")
         B, _, h, w = z.shape
-        return self.vae_engine("decode", B, h, w).run(z).clone()
+        if tiled and tile_size <= 0:
+            raise ValueError("vae_decode(tiled=True) needs a positive tile_size (latent pixels)")
+        return self.vae_engine("decode", B, h, w, tile_size if tiled else 0).run(z).clone()
 
     def prepare_condition(self, clean: torch.Tensor, prompt: List[str]) -> Dict[str, torch.Tensor]:
         if prompt is None:

@@ -255,12 +255,22 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
 # ----------------------------------------------------------------------------------------------
 # VAE
 # ----------------------------------------------------------------------------------------------
-def emit_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act) -> Act:
-    """model/vae.py:103-124."""
-    n1 = em.group_norm(x, p + "norm1.", 1e-6, True)
+def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool):
+    """GroupNorm as a suspension point of a VAE emission generator: yields the activation (the driver answers with the
+    fp64 sums slice to fill), emits the statistics launch, yields again (the driver may pool the sums across tiles),
+    then emits the apply launch.  Plain and tiled VAE share every other line of emission code."""
+    sums = yield x
+    apply = em.gn_stats_into(x, prefix, 1e-6, silu, sums)
+    yield None
+    return apply()
+
+
+def _g_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act):
+    """model/vae.py:103-124 (tiled form: resblock2task, utils/tilevae/tilevae.py:86-106)."""
+    n1 = yield from _g_norm(em, x, p + "norm1.", True)
     h = em.conv(n1, p + "conv1.", name="vae.conv1")
     em.free(n1)
-    n2 = em.group_norm(h, p + "norm2.", 1e-6, True)
+    n2 = yield from _g_norm(em, h, p + "norm2.", True)
     em.free(h)
     if l.cin != l.cout:
         skip = em.conv(x, p + "nin_shortcut.", taps=1, name="vae.nin_shortcut").t
@@ -273,14 +283,15 @@ def emit_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act) -> Act:
     return y
 
 
-def emit_vae_attn(em: Emitter, p: str, x: Act) -> Act:
+def _g_vae_attn(em: Emitter, p: str, x: Act):
     """model/vae.py:279-308: single-head attention with d = C (512): too wide for the fused kernel's register
-    budget, and only 2 calls per image, so it runs as QK^T GEMM (fp32 scores) -> row softmax -> PV GEMM."""
+    budget, and only 2 calls per image, so it runs as QK^T GEMM (fp32 scores) -> row softmax -> PV GEMM.
+    In the tiled VAE the same code runs per tile (tile-local attention, utils/tilevae/attn.py:85-115)."""
     B, N, C = x.B, x.H * x.W, x.C
     rows = B * N
-    if N % 8:
-        raise ValueError("VAE attention needs h*w to be a multiple of 8")
-    n = em.group_norm(x, p + "norm.", 1e-6, False)
+    if N % 4:
+        raise ValueError("VAE attention needs h*w to be a multiple of 4")
+    n = yield from _g_norm(em, x, p + "norm.", False)
     wqk, bqk = em.store.linear([p + "q.weight", p + "k.weight"], [p + "q.bias", p + "k.bias"])
     qk = em.gemm(n.t, wqk, rows, 2 * C, C, bias=bqk, name="vae.attn.qk")
     wv, _ = em.store.linear([p + "v.weight"])
@@ -294,10 +305,11 @@ def emit_vae_attn(em: Emitter, p: str, x: Act) -> Act:
                                name="vae.attn.scores"))
     em.free(qk)
     pr = em.new(rows, lds)
-    em.prog.add(ops.make_softmax_rows(dtype=em.dtype, s=s, rows=rows, cols=N, ld_s=lds, p=pr, ld_p=lds))
+    em.prog.add(ops.make_softmax_rows(dtype=em.dtype, s=s, rows=rows, cols=N, ld_s=lds, p=pr, ld_p=lds, cols_pad=lds))
     em.free(s)
     o = em.new(rows, C)
-    em.prog.add(ops.make_igemm(dtype=em.dtype, a1=pr, w=vt, out=o, M=N, N=C, C1=N, ld1=lds, ldw=ldv, ldc=C, Z=B,
+    # K is padded to a multiple of 8: the pad columns of P are exact zeros, those of V^T hold the (finite) bias
+    em.prog.add(ops.make_igemm(dtype=em.dtype, a1=pr, w=vt, out=o, M=N, N=C, C1=lds, ld1=lds, ldw=ldv, ldc=C, Z=B,
                                a_zs=(N * lds, 0), w_zs=(C * ldv, 0), o_zs=(N * C, 0), name="vae.attn.pv"))
     em.free(pr, vt)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
@@ -306,8 +318,9 @@ def emit_vae_attn(em: Emitter, p: str, x: Act) -> Act:
     return Act(y, x.B, x.H, x.W, C)
 
 
-def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool) -> Act:
-    """Encoder.forward (model/vae.py:421-446) / Decoder.forward (:527-560) over the flat layer list."""
+def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool):
+    """Encoder.forward (model/vae.py:421-446) / Decoder.forward (:527-560) over the flat layer list, as a generator
+    suspended at every GroupNorm (see _g_norm)."""
     h = x
     first = True
     for l in layers:
@@ -316,15 +329,15 @@ def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32:
         if l.kind == "conv":
             y = em.conv(h, p, out_f32=(final_f32 and last), name="vae.conv_in" if first else "vae.conv_out")
         elif l.kind == "res":
-            y = emit_vae_resblock(em, p, l, h)
+            y = yield from _g_vae_resblock(em, p, l, h)
         elif l.kind == "attn":
-            y = emit_vae_attn(em, p, h)
+            y = yield from _g_vae_attn(em, p, h)
         elif l.kind == "down":
             y = em.conv(h, p, stride=2, pad_tl=0, name="vae.downsample")     # pad (0,1,0,1) + stride 2: vae.py:54-61
         elif l.kind == "up":
             y = em.conv(h, p, ups=True, name="vae.upsample.conv")           # nearest x2 + conv: vae.py:35-39
         elif l.kind == "norm_out":
-            y = em.group_norm(h, p, 1e-6, True)
+            y = yield from _g_norm(em, h, p, True)
         else:
             raise ValueError(l.kind)
         if not first:
@@ -332,3 +345,79 @@ def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32:
         first = False
         h = y
     return h
+
+
+def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool) -> Act:
+    """Untiled network: every GroupNorm uses its own statistics."""
+    gen = gen_vae_net(em, P, layers, x, final_f32)
+    sums = None
+    try:
+        req = next(gen)
+        while True:
+            sums = em.arena.alloc((req.B, 32, 2), torch.float64)
+            gen.send(sums)            # statistics launch emitted
+            prev = sums
+            req = gen.send(None)      # apply launch emitted, emission continues up to the next GroupNorm
+            em.arena.free(prev)
+    except StopIteration as done:
+        em.arena.free(sums)
+        return done.value
+
+
+def emit_vae_net_tiled(em: Emitter, P: str, layers: List[VaeLayer], tiles: List[Act], final_f32: bool) -> List[Act]:
+    """VAEHook.vae_tile_forward (utils/tilevae/tilevae.py:452-579, non-fast mode): all tiles advance to their next
+    GroupNorm, their per-(image, group) statistics are pooled with pixel-count weights (GroupNormParam.summary,
+    :263-278) by edtr_gn_pool, the shared statistics normalise every tile, repeat."""
+    gens = [gen_vae_net(em, P, layers, t, final_f32) for t in tiles]
+    reqs = [next(g) for g in gens]
+    results: List[Optional[Act]] = [None] * len(gens)
+    dev = tiles[0].t.device
+    while any(r is None for r in results):
+        T = len(gens)
+        BG = reqs[0].B * 32
+        pix = [float(r.H * r.W) for r in reqs]
+        weights = torch.tensor([v / sum(pix) for v in pix], dtype=torch.float32, device=dev)
+        counts = torch.tensor([v * (reqs[0].C // 32) for v in pix], dtype=torch.float32, device=dev)
+        sums = em.arena.alloc((T, BG, 2), torch.float64)
+        for k, g in enumerate(gens):
+            g.send(sums[k])
+        em.prog.add(ops.make_gn_pool(sums=sums, weights=weights, counts=counts, T=T, BG=BG))
+        for k, g in enumerate(gens):
+            try:
+                reqs[k] = g.send(None)
+            except StopIteration as done:
+                results[k] = done.value
+        em.arena.free(sums)
+    return results
+
+
+def split_tiles(h: int, w: int, tile_size: int, is_decoder: bool):
+    """Tile input / output boxes [x1, x2, y1, y2] (VAEHook.split_tiles + get_best_tile_size,
+    utils/tilevae/tilevae.py:325-395; pad 11 latent px for the decoder, 32 image px for the encoder)."""
+    pad = 11 if is_decoder else 32
+
+    def best(lower: int, upper: int) -> int:
+        divider = 32
+        while divider >= 2:
+            rem = lower % divider
+            if rem == 0:
+                return lower
+            cand = lower - rem + divider
+            if cand <= upper:
+                return cand
+            divider //= 2
+        return lower
+
+    nh = max(math.ceil((h - 2 * pad) / tile_size), 1)
+    nw = max(math.ceil((w - 2 * pad) / tile_size), 1)
+    th = best(math.ceil((h - 2 * pad) / nh), tile_size)
+    tw = best(math.ceil((w - 2 * pad) / nw), tile_size)
+    ins, outs = [], []
+    for i in range(nh):
+        for j in range(nw):
+            ib = [pad + j * tw, min(pad + (j + 1) * tw, w), pad + i * th, min(pad + (i + 1) * th, h)]
+            ob = [ib[0] if ib[0] > pad else 0, ib[1] if ib[1] < w - pad else w,
+                  ib[2] if ib[2] > pad else 0, ib[3] if ib[3] < h - pad else h]
+            outs.append([v * 8 if is_decoder else v // 8 for v in ob])
+            ins.append([max(0, ib[0] - pad), min(w, ib[1] + pad), max(0, ib[2] - pad), min(h, ib[3] + pad)])
+    return ins, outs

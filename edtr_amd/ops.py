@@ -135,8 +135,8 @@ def make_layernorm(*, dtype, x, rows, C, ldx, gamma, beta, eps, y, ldy, name="la
     return Rec(L.load().edtr_layernorm, args, (x, gamma, beta, y), name, 0.0, 4.0 * rows * C)
 
 
-def make_softmax_rows(*, dtype, s, rows, cols, ld_s, p, ld_p, name="softmax_rows") -> Rec:
-    args = (dt_code(dtype), ptr(s), rows, cols, ld_s, ptr(p), ld_p)
+def make_softmax_rows(*, dtype, s, rows, cols, ld_s, p, ld_p, cols_pad=0, name="softmax_rows") -> Rec:
+    args = (dt_code(dtype), ptr(s), rows, cols, ld_s, ptr(p), ld_p, cols_pad)
     return Rec(L.load().edtr_softmax_rows, args, (s, p), name, 0.0, 10.0 * rows * cols)
 
 
@@ -180,6 +180,15 @@ def make_tile_accumulate(*, tile, wts, out, count, B, C, H, W, th, tw, hi, wi, n
 
 def make_divide(*, num, den, out, n, name="divide") -> Rec:
     return Rec(L.load().edtr_divide, (ptr(num), ptr(den), ptr(out), n), (num, den, out), name)
+
+
+def make_gn_pool(*, sums, weights, counts, T, BG, name="gn_pool") -> Rec:
+    return Rec(L.load().edtr_gn_pool, (ptr(sums), ptr(weights), ptr(counts), T, BG), (sums, weights, counts), name)
+
+
+def make_copy3d(*, src, src_plane, src_row, dst, dst_plane, dst_row, planes, rows, cols, name="copy3d") -> Rec:
+    args = (ptr(src), src_plane, src_row, ptr(dst), dst_plane, dst_row, planes, rows, cols)
+    return Rec(L.load().edtr_copy3d_f32, args, (src, dst), name, 0.0, 8.0 * planes * rows * cols)
 
 
 def make_wavelet_level(*, src, low, high, planes, H, W, radius, name="wavelet_level") -> Rec:

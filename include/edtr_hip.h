@@ -162,11 +162,12 @@ int edtr_gn_apply(const edtr_gn_params* p, edtr_stream_t stream);
 int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int ldx, const float* gamma,
                    const float* beta, float eps, void* y, int ldy, edtr_stream_t stream);
 
-/* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p).
+/* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p); columns cols..cols_pad-1
+ * of every output row are written as zeros (so the row can feed a GEMM whose K is padded to a multiple of 8).
  * replaces: the softmax inside F.scaled_dot_product_attention of the d=512 single-head VAE
  *           attention, reference model/vae.py:298. */
 int edtr_softmax_rows(int dtype, const float* s, int64_t rows, int cols, int64_t ld_s, void* p,
-                      int64_t ld_p, edtr_stream_t stream);
+                      int64_t ld_p, int cols_pad, edtr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / elementwise helpers.
@@ -205,6 +206,17 @@ int edtr_tile_accumulate(const float* tile, const float* wts, float* out, float*
                          int C, int H, int W, int th, int tw, int hi, int wi, edtr_stream_t stream);
 /* out = num / den elementwise (fp32).  replaces: utils/common.py:425. */
 int edtr_divide(const float* num, const float* den, float* out, int64_t n, edtr_stream_t stream);
+
+/* Tiled VAE (reference utils/tilevae/tilevae.py:232-304, GroupNormParam): sums is [T][BG][2] fp64 holding, per tile,
+ * the edtr_gn_stats result of each (image, group).  Replaces them IN PLACE by the pair that makes edtr_gn_apply use the
+ * tile-pooled statistics: mean = sum_t weights[t]*mean_t, var = sum_t weights[t]*var_t (biased per-tile variances; the
+ * between-tile spread of the means is ignored exactly as the reference does); counts[t] = elements per group of tile t. */
+int edtr_gn_pool(double* sums, const float* weights, const float* counts, int T, int BG, edtr_stream_t stream);
+/* dst[p][y][x] = src[p][y][x] for planes x rows x cols fp32 elements with independent plane / row strides (elements).
+ * replaces: the tile slicing `z[:, :, y1:y2, x1:x2]` and crop_valid_region placement, utils/tilevae/tilevae.py:218-229,468,548. */
+int edtr_copy3d_f32(const float* src, int64_t src_plane_stride, int64_t src_row_stride, float* dst,
+                    int64_t dst_plane_stride, int64_t dst_row_stride, int planes, int rows, int cols,
+                    edtr_stream_t stream);
 
 /* One level of the wavelet colour fix on fp32 NCHW planes: low = blur3x3(in; dilation radius, replicate pad) and, when
  * high_accum != NULL, high_accum += in - low.  `low` must not alias `in`.

@@ -500,3 +500,146 @@ def wavelet_decomposition(img: torch.Tensor, levels: int = 5):
 def wavelet_reconstruction(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
     """content high-frequency + style low-frequency.  utils/common.py:136-147."""
     return wavelet_decomposition(content)[0] + wavelet_decomposition(style)[1]
+
+
+# ------------------------------------------------------------------------------------------
+# a21  tiled VAE (VAEHook): padded tiles, GroupNorm statistics pooled across tiles
+# ------------------------------------------------------------------------------------------
+
+def _best_tile_size(lower: int, upper: int) -> int:
+    """utils/tilevae/tilevae.py:325-338."""
+    divider = 32
+    while divider >= 2:
+        rem = lower % divider
+        if rem == 0:
+            return lower
+        cand = lower - rem + divider
+        if cand <= upper:
+            return cand
+        divider //= 2
+    return lower
+
+
+def split_tiles(h: int, w: int, tile_size: int, is_decoder: bool):
+    """Input / output bounding boxes [x1, x2, y1, y2] of every tile.  utils/tilevae/tilevae.py:340-395
+    (pad = 11 latent px for the decoder, 32 image px for the encoder, :315)."""
+    pad = 11 if is_decoder else 32
+    nh = max(math.ceil((h - 2 * pad) / tile_size), 1)
+    nw = max(math.ceil((w - 2 * pad) / tile_size), 1)
+    th = _best_tile_size(math.ceil((h - 2 * pad) / nh), tile_size)
+    tw = _best_tile_size(math.ceil((w - 2 * pad) / nw), tile_size)
+    ins, outs = [], []
+    for i in range(nh):
+        for j in range(nw):
+            ib = [pad + j * tw, min(pad + (j + 1) * tw, w), pad + i * th, min(pad + (i + 1) * th, h)]
+            ob = [ib[0] if ib[0] > pad else 0, ib[1] if ib[1] < w - pad else w,
+                  ib[2] if ib[2] > pad else 0, ib[3] if ib[3] < h - pad else h]
+            outs.append([v * 8 if is_decoder else v // 8 for v in ob])
+            ins.append([max(0, ib[0] - pad), min(w, ib[1] + pad), max(0, ib[2] - pad), min(h, ib[3] + pad)])
+    return ins, outs
+
+
+def _vae_tile_tasks(sd: SD, dd: dict, p: str, is_decoder: bool, x: torch.Tensor):
+    """One tile's pass through the encoder / decoder as a generator that suspends at every GroupNorm: it yields
+    (tensor, norm prefix) and is resumed with the normalised tensor (affine applied, no activation).
+    Task order of build_task_queue / resblock2task / attn2task, utils/tilevae/tilevae.py:77-165."""
+    nlev = len(dd["ch_mult"])
+
+    def res(q, h):
+        skip = conv(sd, q + "nin_shortcut.", h, padding=0) if (q + "nin_shortcut.weight") in sd else h
+        n = yield (h, q + "norm1.")
+        h = conv(sd, q + "conv1.", F.silu(n))
+        n = yield (h, q + "norm2.")
+        return conv(sd, q + "conv2.", F.silu(n)) + skip
+
+    def attn(q, h):
+        n = yield (h, q + "norm.")
+        b, c, hh, ww = n.shape
+        qq, kk, vv = (conv(sd, q + nm + ".", n, padding=0).reshape(b, c, hh * ww).transpose(1, 2) for nm in "qkv")
+        w_ = torch.softmax((qq @ kk.transpose(1, 2)) * (1.0 / math.sqrt(c)), dim=-1)
+        o = (w_ @ vv).transpose(1, 2).reshape(b, c, hh, ww)
+        return h + conv(sd, q + "proj_out.", o, padding=0)      # tile-LOCAL attention (utils/tilevae/attn.py:85-115)
+
+    h = conv(sd, p + "conv_in.", x)
+    if is_decoder:
+        h = yield from res(p + "mid.block_1.", h)
+        h = yield from attn(p + "mid.attn_1.", h)
+        h = yield from res(p + "mid.block_2.", h)
+        for lvl in reversed(range(nlev)):
+            for blk in range(dd["num_res_blocks"] + 1):
+                h = yield from res(f"{p}up.{lvl}.block.{blk}.", h)
+            if lvl != 0:
+                h = conv(sd, f"{p}up.{lvl}.upsample.conv.", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+    else:
+        for lvl in range(nlev):
+            for blk in range(dd["num_res_blocks"]):
+                h = yield from res(f"{p}down.{lvl}.block.{blk}.", h)
+            if lvl != nlev - 1:
+                h = conv(sd, f"{p}down.{lvl}.downsample.conv.", F.pad(h, (0, 1, 0, 1)), stride=2, padding=0)
+        h = yield from res(p + "mid.block_1.", h)
+        h = yield from attn(p + "mid.attn_1.", h)
+        h = yield from res(p + "mid.block_2.", h)
+    n = yield (h, p + "norm_out.")
+    return conv(sd, p + "conv_out.", F.silu(n))
+
+
+def tiled_vae_net(sd: SD, dd: dict, p: str, x: torch.Tensor, tile_size: int, is_decoder: bool) -> torch.Tensor:
+    """VAEHook.__call__ / vae_tile_forward (non-fast mode), utils/tilevae/tilevae.py:317-323, 452-579.
+    Every tile advances to its next GroupNorm; the per-tile (variance, mean) of each (image, group) are averaged with
+    weights proportional to the tile's pixel count (GroupNormParam.summary, :263-278 — between-tile mean spread is
+    ignored on purpose) and the shared statistics normalise every tile (custom_group_norm, :188-215, eps 1e-6)."""
+    pad = 11 if is_decoder else 32
+    b, _, hh, ww = x.shape
+    if max(hh, ww) <= 2 * pad + tile_size:
+        return vae_decoder(sd, dd, x, p) if is_decoder else vae_encoder(sd, dd, x, p)
+    ins, outs = split_tiles(hh, ww, tile_size, is_decoder)
+    gens = [_vae_tile_tasks(sd, dd, p, is_decoder, x[:, :, ib[2]:ib[3], ib[0]:ib[1]]) for ib in ins]
+    pending = [next(g) for g in gens]
+    results = [None] * len(gens)
+    while any(r is None for r in results):
+        live = [i for i, r in enumerate(results) if r is None]
+        stats, pix = [], []
+        for i in live:
+            t, _ = pending[i]
+            c = t.shape[1]
+            r = t.reshape(b * 32, (c // 32) * t.shape[2] * t.shape[3])
+            stats.append((r.var(dim=1, unbiased=False), r.mean(dim=1)))
+            pix.append(float(t.shape[2] * t.shape[3]))
+        wts = torch.tensor(pix) / max(pix)
+        wts = wts / wts.sum()
+        var = sum(wgt * s[0] for wgt, s in zip(wts, stats))
+        mean = sum(wgt * s[1] for wgt, s in zip(wts, stats))
+        for i in live:
+            t, q = pending[i]
+            c = t.shape[1]
+            shp = (b, 32, 1, 1, 1)
+            n = ((t.reshape(b, 32, c // 32, t.shape[2], t.shape[3]) - mean.reshape(shp))
+                 / torch.sqrt(var.reshape(shp) + 1e-6)).reshape(t.shape)
+            n = n * sd[q + "weight"].reshape(1, -1, 1, 1) + sd[q + "bias"].reshape(1, -1, 1, 1)
+            try:
+                pending[i] = gens[i].send(n)
+            except StopIteration as done:
+                results[i] = done.value
+    out = None
+    for tile, ib, ob in zip(results, ins, outs):
+        if out is None:
+            out = torch.zeros((b, tile.shape[1], hh * 8 if is_decoder else hh // 8, ww * 8 if is_decoder else ww // 8))
+        pb = [v * 8 if is_decoder else v // 8 for v in ib]
+        mg = [ob[k] - pb[k] for k in range(4)]      # crop_valid_region, :218-229
+        out[:, :, ob[2]:ob[3], ob[0]:ob[1]] = tile[:, :, mg[2]:tile.shape[2] + mg[3], mg[0]:tile.shape[3] + mg[1]]
+    return out
+
+
+def vae_encode_tiled(sd: SD, cfg: dict, image: torch.Tensor, tile_size: int, p: str = "vae.") -> torch.Tensor:
+    """ControlLDM.vae_encode(sample=False, tiled=True), model/cldm.py:114-134."""
+    dd = cfg["vae_cfg"]["ddconfig"]
+    h = tiled_vae_net(sd, dd, p + "encoder.", image, tile_size, False)
+    mean, _ = torch.chunk(conv(sd, p + "quant_conv.", h, padding=0), 2, dim=1)
+    return mean * cfg["latent_scale_factor"]
+
+
+def vae_decode_tiled(sd: SD, cfg: dict, z: torch.Tensor, tile_size: int, p: str = "vae.") -> torch.Tensor:
+    """ControlLDM.vae_decode(tiled=True), model/cldm.py:142-156."""
+    dd = cfg["vae_cfg"]["ddconfig"]
+    z = conv(sd, p + "post_quant_conv.", z / cfg["latent_scale_factor"], padding=0)
+    return tiled_vae_net(sd, dd, p + "decoder.", z, tile_size, True)

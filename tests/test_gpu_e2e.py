@@ -172,3 +172,32 @@ def test_wavelet_colour_fix_vs_reference_golden(golden_dir):
     assert rel_err(lo, g["low"]) < 1e-6
     assert rel_err(hi, g["high"]) < 1e-5
     assert rel_err(rec, g["recon"]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_tiled_vae_vs_reference_golden(golden_dir, dtype):
+    """VAEHook paths (a21): tiled encode (tile 64 px -> 6 padded tiles) and tiled decode (tile 8 latent px -> 6 tiles) with
+    GroupNorm statistics pooled across tiles, against the REFERENCE's tiled outputs (which differ from the untiled ones by
+    6 % / 2 %, so this is not satisfied by the plain VAE)."""
+    from edtr_amd import synth
+    from edtr_amd.testing import build_synthetic_cldm, rel_err
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "tiled_vae.npz"))
+    cldm = build_synthetic_cldm(synth.tiny_config(), dev, dtype)
+    img = synth.synth_input("tvae:img", (1, 3, 192, 256), -1.0, 1.0).to(dev)
+    zin = synth.synth_normal("tvae:z", (1, 4, 32, 40)).to(dev)
+    z_t = cldm.vae_encode(img, sample=False, tiled=True, tile_size=64)
+    d_t = cldm.vae_decode(zin, tiled=True, tile_size=8)
+    z_p = cldm.vae_encode(img, sample=False)
+    small = cldm.vae_encode(img[:, :, :128, :128].contiguous(), sample=False, tiled=True, tile_size=64)   # falls back to untiled
+    small_p = cldm.vae_encode(img[:, :, :128, :128].contiguous(), sample=False)
+    torch.cuda.synchronize()
+    e_enc, e_dec, e_plain = rel_err(z_t, g["z_tiled"]), rel_err(d_t, g["dec_tiled"]), rel_err(z_p, g["z_plain"])
+    print(f"\n[tiled vae {dtype}] enc={e_enc:.2e} dec={e_dec:.2e} plain_enc={e_plain:.2e} "
+          f"(reference tiled-vs-plain gap: enc {rel_err(g['z_tiled'], g['z_plain']):.2e})")
+    tol = TOL[dtype]
+    assert e_enc < tol["z_pre"] and e_plain < tol["z_pre"]
+    assert e_dec < tol["img"]
+    assert rel_err(small, small_p) == 0.0

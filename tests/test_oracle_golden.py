@@ -167,3 +167,25 @@ def test_sd21_blocks(golden_dir):
         assert rel_err(O.vae_encode(sd, cfg, img), g["vae_z"]) < 5e-5
         zin = synth.synth_normal("sd21:zdec", (1, 4, 32, 32))
         assert rel_err(O.vae_decode(sd, cfg, zin), g["vae_dec"]) < 5e-5
+
+
+def test_tiled_vae(golden_dir):
+    """VAEHook restatement: tile geometry and the cross-tile GroupNorm pooling vs the reference's tiled outputs."""
+    g = np.load(os.path.join(golden_dir, "tiled_vae.npz"))
+    for name, (h, w, ts, dec) in {"enc_1024_256": (1024, 1024, 256, False), "enc_192x256_64": (192, 256, 64, False),
+                                  "dec_128_64": (128, 128, 64, True), "dec_32x40_8": (32, 40, 8, True),
+                                  "enc_560x760_256": (560, 760, 256, False)}.items():
+        ib, ob = O.split_tiles(h, w, ts, dec)
+        np.testing.assert_array_equal(np.array(ib), g[f"bbox_in_{name}"])
+        np.testing.assert_array_equal(np.array(ob), g[f"bbox_out_{name}"])
+    cfg = synth.tiny_config()
+    sd = synth_sd(os.path.join(golden_dir, "manifest_tiny.json"), parts=("vae",))
+    img = synth.synth_input("tvae:img", (1, 3, 192, 256), -1.0, 1.0)
+    zin = synth.synth_normal("tvae:z", (1, 4, 32, 40))
+    with torch.no_grad():
+        assert rel_err(O.vae_encode_tiled(sd, cfg, img, 64), g["z_tiled"]) < 2e-5
+        assert rel_err(O.vae_decode_tiled(sd, cfg, zin, 8), g["dec_tiled"]) < 2e-5
+        assert rel_err(O.vae_encode(sd, cfg, img), g["z_plain"]) < 2e-5
+        # small inputs fall back to the plain network (tilevae.py:317-323)
+        small = synth.synth_input("tvae:small", (1, 3, 128, 128), -1.0, 1.0)
+        assert rel_err(O.vae_encode_tiled(sd, cfg, small, 64), O.vae_encode(sd, cfg, small)) == 0.0

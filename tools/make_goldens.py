@@ -238,6 +238,34 @@ def gen_tiled():
     print("tiled.npz written")
 
 
+def gen_tiledvae():
+    """VAEHook paths (reference utils/tilevae/tilevae.py) on the tiny config: tiled encode (tile 64 px, pad 32) of a
+    192x256 image and tiled decode (tile 8 latent px, pad 11) of a 32x40 latent, plus tile geometry tables."""
+    ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
+    from utils.tilevae import VAEHook
+    cldm, cfg = build_reference_cldm("tiny")
+    out = {}
+    for name, (h, w, ts, dec) in {"enc_1024_256": (1024, 1024, 256, False), "enc_192x256_64": (192, 256, 64, False),
+                                  "dec_128_64": (128, 128, 64, True), "dec_32x40_8": (32, 40, 8, True),
+                                  "enc_560x760_256": (560, 760, 256, False)}.items():
+        hook = VAEHook(None, ts, dec, False, False, True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ib, ob = hook.split_tiles(h, w)
+        out[f"bbox_in_{name}"] = np.array(ib, dtype=np.int32)
+        out[f"bbox_out_{name}"] = np.array(ob, dtype=np.int32)
+    img = synth.synth_input("tvae:img", (1, 3, 192, 256), -1.0, 1.0)
+    zin = synth.synth_normal("tvae:z", (1, 4, 32, 40))
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        out["z_tiled"] = cldm.vae_encode(img, sample=False, tiled=True, tile_size=64).numpy()
+        out["z_plain"] = cldm.vae_encode(img, sample=False).numpy()
+        out["dec_tiled"] = cldm.vae_decode(zin, tiled=True, tile_size=8).numpy()
+        out["dec_plain"] = cldm.vae_decode(zin).numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiled_vae.npz"), **out)
+    print("tiled_vae.npz written; tiled vs plain rel diff: enc",
+          float(np.linalg.norm(out["z_tiled"] - out["z_plain"]) / np.linalg.norm(out["z_plain"])), "dec",
+          float(np.linalg.norm(out["dec_tiled"] - out["dec_plain"]) / np.linalg.norm(out["dec_plain"])))
+
+
 def gen_wavelet():
     _, _, _, ref_common = ref_import.import_reference()
     a = synth.synth_input("wav:content", (2, 3, 96, 80), 0.0, 1.0)
@@ -252,13 +280,13 @@ def gen_wavelet():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,wavelet")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
-        {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled,
+        {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
          "wavelet": gen_wavelet}[name]()
 
 
