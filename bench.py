@@ -47,6 +47,9 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
     ap.add_argument("--no-graph", action="store_true", help="replay launch lists eagerly instead of hipGraphs")
+    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="batches in flight: 2 = consecutive steps alternate between two HIP streams / buffer sets, so "
+                         "the low-occupancy phases of one batch overlap the other (throughput mode)")
     ap.add_argument("--serial-lanes", action="store_true", help="capture ControlNet and the UNet encoder on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -116,7 +119,7 @@ def main() -> None:
     pre_res = pre_res_g[sl].to(dev)
     c_txt = c_txt1.expand(B, -1, -1).contiguous().to(dev)
     noises = [n[sl].to(dev) for n in noises_g]
-    t200 = torch.full((B,), 200, dtype=torch.int64, device=dev)
+    t200 = torch.full((B,), 200, dtype=torch.int64)   # host tensor: q_sample reads it without a device sync
 
     def one_pass():
         z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
@@ -134,8 +137,12 @@ def main() -> None:
         torch.cuda.synchronize()
 
     # ---- warm-up (builds the kernel programs on the first pass), optional hipGraph capture
+    slots = list(range(args.inflight))
+    streams = [torch.cuda.Stream() for _ in slots]
     t0 = time.time()
-    img, z = one_pass()
+    for sl_ in slots:
+        cldm.engine_slot = sl_
+        img, z = one_pass()
     torch.cuda.synchronize()
     log(f"[rank {rank}] first pass (program build + weight packing) {time.time() - t0:.1f}s")
     if not args.no_graph:
@@ -143,12 +150,24 @@ def main() -> None:
             e.step_prog.capture(parallel_lanes=not args.serial_lanes)
         for e in cldm._vae_engines.values():
             e.prog.capture()
-    for _ in range(max(0, args.warmup - 1) + (0 if args.no_graph else 1)):
-        img, z = one_pass()
+
+    def run_steps(n):
+        out = None
+        for i in range(n):
+            k = i % args.inflight
+            cldm.engine_slot = k
+            with torch.cuda.stream(streams[k]):
+                out = one_pass()
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        return out
+
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    img, z = run_steps(max(1, args.warmup) * args.inflight)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        img, z = one_pass()
+    img, z = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -165,7 +184,8 @@ def main() -> None:
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"EDTR-det s4 ({args.config}): vae_encode + q_sample(t=200) + 4 x (ControlNet+UNet) + "
                                f"vae_decode, batch {B}/GPU of {S}x{S}", "global_batch": GB, "image_size": S,
-                   "denoise_steps": 4, "parallelism": f"batch-sharded x{world}", "graphs": not args.no_graph},
+                   "denoise_steps": 4, "parallelism": f"batch-sharded x{world}", "graphs": not args.no_graph,
+                   "batches_in_flight": args.inflight},
         "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE / (world * PEAK_TFLOPS * 1e12), 4) if S == 512 and args.config == "sd21" else None,
     }
 
@@ -184,10 +204,12 @@ def roofline_pass(cldm, args) -> dict:
     """Per-launch HIP-event timing of every program once (eager replay on the launch stream), aggregated by kernel."""
     agg = {}
     progs = []
-    for e in cldm._cldm_engines.values():
-        progs.append((e.step_prog, 4))
-    for e in cldm._vae_engines.values():
-        progs.append((e.prog, 1))
+    for key, e in cldm._cldm_engines.items():
+        if key[-1] == 0:            # one buffer slot is enough: the slots run identical programs
+            progs.append((e.step_prog, 4))
+    for key, e in cldm._vae_engines.items():
+        if key[-1] == 0:
+            progs.append((e.prog, 1))
     for prog, mult in progs:
         g, prog.graph = prog.graph, None
         prog.run_timed()                      # warm

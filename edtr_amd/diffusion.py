@@ -47,6 +47,9 @@ class Diffusion(nn.Module):
         self.register("sqrt_one_minus_alphas_cumprod", np.sqrt(1.0 - ac))
         self.register("sqrt_recip_alphas_cumprod", np.sqrt(1.0 / ac))
         self.register("sqrt_recipm1_alphas_cumprod", np.sqrt(1.0 / ac - 1))
+        # host copies of the two q_sample tables: reading the device buffers would synchronise the stream
+        self._host_sqrt_ac = np.sqrt(ac).astype(np.float32).tolist()
+        self._host_sqrt_1mac = np.sqrt(1.0 - ac).astype(np.float32).tolist()
 
     def register(self, name: str, value: np.ndarray) -> None:
         self.register_buffer(name, torch.tensor(value, dtype=torch.float32))
@@ -59,8 +62,8 @@ class Diffusion(nn.Module):
         x_start = x_start.contiguous().float()
         noise = noise.contiguous().float()
         out = torch.empty_like(x_start)
-        tl = t.tolist()
-        a_tab, b_tab = self.sqrt_alphas_cumprod.tolist(), self.sqrt_one_minus_alphas_cumprod.tolist()
+        tl = t.tolist()      # pass a host tensor to avoid a device sync
+        a_tab, b_tab = self._host_sqrt_ac, self._host_sqrt_1mac
         if len(set(tl)) == 1:
             ops.launch(ops.make_axpby(x=x_start, y=noise, a=a_tab[tl[0]], b=b_tab[tl[0]], out=out, n=x_start.numel()))
         else:

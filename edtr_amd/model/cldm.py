@@ -283,6 +283,9 @@ class ControlLDM(nn.Module):
         self.scale_factor = latent_scale_factor
         self.control_scales = [1.0] * 13
         self.compute_dtype = default_compute_dtype()
+        # engines (static buffers + programs) are cached per shape AND per slot: a caller that keeps two batches in
+        # flight on two HIP streams flips the slot so the batches never share a buffer (bench.py --inflight 2)
+        self.engine_slot = 0
         self._weights = None
         self._fingerprint = None
         self._cldm_engines: Dict[tuple, CldmEngine] = {}
@@ -320,14 +323,14 @@ class ControlLDM(nn.Module):
 
     def cldm_engine(self, B: int, h: int, w: int, nctx: int = 77) -> CldmEngine:
         self._check_fresh()
-        key = (B, h, w, nctx)
+        key = (B, h, w, nctx, self.engine_slot)
         if key not in self._cldm_engines:
             self._cldm_engines[key] = CldmEngine(self, B, h, w, nctx)
         return self._cldm_engines[key]
 
     def vae_engine(self, kind: str, B: int, H: int, W: int, tile_size: int = 0) -> VaeEngine:
         self._check_fresh()
-        key = (kind, B, H, W, tile_size)
+        key = (kind, B, H, W, tile_size, self.engine_slot)
         if key not in self._vae_engines:
             self._vae_engines[key] = VaeEngine(self, kind, B, H, W, tile_size)
         return self._vae_engines[key]
