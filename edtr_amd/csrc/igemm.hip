@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     // offset per row (its pixel's centre tap / its weight row) and a 9-bit "tap in range" mask; a K-tile only moves the
     // wave-uniform soffset (SALU).  Halo / tail lanes present an out-of-range offset and the buffer range check makes
     // the DMA write zeros (verified on gfx950: tools/exp/buffer_lds_probe.hip) — no zero page, no 64-bit VALU address math.
-    uint32_t voff_a[4], voff_w[4], a_mask[4];
+    uint32_t voff_a[4], voff_w[4], a_mask[4], a_par[4];
     u32x4 srd_a, srd_w;
     if constexpr (FAST) {
         const int64_t bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
@@ -422,14 +422,19 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t mask = 0;
+            a_par[j] = 0;
             if (SPATIAL) {
-                const int64_t pc = (int64_t)a_pix[j] + (int64_t)(a_iy0[j] + p.pad_t) * p.IW + (a_ix0[j] + p.pad_l);
+                // output pixel in the (possibly 2x upsampled) logical input grid; source pixel of the centre tap
+                const int ly = a_iy0[j] + p.pad_t, lx = a_ix0[j] + p.pad_l;
+                const int sy = p.upsample2x ? ly >> 1 : ly, sx = p.upsample2x ? lx >> 1 : lx;
+                a_par[j] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
+                const int64_t pc = (int64_t)a_pix[j] + (int64_t)sy * p.IW + sx;
                 voff_a[j] = (uint32_t)((pc * p.ld1 + coff[j]) * 2);
                 const int ntap = p.taps;
                 for (int t = 0; t < ntap; ++t) {
                     const int ky = ntap == 9 ? (t * 11) >> 5 : p.pad_t, kx = ntap == 9 ? t - 3 * ky : p.pad_l;
                     const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                    if (a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
+                    if (a_ok[j] && iy >= 0 && iy < LH && ix >= 0 && ix < LW) mask |= 1u << t;
                 }
             } else {
                 voff_a[j] = a_ok[j] ? (uint32_t)(((int64_t)a_pix[j] * p.ld1 + coff[j]) * 2) : kOobOffset;
@@ -447,10 +452,21 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
             run_c0 += BK;
             if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
             uint32_t soff_a, tapbit = 1u;
+            uint32_t dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;    // upsample: per-parity source offsets (bias included, >= 0)
             if (SPATIAL) {
                 int ky = p.pad_t, kx = p.pad_l;     // 1x1 conv in spatial mode: the centre tap
                 if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
-                soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + c0) * 2);
+                if (p.upsample2x) {
+                    // source row of logical row ly + ky - pad is (ly >> 1) + ((parity + ky - pad) >> 1)
+                    const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
+                    dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                    dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                    dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                    dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                    soff_a = (uint32_t)(c0 * 2);
+                } else {
+                    soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + c0) * 2);
+                }
             } else {
                 soff_a = (uint32_t)kt * (BK * 2);
             }
@@ -459,7 +475,11 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
             const uint32_t sw = sa + A_BYTES;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t vo = SPATIAL ? ((a_mask[j] & tapbit) ? voff_a[j] : kOobOffset) : voff_a[j];
+                uint32_t vo = voff_a[j];
+                if (SPATIAL) {
+                    if (p.upsample2x) vo += ((a_par[j] & 1u) ? dy1 : dy0) + ((a_par[j] & 2u) ? dx1 : dx0);
+                    vo = (a_mask[j] & tapbit) ? vo : kOobOffset;
+                }
                 dma16_buf(vo, srd_a, soff_a, sa + j * 1024);
             }
 #pragma unroll
@@ -1067,7 +1087,7 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
         const int64_t a_rows = spatial ? (int64_t)(p.M / (p.OH * p.OW)) * p.IH * p.IW : p.M;
         const int64_t a_bytes = (a_rows + (spatial ? 3 * (int64_t)p.IW + 3 : 0)) * p.ld1 * 2 + (int64_t)p.K * 2;
         const int64_t w_bytes = (int64_t)p.N * p.ldw * 2 + (int64_t)p.K * 2;
-        const bool fast = !p.upsample2x && a_bytes < 0xF0000000LL && w_bytes < 0xF0000000LL;
+        const bool fast = (!p.upsample2x || (p.stride == 1 && tile == 3)) && a_bytes < 0xF0000000LL && w_bytes < 0xF0000000LL;
         if (tile == 4) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_p3<T, true>(p, s) : launch_p3<T, false>(p, s);
@@ -1128,15 +1148,14 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (p.splitk > (p.K + 63) / 64) return EDTR_E_SHAPE;
     }
 
+    // the LDS-DMA main loops need every 64-wide K-tile inside one tap of one source
+    const bool dma_ok = p.C2 == 0 && (p.C1 & 63) == 0;
     int tile = p.tile;
-    if (tile == 0) {
+    if (tile == 0) {   // default: the 2-stage LDS-DMA 128x128 kernel wherever it applies (fastest at every measured shape)
         const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.Z;
-        tile = big >= 200 ? 1 : 2;
+        tile = dma_ok ? 3 : (big >= 200 ? 1 : 2);
     }
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
-    // the LDS-DMA main loop needs every 64-wide K-tile inside one tap of one source
-    const bool dma_ok = p.C2 == 0 && (p.C1 & 63) == 0;
-    if (tile == 1 && dma_ok && !p.tile) tile = 3;
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (tile < 1 || tile > 5) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);

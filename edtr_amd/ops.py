@@ -94,7 +94,7 @@ def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int
         return 0, 1
     want = max(1, round(480 / b128))
     s = max(1, min(want, nkt // 6, 8))
-    return 1, s
+    return 0, s      # tile 0 = library default (LDS-DMA 128x128 main loop whenever Cin % 64 == 0)
 
 
 # --------------------------------------------------------------------------------------------
