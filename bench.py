@@ -259,6 +259,10 @@ def kernel_of(name: str) -> str:
         return "flash_attn64_kernel"
     if name.endswith(".stats"):
         return "gn_stats_kernel"
+    if name.endswith(".finalize"):
+        return "gn_finalize_kernel"
+    if name.startswith("gn_pool") or name.startswith("copy3d") or name.startswith("wavelet"):
+        return name.split(".")[0] + "_kernel"
     if name.endswith(".apply"):
         return "gn_apply_kernel"
     for k in ("layernorm", "softmax_rows", "nchw_to_nhwc", "nhwc_to_nchw", "add", "timestep_embedding", "cast16",

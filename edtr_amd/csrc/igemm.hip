@@ -127,6 +127,12 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
     const int n_out = geglu ? p.N / 2 : p.N;
     const int no0 = geglu ? n0 / 2 : n0;
     const int vec_per_row = BNO / 8;
+    // fused GroupNorm statistics of the tensor being written (per-column sum / sum of squares over this tile's rows):
+    // each thread keeps the same 8 columns for all of its row vectors (16 vectors per 128-column row, 256 threads)
+    const bool gn_acc = p.gn_partial != nullptr && !geglu && p.splitk <= 1 && NI == 2 && MI == 2;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
     for (int v = tid; v < BM * vec_per_row; v += kThreads) {
         const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
         const int m = m0 + ml, n = no0 + n8 * 8;
@@ -143,6 +149,33 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
             continue;
         }
         finish_vector<T>(p, f, m, n, !geglu, o_zoff);
+        if (gn_acc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
+        }
+    }
+    if (gn_acc) {
+        // lanes l, l+16, l+32, l+48 of a wave own the same columns: fold them, then fold the 4 waves through LDS
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gs[j] += __shfl_xor(gs[j], 16, 64); gs[j] += __shfl_xor(gs[j], 32, 64);
+            gq[j] += __shfl_xor(gq[j], 16, 64); gq[j] += __shfl_xor(gq[j], 32, 64);
+        }
+        __syncthreads();                       // every thread is done reading the staged tile
+        if (lane < 16) {
+            float* dst = stage + (wave * 128 + lane * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float a = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += stage[(w * 128 + tid) * 2]; q += stage[(w * 128 + tid) * 2 + 1]; }
+            float* dst = p.gn_partial + ((int64_t)(m0 / BM) * p.N + n0 + tid) * 2;
+            dst[0] = a;
+            dst[1] = q;
+        }
     }
 }
 
@@ -1105,6 +1138,44 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
 
 }  // namespace
 
+namespace {
+// Second stage of the fused GroupNorm statistics: partial[(image, row tile)][C][2] fp32 -> sums[image][group][2] fp64.
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* partial, int tiles_per_image, int C, int groups,
+                                                         double* sums) {
+    __shared__ double red_s[256], red_q[256];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups;
+    const int total = tiles_per_image * cpg;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int t = i / cpg, c = g * cpg + (i - t * cpg);
+        const float* src = partial + (((int64_t)b * tiles_per_image + t) * C + c) * 2;
+        s += (double)src[0];
+        q += (double)src[1];
+    }
+    red_s[threadIdx.x] = s;
+    red_q[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red_s[threadIdx.x] += red_s[threadIdx.x + o]; red_q[threadIdx.x] += red_q[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[((int64_t)b * groups + g) * 2] = red_s[0];
+        sums[((int64_t)b * groups + g) * 2 + 1] = red_q[0];
+    }
+}
+}  // namespace
+
+extern "C" int edtr_gn_finalize(const float* partial, int tiles_per_image, int B, int C, int groups, double* sums,
+                                edtr_stream_t stream) {
+    if (!partial || !sums) return EDTR_E_NULL;
+    if (tiles_per_image <= 0 || B <= 0 || C <= 0 || groups <= 0 || C % groups) return EDTR_E_SHAPE;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
+                       tiles_per_image, C, groups, sums);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (!pp) return EDTR_E_NULL;
     edtr_igemm_params p = *pp;
@@ -1157,6 +1228,8 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     }
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
+    if (p.gn_partial && (tile == 2 || tile >= 4 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
+        return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
     if (tile < 1 || tile > 5) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);

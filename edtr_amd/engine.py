@@ -254,6 +254,7 @@ class Act:
     H: int
     W: int
     C: int
+    gnp: Optional[torch.Tensor] = None    # fused GroupNorm partials written by the producing igemm ([rows/128][C][2] fp32)
 
     @property
     def ld(self) -> int:
@@ -275,18 +276,25 @@ class Emitter:
     def free(self, *ts) -> None:
         for t in ts:
             if isinstance(t, Act):
+                self.arena.free(t.gnp)
                 t = t.t
             self.arena.free(t)
 
     # -- GEMM family ------------------------------------------------------------------------
     def gemm(self, a: torch.Tensor, w: torch.Tensor, M: int, N: int, K: int, *, bias=None, out=None, act=0,
-             residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", **kw) -> torch.Tensor:
+             residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,
+             **kw) -> torch.Tensor:
         """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld)."""
         n_out = N // 2 if act == L.ACT_GEGLU else N
         if out is None:
             out = self.new(M, n_out, torch.float32 if out_f32 else None)
         tile, splitk = ops.choose_splitk(M, N, K, kw.get("Z", 1), act) if "tile" not in kw else (kw.pop("tile"), 1)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
+        self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
+        if (stats_hw and act == 0 and not out_f32 and out.stride(0) == N and "Z" not in kw
+                and ops.gn_fusable(M, N, K, stats_hw, splitk=splitk)):
+            self.last_gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
+            kw["gn_partial"] = self.last_gnp
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=a, w=w, out=out, M=M, N=N, C1=K, ld1=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
             bias_n=bias, act=act, residual=residual, ldr=residual.stride(0) if residual is not None else 0,
@@ -296,7 +304,7 @@ class Emitter:
         return out
 
     def conv(self, x: Act, prefix: str, *, taps=9, stride=1, pad_tl=1, ups=False, rowvec=None, residual=None,
-             out=None, out_f32=False, alpha=1.0, name=None) -> Act:
+             out=None, out_f32=False, alpha=1.0, name=None, stats=False) -> Act:
         """3x3 (or 1x1) convolution of an NHWC activation with the packed weight ``prefix``."""
         w, bias = self.store.conv(prefix, cin_pad=x.C)
         N = w.shape[0]
@@ -315,14 +323,17 @@ class Emitter:
             bias = bias * alpha  # epilogue applies alpha before the bias
         tile, splitk = ops.choose_splitk(M, N, taps * x.C)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
+        gnp = None
+        if stats and not out_f32 and out.stride(0) == N and ops.gn_fusable(M, N, x.C, OH * OW, splitk=splitk):
+            gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=x.t, w=w, out=out, taps=taps, M=M, N=N, C1=x.C, ld1=x.ld, ldw=w.stride(0),
             ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
             ldr=residual.stride(0) if residual is not None else 0, out_f32=out_f32, alpha=alpha, tile=tile, splitk=splitk,
-            workspace=ws, name=name or ("conv3x3" if taps == 9 else "conv1x1")))
+            workspace=ws, gn_partial=gnp, name=name or ("conv3x3" if taps == 9 else "conv1x1")))
         self.arena.free(ws)
-        return Act(out, x.B, OH, OW, N)
+        return Act(out, x.B, OH, OW, N, gnp)
 
     # -- norms --------------------------------------------------------------------------------
     def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, y: torch.Tensor):
@@ -337,6 +348,8 @@ class Emitter:
         sums = self.arena.alloc((x.B, 32, 2), torch.float64)
         y = out if out is not None else self.new(x.rows, x.C)
         st, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
+        if x.gnp is not None:    # the producer's epilogue already reduced this tensor per 128-row tile
+            st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
         self.prog.add(st)
         self.prog.add(ap)
         self.arena.free(sums)
@@ -347,6 +360,8 @@ class Emitter:
         Returns a closure that emits the apply half and yields the normalised activation."""
         y = self.new(x.rows, x.C)
         st, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
+        if x.gnp is not None:
+            st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
         self.prog.add(st)
 
         def apply() -> Act:

@@ -14,7 +14,7 @@ ACT_NONE, ACT_GEGLU, ACT_SILU = 0, 1, 2
 
 DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
-    "edtr_gn_stats", "edtr_gn_apply", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
+    "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy",
@@ -41,6 +41,7 @@ class IgemmParams(C.Structure):
         ("o_zs_outer", C.c_int64), ("o_zs_inner", C.c_int64),
         ("tile", C.c_int32), ("splitk", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("gn_partial", C.c_void_p),
     ]
 
 
@@ -91,6 +92,7 @@ def load() -> C.CDLL:
     lib.edtr_flash_attn64.argtypes = [C.POINTER(AttnParams), vp]
     lib.edtr_gn_stats.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_apply.argtypes = [C.POINTER(GnParams), vp]
+    lib.edtr_gn_finalize.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.edtr_layernorm.argtypes = [i32, vp, i64, i32, i32, vp, vp, f32, vp, i32, vp]
     lib.edtr_softmax_rows.argtypes = [i32, vp, i64, i32, i64, vp, i64, i32, vp]
     lib.edtr_nchw_to_nhwc.argtypes = [i32, vp, i32, i32, i64, vp, i32, i32, i32, f32, f32, vp]

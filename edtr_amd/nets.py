@@ -87,7 +87,7 @@ def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, of
     """model/unet.py:203-223: GN-SiLU-conv (+bias +emb row) ; GN-SiLU-conv (+bias) + skip(x)."""
     p = P + l.prefix
     n1 = em.group_norm(x, p + "in_layers.0.", 1e-5, True)
-    h = em.conv(n1, p + "in_layers.2.", rowvec=table[:, offs[l.prefix]:], name="res.conv1")
+    h = em.conv(n1, p + "in_layers.2.", rowvec=table[:, offs[l.prefix]:], name="res.conv1", stats=True)
     em.free(n1)
     n2 = em.group_norm(h, p + "out_layers.0.", 1e-5, True)
     em.free(h)
@@ -95,7 +95,7 @@ def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, of
         skip = em.conv(x, p + "skip_connection.", taps=1, name="res.skip1x1").t
     else:
         skip = x.t
-    y = em.conv(n2, p + "out_layers.3.", residual=skip, out=out, name="res.conv2")
+    y = em.conv(n2, p + "out_layers.3.", residual=skip, out=out, name="res.conv2", stats=out is None)
     em.free(n2)
     if l.cin != l.cout:
         em.free(skip)
@@ -153,9 +153,9 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out")
     em.free(g, t2)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
-    y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out")
+    y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out", stats_hw=0 if out is not None else N)
     em.free(t3)
-    return Act(y, x.B, x.H, x.W, C)
+    return Act(y, x.B, x.H, x.W, C, em.last_gnp)
 
 
 def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv, out=None, keep_input=True) -> Act:
@@ -165,15 +165,15 @@ def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv
     for i, l in enumerate(layers):
         tgt = out if i == len(layers) - 1 else None
         if l.kind == "conv":
-            y = em.conv(h, P + l.prefix, out=tgt, name="conv_in")
+            y = em.conv(h, P + l.prefix, out=tgt, name="conv_in", stats=tgt is None)
         elif l.kind == "res":
             y = emit_resblock(em, P, l, h, table, offs, out=tgt)
         elif l.kind == "attn":
             y = emit_spatial_transformer(em, P, l, h, kv, out=tgt)
         elif l.kind == "down":
-            y = em.conv(h, P + l.prefix + "op.", stride=2, out=tgt, name="downsample")      # model/unet.py:99-108
+            y = em.conv(h, P + l.prefix + "op.", stride=2, out=tgt, name="downsample", stats=tgt is None)  # unet.py:99-108
         elif l.kind == "up":
-            y = em.conv(h, P + l.prefix + "conv.", ups=True, out=tgt, name="upsample.conv")  # model/unet.py:70-79
+            y = em.conv(h, P + l.prefix + "conv.", ups=True, out=tgt, name="upsample.conv", stats=tgt is None)  # unet.py:70-79
         else:
             raise ValueError(l.kind)
         if h is not x or not keep_input:
@@ -268,7 +268,7 @@ def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool):
 def _g_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act):
     """model/vae.py:103-124 (tiled form: resblock2task, utils/tilevae/tilevae.py:86-106)."""
     n1 = yield from _g_norm(em, x, p + "norm1.", True)
-    h = em.conv(n1, p + "conv1.", name="vae.conv1")
+    h = em.conv(n1, p + "conv1.", name="vae.conv1", stats=True)
     em.free(n1)
     n2 = yield from _g_norm(em, h, p + "norm2.", True)
     em.free(h)
@@ -276,7 +276,7 @@ def _g_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act):
         skip = em.conv(x, p + "nin_shortcut.", taps=1, name="vae.nin_shortcut").t
     else:
         skip = x.t
-    y = em.conv(n2, p + "conv2.", residual=skip, name="vae.conv2")
+    y = em.conv(n2, p + "conv2.", residual=skip, name="vae.conv2", stats=True)
     em.free(n2)
     if l.cin != l.cout:
         em.free(skip)
@@ -313,9 +313,9 @@ def _g_vae_attn(em: Emitter, p: str, x: Act):
                                a_zs=(N * lds, 0), w_zs=(C * ldv, 0), o_zs=(N * C, 0), name="vae.attn.pv"))
     em.free(pr, vt)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
-    y = em.gemm(o, wo, rows, C, C, bias=bo, residual=x.t, name="vae.attn.proj_out")
+    y = em.gemm(o, wo, rows, C, C, bias=bo, residual=x.t, name="vae.attn.proj_out", stats_hw=N)
     em.free(o)
-    return Act(y, x.B, x.H, x.W, C)
+    return Act(y, x.B, x.H, x.W, C, em.last_gnp)
 
 
 def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool):
@@ -327,15 +327,15 @@ def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: 
         p = P + l.prefix
         last = l is layers[-1]
         if l.kind == "conv":
-            y = em.conv(h, p, out_f32=(final_f32 and last), name="vae.conv_in" if first else "vae.conv_out")
+            y = em.conv(h, p, out_f32=(final_f32 and last), name="vae.conv_in" if first else "vae.conv_out", stats=first)
         elif l.kind == "res":
             y = yield from _g_vae_resblock(em, p, l, h)
         elif l.kind == "attn":
             y = yield from _g_vae_attn(em, p, h)
         elif l.kind == "down":
-            y = em.conv(h, p, stride=2, pad_tl=0, name="vae.downsample")     # pad (0,1,0,1) + stride 2: vae.py:54-61
+            y = em.conv(h, p, stride=2, pad_tl=0, name="vae.downsample", stats=True)     # pad (0,1,0,1) + stride 2: vae.py:54-61
         elif l.kind == "up":
-            y = em.conv(h, p, ups=True, name="vae.upsample.conv")           # nearest x2 + conv: vae.py:35-39
+            y = em.conv(h, p, ups=True, name="vae.upsample.conv", stats=True)           # nearest x2 + conv: vae.py:35-39
         elif l.kind == "norm_out":
             y = yield from _g_norm(em, h, p, True)
         else:

@@ -59,7 +59,8 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                bias_n: Optional[torch.Tensor] = None, bias_m: Optional[torch.Tensor] = None,
                rowvec: Optional[torch.Tensor] = None, rowvec_ld: int = 0, rows_per_image: int = 0, act: int = 0,
                residual: Optional[torch.Tensor] = None, ldr: int = 0, out_f32: bool = False, n_valid: int = 0,
-               tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None, name: str = "igemm") -> Rec:
+               tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None,
+               gn_partial: Optional[torch.Tensor] = None, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -79,8 +80,10 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     p.splitk = splitk
     if splitk > 1:
         p.workspace, p.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
+    p.gn_partial = ptr(gn_partial)
     flops = 2.0 * M * N * p.K * Z
-    return Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace), name, flops)
+    return Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
+                                                     gn_partial), name, flops)
 
 
 def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int, int]:
@@ -128,6 +131,19 @@ def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, gr
     nb = 2.0 * B * HW * C
     return (Rec(lib.edtr_gn_stats, (ct.byref(p),), keep, name + ".stats", 0.0, nb),
             Rec(lib.edtr_gn_apply, (ct.byref(p),), keep, name + ".apply", 0.0, 2 * nb))
+
+
+def make_gn_finalize(*, partial, tiles_per_image, B, C, sums, groups: int = 32, name="gn.finalize") -> Rec:
+    return Rec(L.load().edtr_gn_finalize, (ptr(partial), tiles_per_image, B, C, groups, ptr(sums)), (partial, sums), name)
+
+
+def gn_fusable(M: int, N: int, C1: int, hw: int, taps: int = 1, C2: int = 0, splitk: int = 1) -> bool:
+    """Can the producing edtr_igemm also emit GroupNorm partials?  (whole 128-row tiles inside one image, 128x128 kernel)"""
+    if splitk > 1 or C2 or hw % 128 or M % 128 or N % 32:
+        return False
+    dma_ok = C1 % 64 == 0
+    big = ((M + 127) // 128) * ((N + 127) // 128)
+    return dma_ok or big >= 200
 
 
 def make_layernorm(*, dtype, x, rows, C, ldx, gamma, beta, eps, y, ldy, name="layernorm") -> Rec:

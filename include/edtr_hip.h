@@ -108,6 +108,11 @@ typedef struct edtr_igemm_params {
      * second launch sums the slabs and applies the epilogue.  splitk <= 1 disables it.  Needs Z == 1, no GEGLU. */
     int32_t splitk;
     void* workspace; int64_t workspace_bytes;
+    /* fused GroupNorm statistics of the OUTPUT (optional): the epilogue also writes, per 128-row tile, the per-column
+     * sum and sum of squares of the values it stores: gn_partial[(M/128)][N][2] fp32.  edtr_gn_finalize folds them into
+     * the fp64 sums edtr_gn_apply consumes, so the separate statistics pass over the tensor (edtr_gn_stats) disappears.
+     * Needs M % 128 == 0, 16-bit output, no GEGLU / split-K / z-batching, tile 0/1/3. */
+    float* gn_partial;
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -155,6 +160,10 @@ typedef struct edtr_gn_params {
 } edtr_gn_params;
 
 int edtr_gn_stats(const edtr_gn_params* p, edtr_stream_t stream);
+/* Fold the per-tile column partials written by an edtr_igemm epilogue (gn_partial, tiles_per_image = H*W/128 tiles per
+ * image, C columns) into sums[B][groups][2] — a drop-in replacement for edtr_gn_stats on that tensor. */
+int edtr_gn_finalize(const float* partial, int tiles_per_image, int B, int C, int groups, double* sums,
+                     edtr_stream_t stream);
 int edtr_gn_apply(const edtr_gn_params* p, edtr_stream_t stream);
 
 /* LayerNorm over the last dimension, rows x C (C <= 2048), fp32 math, 16-bit in/out.

@@ -462,3 +462,33 @@ def test_graph_capture_replay():
     s.synchronize()
     assert float(o2[0]) == (3.0 + 2.0) * 2 + 2.0
     L.check(lib.edtr_graph_destroy(g), "graph_destroy")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,tile", [(64, 0), (64, 3), (40, 1)])
+def test_fused_groupnorm_partials(dtype, cin, tile):
+    """The igemm epilogue's per-tile column sums + edtr_gn_finalize reproduce edtr_gn_stats on the stored tensor."""
+    ops = _ops()
+    d = dev()
+    B, H, W, cout = 2, 16, 24, 96          # HW = 384 = 3 row tiles per image
+    x = rnd((B, cin, H, W), 90)
+    w = rnd((cout, cin, 3, 3), 91, 1 / math.sqrt(9 * cin))
+    x16, _ = nhwc16(x, dtype)
+    wp = ops.pack_conv_weight(w, dtype).to(d)
+    bias = rnd((cout,), 92).to(d)
+    M = B * H * W
+    out = torch.empty((M, cout), dtype=dtype, device=d)
+    gnp = torch.full((M // 128, cout, 2), 123.0, dtype=torch.float32, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=x16, w=wp, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin,
+                              ldc=cout, spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, tile=tile, gn_partial=gnp))
+    s_fused = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    ops.launch(ops.make_gn_finalize(partial=gnp, tiles_per_image=(H * W) // 128, B=B, C=cout, sums=s_fused))
+    s_ref = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    g = torch.ones(cout, device=d)
+    st, _ = ops.make_gn(dtype=dtype, x=out, ldx=cout, B=B, HW=H * W, C=cout, sums=s_ref, gamma=g, beta=g, eps=1e-5,
+                        silu=False, y=torch.empty_like(out), ldy=cout)
+    ops.launch(st)
+    torch.cuda.synchronize()
+    # the fused sums use the values BEFORE the 16-bit rounding of the store: agreement to rounding noise
+    assert rel(s_fused[..., 1], s_ref[..., 1]) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    assert float((s_fused[..., 0] - s_ref[..., 0]).abs().max()) < (0.5 if dtype == torch.bfloat16 else 0.06)
