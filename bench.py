@@ -40,8 +40,8 @@ def log(*a):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE config 2: 8)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
@@ -203,6 +203,7 @@ def main() -> None:
 def roofline_pass(cldm, args) -> dict:
     """Per-launch HIP-event timing of every program once (eager replay on the launch stream), aggregated by kernel."""
     agg = {}
+    shapes = {}
     progs = []
     for key, e in cldm._cldm_engines.items():
         if key[-1] == 0:            # one buffer slot is enough: the slots run identical programs
@@ -215,8 +216,13 @@ def roofline_pass(cldm, args) -> dict:
         prog.run_timed()                      # warm
         rows = prog.run_timed()
         prog.graph = g
-        for name, ms, flops, nbytes in rows:
+        for name, ms, flops, nbytes, tag in rows:
             kind = kernel_of(name)
+            if tag:
+                sh = shapes.setdefault(tag, [0.0, 0.0, 0])
+                sh[0] += ms * mult
+                sh[1] += flops * mult
+                sh[2] += mult
             a = agg.setdefault(kind, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "by_name": {}})
             a["ms"] += ms * mult
             a["flops"] += flops * mult
@@ -235,6 +241,10 @@ def roofline_pass(cldm, args) -> dict:
             for name, (ms, fl, n) in sorted(a["by_name"].items(), key=lambda kv: -kv[1][0])[:12]:
                 tfn = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 log(f"    {name:28s} {ms:9.3f} ms  n={n:5d}  {tfn:8.1f} TFLOP/s")
+    if args.breakdown:
+        log("--- igemm launches by shape (top 45 by time) ---")
+        for tag, (ms, fl, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:45]:
+            log(f"    {tag:58s} {ms:8.3f} ms  n={n:4d}  {ms / n * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s")
     ig = agg.get("igemm_kernel")
     at = agg.get("flash_attn64_kernel")
     out = {}

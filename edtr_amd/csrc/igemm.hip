@@ -11,6 +11,26 @@
 // residual / activation are applied on 8-wide row vectors and stored with 16-byte writes.
 #include "common.h"
 
+// Diagnostic build only (tools/exp/igemm_stamps.py compiles with -DEDTR_STAMPS): thread 0 of every workgroup stores
+// s_memtime at a few phase boundaries into p.workspace (otherwise unused when splitk <= 1).  The product library
+// is built without the flag and contains no stamp code.
+#ifdef EDTR_STAMPS
+#define STAMP_VALUE 0
+#define EDTR_STAMP(i)                                                                                                  \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && p.workspace && p.splitk <= 1) {                                                        \
+            uint64_t* sb__ = static_cast<uint64_t*>(p.workspace) +                                                     \
+                             (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16;             \
+            if ((i) == 5) sb__[5] = (uint64_t)__builtin_amdgcn_s_getreg(63492) | ((uint64_t)__builtin_amdgcn_s_getreg(63508) << 32); \
+            else if ((i) == 6 || (i) == 7) sb__[i] = __builtin_amdgcn_s_memrealtime();                             \
+            else if ((i) >= 8) sb__[i] = (uint64_t)(STAMP_VALUE);                                             \
+            else sb__[i] = __builtin_amdgcn_s_memtime();                                                               \
+        }                                                                                                              \
+    } while (0)
+#else
+#define EDTR_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -85,6 +105,116 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
     }
 }
 
+// Second half of the tile epilogue: the staged fp32 tile [BM][BNO] -> 8-column row vectors -> bias / time-embedding
+// row / SiLU / residual -> 16-byte stores.  A thread owns ONE 8-column group for all of its ITER rows (256 threads,
+// BNO/8 groups), so the per-column operands (bias, and the time-embedding row when the tile lies inside one image) are
+// loaded once, and the ITER residual vectors are requested up front — before the barrier that publishes the staged
+// tile — so that their L2/HBM latency overlaps the staging instead of serialising ITER dependent round trips
+// (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
+template <typename T, int BM, int BNO, bool GEGLU>
+__device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
+                                           int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8]) {
+    constexpr int VPR = BNO / 8, RPI = kThreads / VPR, ITER = BM / RPI;
+    const int tid = threadIdx.x;
+    const int n8 = tid % VPR, r0 = tid / VPR;
+    const int n = no0 + n8 * 8;
+    const bool n_ok = n < n_out;
+
+    if (p.splitk > 1) {                       // fp32 partial slab, finished by splitk_reduce_kernel
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int ml = r0 + RPI * it, m = m0 + ml;
+            if (m < p.M && n_ok) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+                float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
+                *reinterpret_cast<f32x4*>(o) = s0;
+                *reinterpret_cast<f32x4*>(o + 4) = s1;
+            }
+        }
+        return;
+    }
+
+    U4 res[ITER];
+    if (p.residual) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int m = m0 + r0 + RPI * it;
+            res[it] = (m < p.M && n_ok) ? ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n) : zero16();
+        }
+    }
+    float cb[8];                              // per-column addend: bias (+ time-embedding row when uniform over the tile)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cb[j] = 0.0f;
+    if (!GEGLU && p.bias_n && n_ok) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias_n + n), b1 = *reinterpret_cast<const f32x4*>(p.bias_n + n + 4);
+        cb[0] = b0[0]; cb[1] = b0[1]; cb[2] = b0[2]; cb[3] = b0[3]; cb[4] = b1[0]; cb[5] = b1[1]; cb[6] = b1[2]; cb[7] = b1[3];
+    }
+    bool rv_rows = false;                     // time-embedding row differs between this tile's rows
+    if (p.rowvec) {
+        const int m_last = min(m0 + BM, p.M) - 1;
+        const int img0 = m0 / p.rows_per_image;
+        rv_rows = (m_last / p.rows_per_image) != img0;
+        if (!rv_rows && n_ok) {
+            const float* rv = p.rowvec + (int64_t)img0 * p.rowvec_ld + n;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv), b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+            cb[0] += b0[0]; cb[1] += b0[1]; cb[2] += b0[2]; cb[3] += b0[3]; cb[4] += b1[0]; cb[5] += b1[1]; cb[6] += b1[2]; cb[7] += b1[3];
+        }
+    }
+    const float alpha = GEGLU ? 1.0f : p.alpha;
+    const bool silu = p.act == EDTR_ACT_SILU;
+    __syncthreads();                          // staged tile visible
+
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int ml = r0 + RPI * it, m = m0 + ml;
+        if (m < p.M && n_ok) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+            float f[8];
+            f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], alpha, cb[j]);
+            if (p.bias_m) {
+                const float bm = p.bias_m[m];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] += bm;
+            }
+            if (rv_rows) {
+                const float* rv = p.rowvec + (int64_t)(m / p.rows_per_image) * p.rowvec_ld + n;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] += rv[j];
+            }
+            if (silu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+            }
+            if (p.residual) {
+                float rf[8];
+                unpack8<T>(res[it], rf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] += rf[j];
+            }
+            const int64_t oidx = o_zoff + (int64_t)m * p.ldc + n;
+            if (p.out_f32) {
+                float* o = static_cast<float*>(p.out) + oidx;
+                f32x4 o0, o1;
+                o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2]; o0[3] = f[3];
+                o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
+                *reinterpret_cast<f32x4*>(o) = o0;
+                *reinterpret_cast<f32x4*>(o + 4) = o1;
+            } else {
+                stg16(static_cast<uint16_t*>(p.out) + oidx, pack8<T>(f));
+            }
+            if (gn_acc) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
+            }
+        }
+    }
+}
+
 // Tile epilogue shared by both main-loop variants: accumulators -> LDS (fp32) -> row vectors of 8 columns.
 template <typename T, int MI, int NI>
 __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16 (&acc)[MI][NI], char* smem, int m0, int n0,
@@ -122,38 +252,16 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
                     stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
                 }
     }
-    __syncthreads();
-
     const int n_out = geglu ? p.N / 2 : p.N;
     const int no0 = geglu ? n0 / 2 : n0;
-    const int vec_per_row = BNO / 8;
     // fused GroupNorm statistics of the tensor being written (per-column sum / sum of squares over this tile's rows):
     // each thread keeps the same 8 columns for all of its row vectors (16 vectors per 128-column row, 256 threads)
     const bool gn_acc = p.gn_partial != nullptr && !geglu && p.splitk <= 1 && NI == 2 && MI == 2;
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    for (int v = tid; v < BM * vec_per_row; v += kThreads) {
-        const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
-        const int m = m0 + ml, n = no0 + n8 * 8;
-        if (m >= p.M || n >= n_out) continue;
-        float f[8];
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
-        f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
-        f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
-        if (p.splitk > 1) {
-            float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
-            *reinterpret_cast<f32x4*>(o) = s0;
-            *reinterpret_cast<f32x4*>(o + 4) = s1;
-            continue;
-        }
-        finish_vector<T>(p, f, m, n, !geglu, o_zoff);
-        if (gn_acc) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
-        }
-    }
+    if (geglu) rows_phase<T, BM, BN / 2, true>(p, stage, m0, no0, n_out, o_zoff, false, gs, gq);
+    else rows_phase<T, BM, BN, false>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
     if (gn_acc) {
         // lanes l, l+16, l+32, l+48 of a wave own the same columns: fold them, then fold the 4 waves through LDS
 #pragma unroll
@@ -367,11 +475,10 @@ __device__ __forceinline__ u32x4 make_srd(const void* base) {
 }
 
 __device__ __forceinline__ void dma16_buf(uint32_t voff, const u32x4& srd, uint32_t soff, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :
                  : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
-                 : "memory");
+                 : "memory");   // M0 is free here: hipcc keeps no value in it across statements on gfx950
 }
 
 __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
@@ -388,6 +495,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
 // ------------------------------------------------------------------------------------------------------
 template <typename T, bool SPATIAL, bool FAST>
 __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm_params p) {
+    EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
     constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -422,6 +530,20 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     bool a_ok[4], w_ok[4];
     int64_t w_row[4];
     const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    // (image, oy, ox) of the tile's first row by ONE exact division pair on wave-uniform values; the 128 rows of the
+    // tile are then reached with two small float-reciprocal divmods each (operands < 2^20, one fix-up step either
+    // way makes them exact) instead of two 32-bit integer divisions per row (~40 VALU instructions each).
+    int b0 = 0, oy0 = 0, ox0 = 0;
+    float rcp_ow = 0.0f, rcp_oh = 0.0f;
+    if (SPATIAL) {
+        const int hw = p.OH * p.OW;
+        b0 = m0 / hw;
+        const int rem0 = m0 - b0 * hw;
+        oy0 = rem0 / p.OW;
+        ox0 = rem0 - oy0 * p.OW;
+        rcp_ow = 1.0f / (float)p.OW;
+        rcp_oh = 1.0f / (float)p.OH;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = wave * 32 + 8 * j + rsub;
@@ -429,12 +551,17 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         const int m = m0 + row;
         a_ok[j] = m < p.M;
         if (SPATIAL) {
-            const int hw = p.OH * p.OW;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const int x = ox0 + row;
+            int qx = (int)((float)x * rcp_ow), ox = x - qx * p.OW;
+            if (ox >= p.OW) { ++qx; ox -= p.OW; }
+            if (ox < 0) { --qx; ox += p.OW; }
+            const int y = oy0 + qx;
+            int qy = (int)((float)y * rcp_oh), oy = y - qy * p.OH;
+            if (oy >= p.OH) { ++qy; oy -= p.OH; }
+            if (oy < 0) { --qy; oy += p.OH; }
             a_iy0[j] = oy * p.stride - p.pad_t;
             a_ix0[j] = ox * p.stride - p.pad_l;
-            a_pix[j] = b * p.IH * p.IW;
+            a_pix[j] = (b0 + qy) * p.IH * p.IW;
         } else {
             a_iy0[j] = 0; a_ix0[j] = 0; a_pix[j] = m;
         }
@@ -463,11 +590,19 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
                 a_par[j] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
                 const int64_t pc = (int64_t)a_pix[j] + (int64_t)sy * p.IW + sx;
                 voff_a[j] = (uint32_t)((pc * p.ld1 + coff[j]) * 2);
-                const int ntap = p.taps;
-                for (int t = 0; t < ntap; ++t) {
-                    const int ky = ntap == 9 ? (t * 11) >> 5 : p.pad_t, kx = ntap == 9 ? t - 3 * ky : p.pad_l;
-                    const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                    if (a_ok[j] && iy >= 0 && iy < LH && ix >= 0 && ix < LW) mask |= 1u << t;
+                // tap t = 3 ky + kx is in range iff row ky and column kx are: mask = rowbits (x) colbits
+                if (p.taps == 9) {
+                    uint32_t rb = 0, cbits = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int iy = a_iy0[j] + k, ix = a_ix0[j] + k;
+                        rb |= (iy >= 0 && iy < LH) ? (1u << (3 * k)) : 0u;
+                        cbits |= (ix >= 0 && ix < LW) ? (1u << k) : 0u;
+                    }
+                    mask = a_ok[j] ? rb * cbits : 0u;
+                } else {
+                    const int iy = a_iy0[j] + p.pad_t, ix = a_ix0[j] + p.pad_l;
+                    mask = (a_ok[j] && iy >= 0 && iy < LH && ix >= 0 && ix < LW) ? 1u : 0u;
                 }
             } else {
                 voff_a[j] = a_ok[j] ? (uint32_t)(((int64_t)a_pix[j] * p.ld1 + coff[j]) * 2) : kOobOffset;
@@ -479,27 +614,46 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     }
     int run_tap = 0, run_c0 = 0;   // (tap, channel offset) of the NEXT tile to issue; tiles are issued in order
 
+    // Per-lane A offsets of the CURRENT filter tap (halo / tail lanes -> out of range), recomputed only when the tap
+    // changes (every Cin/64 K-tiles); within a tap a K-tile moves just the wave-uniform soffset, so the issue of a
+    // K-tile is 8 x (M0 write + buffer_load ... lds) and a handful of SALU instructions.
+    uint32_t vsel[4] = {0u, 0u, 0u, 0u};
+    uint32_t soff_tap = 0;
+    int sel_tap = -1;
+    auto select_tap = [&](int tap) {
+        if constexpr (FAST && SPATIAL) {
+            int ky = p.pad_t, kx = p.pad_l;     // 1x1 conv in spatial mode: the centre tap
+            uint32_t tapbit = 1u;
+            if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
+            if (p.upsample2x) {
+                // source row of logical row ly + ky - pad is (ly >> 1) + ((parity + ky - pad) >> 1); bias included, >= 0
+                const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
+                const uint32_t dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                const uint32_t dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                const uint32_t dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                const uint32_t dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t vo = voff_a[j] + ((a_par[j] & 1u) ? dy1 : dy0) + ((a_par[j] & 2u) ? dx1 : dx0);
+                    vsel[j] = (a_mask[j] & tapbit) ? vo : kOobOffset;
+                }
+                soff_tap = 0;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vsel[j] = (a_mask[j] & tapbit) ? voff_a[j] : kOobOffset;
+                soff_tap = (uint32_t)(((ky * p.IW + kx) * p.ld1) * 2);
+            }
+        }
+    };
+
     auto issue_tile = [&](int kt, int buf) {
         if constexpr (FAST) {
-            const int tap = run_tap, c0 = run_c0;
-            run_c0 += BK;
-            if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
-            uint32_t soff_a, tapbit = 1u;
-            uint32_t dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;    // upsample: per-parity source offsets (bias included, >= 0)
-            if (SPATIAL) {
-                int ky = p.pad_t, kx = p.pad_l;     // 1x1 conv in spatial mode: the centre tap
-                if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
-                if (p.upsample2x) {
-                    // source row of logical row ly + ky - pad is (ly >> 1) + ((parity + ky - pad) >> 1)
-                    const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
-                    dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
-                    dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
-                    dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
-                    dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
-                    soff_a = (uint32_t)(c0 * 2);
-                } else {
-                    soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + c0) * 2);
-                }
+            uint32_t soff_a;
+            if constexpr (SPATIAL) {
+                if (run_tap != sel_tap) { select_tap(run_tap); sel_tap = run_tap; }
+                soff_a = soff_tap + (uint32_t)(run_c0 * 2);
+                run_c0 += BK;
+                if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
             } else {
                 soff_a = (uint32_t)kt * (BK * 2);
             }
@@ -507,14 +661,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
             const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
             const uint32_t sw = sa + A_BYTES;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t vo = voff_a[j];
-                if (SPATIAL) {
-                    if (p.upsample2x) vo += ((a_par[j] & 1u) ? dy1 : dy0) + ((a_par[j] & 2u) ? dx1 : dx0);
-                    vo = (a_mask[j] & tapbit) ? vo : kOobOffset;
-                }
-                dma16_buf(vo, srd_a, soff_a, sa + j * 1024);
-            }
+            for (int j = 0; j < 4; ++j) dma16_buf(SPATIAL ? vsel[j] : voff_a[j], srd_a, soff_a, sa + j * 1024);
 #pragma unroll
             for (int j = 0; j < 4; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
             return;
@@ -567,22 +714,41 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         nkt = min(per, nkt_all - kt0);
         if (nkt < 0) nkt = 0;
     }
-    if (SPATIAL && p.taps == 9) {
+    if (SPATIAL) {
         run_tap = (kt0 * BK) / Cin;
         run_c0 = kt0 * BK - run_tap * Cin;
     }
+    EDTR_STAMP(1);
     if (nkt > 0) issue_tile(kt0, 0);
 
+#ifdef EDTR_STAMPS
+    uint64_t stamp_acc[4] = {0, 0, 0, 0};
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
+#ifdef EDTR_STAMPS
+        const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+#endif
         if (kt + 1 < nkt) {
             issue_tile(kt0 + kt + 1, cur ^ 1);
+#ifdef EDTR_STAMPS
+            stamp_acc[0] += __builtin_amdgcn_s_memtime() - ts0;
+#endif
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMAs of tile kt have landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#ifdef EDTR_STAMPS
+        const uint64_t ts1 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();                           // ... and every other wave's
         asm volatile("" ::: "memory");
+#ifdef EDTR_STAMPS
+        const uint64_t ts2 = __builtin_amdgcn_s_memtime();
+        stamp_acc[1] += ts1 - ts0;      // issue + own vmcnt wait
+        stamp_acc[2] += ts2 - ts1;      // barrier wait
+        if (kt == 0) EDTR_STAMP(2);
+#endif
         const char* sa = smem + cur * STAGE;
         const char* sw = sa + A_BYTES;
 #pragma unroll
@@ -601,11 +767,32 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma(af[mi], bf[ni], acc[mi][ni]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef EDTR_STAMPS
+        stamp_acc[3] += __builtin_amdgcn_s_memtime() - ts2;     // ds_read + MFMA issue section
+#endif
         __builtin_amdgcn_s_barrier();                           // buffer `cur` may be refilled next iteration
         asm volatile("" ::: "memory");
     }
     if (nkt == 0) __syncthreads();
+    EDTR_STAMP(3);
+#ifdef EDTR_STAMPS
+#undef STAMP_VALUE
+#define STAMP_VALUE stamp_acc[0]
+    EDTR_STAMP(8);
+#undef STAMP_VALUE
+#define STAMP_VALUE stamp_acc[1]
+    EDTR_STAMP(9);
+#undef STAMP_VALUE
+#define STAMP_VALUE stamp_acc[2]
+    EDTR_STAMP(10);
+#undef STAMP_VALUE
+#define STAMP_VALUE stamp_acc[3]
+    EDTR_STAMP(11);
+#undef STAMP_VALUE
+#define STAMP_VALUE 0
+#endif
     tile_epilogue<T, MI, NI>(p, acc, smem, m0, n0, o_zoff);
+    EDTR_STAMP(4); EDTR_STAMP(7);
 }
 
 template <typename T, bool SPATIAL, bool FAST>
@@ -1207,6 +1394,8 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if ((p.a_zs_outer & 7) || (p.a_zs_inner & 7) || (p.w_zs_outer & 7) || (p.w_zs_inner & 7) ||
         (p.o_zs_outer & 3) || (p.o_zs_inner & 3))
         return EDTR_E_ALIGN;
+    // the epilogue reads bias / time-embedding rows as 16-byte vectors
+    if ((p.bias_n && !aligned16(p.bias_n)) || (p.rowvec && (!aligned16(p.rowvec) || (p.rowvec_ld & 3)))) return EDTR_E_ALIGN;
     if (p.n_valid < 0 || p.n_valid > p.N) return EDTR_E_SHAPE;
     if (p.residual && p.Z != 1) return EDTR_E_UNSUPPORTED;  // residual / rowvec are not z-batched
     if (p.rowvec && p.Z != 1) return EDTR_E_UNSUPPORTED;

@@ -229,7 +229,7 @@ class Program:
             self.graph = None
 
     def run_timed(self) -> List[Tuple[str, float, float, float]]:
-        """[(name, ms, flops, bytes)] per launch, HIP events on the launch stream."""
+        """[(name, ms, flops, bytes, shape tag)] per launch, HIP events on the launch stream."""
         s = ops.stream_ptr()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(self.recs) + 1)]
         evs[0].record()
@@ -237,7 +237,7 @@ class Program:
             r.launch(s)
             evs[i + 1].record()
         torch.cuda.synchronize()
-        return [(r.name, evs[i].elapsed_time(evs[i + 1]), r.flops, r.bytes) for i, r in enumerate(self.recs)]
+        return [(r.name, evs[i].elapsed_time(evs[i + 1]), r.flops, r.bytes, r.tag) for i, r in enumerate(self.recs)]
 
     def total_flops(self) -> float:
         return sum(r.flops for r in self.recs)

@@ -34,10 +34,11 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 class Rec:
     """One pre-built kernel launch."""
-    __slots__ = ("fn", "args", "keep", "name", "flops", "bytes")
+    __slots__ = ("fn", "args", "keep", "name", "flops", "bytes", "tag")
 
     def __init__(self, fn, args, keep, name, flops=0.0, nbytes=0.0):
         self.fn, self.args, self.keep, self.name, self.flops, self.bytes = fn, args, keep, name, flops, nbytes
+        self.tag = ""           # shape tag for the per-shape bench breakdown
 
     def launch(self, stream: int) -> None:
         code = self.fn(*self.args, stream)
@@ -82,8 +83,12 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
         p.workspace, p.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     p.gn_partial = ptr(gn_partial)
     flops = 2.0 * M * N * p.K * Z
-    return Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
-                                                     gn_partial), name, flops)
+    rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
+                                                    gn_partial), name, flops)
+    rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
+               + (" up2" if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
+               + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else ""))
+    return rec
 
 
 def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int, int]:

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Diagnostic: in-kernel phase timeline of igemm_dma_kernel (s_memtime stamps, see EDTR_STAMP in igemm.hip).
+
+  python tools/exp/igemm_stamps.py build      # here (cross-compiles tools/exp/_build/libigemm_stamps.so for gfx950)
+  python tools/exp/igemm_stamps.py run        # on the GPU box (gpurun)
+
+Not part of the product path: it loads its own stamped build of igemm.hip, never edtr_amd/libedtr_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tools", "exp", "_build")
+SO = os.path.join(OUT, "libigemm_stamps.so")
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(ROOT, "edtr_amd", "csrc", "igemm.hip")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DEDTR_STAMPS",
+                    src, "-o", SO], check=True)
+    print(SO)
+
+
+def run():
+    import numpy as np
+    import torch
+    from edtr_amd import lib as L
+    dev = torch.device("cuda:0")
+    lib = C.CDLL(SO)
+    lib.edtr_igemm.argtypes = [C.POINTER(L.IgemmParams), C.c_void_p]
+    DT = torch.bfloat16
+
+    def case(label, M, N, Cin, taps=1, H=0, residual=False, act=0):
+        K = taps * Cin
+        a = (torch.randn(M, Cin, device=dev)).to(DT)
+        w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(DT)
+        n_out = N // 2 if act == 1 else N
+        out = torch.empty(M, n_out, dtype=DT, device=dev)
+        res = torch.randn(M, n_out, device=dev).to(DT) if residual else None
+        bias = torch.zeros(N, device=dev)
+        nb = ((M + 127) // 128) * ((N + 127) // 128)
+        stamps = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
+        p = L.IgemmParams()
+        p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = 0 if DT == torch.bfloat16 else 1, taps, M, N, K, 1, 1
+        p.a1, p.C1, p.ld1 = a.data_ptr(), Cin, Cin
+        if H:
+            p.IH = p.IW = p.OH = p.OW = H
+            p.stride, p.pad_t, p.pad_l = 1, (1 if taps == 9 else 0), (1 if taps == 9 else 0)
+        p.w, p.ldw, p.alpha = w.data_ptr(), K, 1.0
+        p.bias_n, p.act = bias.data_ptr(), act
+        if res is not None:
+            p.residual, p.ldr = res.data_ptr(), n_out
+        p.out, p.ldc = out.data_ptr(), n_out
+        p.tile, p.splitk = 3, 1
+        p.workspace, p.workspace_bytes = stamps.data_ptr(), stamps.numel() * 8
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            assert lib.edtr_igemm(C.byref(p), s) == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            lib.edtr_igemm(C.byref(p), s)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        st = stamps.cpu().numpy().reshape(nb, 16).astype(np.int64)
+        d = lambda i, j: st[:, j] - st[:, i]
+        pro, first, loop, epi, tot = d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(0, 4)
+        rt0 = st[:, 6] - st[:, 6].min()
+        rt1 = st[:, 7] - st[:, 6].min()
+        span_us = rt1.max() / 100.0
+        life_us = np.median(st[:, 7] - st[:, 6]) / 100.0
+        nkt = K // 64
+        hw = st[:, 5] & 0xFFFFFFFF
+        xcc = (st[:, 5] >> 32) & 0xF
+        cu = (hw >> 8) & 0xF
+        se = (hw >> 13) & 0x7
+        slots = len(set(zip(xcc.tolist(), se.tolist(), cu.tolist())))
+        starts = np.sort(rt0) / 100.0
+        # how many workgroups start in the first microsecond = resident slots
+        first_wave = int((starts < 1.0).sum())
+        flops = 2.0 * M * N * K
+        print(f"{label:34s} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF | WGs {nb:5d} first-us {first_wave:4d} CUs {slots:3d} | span {span_us:6.1f} us "
+              f"WG life {life_us:5.1f} us | cycles med: prologue {int(np.median(pro)):5d} first-tile {int(np.median(first)):5d} "
+              f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d} | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}",
+              flush=True)
+
+    B = 8
+    if len(sys.argv) > 2 and sys.argv[2] == "spatial1":
+        case("1x1 spatial 64^2 K320 N320", B * 4096, 320, 320, taps=1, H=64)
+        case("1x1 spatial 64^2 K1280 N320", B * 4096, 320, 1280, taps=1, H=64)
+        case("gemm 64^2 K1280 N320", B * 4096, 320, 1280)
+        case("1x1 spatial 256^2 K256 N256", B * 65536, 256, 256, taps=1, H=256)
+        case("gemm 256^2 K256 N256", B * 65536, 256, 256)
+        case("gemm 256^2 K2304 N256", B * 65536, 256, 2304)
+        case("conv 256^2 256->256", B * 256 * 256, 256, 256, taps=9, H=256)
+        return
+    case("proj 64^2 K320 N320 +res", B * 4096, 320, 320, residual=True)
+    case("proj 64^2 K320 N320", B * 4096, 320, 320)
+    case("qk 64^2 K320 N640", B * 4096, 640, 320)
+    case("ff.out 64^2 K1280 N320 +res", B * 4096, 320, 1280, residual=True)
+    case("geglu 64^2 K320 N2560", B * 4096, 2560, 320, act=1)
+    case("proj 32^2 K640 N640 +res", B * 1024, 640, 640, residual=True)
+    case("proj 16^2 K1280 N1280 +res", B * 256, 1280, 1280, residual=True)
+    case("conv 64^2 320->320", B * 4096, 320, 320, taps=9, H=64)
+    case("conv 32^2 640->640", B * 1024, 640, 640, taps=9, H=32)
+    case("conv 512^2 128->128", B * 512 * 512, 128, 128, taps=9, H=512)
+    case("conv 256^2 256->256", B * 256 * 256, 256, 256, taps=9, H=256)
+    case("conv 128^2 512->512", B * 128 * 128, 512, 512, taps=9, H=128)
+
+
+if __name__ == "__main__":
+    (build if (len(sys.argv) > 1 and sys.argv[1] == "build") else run)()
