@@ -31,6 +31,9 @@ struct BF16 {
     static __device__ __forceinline__ f32x16 mfma(const U4& a, const U4& b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(const U4& a, const U4& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
 };
 struct F16 {
     using vec8 = f16x8_t;
@@ -45,6 +48,9 @@ struct F16 {
     }
     static __device__ __forceinline__ f32x16 mfma(const U4& a, const U4& b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(const U4& a, const U4& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
 };
 

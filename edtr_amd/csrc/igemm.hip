@@ -9,6 +9,7 @@
 // LDS tiles are [rows][64 x 16-bit] with the XOR swizzle of common.h (conflict-free ds_read_b128).
 // The epilogue stages the fp32 accumulators through LDS so that bias / time-embedding row vector /
 // residual / activation are applied on 8-wide row vectors and stored with 16-byte writes.
+#include <type_traits>
 #include "common.h"
 
 // Diagnostic build only (tools/exp/igemm_stamps.py compiles with -DEDTR_STAMPS): thread 0 of every workgroup stores
@@ -111,10 +112,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // loaded once, and the ITER residual vectors are requested up front — before the barrier that publishes the staged
 // tile — so that their L2/HBM latency overlaps the staging instead of serialising ITER dependent round trips
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
-template <typename T, int BM, int BNO, bool GEGLU>
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8]) {
-    constexpr int VPR = BNO / 8, RPI = kThreads / VPR, ITER = BM / RPI;
+    constexpr int VPR = BNO / 8, RPI = THREADS / VPR, ITER = BM / RPI;
     const int tid = threadIdx.x;
     const int n8 = tid % VPR, r0 = tid / VPR;
     const int n = no0 + n8 * 8;
@@ -1275,6 +1276,313 @@ int launch_big(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves, ping-pong schedule (tile = 6).  The structure the 128x128 two-barrier loop cannot
+// reach (its L2->LDS traffic is 64 B/clk/CU at MFMA peak and its DMA issue, LDS reads and MFMAs run back to back
+// in each wave): a workgroup of 8 waves per CU, waves w and w+4 share a SIMD and run HALF A PHASE APART (waves
+// 4-7 take one extra barrier before the loop), so on every SIMD one wave issues its 16 MFMAs while its partner
+// issues LDS reads and the LDS-DMA of a future half-tile.
+//   * wave (wr = w>>2, wc = w&3) owns rows {wr*64 .. +63} of BOTH 128-row A halves and columns {wc*32 .. +31} of
+//     BOTH 128-column B halves: 4 quadrants of 64x32, one quadrant x K=64 per phase (16 x v_mfma_f32_16x16x32).
+//   * a K-tile = 4 half-tiles of 16 KiB (A_lo, A_hi, B_lo, B_hi; [128][64] 16-bit, XOR-swizzled on the source
+//     side); two K-tile buffers = 128 KiB LDS.  An iteration = 2 K-tiles = 8 phases; every phase stages ONE
+//     half-tile (2 DMAs per wave):  even tile t+2: B_lo@3 A_lo@4 B_hi@5 A_hi@6, odd tile t+3: B_lo@7 A_lo@8,
+//     B_hi@1 A_hi@2 (next iteration).  Reads: A_lo,B_lo @1/5, B_hi @2/6, A_hi @3/7 (B_lo stays in registers for
+//     phase 4/8).  Every restage is >= 2 phases after the last read of its slot (WAR), every phase waits
+//     vmcnt(6) = "all but the 3 newest half-tiles landed" before its first barrier, and a slot is read >= 1
+//     phase after the wait that retires it (RAW) — three half-tiles stay in flight across the barriers.
+// Buffer addressing only (operands < 4 GiB), Cin % 64 == 0, no GEGLU / split-K.  Epilogue: two passes of
+// 128 rows through the 128 KiB of LDS, then the shared row-vector phase (and the fused GroupNorm partials).
+// ------------------------------------------------------------------------------------------------------
+struct KState { int t, tap, c0; };
+
+template <typename T, bool SPATIAL>
+__global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_params p) {
+    constexpr int HALF = 128 * BK * 2;       // bytes of one half-tile
+    constexpr int BUF = 4 * HALF;            // A_lo, A_hi, B_lo, B_hi
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
+    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
+    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
+    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    // ---- staging geometry: this wave fills rows wave*16 + 8*j + (lane>>3), j = 0,1, of every half-tile
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int Cin = p.C1;
+    const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    uint32_t voff_a[4], voff_w[4], a_mask[4], a_par[4];   // index = half * 2 + j
+    int b0 = 0, oy0 = 0, ox0 = 0;
+    float rcp_ow = 0.0f, rcp_oh = 0.0f;
+    if (SPATIAL) {
+        const int hw = p.OH * p.OW;
+        b0 = m0 / hw;
+        const int rem0 = m0 - b0 * hw;
+        oy0 = rem0 / p.OW;
+        ox0 = rem0 - oy0 * p.OW;
+        rcp_ow = 1.0f / (float)p.OW;
+        rcp_oh = 1.0f / (float)p.OH;
+    }
+    const int64_t a_bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
+    const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - a_bias);
+    const u32x4 srd_w = make_srd(wp);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rih = wave * 16 + 8 * (q & 1) + rsub;               // row inside the half-tile
+        const int row = (q >> 1) * 128 + rih;                         // row inside the 256-row tile
+        const int coff = (slot ^ ((rih >> 1) & 7)) * 8;               // logical 8-element chunk held by this LDS slot
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        uint32_t mask = 0;
+        a_par[q] = 0;
+        if (SPATIAL) {
+            const int x = ox0 + row;
+            int qx = (int)((float)x * rcp_ow), ox = x - qx * p.OW;
+            if (ox >= p.OW) { ++qx; ox -= p.OW; }
+            if (ox < 0) { --qx; ox += p.OW; }
+            const int y = oy0 + qx;
+            int qy = (int)((float)y * rcp_oh), oy = y - qy * p.OH;
+            if (oy >= p.OH) { ++qy; oy -= p.OH; }
+            if (oy < 0) { --qy; oy += p.OH; }
+            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            const int ly = iy0 + p.pad_t, lx = ix0 + p.pad_l;
+            const int sy = p.upsample2x ? ly >> 1 : ly, sx = p.upsample2x ? lx >> 1 : lx;
+            a_par[q] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
+            const int64_t pc = (int64_t)(b0 + qy) * p.IH * p.IW + (int64_t)sy * p.IW + sx;
+            voff_a[q] = (uint32_t)((pc * p.ld1 + coff) * 2);
+            if (p.taps == 9) {
+                uint32_t rb = 0, cbits = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int iy = iy0 + k, ix = ix0 + k;
+                    rb |= (iy >= 0 && iy < LH) ? (1u << (3 * k)) : 0u;
+                    cbits |= (ix >= 0 && ix < LW) ? (1u << k) : 0u;
+                }
+                mask = ok ? rb * cbits : 0u;
+            } else {
+                mask = (ok && ly >= 0 && ly < LH && lx >= 0 && lx < LW) ? 1u : 0u;
+            }
+        } else {
+            voff_a[q] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
+            mask = 1u;
+        }
+        a_mask[q] = mask;
+        const int n = n0 + row;
+        voff_w[q] = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
+    }
+
+    const int nkt = p.K / BK;
+    auto advance2 = [&](KState& s) {
+        s.t += 2;
+        if (SPATIAL) {
+            s.c0 += 2 * BK;
+            while (s.c0 >= Cin) { s.c0 -= Cin; ++s.tap; }
+        }
+    };
+    // stage half-tile `H` (0 = A_lo, 1 = A_hi, 2 = B_lo, 3 = B_hi) of K-tile s.t into buffer `buf`
+    auto stage_half = [&](const KState& s, int buf, auto Hc) {
+        constexpr int H = decltype(Hc)::value;
+        const bool live = s.t < nkt;
+        const uint32_t dst = smem_base + buf * BUF + H * HALF + wave * 2048;
+        if constexpr (H < 2) {
+            uint32_t soff = (uint32_t)s.t * (BK * 2), tapbit = 1u;
+            uint32_t dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
+            if (SPATIAL) {
+                int ky = p.pad_t, kx = p.pad_l;
+                if (p.taps == 9) { ky = (s.tap * 11) >> 5; kx = s.tap - 3 * ky; tapbit = 1u << s.tap; }
+                if (p.upsample2x) {
+                    const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
+                    dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                    dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                    dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                    dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                    soff = (uint32_t)(s.c0 * 2);
+                } else {
+                    soff = (uint32_t)(((ky * p.IW + kx) * p.ld1 + s.c0) * 2);
+                }
+            }
+            if (!live) tapbit = 0u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                constexpr int q0 = H * 2;
+                uint32_t vo = voff_a[q0 + j];
+                if (SPATIAL && p.upsample2x) vo += ((a_par[q0 + j] & 1u) ? dy1 : dy0) + ((a_par[q0 + j] & 2u) ? dx1 : dx0);
+                vo = (a_mask[q0 + j] & tapbit) ? vo : kOobOffset;
+                dma16_buf(vo, srd_a, soff, dst + j * 1024);
+            }
+        } else {
+            const uint32_t soff = (uint32_t)s.t * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                constexpr int q0 = (H - 2) * 2;
+                const uint32_t vo = live ? voff_w[q0 + j] : kOobOffset;
+                dma16_buf(vo, srd_w, soff, dst + j * 1024);
+            }
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    using H2 = std::integral_constant<int, 2>;
+    using H3 = std::integral_constant<int, 3>;
+
+    // ---- fragment read geometry (conflict-free ds_read_b128 of the swizzled image, see common.h tile_off)
+    const int a_rd = tile_off(wr * 64 + l15, lq);      // + blk * 2048, ^ 64 for the second k-step
+    const int b_rd = tile_off(wc * 32 + l15, lq);
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[i][j][a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    U4 afr[4][2], bfr[2][2][2];
+
+    auto read_a = [&](int buf, int ah) {
+        const char* base = smem + buf * BUF + ah * HALF;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            afr[mb][0] = *reinterpret_cast<const U4*>(base + a_rd + mb * 2048);
+            afr[mb][1] = *reinterpret_cast<const U4*>(base + (a_rd ^ 64) + mb * 2048);
+        }
+    };
+    auto read_b = [&](int buf, auto BHc) {
+        constexpr int BH = decltype(BHc)::value;
+        const char* base = smem + buf * BUF + (2 + BH) * HALF;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            bfr[BH][nb][0] = *reinterpret_cast<const U4*>(base + b_rd + nb * 2048);
+            bfr[BH][nb][1] = *reinterpret_cast<const U4*>(base + (b_rd ^ 64) + nb * 2048);
+        }
+    };
+    auto mma = [&](auto AHc, auto BHc) {
+        constexpr int AH = decltype(AHc)::value, BH = decltype(BHc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[AH][BH][mb][nb] = T::mfma16(afr[mb][ks], bfr[BH][nb][ks], acc[AH][BH][mb][nb]);
+    };
+    // second half of every phase: wait for the half-tiles that must have landed, rendezvous, multiply, rendezvous
+    auto compute = [&](auto AHc, auto BHc) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(AHc, BHc);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: K-tile 0 complete, K-tile 1's B_lo / A_lo (its B_hi / A_hi are staged by phases 1 and 2)
+    KState sE{0, 0, 0}, sO{1, 0, BK};
+    if (SPATIAL) { while (sO.c0 >= Cin) { sO.c0 -= Cin; ++sO.tap; } }
+    stage_half(sE, 0, H0{}); stage_half(sE, 0, H1{}); stage_half(sE, 0, H2{}); stage_half(sE, 0, H3{});
+    stage_half(sO, 1, H2{}); stage_half(sO, 1, H0{});
+    advance2(sE);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run half a phase behind their SIMD partners
+    asm volatile("" ::: "memory");
+
+    const int niter = (nkt + 1) >> 1;
+    for (int it = 0; it < niter; ++it) {
+        // even K-tile (buffer 0)
+        read_b(0, H0{}); read_a(0, 0); stage_half(sO, 1, H3{}); compute(H0{}, H0{});                 // phase 1
+        read_b(0, H1{});               stage_half(sO, 1, H1{}); compute(H0{}, H1{}); advance2(sO);   // phase 2
+        read_a(0, 1);                  stage_half(sE, 0, H2{}); compute(H1{}, H1{});                 // phase 3
+                                       stage_half(sE, 0, H0{}); compute(H1{}, H0{});                 // phase 4
+        // odd K-tile (buffer 1)
+        read_b(1, H0{}); read_a(1, 0); stage_half(sE, 0, H3{}); compute(H0{}, H0{});                 // phase 5
+        read_b(1, H1{});               stage_half(sE, 0, H1{}); compute(H0{}, H1{}); advance2(sE);   // phase 6
+        read_a(1, 1);                  stage_half(sO, 1, H2{}); compute(H1{}, H1{});                 // phase 7
+                                       stage_half(sO, 1, H0{}); compute(H1{}, H0{});                 // phase 8
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two wave groups
+    __syncthreads();
+
+    // ---- epilogue: rows of A half `h` (128 x 256 fp32 = the whole 128 KiB) per pass
+    float* stage = reinterpret_cast<float*>(smem);
+    const bool gn_acc = p.gn_partial != nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[(wr * 64 + mb * 16 + 4 * lq + r) * 256 + bh * 128 + wc * 32 + nb * 16 + l15] = acc[h][bh][mb][nb][r];
+        float gs[8], gq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
+        rows_phase<T, 128, 256, false, 512>(p, stage, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs, gq);
+        __syncthreads();                       // every thread is done reading the staged rows
+        if (gn_acc) {
+            // thread (row group tid/32, column group tid%32): lanes l and l^32 share a column group; fold, then the 8 waves
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gs[j] += __shfl_xor(gs[j], 32, 64); gq[j] += __shfl_xor(gq[j], 32, 64); }
+            if (lane < 32) {
+                float* dst = stage + (wave * 256 + lane * 8) * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+            }
+            __syncthreads();
+            if (tid < 256 && n0 + tid < p.N && m0 + h * 128 < p.M) {
+                float a = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { a += stage[(w * 256 + tid) * 2]; q += stage[(w * 256 + tid) * 2 + 1]; }
+                float* dst = p.gn_partial + ((int64_t)((m0 >> 7) + h) * p.N + n0 + tid) * 2;
+                dst[0] = a;
+                dst[1] = q;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, bool SPATIAL>
+int launch_256(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int lds = 2 * 4 * 128 * BK * 2;     // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_256_kernel<T, SPATIAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
+    dim3 grid(nbm * nbn, 1, p.Z);
+    hipLaunchKernelGGL((igemm_256_kernel<T, SPATIAL>), grid, dim3(512), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 template <typename T, int MI, int NI, bool SPATIAL>
 int launch(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -1300,14 +1608,19 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
+// buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
+static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
+    const int64_t a_rows = spatial ? (int64_t)(p.M / (p.OH * p.OW)) * p.IH * p.IW : p.M;
+    const int64_t a_bytes = (a_rows + (spatial ? 3 * (int64_t)p.IW + 3 : 0)) * p.ld1 * 2 + (int64_t)p.K * 2;
+    const int64_t w_bytes = (int64_t)p.N * p.ldw * 2 + (int64_t)p.K * 2;
+    return a_bytes < 0xF0000000LL && w_bytes < 0xF0000000LL;
+}
+
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile == 3 || tile == 4 || tile == 5) {
+    if (tile >= 3 && tile <= 6) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
-        const int64_t a_rows = spatial ? (int64_t)(p.M / (p.OH * p.OW)) * p.IH * p.IW : p.M;
-        const int64_t a_bytes = (a_rows + (spatial ? 3 * (int64_t)p.IW + 3 : 0)) * p.ld1 * 2 + (int64_t)p.K * 2;
-        const int64_t w_bytes = (int64_t)p.N * p.ldw * 2 + (int64_t)p.K * 2;
-        const bool fast = (!p.upsample2x || (p.stride == 1 && tile == 3)) && a_bytes < 0xF0000000LL && w_bytes < 0xF0000000LL;
+        const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile == 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 4) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_p3<T, true>(p, s) : launch_p3<T, false>(p, s);
@@ -1315,6 +1628,10 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
         if (tile == 5) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_big<T, true>(p, s) : launch_big<T, false>(p, s);
+        }
+        if (tile == 6) {
+            if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_256<T, true>(p, s) : launch_256<T, false>(p, s);
         }
         if (!spatial) return fast ? launch_dma<T, false, true>(p, s) : launch_dma<T, false, false>(p, s);
         return fast ? launch_dma<T, true, true>(p, s) : launch_dma<T, true, false>(p, s);
@@ -1411,15 +1728,22 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     // the LDS-DMA main loops need every 64-wide K-tile inside one tap of one source
     const bool dma_ok = p.C2 == 0 && (p.C1 & 63) == 0;
     int tile = p.tile;
-    if (tile == 0) {   // default: the 2-stage LDS-DMA 128x128 kernel wherever it applies (fastest at every measured shape)
+    if (tile == 0) {   // default: the LDS-DMA kernels wherever they apply
         const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.Z;
         tile = dma_ok ? 3 : (big >= 200 ? 1 : 2);
+        // 256x256 ping-pong kernel: large-K convolutions whose 256-column tiles are mostly full and fill >= half the CUs
+        // (measured on MI355X: 1.17-1.32 PFLOP/s vs 0.98-1.05 for the 128x128 loop on the VAE convolutions)
+        const int nbn256 = (p.N + 255) / 256;
+        const int64_t nb256 = (int64_t)((p.M + 255) / 256) * nbn256 * p.Z;
+        if (dma_ok && p.splitk <= 1 && p.act != EDTR_ACT_GEGLU && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4 &&
+            (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
+            tile = 6;
     }
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
-    if (p.gn_partial && (tile == 2 || tile >= 4 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
+    if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 5) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 6) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }
