@@ -1583,6 +1583,298 @@ int launch_256(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 256x128x64 tile, 8 waves, the same ping-pong structure for narrow outputs (tile = 7; N = 128 VAE convs, N that
+// fills 128- but not 256-column tiles).  A K-tile = 3 units of 16 KiB (A_lo, A_hi, B) and 2 phases (A_lo x B,
+// A_hi x B; 16 MFMAs each, B fragments stay in registers); THREE K-tile buffers (144 KiB): while tile u is
+// multiplied, tile u+2 is staged into the buffer tile u-1 has just left — A_lo and B in the odd phase, A_hi in
+// the even one — which is exactly ">= 2 phases after the slot's last read, >= 4 phases before its next one".
+// ------------------------------------------------------------------------------------------------------
+
+template <typename T, bool SPATIAL>
+__global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_params p) {
+    constexpr int HALF = 128 * BK * 2;       // bytes of one unit (128 rows x 64 k)
+    constexpr int BUF = 3 * HALF;            // A_lo, A_hi, B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int m0 = tm * 256, n0 = tn * 128;
+
+    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
+    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
+    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
+    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    // ---- staging geometry: this wave fills rows wave*16 + 8*j + (lane>>3), j = 0,1, of every half-tile
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int Cin = p.C1;
+    const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    uint32_t voff_a[4], voff_w[4], a_mask[4], a_par[4];   // index = half * 2 + j
+    int b0 = 0, oy0 = 0, ox0 = 0;
+    float rcp_ow = 0.0f, rcp_oh = 0.0f;
+    if (SPATIAL) {
+        const int hw = p.OH * p.OW;
+        b0 = m0 / hw;
+        const int rem0 = m0 - b0 * hw;
+        oy0 = rem0 / p.OW;
+        ox0 = rem0 - oy0 * p.OW;
+        rcp_ow = 1.0f / (float)p.OW;
+        rcp_oh = 1.0f / (float)p.OH;
+    }
+    const int64_t a_bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
+    const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - a_bias);
+    const u32x4 srd_w = make_srd(wp);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rih = wave * 16 + 8 * (q & 1) + rsub;               // row inside the half-tile
+        const int row = (q >> 1) * 128 + rih;                         // row inside the 256-row tile
+        const int coff = (slot ^ ((rih >> 1) & 7)) * 8;               // logical 8-element chunk held by this LDS slot
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        uint32_t mask = 0;
+        a_par[q] = 0;
+        if (SPATIAL) {
+            const int x = ox0 + row;
+            int qx = (int)((float)x * rcp_ow), ox = x - qx * p.OW;
+            if (ox >= p.OW) { ++qx; ox -= p.OW; }
+            if (ox < 0) { --qx; ox += p.OW; }
+            const int y = oy0 + qx;
+            int qy = (int)((float)y * rcp_oh), oy = y - qy * p.OH;
+            if (oy >= p.OH) { ++qy; oy -= p.OH; }
+            if (oy < 0) { --qy; oy += p.OH; }
+            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            const int ly = iy0 + p.pad_t, lx = ix0 + p.pad_l;
+            const int sy = p.upsample2x ? ly >> 1 : ly, sx = p.upsample2x ? lx >> 1 : lx;
+            a_par[q] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
+            const int64_t pc = (int64_t)(b0 + qy) * p.IH * p.IW + (int64_t)sy * p.IW + sx;
+            voff_a[q] = (uint32_t)((pc * p.ld1 + coff) * 2);
+            if (p.taps == 9) {
+                uint32_t rb = 0, cbits = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int iy = iy0 + k, ix = ix0 + k;
+                    rb |= (iy >= 0 && iy < LH) ? (1u << (3 * k)) : 0u;
+                    cbits |= (ix >= 0 && ix < LW) ? (1u << k) : 0u;
+                }
+                mask = ok ? rb * cbits : 0u;
+            } else {
+                mask = (ok && ly >= 0 && ly < LH && lx >= 0 && lx < LW) ? 1u : 0u;
+            }
+        } else {
+            voff_a[q] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
+            mask = 1u;
+        }
+        a_mask[q] = mask;
+        const int n = n0 + rih;                                        // B is one unit: rows q = 0,1 only
+        voff_w[q] = (q < 2 && n < nvalid) ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
+    }
+
+    const int nkt = p.K / BK;
+    auto advance1 = [&](KState& s) {
+        s.t += 1;
+        if (SPATIAL) {
+            s.c0 += BK;
+            if (s.c0 >= Cin) { s.c0 -= Cin; ++s.tap; }
+        }
+    };
+    // stage unit `H` (0 = A_lo, 1 = A_hi, 2 = B) of K-tile s.t into buffer `buf`
+    auto stage_half = [&](const KState& s, int buf, auto Hc) {
+        constexpr int H = decltype(Hc)::value;
+        const bool live = s.t < nkt;
+        const uint32_t dst = smem_base + buf * BUF + H * HALF + wave * 2048;
+        if constexpr (H < 2) {
+            uint32_t soff = (uint32_t)s.t * (BK * 2), tapbit = 1u;
+            uint32_t dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
+            if (SPATIAL) {
+                int ky = p.pad_t, kx = p.pad_l;
+                if (p.taps == 9) { ky = (s.tap * 11) >> 5; kx = s.tap - 3 * ky; tapbit = 1u << s.tap; }
+                if (p.upsample2x) {
+                    const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
+                    dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                    dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                    dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                    dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                    soff = (uint32_t)(s.c0 * 2);
+                } else {
+                    soff = (uint32_t)(((ky * p.IW + kx) * p.ld1 + s.c0) * 2);
+                }
+            }
+            if (!live) tapbit = 0u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                constexpr int q0 = H * 2;
+                uint32_t vo = voff_a[q0 + j];
+                if (SPATIAL && p.upsample2x) vo += ((a_par[q0 + j] & 1u) ? dy1 : dy0) + ((a_par[q0 + j] & 2u) ? dx1 : dx0);
+                vo = (a_mask[q0 + j] & tapbit) ? vo : kOobOffset;
+                dma16_buf(vo, srd_a, soff, dst + j * 1024);
+            }
+        } else {
+            const uint32_t soff = (uint32_t)s.t * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t vo = live ? voff_w[j] : kOobOffset;
+                dma16_buf(vo, srd_w, soff, dst + j * 1024);
+            }
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    using H2 = std::integral_constant<int, 2>;
+
+    // ---- fragment read geometry (conflict-free ds_read_b128 of the swizzled image, see common.h tile_off)
+    const int a_rd = tile_off(wr * 64 + l15, lq);      // + blk * 2048, ^ 64 for the second k-step
+    const int b_rd = tile_off(wc * 32 + l15, lq);
+
+    f32x4 acc[2][4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[i][a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    U4 afr[4][2], bfr[2][2];
+
+    auto read_a = [&](int buf, int ah) {
+        const char* base = smem + buf * BUF + ah * HALF;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            afr[mb][0] = *reinterpret_cast<const U4*>(base + a_rd + mb * 2048);
+            afr[mb][1] = *reinterpret_cast<const U4*>(base + (a_rd ^ 64) + mb * 2048);
+        }
+    };
+    auto read_b = [&](int buf) {
+        const char* base = smem + buf * BUF + 2 * HALF;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            bfr[nb][0] = *reinterpret_cast<const U4*>(base + b_rd + nb * 2048);
+            bfr[nb][1] = *reinterpret_cast<const U4*>(base + (b_rd ^ 64) + nb * 2048);
+        }
+    };
+    auto mma = [&](auto AHc) {
+        constexpr int AH = decltype(AHc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[AH][mb][nb] = T::mfma16(afr[mb][ks], bfr[nb][ks], acc[AH][mb][nb]);
+    };
+    // second half of every phase: wait for the units that must have landed, rendezvous, multiply, rendezvous.
+    // Odd phases have staged 2 units (4 DMAs), even phases 1: "all but the newest three phases' stagings" is
+    // vmcnt(10) after an odd phase's staging and vmcnt(8) after an even one's.
+    auto compute = [&](auto AHc) {
+        constexpr int AH = decltype(AHc)::value;
+        if constexpr (AH == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(AHc);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: K-tiles 0 and 1 complete (tile 1 may still be in flight when the loop starts)
+    KState sS{0, 0, 0};
+    stage_half(sS, 0, H0{}); stage_half(sS, 0, H2{}); stage_half(sS, 0, H1{});
+    advance1(sS);
+    stage_half(sS, 1, H0{}); stage_half(sS, 1, H2{}); stage_half(sS, 1, H1{});
+    advance1(sS);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run half a phase behind their SIMD partners
+    asm volatile("" ::: "memory");
+
+    // K-tile u lives in buffer u % 3; while u is multiplied, u+2 is staged into the buffer u-1 has just left
+    const int niter = (nkt + 2) / 3;
+    for (int it = 0; it < niter; ++it) {
+        read_b(0); read_a(0, 0); stage_half(sS, 2, H0{}); stage_half(sS, 2, H2{}); compute(H0{});
+        read_a(0, 1);            stage_half(sS, 2, H1{}); compute(H1{}); advance1(sS);
+        read_b(1); read_a(1, 0); stage_half(sS, 0, H0{}); stage_half(sS, 0, H2{}); compute(H0{});
+        read_a(1, 1);            stage_half(sS, 0, H1{}); compute(H1{}); advance1(sS);
+        read_b(2); read_a(2, 0); stage_half(sS, 1, H0{}); stage_half(sS, 1, H2{}); compute(H0{});
+        read_a(2, 1);            stage_half(sS, 1, H1{}); compute(H1{}); advance1(sS);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two wave groups
+    __syncthreads();
+
+    // ---- epilogue: rows of A half `h` (128 x 128 fp32 = 64 KiB) per pass
+    float* stage = reinterpret_cast<float*>(smem);
+    const bool gn_acc = p.gn_partial != nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stage[(wr * 64 + mb * 16 + 4 * lq + r) * 128 + wc * 32 + nb * 16 + l15] = acc[h][mb][nb][r];
+        float gs[8], gq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
+        rows_phase<T, 128, 128, false, 512>(p, stage, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs, gq);
+        __syncthreads();                       // every thread is done reading the staged rows
+        if (gn_acc) {
+            // column group = tid % 16: lanes l, l+16, l+32, l+48 share it; fold them, then the 8 waves through LDS
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gs[j] += __shfl_xor(gs[j], 16, 64); gs[j] += __shfl_xor(gs[j], 32, 64);
+                gq[j] += __shfl_xor(gq[j], 16, 64); gq[j] += __shfl_xor(gq[j], 32, 64);
+            }
+            if (lane < 16) {
+                float* dst = stage + (wave * 128 + lane * 8) * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+            }
+            __syncthreads();
+            if (tid < 128 && n0 + tid < p.N && m0 + h * 128 < p.M) {
+                float a = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { a += stage[(w * 128 + tid) * 2]; q += stage[(w * 128 + tid) * 2 + 1]; }
+                float* dst = p.gn_partial + ((int64_t)((m0 >> 7) + h) * p.N + n0 + tid) * 2;
+                dst[0] = a;
+                dst[1] = q;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, bool SPATIAL>
+int launch_256x128(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int lds = 3 * 3 * 128 * BK * 2;     // 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_256x128_kernel<T, SPATIAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
+    dim3 grid(nbm * nbn, 1, p.Z);
+    hipLaunchKernelGGL((igemm_256x128_kernel<T, SPATIAL>), grid, dim3(512), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 template <typename T, int MI, int NI, bool SPATIAL>
 int launch(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -1618,9 +1910,9 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 6) {
+    if (tile >= 3 && tile <= 7) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
-        const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile == 6))) && igemm_fast_addressable(p, spatial);
+        const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 4) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_p3<T, true>(p, s) : launch_p3<T, false>(p, s);
@@ -1629,8 +1921,9 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_big<T, true>(p, s) : launch_big<T, false>(p, s);
         }
-        if (tile == 6) {
+        if (tile == 6 || tile == 7) {
             if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+            if (tile == 7) return spatial ? launch_256x128<T, true>(p, s) : launch_256x128<T, false>(p, s);
             return spatial ? launch_256<T, true>(p, s) : launch_256<T, false>(p, s);
         }
         if (!spatial) return fast ? launch_dma<T, false, true>(p, s) : launch_dma<T, false, false>(p, s);
@@ -1743,7 +2036,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 6) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 7) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

@@ -58,7 +58,10 @@ def nhwc16(x, dtype, pad_to=None):
                                         (77, 640, 1024, 5), (520, 1280, 320, 5),
                                         # tile 6 = 256x256 tile, 8 waves, ping-pong 8-phase schedule (odd K-tile counts too)
                                         (256, 128, 64, 6), (300, 72, 192, 6), (4096, 320, 320, 6), (130, 136, 128, 6),
-                                        (77, 640, 1024, 6), (520, 1280, 320, 6), (1000, 520, 1152, 6)])
+                                        (77, 640, 1024, 6), (520, 1280, 320, 6), (1000, 520, 1152, 6),
+                                        # tile 7 = 256x128 tile, 8 waves, ping-pong over three K-tile buffers
+                                        (256, 128, 64, 7), (300, 72, 192, 7), (4096, 320, 320, 7), (130, 136, 128, 7),
+                                        (77, 640, 1024, 7), (520, 1280, 320, 7), (1000, 520, 1152, 7), (700, 128, 256, 7)])
 def test_gemm_bias_residual(dtype, M, N, K, tile):
     ops = _ops()
     a = rnd((M, K), 1).to(dtype)
@@ -193,7 +196,8 @@ def test_gemm_batched_strided(dtype):
                                   "s1_dma", "s2_dma", "vae_down_dma", "up_dma", "small_cout_dma",
                                   "s1_p3", "s2_p3", "vae_down_p3", "small_cout_p3",
                                   "s1_big", "s2_big", "vae_down_big", "small_cout_big",
-                                  "s1_256", "s2_256", "vae_down_256", "up_256", "small_cout_256"])
+                                  "s1_256", "s2_256", "vae_down_256", "up_256", "small_cout_256",
+                                  "s1_256n", "s2_256n", "vae_down_256n", "up_256n", "small_cout_256n"])
 def test_conv3x3(dtype, case):
     tile = 0
     if case.endswith("_dma"):
@@ -204,6 +208,8 @@ def test_conv3x3(dtype, case):
         case, tile = case[:-4], 5
     if case.endswith("_256"):
         case, tile = case[:-4], 6
+    if case.endswith("_256n"):
+        case, tile = case[:-5], 7
     ops = _ops()
     d = dev()
     B, H, W = 2, 12, 20
@@ -471,7 +477,7 @@ def test_graph_capture_replay():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,tile", [(64, 0), (64, 3), (40, 1), (64, 6)])
+@pytest.mark.parametrize("cin,tile", [(64, 0), (64, 3), (40, 1), (64, 6), (64, 7)])
 def test_fused_groupnorm_partials(dtype, cin, tile):
     """The igemm epilogue's per-tile column sums + edtr_gn_finalize reproduce edtr_gn_stats on the stored tensor."""
     ops = _ops()
