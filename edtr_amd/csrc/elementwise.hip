@@ -131,6 +131,25 @@ inline unsigned blocks_for(int64_t n) {
 
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(256) zero_kernel(U4* dst, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = zero16();
+}
+}  // namespace
+
+extern "C" int edtr_zero_bytes(void* ptr, int64_t bytes, edtr_stream_t stream) {
+    if (!ptr) return EDTR_E_NULL;
+    if (bytes < 0) return EDTR_E_SHAPE;
+    if ((bytes & 15) || !aligned16(ptr)) return EDTR_E_ALIGN;
+    if (bytes == 0) return EDTR_OK;
+    const int64_t n16 = bytes >> 4;
+    int64_t blocks = (n16 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<U4*>(ptr), n16);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 extern "C" int edtr_abi_version(void) { return EDTR_ABI_VERSION; }
 
 extern "C" const char* edtr_error_string(int code) {

@@ -251,8 +251,10 @@ extern "C" int edtr_gn_stats(const edtr_gn_params* pp, edtr_stream_t stream) {
     const edtr_gn_params& p = *pp;
     if (int e = check_gn(p, false)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(p.sums, 0, sizeof(double) * 2 * p.groups * p.B, s);
-    if (e != hipSuccess) return (int)e;
+    if (!p.sums_zeroed) {
+        hipError_t e = hipMemsetAsync(p.sums, 0, sizeof(double) * 2 * p.groups * p.B, s);
+        if (e != hipSuccess) return (int)e;
+    }
     const int CV = p.C >> 3;
     int R = CV >= 256 ? 1 : 256 / CV;
     if (R < 1) R = 1;

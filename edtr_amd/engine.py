@@ -164,6 +164,25 @@ class Program:
         self.marks: Dict[int, str] = {}     # index into recs -> "fork" / "join" placed BEFORE that launch
         self.lane = 0
         self.graph = None
+        self.sums_pool: Optional[torch.Tensor] = None   # GroupNorm [B][32][2] fp64 accumulators, zeroed by ONE launch
+        self.sums_used = 0
+
+    SUMS_SLOTS = 384
+
+    def sums_slot(self, arena: "Arena", B: int) -> torch.Tensor:
+        """A never-reused [B, 32, 2] fp64 GroupNorm accumulator out of a pool that the program's FIRST launch zeroes
+        (a hipMemsetAsync per edtr_gn_stats call costs two extra tiny kernels per node inside the hipGraph)."""
+        if self.sums_pool is None:
+            self.sums_pool = arena.alloc((self.SUMS_SLOTS, B, 32, 2), torch.float64)
+            rec = ops.make_zero(self.sums_pool, name="gn.zero_pool")
+            self.recs.insert(0, rec)
+            self.lanes.insert(0, 0)
+            self.marks = {k + 1: v for k, v in self.marks.items()}
+        if self.sums_used >= self.SUMS_SLOTS or self.sums_pool.shape[1] != B:
+            raise RuntimeError("GroupNorm accumulator pool exhausted")
+        t = self.sums_pool[self.sums_used]
+        self.sums_used += 1
+        return t
 
     def add(self, rec: Rec) -> Rec:
         self.recs.append(rec)
@@ -336,23 +355,28 @@ class Emitter:
         return Act(out, x.B, OH, OW, N, gnp)
 
     # -- norms --------------------------------------------------------------------------------
-    def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, y: torch.Tensor):
+    def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, y: torch.Tensor,
+                 sums_zeroed: bool = False):
         gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
         c_real = self.store.params[prefix + "weight"].numel()
         if c_real != x.C:
             raise ValueError(f"GroupNorm {prefix}: activation has {x.C} channels, parameter has {c_real}")
         return ops.make_gn(dtype=self.dtype, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C, sums=sums, gamma=gamma,
-                           beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0))
+                           beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed)
 
     def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None) -> Act:
-        sums = self.arena.alloc((x.B, 32, 2), torch.float64)
         y = out if out is not None else self.new(x.rows, x.C)
-        st, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
         if x.gnp is not None:    # the producer's epilogue already reduced this tensor per 128-row tile
+            sums = self.arena.alloc((x.B, 32, 2), torch.float64)
+            _, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
             st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
+        else:                    # atomically accumulated statistics: a pre-zeroed pool slot, never reused in this program
+            sums = self.prog.sums_slot(self.arena, x.B)
+            st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=True)
         self.prog.add(st)
         self.prog.add(ap)
-        self.arena.free(sums)
+        if x.gnp is not None:
+            self.arena.free(sums)
         return Act(y, x.B, x.H, x.W, x.C)
 
     def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor):

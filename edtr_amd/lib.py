@@ -17,7 +17,7 @@ DECLARED_SYMBOLS = [
     "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
-    "edtr_graph_destroy",
+    "edtr_graph_destroy", "edtr_zero_bytes",
 ]
 
 
@@ -64,6 +64,7 @@ class GnParams(C.Structure):
         ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("eps", C.c_float), ("silu", C.c_int32),
         ("y", C.c_void_p), ("ldy", C.c_int32),
+        ("sums_zeroed", C.c_int32),
     ]
 
 
@@ -114,7 +115,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("edtr_error_string",):
             fn.restype = i32
-    if lib.edtr_abi_version() != 1:
+    lib.edtr_zero_bytes.argtypes = [vp, i64, vp]
+    if lib.edtr_abi_version() != 2:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -93,15 +93,19 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
 
 def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int, int]:
     """(tile, splitk) heuristic for the 256-CU MI355X: when the 128x128 tile grid cannot fill the chip, cut K so
-    that ~512-1024 workgroups exist, keeping >= 6 K-tiles (of 64) per split."""
+    that ~480 workgroups exist — but only while every split keeps enough K-tiles (of 64) to amortise the fp32 slab
+    round trip of the reducer: >= 20 per split (>= 12 when fewer than 64 tiles exist at all).  Measured with
+    tools/bench_kernels.py gsplitk / splitk: M=2048 N=1280 K=1280 runs 18.5 us unsplit vs 24.8 us at 3 splits, while
+    K=5120 gains (53.5 -> 42.3 us) and the 8x8-level convolutions (M=512, K=11520) gain 3x at 8 splits."""
     if Z != 1 or act == L.ACT_GEGLU:
         return 0, 1
     nkt = (K + 63) // 64
     b128 = ((M + 127) // 128) * ((N + 127) // 128)
-    if b128 >= 200 or nkt < 12:
+    if b128 >= 200 or nkt < 24:
         return 0, 1
     want = max(1, round(480 / b128))
-    s = max(1, min(want, nkt // 6, 8))
+    per_split = 12 if b128 <= 64 else 20
+    s = max(1, min(want, nkt // per_split, 8))
     return 0, s      # tile 0 = library default (LDS-DMA 128x128 main loop whenever Cin % 64 == 0)
 
 
@@ -124,13 +128,20 @@ def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_l
 # --------------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------------
-def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, groups: int = 32, name="gn"):
+def make_zero(t: torch.Tensor, name: str = "zero") -> Rec:
+    nbytes = t.numel() * t.element_size()
+    return Rec(L.load().edtr_zero_bytes, (ptr(t), nbytes), (t,), name, 0.0, float(nbytes))
+
+
+def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, groups: int = 32, name="gn",
+            sums_zeroed: bool = False):
     """Returns (stats_rec, apply_rec)."""
     p = L.GnParams()
     p.dtype, p.B, p.HW, p.C, p.groups = dt_code(dtype), B, HW, C, groups
     p.x, p.ldx, p.sums = ptr(x), ldx, ptr(sums)
     p.gamma, p.beta, p.eps, p.silu = ptr(gamma), ptr(beta), eps, int(silu)
     p.y, p.ldy = ptr(y), ldy
+    p.sums_zeroed = int(sums_zeroed)
     keep = (p, x, sums, gamma, beta, y)
     lib = L.load()
     nb = 2.0 * B * HW * C

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 1
+#define EDTR_ABI_VERSION 2
 
 enum edtr_dtype { EDTR_BF16 = 0, EDTR_F16 = 1 };
 
@@ -157,6 +157,8 @@ typedef struct edtr_gn_params {
     float eps;
     int32_t silu;                   /* 0 / 1 */
     void* y; int32_t ldy;
+    int32_t sums_zeroed;            /* edtr_gn_stats only: nonzero = the caller has already zeroed `sums` (e.g. one edtr_zero_bytes
+                                       over a pool of them), so no per-call memset node is enqueued */
 } edtr_gn_params;
 
 int edtr_gn_stats(const edtr_gn_params* p, edtr_stream_t stream);
@@ -181,6 +183,10 @@ int edtr_softmax_rows(int dtype, const float* s, int64_t rows, int cols, int64_t
 /* ------------------------------------------------------------------------------------------
  * Layout / elementwise helpers.
  * ---------------------------------------------------------------------------------------- */
+/* Zero `bytes` bytes (a multiple of 16, 16-byte aligned) with ONE kernel launch (hipMemsetAsync costs two tiny kernels per
+ * node inside a hipGraph).  replaces: the implicit zero-initialisation of the reduction buffers that torch's
+ * native_group_norm allocates per call (reference model/util.py:146-163 via nn.GroupNorm). */
+int edtr_zero_bytes(void* ptr, int64_t bytes, edtr_stream_t stream);
 /* NCHW fp32 [B][C][HW] -> NHWC 16-bit: dst[(b*HW+p)*ld + coff + c] = scale*src + shift; when
  * zero_pad_to > C the channels C..zero_pad_to-1 (relative to coff) are written as 0.
  * replaces: `.type(self.dtype)` + rearranges (model/controlnet.py:266-269; model/attention.py:292)

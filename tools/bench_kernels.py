@@ -51,15 +51,16 @@ def bench_conv(B, H, Cin, Cout, stride=1, ups=False, tile=0, extra=None):
     return ms, rec.flops / ms / 1e9
 
 
-def bench_gemm(M, N, K, tile=0, act=0, residual=False):
+def bench_gemm(M, N, K, tile=0, act=0, residual=False, splitk=1):
     a = rnd(M, K)
     w = rnd(N, K, scale=1 / math.sqrt(K))
     n_out = N // 2 if act == 1 else N
     out = torch.empty((M, n_out), dtype=DT, device=dev)
     res = rnd(M, n_out) if residual else None
     bias = torch.zeros(N, device=dev)
+    ws = torch.empty(splitk * M * N, dtype=torch.float32, device=dev) if splitk > 1 else None
     rec = ops.make_igemm(dtype=DT, a1=a, w=w, out=out, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=n_out, bias_n=bias, act=act,
-                         residual=res, ldr=n_out, tile=tile)
+                         residual=res, ldr=n_out, tile=tile, splitk=splitk, workspace=ws)
     ms = timeit(rec)
     return ms, rec.flops / ms / 1e9
 
@@ -116,6 +117,18 @@ def main():
                     ms, tf = bench_conv(B, H, ci, co, tile=t, extra={"splitk": S})
                     row += f" | t{t}s{S}: {ms:6.3f} {tf:5.0f}"
             print(row, flush=True)
+    if what in ("gsplitk",):
+        print(f"--- gemm split-K sweep (B={B}) ---")
+        for M, N, K in [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (512, 1280, 1280), (512, 1280, 5120),
+                        (512, 2560, 1280), (8192, 640, 640), (8192, 640, 2560)]:
+            row = f"M={M:5d} N={N:5d} K={K:5d}"
+            for S in (1, 2, 3, 4, 6, 8):
+                if S > K // 64:
+                    continue
+                ms, tf = bench_gemm(M, N, K, tile=0, residual=True, splitk=S)
+                row += f" | s{S}: {ms * 1e3:6.1f}us {tf:5.0f}"
+            print(row, flush=True)
+        return
     if what in ("gemm", "all"):
         print(f"--- gemm (B={B}) ---")
         for hw, c in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
