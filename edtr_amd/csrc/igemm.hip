@@ -115,18 +115,20 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8]) {
-    constexpr int VPR = BNO / 8, RPI = THREADS / VPR, ITER = BM / RPI;
+    // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
+    constexpr int VPR = BNO / 8, RPI = THREADS / VPR, ITER = (BM + RPI - 1) / RPI;
+    constexpr bool EXACT = (THREADS % VPR == 0) && (BM % RPI == 0);
     const int tid = threadIdx.x;
     const int n8 = tid % VPR, r0 = tid / VPR;
     const int n = no0 + n8 * 8;
-    const bool n_ok = n < n_out;
+    const bool n_ok = n < n_out && (EXACT || r0 < RPI);
 
     if (p.splitk > 1) {                       // fp32 partial slab, finished by splitk_reduce_kernel
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int ml = r0 + RPI * it, m = m0 + ml;
-            if (m < p.M && n_ok) {
+            if (m < p.M && n_ok && (EXACT || ml < BM)) {
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
                 const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
                 float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
@@ -142,7 +144,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int m = m0 + r0 + RPI * it;
-            res[it] = (m < p.M && n_ok) ? ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n) : zero16();
+            res[it] = (m < p.M && n_ok && (EXACT || r0 + RPI * it < BM)) ? ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n) : zero16();
         }
     }
     float cb[8];                              // per-column addend: bias (+ time-embedding row when uniform over the tile)
@@ -170,7 +172,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int ml = r0 + RPI * it, m = m0 + ml;
-        if (m < p.M && n_ok) {
+        if (m < p.M && n_ok && (EXACT || ml < BM)) {
             const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
             const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
             float f[8];
@@ -1875,6 +1877,252 @@ int launch_256x128(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 128x160x64 tile (tile = 8): the SD-2.1 channel counts are 320 / 640 / 1280 = 2 / 4 / 8 x 160, so a 160-column
+// tile wastes nothing where the 128-column grid pads N = 320 to 384 (one third-empty tile in three), and at the
+// 64x64-latent level (M = 32768, N = 320) it makes 256 x 2 = 512 workgroups — exactly one resident round at two
+// workgroups per CU instead of 768 (one and a half).  Same two-stage buffer-addressed LDS-DMA loop as tile 3; 4 waves
+// as 2 x 2, a wave owns 64 rows x 80 columns = 4 x 5 blocks of v_mfma_f32_16x16x32 (80 accumulator registers).
+// Per K-tile a wave issues 4 A + 5 W pieces (vmcnt(9)).  LDS: 2 x (16 + 20) KiB; the epilogue stages 64 rows x 160
+// columns of fp32 (40 KiB) per pass, two passes.  Buffer addressing only, no GEGLU, no split-K.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, bool SPATIAL>
+__global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igemm_params p) {
+    constexpr int BM = 128, BN = 160;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
+    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
+    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
+    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    // ---- staging geometry: A rows wave*32 + 8j + (lane>>3), j < 4; W rows wave*40 + 8j + (lane>>3), j < 5
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int Cin = p.C1;
+    const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    uint32_t voff_a[4], voff_w[5], a_mask[4], a_par[4];
+    int b0 = 0, oy0 = 0, ox0 = 0;
+    float rcp_ow = 0.0f, rcp_oh = 0.0f;
+    if (SPATIAL) {
+        const int hw = p.OH * p.OW;
+        b0 = m0 / hw;
+        const int rem0 = m0 - b0 * hw;
+        oy0 = rem0 / p.OW;
+        ox0 = rem0 - oy0 * p.OW;
+        rcp_ow = 1.0f / (float)p.OW;
+        rcp_oh = 1.0f / (float)p.OH;
+    }
+    const int64_t a_bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
+    const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - a_bias);
+    const u32x4 srd_w = make_srd(wp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + 8 * j + rsub;
+        const int coff = (slot ^ ((row >> 1) & 7)) * 8;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        uint32_t mask = 0;
+        a_par[j] = 0;
+        if (SPATIAL) {
+            const int x = ox0 + row;
+            int qx = (int)((float)x * rcp_ow), ox = x - qx * p.OW;
+            if (ox >= p.OW) { ++qx; ox -= p.OW; }
+            if (ox < 0) { --qx; ox += p.OW; }
+            const int y = oy0 + qx;
+            int qy = (int)((float)y * rcp_oh), oy = y - qy * p.OH;
+            if (oy >= p.OH) { ++qy; oy -= p.OH; }
+            if (oy < 0) { --qy; oy += p.OH; }
+            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            const int ly = iy0 + p.pad_t, lx = ix0 + p.pad_l;
+            const int sy = p.upsample2x ? ly >> 1 : ly, sx = p.upsample2x ? lx >> 1 : lx;
+            a_par[j] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
+            const int64_t pc = (int64_t)(b0 + qy) * p.IH * p.IW + (int64_t)sy * p.IW + sx;
+            voff_a[j] = (uint32_t)((pc * p.ld1 + coff) * 2);
+            if (p.taps == 9) {
+                uint32_t rb = 0, cbits = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int iy = iy0 + k, ix = ix0 + k;
+                    rb |= (iy >= 0 && iy < LH) ? (1u << (3 * k)) : 0u;
+                    cbits |= (ix >= 0 && ix < LW) ? (1u << k) : 0u;
+                }
+                mask = ok ? rb * cbits : 0u;
+            } else {
+                mask = (ok && ly >= 0 && ly < LH && lx >= 0 && lx < LW) ? 1u : 0u;
+            }
+        } else {
+            voff_a[j] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
+            mask = 1u;
+        }
+        a_mask[j] = mask;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int row = wave * 40 + 8 * j + rsub;
+        const int coff = (slot ^ ((row >> 1) & 7)) * 8;
+        const int n = n0 + row;
+        voff_w[j] = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
+    }
+
+    int run_tap = 0, run_c0 = 0, sel_tap = -1;
+    uint32_t vsel[4] = {0u, 0u, 0u, 0u};
+    uint32_t soff_tap = 0;
+    auto select_tap = [&](int tap) {
+        if constexpr (SPATIAL) {
+            int ky = p.pad_t, kx = p.pad_l;
+            uint32_t tapbit = 1u;
+            if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
+            if (p.upsample2x) {
+                const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
+                const uint32_t dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                const uint32_t dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                const uint32_t dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                const uint32_t dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t vo = voff_a[j] + ((a_par[j] & 1u) ? dy1 : dy0) + ((a_par[j] & 2u) ? dx1 : dx0);
+                    vsel[j] = (a_mask[j] & tapbit) ? vo : kOobOffset;
+                }
+                soff_tap = 0;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vsel[j] = (a_mask[j] & tapbit) ? voff_a[j] : kOobOffset;
+                soff_tap = (uint32_t)(((ky * p.IW + kx) * p.ld1) * 2);
+            }
+        }
+    };
+    auto issue_tile = [&](int kt, int buf) {
+        uint32_t soff_a;
+        if constexpr (SPATIAL) {
+            if (run_tap != sel_tap) { select_tap(run_tap); sel_tap = run_tap; }
+            soff_a = soff_tap + (uint32_t)(run_c0 * 2);
+            run_c0 += BK;
+            if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
+        } else {
+            soff_a = (uint32_t)kt * (BK * 2);
+        }
+        const uint32_t soff_w = (uint32_t)kt * (BK * 2);
+        const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
+        const uint32_t sw = smem_base + buf * STAGE + A_BYTES + wave * (40 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16_buf(SPATIAL ? vsel[j] : voff_a[j], srd_a, soff_a, sa + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
+    };
+
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int a_rd = tile_off(wm * 64 + l15, lq);      // + mb * 2048; ^ 64 for the second k-step
+    const int b_rd = tile_off(wn * 80 + l15, lq);      // + nb * 2048
+    const int nkt = p.K / BK;
+    if (nkt > 0) issue_tile(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) {
+            issue_tile(kt + 1, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this wave's 9 DMAs of tile kt have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sa = smem + cur * STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            U4 af[4], bf[5];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const U4*>(sa + (a_rd ^ (ks * 64)) + mb * 2048);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) bf[nb] = *reinterpret_cast<const U4*>(sw + (b_rd ^ (ks * 64)) + nb * 2048);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb) acc[mb][nb] = T::mfma16(af[mb], bf[nb], acc[mb][nb]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (nkt == 0) __syncthreads();
+
+    // ---- epilogue: two passes of 64 rows x 160 columns (the rows of the waves with wm == h)
+    float* stage = reinterpret_cast<float*>(smem);
+    const bool gn_acc = p.gn_partial != nullptr;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (wm == h) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stage[(mb * 16 + 4 * lq + r) * BN + wn * 80 + nb * 16 + l15] = acc[mb][nb][r];
+        }
+        rows_phase<T, 64, BN, false, kThreads>(p, stage, m0 + h * 64, n0, p.N, o_zoff, gn_acc, gs, gq);
+        __syncthreads();                       // every thread is done reading the staged rows
+    }
+    if (gn_acc) {
+        // thread (row group r0 = tid / 20 < 12, column group tid % 20) -> LDS [r0][160][2], then 160 threads fold the 12 row groups
+        const int n8 = tid % 20, r0 = tid / 20;
+        if (r0 < 12) {
+            float* dst = stage + (r0 * BN + n8 * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N && m0 < p.M) {
+            float a = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 12; ++g) { a += stage[(g * BN + tid) * 2]; q += stage[(g * BN + tid) * 2 + 1]; }
+            float* dst = p.gn_partial + ((int64_t)(m0 >> 7) * p.N + n0 + tid) * 2;
+            dst[0] = a;
+            dst[1] = q;
+        }
+    }
+}
+
+template <typename T, bool SPATIAL>
+int launch_n160(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int lds = 2 * (128 + 160) * BK * 2;     // 72 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_n160_kernel<T, SPATIAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nbm = (p.M + 127) / 128, nbn = (p.N + 159) / 160;
+    dim3 grid(nbm * nbn, 1, p.Z);
+    hipLaunchKernelGGL((igemm_n160_kernel<T, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 template <typename T, int MI, int NI, bool SPATIAL>
 int launch(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -1910,7 +2158,7 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 7) {
+    if (tile >= 3 && tile <= 8) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 4) {
@@ -1920,6 +2168,10 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
         if (tile == 5) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_big<T, true>(p, s) : launch_big<T, false>(p, s);
+        }
+        if (tile == 8) {
+            if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_n160<T, true>(p, s) : launch_n160<T, false>(p, s);
         }
         if (tile == 6 || tile == 7) {
             if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
@@ -2028,15 +2280,22 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         // (measured on MI355X: 1.17-1.32 PFLOP/s vs 0.98-1.05 for the 128x128 loop on the VAE convolutions)
         const int nbn256 = (p.N + 255) / 256;
         const int64_t nb256 = (int64_t)((p.M + 255) / 256) * nbn256 * p.Z;
-        if (dma_ok && p.splitk <= 1 && p.act != EDTR_ACT_GEGLU && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4 &&
-            (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
+        const bool pp_ok = dma_ok && p.splitk <= 1 && p.act != EDTR_ACT_GEGLU && (!p.upsample2x || p.stride == 1) &&
+                           igemm_fast_addressable(p, spatial);
+        // 128x160 tile: the SD UNet widths 320 / 640 / 1280 are multiples of 160 (no padded columns; N = 320 at M = 32768 is
+        // one resident round).  Measured faster than the 128-wide grid whenever >= 200 tiles exist, except the
+        // short-K GEMMs whose N the 128-wide grid also divides (two-pass epilogue).
+        const int64_t nb160 = (int64_t)((p.M + 127) / 128) * (p.N / 160) * p.Z;
+        if (pp_ok && p.N % 160 == 0 && nb160 >= 200 && (p.N % 128 != 0 || p.K >= 640))
+            tile = 8;
+        else if (pp_ok && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4)
             tile = 6;
     }
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 7) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 8) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

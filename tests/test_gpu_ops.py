@@ -61,7 +61,10 @@ def nhwc16(x, dtype, pad_to=None):
                                         (77, 640, 1024, 6), (520, 1280, 320, 6), (1000, 520, 1152, 6),
                                         # tile 7 = 256x128 tile, 8 waves, ping-pong over three K-tile buffers
                                         (256, 128, 64, 7), (300, 72, 192, 7), (4096, 320, 320, 7), (130, 136, 128, 7),
-                                        (77, 640, 1024, 7), (520, 1280, 320, 7), (1000, 520, 1152, 7), (700, 128, 256, 7)])
+                                        (77, 640, 1024, 7), (520, 1280, 320, 7), (1000, 520, 1152, 7), (700, 128, 256, 7),
+                                        # tile 8 = 128x160 tile (N = 320 / 640 / 1280 without column padding)
+                                        (256, 128, 64, 8), (300, 72, 192, 8), (4096, 320, 320, 8), (130, 136, 128, 8),
+                                        (77, 640, 1024, 8), (520, 1280, 320, 8), (1000, 520, 1152, 8), (700, 160, 256, 8)])
 def test_gemm_bias_residual(dtype, M, N, K, tile):
     ops = _ops()
     a = rnd((M, K), 1).to(dtype)
@@ -197,7 +200,8 @@ def test_gemm_batched_strided(dtype):
                                   "s1_p3", "s2_p3", "vae_down_p3", "small_cout_p3",
                                   "s1_big", "s2_big", "vae_down_big", "small_cout_big",
                                   "s1_256", "s2_256", "vae_down_256", "up_256", "small_cout_256",
-                                  "s1_256n", "s2_256n", "vae_down_256n", "up_256n", "small_cout_256n"])
+                                  "s1_256n", "s2_256n", "vae_down_256n", "up_256n", "small_cout_256n",
+                                  "s1_n160", "s2_n160", "vae_down_n160", "up_n160", "small_cout_n160"])
 def test_conv3x3(dtype, case):
     tile = 0
     if case.endswith("_dma"):
@@ -210,6 +214,8 @@ def test_conv3x3(dtype, case):
         case, tile = case[:-4], 6
     if case.endswith("_256n"):
         case, tile = case[:-5], 7
+    if case.endswith("_n160"):
+        case, tile = case[:-5], 8
     ops = _ops()
     d = dev()
     B, H, W = 2, 12, 20
@@ -477,7 +483,7 @@ def test_graph_capture_replay():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,tile", [(64, 0), (64, 3), (40, 1), (64, 6), (64, 7)])
+@pytest.mark.parametrize("cin,tile", [(64, 0), (64, 3), (40, 1), (64, 6), (64, 7), (64, 8)])
 def test_fused_groupnorm_partials(dtype, cin, tile):
     """The igemm epilogue's per-tile column sums + edtr_gn_finalize reproduce edtr_gn_stats on the stored tensor."""
     ops = _ops()
