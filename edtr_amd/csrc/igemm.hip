@@ -9,6 +9,7 @@
 // LDS tiles are [rows][64 x 16-bit] with the XOR swizzle of common.h (conflict-free ds_read_b128).
 // The epilogue stages the fp32 accumulators through LDS so that bias / time-embedding row vector /
 // residual / activation are applied on 8-wide row vectors and stored with 16-byte writes.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -1886,9 +1887,10 @@ int launch_256x128(const edtr_igemm_params& p, hipStream_t stream) {
 // Per K-tile a wave issues 4 A + 5 W pieces (vmcnt(9)).  LDS: 2 x (16 + 20) KiB; the epilogue stages 64 rows x 160
 // columns of fp32 (40 KiB) per pass, two passes.  Buffer addressing only, no GEGLU, no split-K.
 // ------------------------------------------------------------------------------------------------------
-template <typename T, bool SPATIAL>
+template <typename T, bool SPATIAL, int MB, int NB>
 __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igemm_params p) {
-    constexpr int BM = 128, BN = 160;
+    // wave tile = (16 MB) x (16 NB) as MB x NB blocks of 16x16; workgroup tile = 2 x 2 waves
+    constexpr int BM = 32 * MB, BN = 32 * NB;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1913,12 +1915,12 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
-    // ---- staging geometry: A rows wave*32 + 8j + (lane>>3), j < 4; W rows wave*40 + 8j + (lane>>3), j < 5
+    // ---- staging geometry: A rows wave*8MB + 8j + (lane>>3), j < MB; W rows wave*8NB + 8j + (lane>>3), j < NB
     const int rsub = lane >> 3, slot = lane & 7;
     const int Cin = p.C1;
     const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
     const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
-    uint32_t voff_a[4], voff_w[5], a_mask[4], a_par[4];
+    uint32_t voff_a[MB], voff_w[NB], a_mask[MB], a_par[MB];
     int b0 = 0, oy0 = 0, ox0 = 0;
     float rcp_ow = 0.0f, rcp_oh = 0.0f;
     if (SPATIAL) {
@@ -1934,8 +1936,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - a_bias);
     const u32x4 srd_w = make_srd(wp);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + 8 * j + rsub;
+    for (int j = 0; j < MB; ++j) {
+        const int row = wave * (8 * MB) + 8 * j + rsub;
         const int coff = (slot ^ ((row >> 1) & 7)) * 8;
         const int m = m0 + row;
         const bool ok = m < p.M;
@@ -1975,15 +1977,17 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         a_mask[j] = mask;
     }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int row = wave * 40 + 8 * j + rsub;
+    for (int j = 0; j < NB; ++j) {
+        const int row = wave * (8 * NB) + 8 * j + rsub;
         const int coff = (slot ^ ((row >> 1) & 7)) * 8;
         const int n = n0 + row;
         voff_w[j] = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
     }
 
     int run_tap = 0, run_c0 = 0, sel_tap = -1;
-    uint32_t vsel[4] = {0u, 0u, 0u, 0u};
+    uint32_t vsel[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) vsel[j] = 0u;
     uint32_t soff_tap = 0;
     auto select_tap = [&](int tap) {
         if constexpr (SPATIAL) {
@@ -1997,14 +2001,14 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
                 const uint32_t dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
                 const uint32_t dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < MB; ++j) {
                     const uint32_t vo = voff_a[j] + ((a_par[j] & 1u) ? dy1 : dy0) + ((a_par[j] & 2u) ? dx1 : dx0);
                     vsel[j] = (a_mask[j] & tapbit) ? vo : kOobOffset;
                 }
                 soff_tap = 0;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) vsel[j] = (a_mask[j] & tapbit) ? voff_a[j] : kOobOffset;
+                for (int j = 0; j < MB; ++j) vsel[j] = (a_mask[j] & tapbit) ? voff_a[j] : kOobOffset;
                 soff_tap = (uint32_t)(((ky * p.IW + kx) * p.ld1) * 2);
             }
         }
@@ -2020,29 +2024,43 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
             soff_a = (uint32_t)kt * (BK * 2);
         }
         const uint32_t soff_w = (uint32_t)kt * (BK * 2);
-        const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
-        const uint32_t sw = smem_base + buf * STAGE + A_BYTES + wave * (40 * 128);
+        const uint32_t sa = smem_base + buf * STAGE + wave * (8 * MB * 128);
+        const uint32_t sw = smem_base + buf * STAGE + A_BYTES + wave * (8 * NB * 128);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16_buf(SPATIAL ? vsel[j] : voff_a[j], srd_a, soff_a, sa + j * 1024);
+        for (int j = 0; j < MB; ++j) dma16_buf(SPATIAL ? vsel[j] : voff_a[j], srd_a, soff_a, sa + j * 1024);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
+        for (int j = 0; j < NB; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
     };
 
-    f32x4 acc[4][5];
+    f32x4 acc[MB][NB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    const int a_rd = tile_off(wm * 64 + l15, lq);      // + mb * 2048; ^ 64 for the second k-step
-    const int b_rd = tile_off(wn * 80 + l15, lq);      // + nb * 2048
-    const int nkt = p.K / BK;
-    if (nkt > 0) issue_tile(0, 0);
+    const int a_rd = tile_off(wm * (16 * MB) + l15, lq);      // + mb * 2048; ^ 64 for the second k-step
+    const int b_rd = tile_off(wn * (16 * NB) + l15, lq);      // + nb * 2048
+    const int nkt_all = p.K / BK;
+    int kt0 = 0, nkt = nkt_all;
+    if (p.splitk > 1) {
+        const int per = (nkt_all + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.y * per;
+        nkt = min(per, nkt_all - kt0);
+        if (nkt < 0) nkt = 0;
+    }
+    if (SPATIAL) {
+        run_tap = (kt0 * BK) / Cin;
+        run_c0 = kt0 * BK - run_tap * Cin;
+    }
+    if (nkt > 0) issue_tile(kt0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) {
-            issue_tile(kt + 1, cur ^ 1);
-            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this wave's 9 DMAs of tile kt have landed
+            issue_tile(kt0 + kt + 1, cur ^ 1);
+            // this wave's MB + NB DMAs of tile kt have landed
+            static_assert(MB + NB == 9 || MB + NB == 6, "add the literal wait count for this geometry");
+            if constexpr (MB + NB == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -2052,15 +2070,15 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         const char* sw = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            U4 af[4], bf[5];
+            U4 af[MB], bf[NB];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const U4*>(sa + (a_rd ^ (ks * 64)) + mb * 2048);
+            for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const U4*>(sa + (a_rd ^ (ks * 64)) + mb * 2048);
 #pragma unroll
-            for (int nb = 0; nb < 5; ++nb) bf[nb] = *reinterpret_cast<const U4*>(sw + (b_rd ^ (ks * 64)) + nb * 2048);
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const U4*>(sw + (b_rd ^ (ks * 64)) + nb * 2048);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 5; ++nb) acc[mb][nb] = T::mfma16(af[mb], bf[nb], acc[mb][nb]);
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = T::mfma16(af[mb], bf[nb], acc[mb][nb]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -2068,9 +2086,9 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     }
     if (nkt == 0) __syncthreads();
 
-    // ---- epilogue: two passes of 64 rows x 160 columns (the rows of the waves with wm == h)
+    // ---- epilogue: two passes of 16 MB rows x BN columns (the rows of the waves with wm == h)
     float* stage = reinterpret_cast<float*>(smem);
-    const bool gn_acc = p.gn_partial != nullptr;
+    const bool gn_acc = p.gn_partial != nullptr && p.splitk <= 1;
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
@@ -2078,19 +2096,20 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     for (int h = 0; h < 2; ++h) {
         if (wm == h) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 5; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) stage[(mb * 16 + 4 * lq + r) * BN + wn * 80 + nb * 16 + l15] = acc[mb][nb][r];
+                    for (int r = 0; r < 4; ++r) stage[(mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
         }
-        rows_phase<T, 64, BN, false, kThreads>(p, stage, m0 + h * 64, n0, p.N, o_zoff, gn_acc, gs, gq);
+        rows_phase<T, 16 * MB, BN, false, kThreads>(p, stage, m0 + h * (16 * MB), n0, p.N, o_zoff, gn_acc, gs, gq);
         __syncthreads();                       // every thread is done reading the staged rows
     }
     if (gn_acc) {
-        // thread (row group r0 = tid / 20 < 12, column group tid % 20) -> LDS [r0][160][2], then 160 threads fold the 12 row groups
-        const int n8 = tid % 20, r0 = tid / 20;
-        if (r0 < 12) {
+        // thread (row group r0 = tid / VPR < RG, column group tid % VPR) -> LDS [r0][BN][2], then BN threads fold the row groups
+        constexpr int VPR = BN / 8, RG = kThreads / VPR;
+        const int n8 = tid % VPR, r0 = tid / VPR;
+        if (r0 < RG) {
             float* dst = stage + (r0 * BN + n8 * 8) * 2;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
@@ -2099,7 +2118,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         if (tid < BN && n0 + tid < p.N && m0 < p.M) {
             float a = 0.0f, q = 0.0f;
 #pragma unroll
-            for (int g = 0; g < 12; ++g) { a += stage[(g * BN + tid) * 2]; q += stage[(g * BN + tid) * 2 + 1]; }
+            for (int g = 0; g < RG; ++g) { a += stage[(g * BN + tid) * 2]; q += stage[(g * BN + tid) * 2 + 1]; }
             float* dst = p.gn_partial + ((int64_t)(m0 >> 7) * p.N + n0 + tid) * 2;
             dst[0] = a;
             dst[1] = q;
@@ -2107,19 +2126,27 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     }
 }
 
-template <typename T, bool SPATIAL>
+template <typename T, bool SPATIAL, int MB, int NB>
 int launch_n160(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 2 * (128 + 160) * BK * 2;     // 72 KiB
+    constexpr int BM = 32 * MB, BN = 32 * NB;
+    constexpr int lds = 2 * (BM + BN) * BK * 2;     // 72 KiB for 128 x 160, 48 KiB for 64 x 128
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_n160_kernel<T, SPATIAL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_n160_kernel<T, SPATIAL, MB, NB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int nbm = (p.M + 127) / 128, nbn = (p.N + 159) / 160;
-    dim3 grid(nbm * nbn, 1, p.Z);
-    hipLaunchKernelGGL((igemm_n160_kernel<T, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
+    hipLaunchKernelGGL((igemm_n160_kernel<T, SPATIAL, MB, NB>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
+        int64_t blocks = (nvec + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        EDTR_LAUNCH_CHECK();
+    }
     return EDTR_OK;
 }
 
@@ -2158,7 +2185,7 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 8) {
+    if (tile >= 3 && tile <= 9) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 4) {
@@ -2169,9 +2196,13 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_big<T, true>(p, s) : launch_big<T, false>(p, s);
         }
+        if (tile == 9) {   // 64 x 128: twice the workgroups of tile 3 for small M
+            if (!fast || p.act == EDTR_ACT_GEGLU || p.gn_partial) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_n160<T, true, 2, 4>(p, s) : launch_n160<T, false, 2, 4>(p, s);
+        }
         if (tile == 8) {
-            if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_n160<T, true>(p, s) : launch_n160<T, false>(p, s);
+            if (!fast || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_n160<T, true, 4, 5>(p, s) : launch_n160<T, false, 4, 5>(p, s);
         }
         if (tile == 6 || tile == 7) {
             if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
@@ -2280,22 +2311,31 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         // (measured on MI355X: 1.17-1.32 PFLOP/s vs 0.98-1.05 for the 128x128 loop on the VAE convolutions)
         const int nbn256 = (p.N + 255) / 256;
         const int64_t nb256 = (int64_t)((p.M + 255) / 256) * nbn256 * p.Z;
+        // A/B switch for measurements on ONE device (devices differ by several percent): bit i of EDTR_IGEMM_NO_AUTO
+        // disables the automatic choice of tile i (6, 8, 9); explicit p.tile requests are unaffected.
+        static int no_auto = -1;
+        if (no_auto < 0) {
+            const char* e = getenv("EDTR_IGEMM_NO_AUTO");
+            no_auto = e ? atoi(e) : 0;
+        }
         const bool pp_ok = dma_ok && p.splitk <= 1 && p.act != EDTR_ACT_GEGLU && (!p.upsample2x || p.stride == 1) &&
                            igemm_fast_addressable(p, spatial);
         // 128x160 tile: the SD UNet widths 320 / 640 / 1280 are multiples of 160 (no padded columns; N = 320 at M = 32768 is
         // one resident round).  Measured faster than the 128-wide grid whenever >= 200 tiles exist, except the
         // short-K GEMMs whose N the 128-wide grid also divides (two-pass epilogue).
         const int64_t nb160 = (int64_t)((p.M + 127) / 128) * (p.N / 160) * p.Z;
-        if (pp_ok && p.N % 160 == 0 && nb160 >= 200 && (p.N % 128 != 0 || p.K >= 640))
+        if (pp_ok && !(no_auto & (1 << 8)) && p.N % 160 == 0 && nb160 >= 200 && (p.N % 128 != 0 || p.K >= 640))
             tile = 8;
-        else if (pp_ok && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4)
+        else if (pp_ok && !(no_auto & (1 << 6)) && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4)
             tile = 6;
+        // (the 64x128 tile 9 wins 10-30 % in isolation on the short-K GEMMs of the 16x16 / 8x8 latent levels but cost 1 % of
+        //  whole-path throughput in an A/B on one device — its 3 workgroups per CU crowd the concurrent stream — so it stays opt-in)
     }
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 8) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 9) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

@@ -96,7 +96,7 @@ def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int
     that ~480 workgroups exist — but only while every split keeps enough K-tiles (of 64) to amortise the fp32 slab
     round trip of the reducer: >= 20 per split (>= 12 when fewer than 64 tiles exist at all).  Measured with
     tools/bench_kernels.py gsplitk / splitk: M=2048 N=1280 K=1280 runs 18.5 us unsplit vs 24.8 us at 3 splits, while
-    K=5120 gains (53.5 -> 42.3 us) and the 8x8-level convolutions (M=512, K=11520) gain 3x at 8 splits."""
+    K=5120 gains (53.5 -> 42.3 us) and the 8x8-level convolutions (M=512, K=11520) gain 3.4x at 6 splits."""
     if Z != 1 or act == L.ACT_GEGLU:
         return 0, 1
     nkt = (K + 63) // 64
@@ -105,7 +105,7 @@ def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int
         return 0, 1
     want = max(1, round(480 / b128))
     per_split = 12 if b128 <= 64 else 20
-    s = max(1, min(want, nkt // per_split, 8))
+    s = max(1, min(want, nkt // per_split, 6))
     return 0, s      # tile 0 = library default (LDS-DMA 128x128 main loop whenever Cin % 64 == 0)
 
 

@@ -64,7 +64,10 @@ def nhwc16(x, dtype, pad_to=None):
                                         (77, 640, 1024, 7), (520, 1280, 320, 7), (1000, 520, 1152, 7), (700, 128, 256, 7),
                                         # tile 8 = 128x160 tile (N = 320 / 640 / 1280 without column padding)
                                         (256, 128, 64, 8), (300, 72, 192, 8), (4096, 320, 320, 8), (130, 136, 128, 8),
-                                        (77, 640, 1024, 8), (520, 1280, 320, 8), (1000, 520, 1152, 8), (700, 160, 256, 8)])
+                                        (77, 640, 1024, 8), (520, 1280, 320, 8), (1000, 520, 1152, 8), (700, 160, 256, 8),
+                                        # tile 9 = 64x128 tile (small M)
+                                        (256, 128, 64, 9), (300, 72, 192, 9), (4096, 320, 320, 9), (130, 136, 128, 9),
+                                        (77, 640, 1024, 9), (520, 1280, 320, 9)])
 def test_gemm_bias_residual(dtype, M, N, K, tile):
     ops = _ops()
     a = rnd((M, K), 1).to(dtype)
@@ -201,7 +204,8 @@ def test_gemm_batched_strided(dtype):
                                   "s1_big", "s2_big", "vae_down_big", "small_cout_big",
                                   "s1_256", "s2_256", "vae_down_256", "up_256", "small_cout_256",
                                   "s1_256n", "s2_256n", "vae_down_256n", "up_256n", "small_cout_256n",
-                                  "s1_n160", "s2_n160", "vae_down_n160", "up_n160", "small_cout_n160"])
+                                  "s1_n160", "s2_n160", "vae_down_n160", "up_n160", "small_cout_n160",
+                                  "s1_m64", "s2_m64", "up_m64", "small_cout_m64"])
 def test_conv3x3(dtype, case):
     tile = 0
     if case.endswith("_dma"):
@@ -216,6 +220,8 @@ def test_conv3x3(dtype, case):
         case, tile = case[:-5], 7
     if case.endswith("_n160"):
         case, tile = case[:-5], 8
+    if case.endswith("_m64"):
+        case, tile = case[:-4], 9
     ops = _ops()
     d = dev()
     B, H, W = 2, 12, 20

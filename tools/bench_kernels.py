@@ -122,11 +122,20 @@ def main():
         for M, N, K in [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (512, 1280, 1280), (512, 1280, 5120),
                         (512, 2560, 1280), (8192, 640, 640), (8192, 640, 2560)]:
             row = f"M={M:5d} N={N:5d} K={K:5d}"
-            for S in (1, 2, 3, 4, 6, 8):
-                if S > K // 64:
-                    continue
-                ms, tf = bench_gemm(M, N, K, tile=0, residual=True, splitk=S)
-                row += f" | s{S}: {ms * 1e3:6.1f}us {tf:5.0f}"
+            for t in tiles:
+                for S in (1, 2, 3, 4, 6, 8):
+                    if S > K // 128:
+                        continue
+                    ms, tf = bench_gemm(M, N, K, tile=t, residual=True, splitk=S)
+                    row += f" | t{t}s{S}: {ms * 1e3:5.1f}"
+            print(row, flush=True)
+        print("--- conv3x3 split-K sweep, us ---")
+        for H, ci, co in [(8, 1280, 1280), (8, 2560, 1280), (16, 1280, 1280), (16, 2560, 1280), (16, 640, 1280), (16, 1920, 1280)]:
+            row = f"H={H:4d} {ci:5d}->{co:5d}"
+            for t in tiles:
+                for S in (1, 2, 3, 4, 6, 8, 12):
+                    ms, tf = bench_conv(B, H, ci, co, tile=t, extra={"splitk": S})
+                    row += f" | t{t}s{S}: {ms * 1e3:5.1f}"
             print(row, flush=True)
         return
     if what in ("gemm", "all"):
@@ -137,7 +146,7 @@ def main():
                                          ("ff.out", c, 4 * c, 0, True)]:
                 row = f"{name:9s} M={M:6d} N={N:6d} K={K:5d}"
                 for t in tiles:
-                    if act == 1 and t in (2, 6, 7, 8):
+                    if act == 1 and t in (2, 6, 7, 8, 9):
                         continue
                     ms, tf = bench_gemm(M, N, K, tile=t, act=act, residual=res)
                     row += f" | tile{t}: {ms:8.3f} ms {tf:7.1f} TF"
