@@ -2058,8 +2058,9 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         if (kt + 1 < nkt) {
             issue_tile(kt0 + kt + 1, cur ^ 1);
             // this wave's MB + NB DMAs of tile kt have landed
-            static_assert(MB + NB == 9 || MB + NB == 6, "add the literal wait count for this geometry");
+            static_assert(MB + NB == 9 || MB + NB == 8 || MB + NB == 6, "add the literal wait count for this geometry");
             if constexpr (MB + NB == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if constexpr (MB + NB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2185,7 +2186,7 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 9) {
+    if (tile >= 3 && tile <= 10) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 4) {
@@ -2195,6 +2196,10 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
         if (tile == 5) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_big<T, true>(p, s) : launch_big<T, false>(p, s);
+        }
+        if (tile == 10) {  // 128 x 128 with 16x16x32 MFMAs (experiment: same geometry as tile 3, other MFMA shape)
+            if (!fast || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_n160<T, true, 4, 4>(p, s) : launch_n160<T, false, 4, 4>(p, s);
         }
         if (tile == 9) {   // 64 x 128: twice the workgroups of tile 3 for small M
             if (!fast || p.act == EDTR_ACT_GEGLU || p.gn_partial) return EDTR_E_UNSUPPORTED;
@@ -2328,6 +2333,8 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             tile = 8;
         else if (pp_ok && !(no_auto & (1 << 6)) && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4)
             tile = 6;
+        // (tile 10 — the same 128x128 geometry with 16x16x32 MFMAs — is +9 % in isolation on the 512x512-level N = 128 VAE
+        //  convolutions but -0.5..-1 % on the whole path in the same A/B; opt-in)
         // (the 64x128 tile 9 wins 10-30 % in isolation on the short-K GEMMs of the 16x16 / 8x8 latent levels but cost 1 % of
         //  whole-path throughput in an A/B on one device — its 3 workgroups per CU crowd the concurrent stream — so it stays opt-in)
     }
@@ -2335,7 +2342,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 9) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 10) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

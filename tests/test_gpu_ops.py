@@ -67,7 +67,10 @@ def nhwc16(x, dtype, pad_to=None):
                                         (77, 640, 1024, 8), (520, 1280, 320, 8), (1000, 520, 1152, 8), (700, 160, 256, 8),
                                         # tile 9 = 64x128 tile (small M)
                                         (256, 128, 64, 9), (300, 72, 192, 9), (4096, 320, 320, 9), (130, 136, 128, 9),
-                                        (77, 640, 1024, 9), (520, 1280, 320, 9)])
+                                        (77, 640, 1024, 9), (520, 1280, 320, 9),
+                                        # tile 10 = 128x128 tile with 16x16x32 MFMAs
+                                        (256, 128, 64, 10), (300, 72, 192, 10), (4096, 320, 320, 10), (130, 136, 128, 10),
+                                        (77, 640, 1024, 10)])
 def test_gemm_bias_residual(dtype, M, N, K, tile):
     ops = _ops()
     a = rnd((M, K), 1).to(dtype)
@@ -205,7 +208,8 @@ def test_gemm_batched_strided(dtype):
                                   "s1_256", "s2_256", "vae_down_256", "up_256", "small_cout_256",
                                   "s1_256n", "s2_256n", "vae_down_256n", "up_256n", "small_cout_256n",
                                   "s1_n160", "s2_n160", "vae_down_n160", "up_n160", "small_cout_n160",
-                                  "s1_m64", "s2_m64", "up_m64", "small_cout_m64"])
+                                  "s1_m64", "s2_m64", "up_m64", "small_cout_m64",
+                                  "s1_t10", "vae_down_t10", "up_t10"])
 def test_conv3x3(dtype, case):
     tile = 0
     if case.endswith("_dma"):
@@ -222,6 +226,8 @@ def test_conv3x3(dtype, case):
         case, tile = case[:-5], 8
     if case.endswith("_m64"):
         case, tile = case[:-4], 9
+    if case.endswith("_t10"):
+        case, tile = case[:-4], 10
     ops = _ops()
     d = dev()
     B, H, W = 2, 12, 20
@@ -489,7 +495,7 @@ def test_graph_capture_replay():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,tile", [(64, 0), (64, 3), (40, 1), (64, 6), (64, 7), (64, 8)])
+@pytest.mark.parametrize("cin,tile", [(64, 0), (64, 3), (40, 1), (64, 6), (64, 7), (64, 8), (64, 10)])
 def test_fused_groupnorm_partials(dtype, cin, tile):
     """The igemm epilogue's per-tile column sums + edtr_gn_finalize reproduce edtr_gn_stats on the stored tensor."""
     ops = _ops()
