@@ -617,6 +617,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         }
     }
     int run_tap = 0, run_c0 = 0;   // (tap, channel offset) of the NEXT tile to issue; tiles are issued in order
+    // (fast path) convs walk K channel-chunk major / tap minor, see igemm_256_kernel: the nine taps of a chunk hit L2
 
     // Per-lane A offsets of the CURRENT filter tap (halo / tail lanes -> out of range), recomputed only when the tap
     // changes (every Cin/64 K-tiles); within a tap a K-tile moves just the wave-uniform soffset, so the issue of a
@@ -653,15 +654,15 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     auto issue_tile = [&](int kt, int buf) {
         if constexpr (FAST) {
             uint32_t soff_a;
+            uint32_t soff_w = (uint32_t)kt * (BK * 2);
             if constexpr (SPATIAL) {
                 if (run_tap != sel_tap) { select_tap(run_tap); sel_tap = run_tap; }
                 soff_a = soff_tap + (uint32_t)(run_c0 * 2);
-                run_c0 += BK;
-                if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
+                soff_w = (uint32_t)((run_tap * Cin + run_c0) * 2);   // the weight tile of (tap, chunk) in [Cout][ky][kx][Cin]
+                if (++run_tap == p.taps) { run_tap = 0; run_c0 += BK; }   // next tap of the same 64-channel chunk
             } else {
                 soff_a = (uint32_t)kt * (BK * 2);
             }
-            const uint32_t soff_w = (uint32_t)kt * (BK * 2);
             const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
             const uint32_t sw = sa + A_BYTES;
 #pragma unroll
@@ -719,8 +720,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         if (nkt < 0) nkt = 0;
     }
     if (SPATIAL) {
-        run_tap = (kt0 * BK) / Cin;
-        run_c0 = kt0 * BK - run_tap * Cin;
+        run_c0 = (kt0 / p.taps) * BK;
+        run_tap = kt0 - (kt0 / p.taps) * p.taps;
     }
     EDTR_STAMP(1);
     if (nkt > 0) issue_tile(kt0, 0);
@@ -1392,11 +1393,16 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
     }
 
     const int nkt = p.K / BK;
+    // K order of a 3x3 conv: channel-chunk major, tap minor (K-tile t = chunk t/9, tap t%9).  The nine taps of one
+    // 64-channel chunk re-read (shifted) the same input lines back to back, so they hit L2 while a workgroup walks its
+    // K loop; tap-major order returned to a line only after Cin/64 tiles, by which time the ~4 MiB of input that the 32
+    // resident workgroups of an XCD cover had evicted it (PMC: 2.6-5x the algorithmic fetch bytes).  The weight tile of
+    // (tap, chunk) is simply at K offset tap*Cin + chunk*64 of the unchanged [Cout][ky][kx][Cin] packing.
     auto advance2 = [&](KState& s) {
         s.t += 2;
         if (SPATIAL) {
-            s.c0 += 2 * BK;
-            while (s.c0 >= Cin) { s.c0 -= Cin; ++s.tap; }
+            s.tap += 2;
+            while (s.tap >= p.taps) { s.tap -= p.taps; s.c0 += BK; }
         }
     };
     // stage half-tile `H` (0 = A_lo, 1 = A_hi, 2 = B_lo, 3 = B_hi) of K-tile s.t into buffer `buf`
@@ -1431,7 +1437,7 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
                 dma16_buf(vo, srd_a, soff, dst + j * 1024);
             }
         } else {
-            const uint32_t soff = (uint32_t)s.t * (BK * 2);
+            const uint32_t soff = SPATIAL ? (uint32_t)((s.tap * Cin + s.c0) * 2) : (uint32_t)s.t * (BK * 2);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 constexpr int q0 = (H - 2) * 2;
@@ -1501,8 +1507,8 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
     };
 
     // ---- prologue: K-tile 0 complete, K-tile 1's B_lo / A_lo (its B_hi / A_hi are staged by phases 1 and 2)
-    KState sE{0, 0, 0}, sO{1, 0, BK};
-    if (SPATIAL) { while (sO.c0 >= Cin) { sO.c0 -= Cin; ++sO.tap; } }
+    KState sE{0, 0, 0}, sO{1, 1, 0};
+    if (!SPATIAL || p.taps == 1) { sO.tap = 0; sO.c0 = BK; }
     stage_half(sE, 0, H0{}); stage_half(sE, 0, H1{}); stage_half(sE, 0, H2{}); stage_half(sE, 0, H3{});
     stage_half(sO, 1, H2{}); stage_half(sO, 1, H0{});
     advance2(sE);
@@ -2015,15 +2021,15 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     };
     auto issue_tile = [&](int kt, int buf) {
         uint32_t soff_a;
+        uint32_t soff_w = (uint32_t)kt * (BK * 2);
         if constexpr (SPATIAL) {
             if (run_tap != sel_tap) { select_tap(run_tap); sel_tap = run_tap; }
             soff_a = soff_tap + (uint32_t)(run_c0 * 2);
-            run_c0 += BK;
-            if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
+            soff_w = (uint32_t)((run_tap * Cin + run_c0) * 2);
+            if (++run_tap == p.taps) { run_tap = 0; run_c0 += BK; }      // K order: see igemm_256_kernel
         } else {
             soff_a = (uint32_t)kt * (BK * 2);
         }
-        const uint32_t soff_w = (uint32_t)kt * (BK * 2);
         const uint32_t sa = smem_base + buf * STAGE + wave * (8 * MB * 128);
         const uint32_t sw = smem_base + buf * STAGE + A_BYTES + wave * (8 * NB * 128);
 #pragma unroll
@@ -2049,8 +2055,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         if (nkt < 0) nkt = 0;
     }
     if (SPATIAL) {
-        run_tap = (kt0 * BK) / Cin;
-        run_c0 = kt0 * BK - run_tap * Cin;
+        run_c0 = (kt0 / p.taps) * BK;
+        run_tap = kt0 - (kt0 / p.taps) * p.taps;
     }
     if (nkt > 0) issue_tile(kt0, 0);
     for (int kt = 0; kt < nkt; ++kt) {

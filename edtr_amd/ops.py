@@ -83,8 +83,13 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
         p.workspace, p.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     p.gn_partial = ptr(gn_partial)
     flops = 2.0 * M * N * p.K * Z
+    # algorithmic HBM bytes: every operand once (a conv reads its input image once, not once per tap)
+    a_rows = (M // (p.OH * p.OW)) * p.IH * p.IW if spatial else M
+    n_out = N // 2 if act == L.ACT_GEGLU else N
+    nbytes = Z * (2.0 * a_rows * (C1 + C2) + 2.0 * N * p.K + (4.0 if out_f32 else 2.0) * M * n_out
+                  + (2.0 * M * n_out if residual is not None else 0.0))
     rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
-                                                    gn_partial), name, flops)
+                                                    gn_partial), name, flops, nbytes)
     rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
                + (" up2" if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
                + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else ""))
