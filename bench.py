@@ -253,7 +253,7 @@ def roofline_pass(cldm, args) -> dict:
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
         traffic = None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_hbm_traffic_v4.json")) as f:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_hbm_traffic_v5.json")) as f:
                 traffic = round(json.load(f)["families"]["igemm"]["hbm_side_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
@@ -261,7 +261,7 @@ def roofline_pass(cldm, args) -> dict:
                            "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["n"]),
-                           "traffic_source": "profiles/r01/pmc_hbm_traffic_v4.json (rocprofv3 --pmc, fetch x2 gfx950 correction; includes the split-K reducer launches)",
+                           "traffic_source": "profiles/r01/pmc_hbm_traffic_v5.json (rocprofv3 --pmc, fetch x2 gfx950 correction; includes the split-K reducer launches)",
                            "launches_per_pass": ig["n"], "avg_launch_ms": round(ig["ms"] / ig["n"], 4),
                            "share_of_pass": round(ig["ms"] / total_ms, 3)}
     if at:
