@@ -1593,21 +1593,27 @@ int launch_256(const edtr_igemm_params& p, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// 256x128x64 tile, 8 waves, the same ping-pong structure for narrow outputs (tile = 7; N = 128 VAE convs, N that
-// fills 128- but not 256-column tiles).  A K-tile = 3 units of 16 KiB (A_lo, A_hi, B) and 2 phases (A_lo x B,
-// A_hi x B; 16 MFMAs each, B fragments stay in registers); THREE K-tile buffers (144 KiB): while tile u is
-// multiplied, tile u+2 is staged into the buffer tile u-1 has just left — A_lo and B in the odd phase, A_hi in
-// the even one — which is exactly ">= 2 phases after the slot's last read, >= 4 phases before its next one".
+// 256x128 tile, 8 waves, ping-pong over a RING of six 32-deep K-slices (tile = 7; the N = 128 convolutions of the
+// 512x512 VAE level).  One phase = one 32-deep K-slice: every wave reads 4 A + 4 B fragments (its 64x64 sub-tile),
+// issues 16 v_mfma_f32_16x16x32 and stages 3 pieces (24 KiB per workgroup) of the slice four phases ahead; a slot
+// (16 KiB of A + 8 KiB of B, 64-byte rows, chunk XOR (row>>1)&3: conflict-free for the 16x16x32 operand reads) is
+// restaged two phases after its read and read four phases after its staging, behind vmcnt(9) = "all but the three
+// newest slices landed".  Balanced phases (the first 256x128 attempt alternated 12-read/4-DMA and 8-read/2-DMA
+// phases and lost to the 128x128 loop); L2->LDS demand 47 B/clk/CU at MFMA peak, between tile 3 (64) and tile 6 (32).
+// K order: (64-channel chunk, tap, 32-channel half) so that both halves of a 128-byte line are fetched back to back.
 // ------------------------------------------------------------------------------------------------------
+struct KState32 { int t, tap, c0, h; };
 
 template <typename T, bool SPATIAL>
 __global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_params p) {
-    constexpr int HALF = 128 * BK * 2;       // bytes of one unit (128 rows x 64 k)
-    constexpr int BUF = 3 * HALF;            // A_lo, A_hi, B
+    constexpr int BKP = 32;                  // K depth of a phase
+    constexpr int A_SLOT = 256 * BKP * 2;    // 16 KiB
+    constexpr int SLOT = A_SLOT + 128 * BKP * 2;   // 24 KiB
+    constexpr int RING = 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave >> 1, wc = wave & 1;            // 4 x 2 waves of 64 x 64; waves w and w+4 share a SIMD
     const int l15 = lane & 15, lq = lane >> 4;
 
     const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
@@ -1627,12 +1633,13 @@ __global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_
     const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
-    // ---- staging geometry: this wave fills rows wave*16 + 8*j + (lane>>3), j = 0,1, of every half-tile
-    const int rsub = lane >> 3, slot = lane & 7;
+    // ---- staging geometry: one piece = 16 rows x 64 bytes; lane -> (row = lane>>2, 16-byte slot = lane&3).
+    // This wave fills A rows wave*32 + 16j + (lane>>2), j = 0,1, and B row wave*16 + (lane>>2) of every slice.
+    const int rsub = lane >> 2, slot = lane & 3;
     const int Cin = p.C1;
     const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
     const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
-    uint32_t voff_a[4], voff_w[4], a_mask[4], a_par[4];   // index = half * 2 + j
+    uint32_t voff_a[2], a_mask[2], a_par[2], voff_w;
     int b0 = 0, oy0 = 0, ox0 = 0;
     float rcp_ow = 0.0f, rcp_oh = 0.0f;
     if (SPATIAL) {
@@ -1648,14 +1655,13 @@ __global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_
     const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - a_bias);
     const u32x4 srd_w = make_srd(wp);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int rih = wave * 16 + 8 * (q & 1) + rsub;               // row inside the half-tile
-        const int row = (q >> 1) * 128 + rih;                         // row inside the 256-row tile
-        const int coff = (slot ^ ((rih >> 1) & 7)) * 8;               // logical 8-element chunk held by this LDS slot
+    for (int j = 0; j < 2; ++j) {
+        const int row = wave * 32 + 16 * j + rsub;
+        const int coff = (slot ^ ((row >> 1) & 3)) * 8;               // logical 8-element chunk held by this LDS slot
         const int m = m0 + row;
         const bool ok = m < p.M;
         uint32_t mask = 0;
-        a_par[q] = 0;
+        a_par[j] = 0;
         if (SPATIAL) {
             const int x = ox0 + row;
             int qx = (int)((float)x * rcp_ow), ox = x - qx * p.OW;
@@ -1668,9 +1674,9 @@ __global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_
             const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
             const int ly = iy0 + p.pad_t, lx = ix0 + p.pad_l;
             const int sy = p.upsample2x ? ly >> 1 : ly, sx = p.upsample2x ? lx >> 1 : lx;
-            a_par[q] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
+            a_par[j] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
             const int64_t pc = (int64_t)(b0 + qy) * p.IH * p.IW + (int64_t)sy * p.IW + sx;
-            voff_a[q] = (uint32_t)((pc * p.ld1 + coff) * 2);
+            voff_a[j] = (uint32_t)((pc * p.ld1 + coff) * 2);
             if (p.taps == 9) {
                 uint32_t rb = 0, cbits = 0;
 #pragma unroll
@@ -1684,193 +1690,166 @@ __global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_
                 mask = (ok && ly >= 0 && ly < LH && lx >= 0 && lx < LW) ? 1u : 0u;
             }
         } else {
-            voff_a[q] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
+            voff_a[j] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
             mask = 1u;
         }
-        a_mask[q] = mask;
-        const int n = n0 + rih;                                        // B is one unit: rows q = 0,1 only
-        voff_w[q] = (q < 2 && n < nvalid) ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
+        a_mask[j] = mask;
+    }
+    {
+        const int row = wave * 16 + rsub;
+        const int coff = (slot ^ ((row >> 1) & 3)) * 8;
+        const int n = n0 + row;
+        voff_w = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
     }
 
-    const int nkt = p.K / BK;
-    auto advance1 = [&](KState& s) {
+    const int nph = p.K / BKP;               // K % 64 == 0 -> even
+    auto advance1 = [&](KState32& s) {
         s.t += 1;
+        if (s.h == 0) { s.h = 1; }
+        else {
+            s.h = 0;
+            if (++s.tap == p.taps) { s.tap = 0; s.c0 += 64; }
+        }
+    };
+    // stage the K-slice of `s` into ring slot `slot_i`
+    auto stage = [&](const KState32& s, int slot_i) {
+        const bool live = s.t < nph;
+        const int cc = s.c0 + s.h * BKP;                       // channel offset of this slice inside its tap
+        uint32_t soff_a = (uint32_t)(cc * 2), tapbit = 1u;
+        uint32_t dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
         if (SPATIAL) {
-            s.c0 += BK;
-            if (s.c0 >= Cin) { s.c0 -= Cin; ++s.tap; }
-        }
-    };
-    // stage unit `H` (0 = A_lo, 1 = A_hi, 2 = B) of K-tile s.t into buffer `buf`
-    auto stage_half = [&](const KState& s, int buf, auto Hc) {
-        constexpr int H = decltype(Hc)::value;
-        const bool live = s.t < nkt;
-        const uint32_t dst = smem_base + buf * BUF + H * HALF + wave * 2048;
-        if constexpr (H < 2) {
-            uint32_t soff = (uint32_t)s.t * (BK * 2), tapbit = 1u;
-            uint32_t dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
-            if (SPATIAL) {
-                int ky = p.pad_t, kx = p.pad_l;
-                if (p.taps == 9) { ky = (s.tap * 11) >> 5; kx = s.tap - 3 * ky; tapbit = 1u << s.tap; }
-                if (p.upsample2x) {
-                    const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
-                    dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
-                    dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
-                    dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
-                    dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
-                    soff = (uint32_t)(s.c0 * 2);
-                } else {
-                    soff = (uint32_t)(((ky * p.IW + kx) * p.ld1 + s.c0) * 2);
-                }
-            }
-            if (!live) tapbit = 0u;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                constexpr int q0 = H * 2;
-                uint32_t vo = voff_a[q0 + j];
-                if (SPATIAL && p.upsample2x) vo += ((a_par[q0 + j] & 1u) ? dy1 : dy0) + ((a_par[q0 + j] & 2u) ? dx1 : dx0);
-                vo = (a_mask[q0 + j] & tapbit) ? vo : kOobOffset;
-                dma16_buf(vo, srd_a, soff, dst + j * 1024);
-            }
-        } else {
-            const uint32_t soff = (uint32_t)s.t * (BK * 2);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t vo = live ? voff_w[j] : kOobOffset;
-                dma16_buf(vo, srd_w, soff, dst + j * 1024);
+            int ky = p.pad_t, kx = p.pad_l;
+            if (p.taps == 9) { ky = (s.tap * 11) >> 5; kx = s.tap - 3 * ky; tapbit = 1u << s.tap; }
+            if (p.upsample2x) {
+                const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
+                dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
+                dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+                dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
+            } else {
+                soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + cc) * 2);
             }
         }
-    };
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    using H2 = std::integral_constant<int, 2>;
-
-    // ---- fragment read geometry (conflict-free ds_read_b128 of the swizzled image, see common.h tile_off)
-    const int a_rd = tile_off(wr * 64 + l15, lq);      // + blk * 2048, ^ 64 for the second k-step
-    const int b_rd = tile_off(wc * 32 + l15, lq);
-
-    f32x4 acc[2][4][2];
+        if (!live) tapbit = 0u;
+        const uint32_t soff_w = (uint32_t)((s.tap * Cin + cc) * 2);
+        const uint32_t dst_a = smem_base + slot_i * SLOT + wave * 2048;
+        const uint32_t dst_w = smem_base + slot_i * SLOT + A_SLOT + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[i][a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    U4 afr[4][2], bfr[2][2];
-
-    auto read_a = [&](int buf, int ah) {
-        const char* base = smem + buf * BUF + ah * HALF;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            afr[mb][0] = *reinterpret_cast<const U4*>(base + a_rd + mb * 2048);
-            afr[mb][1] = *reinterpret_cast<const U4*>(base + (a_rd ^ 64) + mb * 2048);
+        for (int j = 0; j < 2; ++j) {
+            uint32_t vo = voff_a[j];
+            if (SPATIAL && p.upsample2x) vo += ((a_par[j] & 1u) ? dy1 : dy0) + ((a_par[j] & 2u) ? dx1 : dx0);
+            vo = (a_mask[j] & tapbit) ? vo : kOobOffset;
+            dma16_buf(vo, srd_a, soff_a, dst_a + j * 1024);
         }
+        dma16_buf(live ? voff_w : kOobOffset, srd_w, soff_w, dst_w);
     };
-    auto read_b = [&](int buf) {
-        const char* base = smem + buf * BUF + 2 * HALF;
+
+    // ---- fragment reads: 64-byte rows, byte offset of chunk c of row r = r*64 + ((c ^ ((r>>1)&3)) << 4); c = lane>>4
+    const int rd_sw = ((lq ^ ((l15 >> 1) & 3)) << 4);
+    const int a_rd = (wr * 64 + l15) * 64 + rd_sw;          // + mb * 1024 (16 rows)
+    const int b_rd = A_SLOT + (wc * 64 + l15) * 64 + rd_sw; // + nb * 1024
+
+    f32x4 acc[4][4];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            bfr[nb][0] = *reinterpret_cast<const U4*>(base + b_rd + nb * 2048);
-            bfr[nb][1] = *reinterpret_cast<const U4*>(base + (b_rd ^ 64) + nb * 2048);
-        }
-    };
-    auto mma = [&](auto AHc) {
-        constexpr int AH = decltype(AHc)::value;
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    U4 af[4], bf[4];
+
+    // one phase: read slice `slot_i`, stage the slice four ahead into slot (slot_i + 4) % 6, rendezvous, multiply
+    auto phase = [&](int slot_i, KState32& s) {
+        const char* base = smem + slot_i * SLOT;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const U4*>(base + a_rd + mb * 1024);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc[AH][mb][nb] = T::mfma16(afr[mb][ks], bfr[nb][ks], acc[AH][mb][nb]);
-    };
-    // second half of every phase: wait for the units that must have landed, rendezvous, multiply, rendezvous.
-    // Odd phases have staged 2 units (4 DMAs), even phases 1: "all but the newest three phases' stagings" is
-    // vmcnt(10) after an odd phase's staging and vmcnt(8) after an even one's.
-    auto compute = [&](auto AHc) {
-        constexpr int AH = decltype(AHc)::value;
-        if constexpr (AH == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        for (int nb = 0; nb < 4; ++nb) bf[nb] = *reinterpret_cast<const U4*>(base + b_rd + nb * 1024);
+        stage(s, (slot_i + 4) % RING);
+        advance1(s);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        mma(AHc);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = T::mfma16(af[mb], bf[nb], acc[mb][nb]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
 
-    // ---- prologue: K-tiles 0 and 1 complete (tile 1 may still be in flight when the loop starts)
-    KState sS{0, 0, 0};
-    stage_half(sS, 0, H0{}); stage_half(sS, 0, H2{}); stage_half(sS, 0, H1{});
-    advance1(sS);
-    stage_half(sS, 1, H0{}); stage_half(sS, 1, H2{}); stage_half(sS, 1, H1{});
-    advance1(sS);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // ---- prologue: slices 0..3
+    KState32 sS{0, 0, 0, 0};
+    stage(sS, 0); advance1(sS);
+    stage(sS, 1); advance1(sS);
+    stage(sS, 2); advance1(sS);
+    stage(sS, 3); advance1(sS);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run half a phase behind their SIMD partners
+    if (wave >= 4) __builtin_amdgcn_s_barrier();        // waves 4-7 run half a phase behind their SIMD partners
     asm volatile("" ::: "memory");
 
-    // K-tile u lives in buffer u % 3; while u is multiplied, u+2 is staged into the buffer u-1 has just left
-    const int niter = (nkt + 2) / 3;
+    const int niter = (nph + RING - 1) / RING;
     for (int it = 0; it < niter; ++it) {
-        read_b(0); read_a(0, 0); stage_half(sS, 2, H0{}); stage_half(sS, 2, H2{}); compute(H0{});
-        read_a(0, 1);            stage_half(sS, 2, H1{}); compute(H1{}); advance1(sS);
-        read_b(1); read_a(1, 0); stage_half(sS, 0, H0{}); stage_half(sS, 0, H2{}); compute(H0{});
-        read_a(1, 1);            stage_half(sS, 0, H1{}); compute(H1{}); advance1(sS);
-        read_b(2); read_a(2, 0); stage_half(sS, 1, H0{}); stage_half(sS, 1, H2{}); compute(H0{});
-        read_a(2, 1);            stage_half(sS, 1, H1{}); compute(H1{}); advance1(sS);
+        phase(0, sS); phase(1, sS); phase(2, sS); phase(3, sS); phase(4, sS); phase(5, sS);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two wave groups
+    if (wave < 4) __builtin_amdgcn_s_barrier();         // re-align the two wave groups
     __syncthreads();
 
-    // ---- epilogue: rows of A half `h` (128 x 128 fp32 = 64 KiB) per pass
-    float* stage = reinterpret_cast<float*>(smem);
+    // ---- epilogue: the whole 256 x 128 fp32 tile (128 KiB) through LDS, then two 128-row row phases
+    float* stage_f = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                stage_f[(wr * 64 + mb * 16 + 4 * lq + r) * 128 + wc * 64 + nb * 16 + l15] = acc[mb][nb][r];
     const bool gn_acc = p.gn_partial != nullptr;
+    float gs[2][8], gq[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    stage[(wr * 64 + mb * 16 + 4 * lq + r) * 128 + wc * 32 + nb * 16 + l15] = acc[h][mb][nb][r];
-        float gs[8], gq[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-        rows_phase<T, 128, 128, false, 512>(p, stage, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs, gq);
+        for (int j = 0; j < 8; ++j) { gs[h][j] = 0.0f; gq[h][j] = 0.0f; }
+        rows_phase<T, 128, 128, false, 512>(p, stage_f + h * 128 * 128, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs[h], gq[h]);
+    }
+    if (gn_acc) {
         __syncthreads();                       // every thread is done reading the staged rows
-        if (gn_acc) {
-            // column group = tid % 16: lanes l, l+16, l+32, l+48 share it; fold them, then the 8 waves through LDS
+        // column group = tid % 16: lanes l, l+16, l+32, l+48 share it; fold them, then the 8 waves through LDS
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                gs[j] += __shfl_xor(gs[j], 16, 64); gs[j] += __shfl_xor(gs[j], 32, 64);
-                gq[j] += __shfl_xor(gq[j], 16, 64); gq[j] += __shfl_xor(gq[j], 32, 64);
+                gs[h][j] += __shfl_xor(gs[h][j], 16, 64); gs[h][j] += __shfl_xor(gs[h][j], 32, 64);
+                gq[h][j] += __shfl_xor(gq[h][j], 16, 64); gq[h][j] += __shfl_xor(gq[h][j], 32, 64);
             }
             if (lane < 16) {
-                float* dst = stage + (wave * 128 + lane * 8) * 2;
+                float* dst = stage_f + ((h * 8 + wave) * 128 + lane * 8) * 2;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+                for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[h][j]; dst[2 * j + 1] = gq[h][j]; }
             }
-            __syncthreads();
-            if (tid < 128 && n0 + tid < p.N && m0 + h * 128 < p.M) {
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int h = tid >> 7, col = tid & 127;
+            if (n0 + col < p.N && m0 + h * 128 < p.M) {
                 float a = 0.0f, q = 0.0f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) { a += stage[(w * 128 + tid) * 2]; q += stage[(w * 128 + tid) * 2 + 1]; }
-                float* dst = p.gn_partial + ((int64_t)((m0 >> 7) + h) * p.N + n0 + tid) * 2;
+                for (int w = 0; w < 8; ++w) { a += stage_f[((h * 8 + w) * 128 + col) * 2]; q += stage_f[((h * 8 + w) * 128 + col) * 2 + 1]; }
+                float* dst = p.gn_partial + ((int64_t)((m0 >> 7) + h) * p.N + n0 + col) * 2;
                 dst[0] = a;
                 dst[1] = q;
             }
-            __syncthreads();
         }
     }
 }
 
 template <typename T, bool SPATIAL>
 int launch_256x128(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 3 * 3 * 128 * BK * 2;     // 144 KiB
+    constexpr int lds = 6 * (256 + 128) * 32 * 2;     // ring of six 24 KiB K-slices = 144 KiB
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_256x128_kernel<T, SPATIAL>),
