@@ -46,6 +46,9 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
+    ap.add_argument("--workload", default="det512", choices=["det512", "seg1024tiled"],
+                    help="det512 = BASELINE configs[1] (default); seg1024tiled = configs[3]: one 1024x1024 image, tiled VAE encoder "
+                         "(256-px tiles), latent-tiled denoiser (64/32 latent tiles), untiled decoder (demo.py:99-124)")
     ap.add_argument("--no-graph", action="store_true", help="replay launch lists eagerly instead of hipGraphs")
     ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="batches in flight: 2 = consecutive steps alternate between two HIP streams / buffer sets, so "
@@ -85,6 +88,10 @@ def main() -> None:
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     cfg = synth.CONFIGS[args.config]()
+    tiled = args.workload == "seg1024tiled"
+    if tiled:
+        args.batch, args.size, args.inflight = 1, 1024, 1
+        args.no_cpu_baseline = args.no_roofline = True
     B, S = args.batch, args.size
     h = S // 8
     ctx_dim = cfg["unet_cfg"]["context_dim"]
@@ -121,13 +128,20 @@ def main() -> None:
     noises = [n[sl].to(dev) for n in noises_g]
     t200 = torch.full((B,), 200, dtype=torch.int64)   # host tensor: q_sample reads it without a device sync
 
+    untiled_forward = cldm.forward
+
     def one_pass():
-        z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
+        if tiled:   # the reference never restores the patched forward (sampler.py:288-303): re-arm it per pass
+            cldm.forward = untiled_forward
+            z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False, tiled=True, tile_size=256)
+        else:
+            z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
         x_T = diffusion.q_sample(z_pre, t200, noises[0])
         with injected_noise(noises[1:]):
             z = sampler.manual_sample_with_timesteps(
                 model=cldm, device=dev, x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=B,
-                cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+                cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False,
+                tiled=tiled, tile_size=64, tile_stride=32)
         return cldm.vae_decode(z), z
 
     def barrier():
@@ -178,11 +192,13 @@ def main() -> None:
     value = GB * args.steps / elapsed
 
     result = {
-        "metric": "restored 512x512 images/sec @ 4 denoise steps",
+        "metric": f"restored {S}x{S} images/sec @ 4 denoise steps",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"EDTR-det s4 ({args.config}): vae_encode + q_sample(t=200) + 4 x (ControlNet+UNet) + "
+        "config": {"workload": (f"EDTR-seg s4 ({args.config}), configs[3]: tiled vae_encode (256-px tiles) + q_sample(t=200) + 4 x latent-tiled "
+                                f"(64/32) ControlNet+UNet + untiled vae_decode, batch {B}/GPU of {S}x{S}") if tiled else
+                               f"EDTR-det s4 ({args.config}): vae_encode + q_sample(t=200) + 4 x (ControlNet+UNet) + "
                                f"vae_decode, batch {B}/GPU of {S}x{S}", "global_batch": GB, "image_size": S,
                    "denoise_steps": 4, "parallelism": f"batch-sharded x{world}", "graphs": not args.no_graph,
                    "batches_in_flight": args.inflight},

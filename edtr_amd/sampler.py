@@ -126,10 +126,17 @@ class SpacedSampler(nn.Module):
     def _install_tiling(self, model, tile_size: int, tile_stride: int) -> None:
         # NB: like the reference (:288-303) the patched forward is never restored.
         forward = model.forward
+
+        def batched(x_tiles, windows, t, cond):
+            # the windows of one latent stacked on the batch axis (window-major, like torch.cat of the per-window batches)
+            n = len(windows)
+            c_img = torch.cat([cond["c_img"][..., hi:he, wi:we] for hi, he, wi, we in windows], dim=0)
+            return forward(x_tiles, t.repeat(n), {"c_txt": cond["c_txt"].repeat(n, 1, 1), "c_img": c_img})
+
         model.forward = make_tiled_fn(
             lambda x_tile, t, cond, hi, hi_end, wi, wi_end: forward(
                 x_tile, t, {"c_txt": cond["c_txt"], "c_img": cond["c_img"][..., hi:hi_end, wi:wi_end]}),
-            tile_size, tile_stride)
+            tile_size, tile_stride, batched_fn=batched)
 
     def _loop(self, model, device, img, batch_size, cond, uncond, cfg_scale, return_intermediates):
         timesteps = np.flip(self.timesteps)
