@@ -201,3 +201,32 @@ def test_tiled_vae_vs_reference_golden(golden_dir, dtype):
     assert e_enc < tol["z_pre"] and e_plain < tol["z_pre"]
     assert e_dec < tol["img"]
     assert rel_err(small, small_p) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sd21_width_networks_vs_reference_golden(golden_dir, dtype):
+    """The FULL SD-2.1-width ControlNet + UNet (one denoise step at the true hot shape, latent 64x64, every real channel
+    count: 320/640/1280, 5/10/20 heads, 1024-wide context) and the full-width VAE encoder / decoder against outputs of the
+    REFERENCE modules on CPU fp32 (tests/golden/sd21_blocks.npz, tools/make_goldens.py).  Exercises the automatic tile
+    choice (128x128, 128x160, 256x256 kernels), split-K, fused GroupNorm statistics and both attention shapes."""
+    from edtr_amd import synth
+    from edtr_amd.testing import build_synthetic_cldm, rel_err
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "sd21_blocks.npz"))
+    cldm = build_synthetic_cldm(synth.sd21_config(), dev, dtype)
+    x = synth.synth_normal("sd21:x", (1, 4, 64, 64)).to(dev)
+    c_img = synth.synth_normal("sd21:c_img", (1, 4, 64, 64)).to(dev)
+    c_txt = synth.synth_input("sd21:c_txt", (1, 77, 1024), -1.0, 1.0).to(dev)
+    t = torch.tensor([200], device=dev)
+    eps = cldm.forward(x, t, {"c_txt": c_txt, "c_img": c_img})
+    img = synth.synth_input("sd21:img", (1, 3, 256, 256), -1.0, 1.0).to(dev)
+    z = cldm.vae_encode(img, sample=False)
+    zin = synth.synth_normal("sd21:zdec", (1, 4, 32, 32)).to(dev)
+    dec = cldm.vae_decode(zin)
+    torch.cuda.synchronize()
+    errs = {"eps": rel_err(eps, g["eps"]), "vae_z": rel_err(z, g["vae_z"]), "vae_dec": rel_err(dec, g["vae_dec"])}
+    print(f"\n[sd21 widths {dtype}] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    tol = TOL[dtype]
+    assert errs["eps"] < tol["eps"] and errs["vae_z"] < tol["z_pre"] and errs["vae_dec"] < tol["img"]
