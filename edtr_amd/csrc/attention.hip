@@ -140,6 +140,15 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
                     if (key >= p.Nk) s[kb][r] = -1e30f;
                 }
         }
+        if (p.causal && (t + 1) * KV > blockIdx.x * 128 + wave * 32) {   // this tile reaches past some query of the wave
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KV + kb * 32 + 16 * (r >> 3) + 8 * lh + (r & 7);
+                    if (key > q_row) s[kb][r] = -1e30f;
+                }
+        }
         // ---- online softmax (per lane = per query; partner lane^32 holds the other 32 keys)
         float mt = s[0][0];
 #pragma unroll
@@ -213,6 +222,7 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
     if (!p.q || !p.k || !p.vt || !p.out) return EDTR_E_NULL;
     if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
     if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return EDTR_E_SHAPE;
+    if (p.causal && p.Nq != p.Nk) return EDTR_E_SHAPE;
     if ((p.q_ld & 7) || (p.k_ld & 7) || (p.vt_ld & 7) || (p.o_ld & 7) || (p.q_bs & 7) || (p.k_bs & 7) ||
         (p.vt_bs & 7) || (p.o_bs & 7))
         return EDTR_E_ALIGN;

@@ -234,6 +234,44 @@ extern "C" int edtr_add(int dtype, const void* a, int lda, const void* b, int ld
     return EDTR_OK;
 }
 
+namespace {
+// out[row][d] = table[token[row]][d] + pos[row % L][d]   (16-bit out, 8 channels per thread)
+template <typename T>
+__global__ void __launch_bounds__(256) embed_tokens_kernel(const int64_t* tokens, const float* table, const float* pos, int rows,
+                                                           int L, int D, int vocab, uint16_t* out, int ld) {
+    const int dv = D >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * dv; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / dv), d0 = (int)(i - (int64_t)row * dv) * 8;
+        int64_t tok = tokens[row];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        const float* tp = table + tok * D + d0;
+        const float* pp = pos + (int64_t)(row % L) * D + d0;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = tp[j] + pp[j];
+        stg16(out + (int64_t)row * ld + d0, pack8<T>(f));
+    }
+}
+}  // namespace
+
+extern "C" int edtr_embed_tokens(int dtype, const int64_t* tokens, const float* table, const float* pos, int rows, int L,
+                                 int D, int vocab, void* out, int ld, edtr_stream_t stream) {
+    if (!tokens || !table || !pos || !out) return EDTR_E_NULL;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (rows <= 0 || L <= 0 || D <= 0 || vocab <= 0) return EDTR_E_SHAPE;
+    if ((D & 7) || (ld & 7) || !aligned16(out)) return EDTR_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned blocks = blocks_for((int64_t)rows * (D >> 3));
+    if (dtype == EDTR_BF16)
+        hipLaunchKernelGGL(embed_tokens_kernel<BF16>, dim3(blocks), dim3(256), 0, s, tokens, table, pos, rows, L, D, vocab,
+                           static_cast<uint16_t*>(out), ld);
+    else
+        hipLaunchKernelGGL(embed_tokens_kernel<F16>, dim3(blocks), dim3(256), 0, s, tokens, table, pos, rows, L, D, vocab,
+                           static_cast<uint16_t*>(out), ld);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 extern "C" int edtr_timestep_embedding(int dtype, const int64_t* t, int B, int dim, void* out, int ld,
                                        edtr_stream_t stream) {
     if (!t || !out) return EDTR_E_NULL;

@@ -64,6 +64,9 @@ __device__ __forceinline__ void finish_vector(const edtr_igemm_params& p, float 
     if (p.act == EDTR_ACT_SILU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+    } else if (p.act == EDTR_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = gelu_erf_f(f[j]);
     }
     if (p.residual) {
         const U4 rv = ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n);
@@ -167,7 +170,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         }
     }
     const float alpha = GEGLU ? 1.0f : p.alpha;
-    const bool silu = p.act == EDTR_ACT_SILU;
+    const bool silu = p.act == EDTR_ACT_SILU, gelu = p.act == EDTR_ACT_GELU;
     __syncthreads();                          // staged tile visible
 
 #pragma unroll
@@ -193,6 +196,9 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             if (silu) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+            } else if (gelu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = gelu_erf_f(f[j]);
             }
             if (p.residual) {
                 float rf[8];
@@ -2263,7 +2269,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (p.OW <= 0 || p.IH <= 0 || p.IW <= 0 || p.stride <= 0) return EDTR_E_SHAPE;
         if (p.M % (p.OH * p.OW) != 0) return EDTR_E_SHAPE;
     }
-    if (p.act < EDTR_ACT_NONE || p.act > EDTR_ACT_SILU) return EDTR_E_DTYPE;
+    if (p.act < EDTR_ACT_NONE || p.act > EDTR_ACT_GELU) return EDTR_E_DTYPE;
     if (p.rowvec && p.rows_per_image <= 0) return EDTR_E_SHAPE;
     // 16-byte rule
     if ((p.K & 7) || (p.N & 7) || (p.C1 & 7) || (p.C2 & 7) || (p.ld1 & 7) || (p.C2 && (p.ld2 & 7)) || (p.ldw & 7))

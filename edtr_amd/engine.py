@@ -136,6 +136,23 @@ class WeightStore:
             self.cache[key] = (wp, b)
         return self.cache[key]
 
+    def rows(self, name: str, r0: int, r1: int, bias: Optional[str] = None):
+        """Rows r0..r1 of one [out, in] matrix (e.g. the q/k or the v part of a fused in_proj) + the matching bias slice."""
+        key = ("rows", name, r0, r1, bias)
+        if key not in self.cache:
+            w = self._p(name)
+            wp = ops.pack_linear_weight(w.reshape(w.shape[0], -1)[r0:r1].contiguous(), self.dtype)
+            b = ops.pad_bias(self._p(bias).reshape(-1)[r0:r1].contiguous(), wp.shape[0]) if bias else None
+            self.cache[key] = (wp, b)
+        return self.cache[key]
+
+    def raw(self, name: str) -> torch.Tensor:
+        """The fp32 parameter itself on the device (embedding tables)."""
+        key = ("raw", name)
+        if key not in self.cache:
+            self.cache[key] = self._p(name).contiguous()
+        return self.cache[key]
+
     def geglu(self, wname: str, bname: str):
         key = ("geglu", wname)
         if key not in self.cache:
@@ -425,14 +442,14 @@ class Emitter:
 
     # -- attention ------------------------------------------------------------------------------
     def flash(self, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B, H, Nq, Nk, k_bs, vt_bs, vt_ld,
-              out=None) -> torch.Tensor:
+              out=None, causal: bool = False) -> torch.Tensor:
         C = H * 64
         if out is None:
             out = self.new(B * Nq, C)
         self.prog.add(ops.make_flash_attn(dtype=self.dtype, q=q, k=k, vt=vt, out=out, B=B, H=H, Nq=Nq, Nk=Nk,
                                           q_bs=Nq * q.stride(0), q_ld=q.stride(0), k_bs=k_bs, k_ld=k.stride(0),
                                           vt_bs=vt_bs, vt_ld=vt_ld, o_bs=Nq * out.stride(0), o_ld=out.stride(0),
-                                          scale=1.0 / math.sqrt(64.0)))
+                                          scale=1.0 / math.sqrt(64.0), causal=causal))
         return out
 
     def vt_gemm(self, wv: torch.Tensor, x: torch.Tensor, *, B, Ntok, Cin, bias_m=None, name="v_transposed") -> Tuple[torch.Tensor, int]:

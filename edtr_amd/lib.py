@@ -10,14 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
 
 BF16, F16 = 0, 1
-ACT_NONE, ACT_GEGLU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
 
 DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
     "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
-    "edtr_graph_destroy", "edtr_zero_bytes",
+    "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens",
 ]
 
 
@@ -53,6 +53,7 @@ class AttnParams(C.Structure):
         ("vt", C.c_void_p), ("vt_bs", C.c_int64), ("vt_ld", C.c_int32),
         ("out", C.c_void_p), ("o_bs", C.c_int64), ("o_ld", C.c_int32),
         ("scale", C.c_float),
+        ("causal", C.c_int32),
     ]
 
 
@@ -116,7 +117,8 @@ def load() -> C.CDLL:
         if name not in ("edtr_error_string",):
             fn.restype = i32
     lib.edtr_zero_bytes.argtypes = [vp, i64, vp]
-    if lib.edtr_abi_version() != 2:
+    lib.edtr_embed_tokens.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
+    if lib.edtr_abi_version() != 3:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

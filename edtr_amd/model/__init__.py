@@ -1,1 +1,2 @@
-from .cldm import ControlLDM, ControlNet, ControlledUnetModel, AutoencoderKL, PromptEncoder  # noqa: F401
+from .cldm import ControlLDM, ControlNet, ControlledUnetModel, AutoencoderKL  # noqa: F401
+from .clip import FrozenOpenCLIPEmbedder  # noqa: F401

@@ -15,6 +15,7 @@ from torch import nn
 from .. import arch, nets
 from .. import ops as ops_mod
 from ..engine import Act, Arena, Emitter, Program, WeightStore
+from .clip import FrozenOpenCLIPEmbedder
 from .params import ParamTree, params_fingerprint
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16}
@@ -77,27 +78,6 @@ class AutoencoderKL(ParamTree):
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError("use ControlLDM.vae_encode / vae_decode")
-
-
-class PromptEncoder(nn.Module):
-    """Placeholder for FrozenOpenCLIPEmbedder (reference model/clip.py:12-65), which is OUT of the accelerated
-    path: EDTR always encodes the fixed prompt "" once per run.  Supply that constant with
-    ``set_embedding`` (e.g. computed once by the reference CLIP on the host) and ``encode`` broadcasts it."""
-
-    def __init__(self, **cfg):
-        super().__init__()
-        self.cfg = cfg
-        self.register_buffer("embedding", None, persistent=False)
-
-    def set_embedding(self, emb: torch.Tensor) -> None:
-        self.embedding = emb
-
-    def encode(self, text) -> torch.Tensor:
-        if self.embedding is None:
-            raise RuntimeError("PromptEncoder.encode: no prompt embedding set; the CLIP text tower is outside the "
-                               "accelerated path. Call cldm.clip.set_embedding(c_txt[1,77,ctx_dim]) first.")
-        n = len(text) if isinstance(text, (list, tuple)) else 1
-        return self.embedding.expand(n, -1, -1).contiguous()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -278,7 +258,7 @@ class ControlLDM(nn.Module):
             raise NotImplementedError("tail_block / woSD is dead code in the reference (no caller) and is not built")
         self.unet = ControlledUnetModel(**unet_cfg)
         self.vae = AutoencoderKL(**vae_cfg)
-        self.clip = PromptEncoder(**clip_cfg)
+        self.clip = FrozenOpenCLIPEmbedder(**clip_cfg)
         self.controlnet = ControlNet(**controlnet_cfg)
         self.scale_factor = latent_scale_factor
         self.control_scales = [1.0] * 13
@@ -338,18 +318,19 @@ class ControlLDM(nn.Module):
     # -- checkpoint ingestion (reference model/cldm.py:46-105) -----------------------------------
     @torch.no_grad()
     def load_pretrained_sd(self, sd: Dict[str, torch.Tensor], is_turbo: bool = False) -> Set[str]:
-        """Strict key-for-key copy of the SD checkpoint's `model.diffusion_model.*` / `first_stage_model.*` entries.
-        The CLIP text tower (`cond_stage_model.*`) is outside the accelerated path and is left in `unused`."""
-        module_map = {"unet": "model.diffusion_model", "vae": "first_stage_model"}
+        """Strict key-for-key copy of the SD checkpoint's `model.diffusion_model.*` / `first_stage_model.*` /
+        `cond_stage_model.*` (turbo: `conditioner.embedders.0.*`) entries, like the reference."""
+        module_map = {"unet": "model.diffusion_model", "vae": "first_stage_model",
+                      "clip": "conditioner.embedders.0" if is_turbo else "cond_stage_model"}
         used: Set[str] = set()
-        for name, module in (("unet", self.unet), ("vae", self.vae)):
+        for name, module in (("unet", self.unet), ("vae", self.vae), ("clip", self.clip)):
             init_sd = {}
             for key in module.state_dict():
                 target = f"{module_map[name]}.{key}"
                 init_sd[key] = sd[target].clone()
                 used.add(target)
             module.load_state_dict(init_sd, strict=True)
-        for module in (self.unet,):
+        for module in (self.clip, self.unet):
             module.eval()
             module.train = disabled_train.__get__(module)
             for p in module.parameters():
@@ -405,6 +386,7 @@ class ControlLDM(nn.Module):
     def prepare_condition(self, clean: torch.Tensor, prompt: List[str]) -> Dict[str, torch.Tensor]:
         if prompt is None:
             prompt = [""] * clean.size(0)
+        self.clip.compute_dtype = self.compute_dtype
         return dict(c_txt=self.clip.encode(prompt), c_img=self.vae_encode(clean * 2 - 1, sample=False))
 
     # -- the denoiser (reference model/cldm.py:166-194) -------------------------------------------

@@ -118,7 +118,7 @@ def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int
 # attention
 # --------------------------------------------------------------------------------------------
 def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld,
-                    scale: float, name: str = "flash_attn64") -> Rec:
+                    scale: float, causal: bool = False, name: str = "flash_attn64") -> Rec:
     p = L.AttnParams()
     p.dtype, p.B, p.H, p.Nq, p.Nk = dt_code(dtype), B, H, Nq, Nk
     p.q, p.q_bs, p.q_ld = ptr(q), q_bs, q_ld
@@ -126,6 +126,7 @@ def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_l
     p.vt, p.vt_bs, p.vt_ld = ptr(vt), vt_bs, vt_ld
     p.out, p.o_bs, p.o_ld = ptr(out), o_bs, o_ld
     p.scale = scale
+    p.causal = int(causal)
     flops = 4.0 * B * H * Nq * Nk * 64
     return Rec(L.load().edtr_flash_attn64, (ct.byref(p),), (p, q, k, vt, out), name, flops)
 
@@ -133,6 +134,11 @@ def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_l
 # --------------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------------
+def make_embed_tokens(*, dtype, tokens, table, pos, rows, L_ctx, D, out, ld, name="embed_tokens") -> Rec:
+    args = (dt_code(dtype), ptr(tokens), ptr(table), ptr(pos), rows, L_ctx, D, table.shape[0], ptr(out), ld)
+    return Rec(L.load().edtr_embed_tokens, args, (tokens, table, pos, out), name, 0.0, 10.0 * rows * D)
+
+
 def make_zero(t: torch.Tensor, name: str = "zero") -> Rec:
     nbytes = t.numel() * t.element_size()
     return Rec(L.load().edtr_zero_bytes, (ptr(t), nbytes), (t,), name, 0.0, float(nbytes))

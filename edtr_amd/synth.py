@@ -132,4 +132,21 @@ def tiny_config() -> dict:
     return cfg
 
 
+def clip_small_config() -> dict:
+    """Reduced text tower for the CLIP goldens: head width 64 like ViT-H (2 heads x 64), 3 layers."""
+    return dict(embed_dim=128, vision_cfg=dict(image_size=32, layers=1, width=64, head_width=32, patch_size=16),
+                text_cfg=dict(context_length=77, vocab_size=49408, width=128, heads=2, layers=3), layer="penultimate")
+
+
+def clip_test_tokens() -> "torch.Tensor":
+    """[4, 77] int64: the empty prompt, a short prompt, a full-length row of hashed ids, a row ending early."""
+    t = torch.zeros((4, 77), dtype=torch.int64)
+    t[0, :2] = torch.tensor([49406, 49407])
+    t[1, :7] = torch.tensor([49406, 320, 1125, 539, 320, 2368, 49407])
+    ids = (hashed_uniform("clip:tokens", 75) * 0.5 + 0.5).mul(49000).long().clamp(1, 49000)
+    t[2, 0], t[2, 1:76], t[2, 76] = 49406, ids, 49407
+    t[3, 0], t[3, 1:40], t[3, 40] = 49406, ids[:39].flip(0), 49407
+    return t
+
+
 CONFIGS = {"sd21": sd21_config, "tiny": tiny_config}

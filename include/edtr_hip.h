@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 2
+#define EDTR_ABI_VERSION 3
 
 enum edtr_dtype { EDTR_BF16 = 0, EDTR_F16 = 1 };
 
@@ -44,7 +44,7 @@ enum edtr_error {
     EDTR_E_UNSUPPORTED = -5
 };
 
-enum edtr_act { EDTR_ACT_NONE = 0, EDTR_ACT_GEGLU = 1, EDTR_ACT_SILU = 2 };
+enum edtr_act { EDTR_ACT_NONE = 0, EDTR_ACT_GEGLU = 1, EDTR_ACT_SILU = 2, EDTR_ACT_GELU = 3 /* exact erf GELU: the CLIP text MLP, model/open_clip/transformer.py:220-224 */ };
 
 typedef void* edtr_stream_t; /* hipStream_t */
 
@@ -135,6 +135,8 @@ typedef struct edtr_attn_params {
     const void* vt; int64_t vt_bs; int32_t vt_ld;
     void* out; int64_t o_bs; int32_t o_ld;
     float scale;
+    int32_t causal;                 /* nonzero: key j contributes to query i only if j <= i (the CLIP text tower's attn_mask,
+                                       reference model/open_clip/model.py build_attention_mask; Nq == Nk) */
 } edtr_attn_params;
 
 int edtr_flash_attn64(const edtr_attn_params* p, edtr_stream_t stream);
@@ -183,6 +185,11 @@ int edtr_softmax_rows(int dtype, const float* s, int64_t rows, int cols, int64_t
 /* ------------------------------------------------------------------------------------------
  * Layout / elementwise helpers.
  * ---------------------------------------------------------------------------------------- */
+/* Token + positional embedding of the CLIP text tower: out[row][:] = table[tokens[row]][:] + pos[row % L][:], 16-bit out
+ * (rows = B*L, D % 8 == 0).  replaces: `self.model.token_embedding(text) + self.model.positional_embedding`, reference
+ * model/clip.py:41-43. */
+int edtr_embed_tokens(int dtype, const int64_t* tokens, const float* table, const float* pos, int rows, int L, int D,
+                      int vocab, void* out, int ld, edtr_stream_t stream);
 /* Zero `bytes` bytes (a multiple of 16, 16-byte aligned) with ONE kernel launch (hipMemsetAsync costs two tiny kernels per
  * node inside a hipGraph).  replaces: the implicit zero-initialisation of the reduction buffers that torch's
  * native_group_norm allocates per call (reference model/util.py:146-163 via nn.GroupNorm). */

@@ -643,3 +643,28 @@ def vae_decode_tiled(sd: SD, cfg: dict, z: torch.Tensor, tile_size: int, p: str 
     dd = cfg["vae_cfg"]["ddconfig"]
     z = conv(sd, p + "post_quant_conv.", z / cfg["latent_scale_factor"], padding=0)
     return tiled_vae_net(sd, dd, p + "decoder.", z, tile_size, True)
+
+
+# ==============================================================================================
+# CLIP text tower: reference model/clip.py:37-58, model/open_clip/transformer.py:199-254,
+# model/open_clip/model.py build_attention_mask (causal).  `sd` holds the reference keys under prefix `p`.
+# ==============================================================================================
+def clip_text_forward(sd: SD, text_cfg: dict, tokens: torch.Tensor, layer_idx: int = 1, p: str = "clip.") -> torch.Tensor:
+    """tokens int64 [B, L] -> fp32 [B, L, W]: token + positional embedding, the first (layers - layer_idx) pre-LN
+    causal transformer blocks (layer "penultimate" = layer_idx 1 skips the last block), ln_final."""
+    W, heads, layers = text_cfg["width"], text_cfg["heads"], text_cfg["layers"]
+    x = sd[p + "model.token_embedding.weight"][tokens] + sd[p + "model.positional_embedding"]
+    B, Lc, _ = x.shape
+    mask = torch.full((Lc, Lc), float("-inf")).triu_(1)
+    for i in range(layers - layer_idx):
+        q = f"{p}model.transformer.resblocks.{i}."
+        h = F.layer_norm(x, (W,), sd[q + "ln_1.weight"], sd[q + "ln_1.bias"], 1e-5)
+        qkv = F.linear(h, sd[q + "attn.in_proj_weight"], sd[q + "attn.in_proj_bias"])
+        qh, kh, vh = (t.reshape(B, Lc, heads, W // heads).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        att = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(W // heads) + mask, dim=-1) @ vh
+        att = att.transpose(1, 2).reshape(B, Lc, W)
+        x = x + F.linear(att, sd[q + "attn.out_proj.weight"], sd[q + "attn.out_proj.bias"])
+        h = F.layer_norm(x, (W,), sd[q + "ln_2.weight"], sd[q + "ln_2.bias"], 1e-5)
+        h = F.gelu(F.linear(h, sd[q + "mlp.c_fc.weight"], sd[q + "mlp.c_fc.bias"]))
+        x = x + F.linear(h, sd[q + "mlp.c_proj.weight"], sd[q + "mlp.c_proj.bias"])
+    return F.layer_norm(x, (W,), sd[p + "model.ln_final.weight"], sd[p + "model.ln_final.bias"], 1e-5)

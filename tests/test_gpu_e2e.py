@@ -230,3 +230,37 @@ def test_sd21_width_networks_vs_reference_golden(golden_dir, dtype):
     print(f"\n[sd21 widths {dtype}] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     tol = TOL[dtype]
     assert errs["eps"] < tol["eps"] and errs["vae_z"] < tol["z_pre"] and errs["vae_dec"] < tol["img"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["small", "vith"])
+def test_clip_text_tower_vs_reference_golden(golden_dir, tag, dtype):
+    """FrozenOpenCLIPEmbedder on the GPU (edtr_embed_tokens, layernorm, igemm with exact-GELU epilogue, causal
+    edtr_flash_attn64) against the reference module's output on the same synthetic weights: empty prompt, short prompt,
+    a full 77-token row and a half-length row (causal mask + ragged last key tile)."""
+    from edtr_amd import synth
+    from edtr_amd.model.clip import FrozenOpenCLIPEmbedder, clip_text_param_spec
+    from edtr_amd.model.params import skip_init
+    from edtr_amd.testing import rel_err
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "clip_text.npz"))
+    cfg = synth.clip_small_config() if tag == "small" else synth.sd21_config()["clip_cfg"]
+    with skip_init():
+        m = FrozenOpenCLIPEmbedder(**cfg)
+    m.load_state_dict({k: synth.synth_param(f"clip{tag}." + k, shp)
+                       for k, shp in clip_text_param_spec(cfg["embed_dim"], cfg["text_cfg"])}, strict=True)
+    m = m.eval().to(dev)
+    m.compute_dtype = dtype
+    tokens = torch.from_numpy(g["tokens"]).to(dev)
+    ref = g["z_small"] if tag == "small" else g["z_vith"].astype(np.float32)
+    z = m(tokens if tag == "small" else tokens[:2])
+    torch.cuda.synchronize()
+    err = rel_err(z, ref)
+    print(f"\n[clip {tag} {dtype}] rel err {err:.2e}")
+    assert err < (4e-3 if dtype == torch.float16 else 3e-2)
+    # encode([""]) goes through the vocabulary-free tokenizer path and equals row 0
+    if tag == "small":
+        z0 = m.encode([""])
+        assert rel_err(z0[0], z[0]) < 1e-6

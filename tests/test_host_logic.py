@@ -94,9 +94,17 @@ def test_strict_checkpoint_loading_tiny():
     sds = synthetic_state_dicts(cfg)
     sd_ckpt = {f"model.diffusion_model.{k}": v for k, v in sds["unet"].items()}
     sd_ckpt.update({f"first_stage_model.{k}": v for k, v in sds["vae"].items()})
-    sd_ckpt["cond_stage_model.model.positional_embedding"] = torch.zeros(77, 64)
+    clip_sd = {k: torch.zeros_like(v) for k, v in m.clip.state_dict().items()}
+    clip_sd["model.positional_embedding"] = torch.full((77, 64), 0.25)
+    sd_ckpt.update({f"cond_stage_model.{k}": v for k, v in clip_sd.items()})
+    sd_ckpt["model_ema.decay"] = torch.zeros(())
     unused = m.load_pretrained_sd(sd_ckpt)
-    assert unused == {"cond_stage_model.model.positional_embedding"}
+    assert unused == {"model_ema.decay"}                                 # unet / vae / clip keys all consumed (cldm.py:46-78)
+    assert float(m.clip.state_dict()["model.positional_embedding"][3, 5]) == 0.25
+    missing = dict(sd_ckpt)
+    missing.pop("cond_stage_model.model.ln_final.bias")
+    with pytest.raises(KeyError):
+        m.load_pretrained_sd(missing)
     assert torch.equal(m.unet.state_dict()["out.2.weight"], sds["unet"]["out.2.weight"])
     m.load_controlnet_from_ckpt(sds["controlnet"])
     bad = dict(sds["controlnet"])
@@ -123,9 +131,9 @@ def test_unsupported_configs_and_cpu_inputs_raise():
     x = torch.zeros(1, 4, 8, 8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(x, torch.zeros(1, dtype=torch.long), {"c_txt": torch.zeros(1, 77, 64), "c_img": x})
-    with pytest.raises(RuntimeError, match="set_embedding"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):            # the CLIP text tower, too, is GPU-only
         m.clip.encode([""])
-    m.clip.set_embedding(torch.ones(1, 77, 64))
+    m.clip.set_embedding(torch.ones(1, 77, 64))                          # optional precomputed-embedding override
     assert m.clip.encode(["", ""]).shape == (2, 77, 64)
 
 
@@ -170,3 +178,25 @@ def test_batch_sharding_helpers():
         shard_slice(4, 4, 8)
     ts = [torch.zeros(n) for n in (10, 20, 30, 40)]
     assert [len(b) for b in bucketize(ts, 100)] == [2, 1, 1]      # 40+80 B, 120 B, 160 B
+
+
+def test_clip_state_dict_spec_equals_reference_manifest(golden_dir):
+    """FrozenOpenCLIPEmbedder keys / shapes / order equal the reference module's state_dict (strict loading of
+    `cond_stage_model.*`), for the small tower and for ViT-H."""
+    import json
+    from edtr_amd import synth
+    from edtr_amd.model.clip import clip_text_param_spec
+    with open(os.path.join(golden_dir, "manifest_clip.json")) as f:
+        man = json.load(f)
+    for tag, cfg in (("small", synth.clip_small_config()), ("vith", synth.sd21_config()["clip_cfg"])):
+        spec = [[k, list(shp)] for k, shp in clip_text_param_spec(cfg["embed_dim"], cfg["text_cfg"])]
+        assert spec == man[tag]
+
+
+def test_clip_tokenizer_empty_prompt_and_truncation():
+    from edtr_amd.model.clip import tokenize
+    t = tokenize(["", "  "])
+    assert t.shape == (2, 77) and t.dtype == torch.int64
+    assert t[0, :3].tolist() == [49406, 49407, 0] and int(t[0].sum()) == 49406 + 49407 and bool((t[0] == t[1]).all())
+    with pytest.raises(RuntimeError):
+        tokenize(["a cat"], bpe_path="/nonexistent/bpe.gz")

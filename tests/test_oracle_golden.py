@@ -189,3 +189,32 @@ def test_tiled_vae(golden_dir):
         # small inputs fall back to the plain network (tilevae.py:317-323)
         small = synth.synth_input("tvae:small", (1, 3, 128, 128), -1.0, 1.0)
         assert rel_err(O.vae_encode_tiled(sd, cfg, small, 64), O.vae_encode(sd, cfg, small)) == 0.0
+
+
+def _clip_sd(tag, cfg):
+    from edtr_amd.model.clip import clip_text_param_spec
+    return {"clip." + k: synth.synth_param(f"clip{tag}." + k, shp) for k, shp in clip_text_param_spec(cfg["embed_dim"], cfg["text_cfg"])}
+
+
+def test_clip_text_small(golden_dir):
+    """CLIP text tower restatement (causal pre-LN transformer, penultimate layer, ln_final) vs the reference's
+    FrozenOpenCLIPEmbedder on a small tower with ViT-H's head width."""
+    g = np.load(os.path.join(golden_dir, "clip_text.npz"))
+    cfg = synth.clip_small_config()
+    tokens = synth.clip_test_tokens()
+    np.testing.assert_array_equal(tokens.numpy(), g["tokens"])
+    with torch.no_grad():
+        z = O.clip_text_forward(_clip_sd("small", cfg), cfg["text_cfg"], tokens, layer_idx=1)
+    assert rel_err(z, g["z_small"]) < 2e-5
+
+
+@pytest.mark.slow
+def test_clip_text_vith(golden_dir):
+    """The full ViT-H text tower (24 layers, width 1024, 16 heads) of configs/det/demo.yaml."""
+    g = np.load(os.path.join(golden_dir, "clip_text.npz"))
+    cfg = synth.sd21_config()["clip_cfg"]
+    tokens = synth.clip_test_tokens()
+    with torch.no_grad():
+        z = O.clip_text_forward(_clip_sd("vith", cfg), cfg["text_cfg"], tokens[:2], layer_idx=1)
+    assert rel_err(z, g["z_vith"].astype(np.float32)) < 1e-3          # golden stored as fp16
+    np.testing.assert_allclose([float(z.abs().mean())], [g["stats_vith"][1]], rtol=2e-2)

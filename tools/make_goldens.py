@@ -278,16 +278,43 @@ def gen_wavelet():
     print("wavelet.npz written")
 
 
+def gen_clip():
+    """The reference FrozenOpenCLIPEmbedder (model/clip.py) on synthetic weights: a small tower (head width 64) and the
+    full ViT-H text tower of configs/det/demo.yaml (24 layers, width 1024, penultimate layer), plus its key manifest."""
+    ref_import.install_stubs()
+    sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    from model.clip import FrozenOpenCLIPEmbedder
+    out = {}
+    tokens = synth.clip_test_tokens()
+    out["tokens"] = tokens.numpy()
+    man = {}
+    for tag, cfg in (("small", synth.clip_small_config()), ("vith", synth.sd21_config()["clip_cfg"])):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = FrozenOpenCLIPEmbedder(**cfg).eval()
+        with torch.no_grad():
+            for key, val in m.state_dict().items():
+                val.copy_(synth.synth_param(f"clip{tag}." + key, tuple(val.shape)))
+            z = m(tokens)
+        man[tag] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        out[f"z_{tag}"] = z.numpy().astype(np.float32) if tag == "small" else z[:2].numpy().astype(np.float16)
+        out[f"stats_{tag}"] = np.array([float(z.mean()), float(z.abs().mean()), float(z.abs().max())])
+        print(tag, out[f"stats_{tag}"])
+    np.savez_compressed(os.path.join(GOLD, "clip_text.npz"), **out)
+    with open(os.path.join(GOLD, "manifest_clip.json"), "w") as f:
+        json.dump(man, f)
+    print("clip_text.npz written")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "wavelet": gen_wavelet}[name]()
+         "wavelet": gen_wavelet, "clip": gen_clip}[name]()
 
 
 if __name__ == "__main__":
