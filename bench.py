@@ -69,7 +69,8 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("EDTR_BENCH_DIST"))   # EDTR_BENCH_DIST=1: exercise the RCCL path on one rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
@@ -113,8 +114,11 @@ def main() -> None:
         cldm.load_controlnet_from_ckpt(sds["controlnet"])
         cldm.vae.load_state_dict(sds["vae"], strict=True)
     cldm = cldm.eval().to(dev)
-    if world > 1:
-        calls, nbytes = broadcast_parameters(cldm, src=0)
+    if use_dist:
+        calls = nbytes = 0
+        for part in (cldm.unet, cldm.controlnet, cldm.vae):      # the CLIP tower is not on this path: c_txt is an input
+            c_, n_ = broadcast_parameters(part, src=0)
+            calls, nbytes = calls + c_, nbytes + n_
         log(f"[rank {rank}] weights broadcast over RCCL: {calls} collectives, {nbytes / 2**30:.2f} GiB")
     log(f"[rank {rank}] model ready in {time.time() - t0:.1f}s")
 
