@@ -264,3 +264,25 @@ def test_clip_text_tower_vs_reference_golden(golden_dir, tag, dtype):
     if tag == "small":
         z0 = m.encode([""])
         assert rel_err(z0[0], z[0]) < 1e-6
+
+
+def test_restore_dataset_driver_shapes_and_psnr():
+    """evalutil.restore_dataset (accelerate-free driver of main/det/test_edtr.py:121-135): ragged images are padded to the
+    model size, restored in batches, colour-fixed, cropped back and scored."""
+    from edtr_amd import evalutil, synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    cldm = build_synthetic_cldm(synth.tiny_config(), dev, torch.float16)
+    cldm.clip.set_embedding(synth.synth_input("drv:c_txt", (1, 77, 64), -1.0, 1.0).to(dev))
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
+    sampler = SpacedSampler(diffusion.betas)
+    imgs = [synth.synth_input(f"drv:img{i}", (3, h, w), 0.0, 1.0) for i, (h, w) in enumerate([(128, 128), (96, 120), (64, 40)])]
+    torch.manual_seed(0)
+    outs, psnr = evalutil.restore_dataset(cldm, diffusion, sampler, imgs, gts=imgs, img_size=128, batch_size=2)
+    assert [tuple(o.shape) for o in outs] == [tuple(i.shape) for i in imgs]
+    assert all(torch.isfinite(o).all() and float(o.min()) >= 0.0 and float(o.max()) <= 1.0 for o in outs)
+    assert torch.isfinite(psnr) and 0.0 < float(psnr) < 60.0

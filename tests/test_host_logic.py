@@ -200,3 +200,19 @@ def test_clip_tokenizer_empty_prompt_and_truncation():
     assert t[0, :3].tolist() == [49406, 49407, 0] and int(t[0].sum()) == 49406 + 49407 and bool((t[0] == t[1]).all())
     with pytest.raises(RuntimeError):
         tokenize(["a cat"], bpe_path="/nonexistent/bpe.gz")
+
+
+def test_eval_helpers_vs_reference_golden(golden_dir):
+    """PSNR / YCbCr (utils/common.py:194-247) against the reference's numbers; list_to_batch / batch_to_list round trip."""
+    from edtr_amd import evalutil
+    g = np.load(os.path.join(golden_dir, "psnr.npz"))
+    a = synth.synth_input("psnr:a", (3, 3, 40, 56), 0.0, 1.0)
+    b = (a + 0.05 * synth.synth_normal("psnr:n", (3, 3, 40, 56))).clamp(0, 1)
+    np.testing.assert_array_equal(evalutil.calculate_psnr_pt(a, b, 0, False).numpy(), g["psnr_0"])
+    np.testing.assert_array_equal(evalutil.calculate_psnr_pt(a, b, 4, True).numpy(), g["psnr_4y"])
+    np.testing.assert_array_equal(evalutil.rgb2ycbcr_pt(a).numpy(), g["ycbcr"])
+    imgs = [a[0, :, :30, :56], a[1, :, :40, :17], a[2]]
+    batch = evalutil.list_to_batch(imgs, 64, "cpu")
+    assert batch.shape == (3, 3, 64, 64) and float(batch[0, :, 30:, :].abs().max()) == 0.0 and float(batch[1, :, :, 17:].abs().max()) == 0.0
+    back = evalutil.batch_to_list(batch, imgs)
+    assert all(torch.equal(x, y) for x, y in zip(back, imgs))

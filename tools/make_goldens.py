@@ -305,16 +305,26 @@ def gen_clip():
     print("clip_text.npz written")
 
 
+def gen_psnr():
+    """PSNR / YCbCr of the reference's utils/common.py on a synthetic image pair (tests/golden/psnr.npz)."""
+    _, _, _, ref_common = ref_import.import_reference()
+    a = synth.synth_input("psnr:a", (3, 3, 40, 56), 0.0, 1.0)
+    b = (a + 0.05 * synth.synth_normal("psnr:n", (3, 3, 40, 56))).clamp(0, 1)
+    np.savez_compressed(os.path.join(GOLD, "psnr.npz"), psnr_0=ref_common.calculate_psnr_pt(a, b, 0, False).numpy(),
+                        psnr_4y=ref_common.calculate_psnr_pt(a, b, 4, True).numpy(), ycbcr=ref_common.rgb2ycbcr_pt(a).numpy())
+    print("psnr.npz written")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "wavelet": gen_wavelet, "clip": gen_clip}[name]()
+         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr}[name]()
 
 
 if __name__ == "__main__":
