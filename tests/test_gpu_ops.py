@@ -522,3 +522,75 @@ def test_fused_groupnorm_partials(dtype, cin, tile):
     # the fused sums use the values BEFORE the 16-bit rounding of the store: agreement to rounding noise
     assert rel(s_fused[..., 1], s_ref[..., 1]) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
     assert float((s_fused[..., 0] - s_ref[..., 0]).abs().max()) < (0.5 if dtype == torch.bfloat16 else 0.06)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,N", [(2, 2, 77), (1, 3, 200), (1, 1, 64), (2, 1, 129)])
+def test_flash_attn64_causal(dtype, B, H, N):
+    """Causal mask of the CLIP text tower (key j <= query i), incl. ragged last tiles and fully masked key tiles."""
+    ops = _ops()
+    d = dev()
+    Cc = H * 64
+    q = rnd((B, N, Cc), 130).to(dtype)
+    k = rnd((B, N, Cc), 131).to(dtype)
+    v = rnd((B, N, Cc), 132).to(dtype)
+    ldv = ops.round_up(N, 8)
+    vt = torch.zeros((B, Cc, ldv), dtype=dtype)
+    vt[:, :, :N] = v.transpose(1, 2)
+    out = torch.empty((B, N, Cc), dtype=dtype, device=d)
+    ops.launch(ops.make_flash_attn(dtype=dtype, q=q.to(d), k=k.to(d), vt=vt.to(d), out=out, B=B, H=H, Nq=N, Nk=N,
+                                   q_bs=N * Cc, q_ld=Cc, k_bs=N * Cc, k_ld=Cc, vt_bs=Cc * ldv, vt_ld=ldv, o_bs=N * Cc,
+                                   o_ld=Cc, scale=0.125, causal=True))
+    torch.cuda.synchronize()
+    qh, kh, vh = (t.float().reshape(B, N, H, 64).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True, scale=0.125).transpose(1, 2).reshape(B, N, Cc)
+    assert rel(out.float().cpu(), ref) < TOL[dtype]
+    with pytest.raises(RuntimeError):          # causal needs Nq == Nk
+        ops.launch(ops.make_flash_attn(dtype=dtype, q=q.to(d), k=k.to(d), vt=vt.to(d), out=out, B=B, H=H, Nq=N, Nk=N - 1,
+                                       q_bs=N * Cc, q_ld=Cc, k_bs=N * Cc, k_ld=Cc, vt_bs=Cc * ldv, vt_ld=ldv,
+                                       o_bs=N * Cc, o_ld=Cc, scale=0.125, causal=True))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 3, 8, 6])
+def test_gemm_gelu_epilogue(dtype, tile):
+    """Exact (erf) GELU epilogue (the CLIP MLP, act = 3) on every main-loop family, with and without split-K."""
+    ops = _ops()
+    d = dev()
+    M, N, K = 308, 320, 256
+    a = rnd((M, K), 140).to(dtype)
+    w = rnd((N, K), 141, 1 / math.sqrt(K)).to(dtype)
+    b = rnd((N,), 142)
+    ref = F.gelu(a.float() @ w.float().t() + b)
+    out = torch.empty((M, N), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=a.to(d), w=w.to(d), out=out, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N,
+                              bias_n=b.to(d), act=3, tile=tile))
+    torch.cuda.synchronize()
+    assert rel(out.float().cpu(), ref) < TOL[dtype]
+    if tile in (0, 3):
+        ws = torch.empty(2 * M * N, dtype=torch.float32, device=d)
+        out2 = torch.empty((M, N), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=a.to(d), w=w.to(d), out=out2, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N,
+                                  bias_n=b.to(d), act=3, tile=tile, splitk=2, workspace=ws))
+        torch.cuda.synchronize()
+        assert rel(out2.float().cpu(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_tokens_and_zero_bytes(dtype):
+    ops = _ops()
+    d = dev()
+    V, Lc, D, B = 1000, 77, 128, 3
+    table, pos = rnd((V, D), 150), rnd((Lc, D), 151)
+    tokens = torch.randint(0, V, (B, Lc), generator=torch.Generator().manual_seed(5))
+    tokens[0, 3], tokens[1, 0] = V + 7, -2          # out-of-range ids are clamped, never read out of bounds
+    out = torch.empty((B * Lc, D), dtype=dtype, device=d)
+    ops.launch(ops.make_embed_tokens(dtype=dtype, tokens=tokens.to(d), table=table.to(d), pos=pos.to(d), rows=B * Lc,
+                                     L_ctx=Lc, D=D, out=out, ld=D))
+    torch.cuda.synchronize()
+    ref = (table[tokens.clamp(0, V - 1)] + pos[None]).reshape(B * Lc, D)
+    assert rel(out.float().cpu(), ref.to(dtype).float()) < 1e-6
+    buf = torch.full((4096 + 16,), 3.0, dtype=torch.float64, device=d)
+    ops.launch(ops.make_zero(buf[2:2 + 4096]))
+    torch.cuda.synchronize()
+    assert float(buf[2:2 + 4096].abs().max()) == 0.0 and float(buf[:2].min()) == 3.0 and float(buf[2 + 4096:].min()) == 3.0
