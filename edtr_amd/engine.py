@@ -190,7 +190,11 @@ class Program:
         """A never-reused [B, 32, 2] fp64 GroupNorm accumulator out of a pool that the program's FIRST launch zeroes
         (a hipMemsetAsync per edtr_gn_stats call costs two extra tiny kernels per node inside the hipGraph)."""
         if self.sums_pool is None:
-            self.sums_pool = arena.alloc((self.SUMS_SLOTS, B, 32, 2), torch.float64)
+            # Its OWN allocation, never arena memory: the pool is live from the program's first launch (which zeroes it), i.e.
+            # earlier than the build-time point of this call — an arena hole freed by launches that precede the first
+            # pooled GroupNorm would be scribbled over by them after the zeroing (found by the full-size batch-invariance
+            # test: wrong results for batch >= 3, where the first GroupNorms are fused and the pool is created late).
+            self.sums_pool = torch.zeros((self.SUMS_SLOTS, B, 32, 2), dtype=torch.float64, device=arena.device)
             rec = ops.make_zero(self.sums_pool, name="gn.zero_pool")
             self.recs.insert(0, rec)
             self.lanes.insert(0, 0)
