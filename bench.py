@@ -368,12 +368,19 @@ def finish_cpu_baseline(handle, pre_res_g, c_txt1, noises_g, img, z, S, rel_err,
         return {"cpu_baseline": {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
                                  "sample": f"1 image {S}x{S}, 4 steps: exceeded the {budget_s:.0f}s budget"}}
     dt, ref_img, ref_z = res
+    ez, ei = rel_err(z[:1], ref_z), rel_err(img[:1], ref_img)
+    tol = 5e-2 if img.dtype == torch.float32 else 5e-2
+    ok = bool(ez == ez and ei == ei and ez < tol and ei < tol)          # NaN-safe
+    if not ok:
+        log(f"!!! PARITY FAILURE: GPU vs CPU oracle rel err latent {ez:.3e}, image {ei:.3e} (tolerance {tol:.0e}) — the "
+            "throughput above is NOT a valid result")
     return {
         "cpu_baseline": {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": threads, "kind": "port",
                          "sample": f"1 image {S}x{S}, 4 steps, fp32 oracle on torch CPU kernels, {threads} threads "
                                    f"of {cores} host cores ({dt:.1f} s)"},
         "parity": {"rel_err_latent_vs_oracle": float(f"{rel_err(z[:1], ref_z):.3e}"),
-                   "rel_err_image_vs_oracle": float(f"{rel_err(img[:1], ref_img):.3e}"), "sample": "image 0 of the batch"},
+                   "rel_err_image_vs_oracle": float(f"{rel_err(img[:1], ref_img):.3e}"), "sample": "image 0 of the batch",
+                   "ok": ok, "tolerance": tol},
     }
 
 
