@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
-SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "swin.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "edtr_hip.h")]
 ARCH = "gfx950"
 

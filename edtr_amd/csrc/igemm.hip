@@ -67,6 +67,9 @@ __device__ __forceinline__ void finish_vector(const edtr_igemm_params& p, float 
     } else if (p.act == EDTR_ACT_GELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = gelu_erf_f(f[j]);
+    } else if (p.act == EDTR_ACT_LRELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], f[j] * p.act_slope);   // slope in [0, 1]
     }
     if (p.residual) {
         const U4 rv = ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n);
@@ -170,7 +173,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         }
     }
     const float alpha = GEGLU ? 1.0f : p.alpha;
-    const bool silu = p.act == EDTR_ACT_SILU, gelu = p.act == EDTR_ACT_GELU;
+    const bool silu = p.act == EDTR_ACT_SILU, gelu = p.act == EDTR_ACT_GELU, lrelu = p.act == EDTR_ACT_LRELU;
     __syncthreads();                          // staged tile visible
 
 #pragma unroll
@@ -199,6 +202,9 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             } else if (gelu) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = gelu_erf_f(f[j]);
+            } else if (lrelu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], f[j] * p.act_slope);
             }
             if (p.residual) {
                 float rf[8];
@@ -2269,7 +2275,8 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (p.OW <= 0 || p.IH <= 0 || p.IW <= 0 || p.stride <= 0) return EDTR_E_SHAPE;
         if (p.M % (p.OH * p.OW) != 0) return EDTR_E_SHAPE;
     }
-    if (p.act < EDTR_ACT_NONE || p.act > EDTR_ACT_GELU) return EDTR_E_DTYPE;
+    if (p.act < EDTR_ACT_NONE || p.act > EDTR_ACT_LRELU) return EDTR_E_DTYPE;
+    if (p.act == EDTR_ACT_LRELU && !(p.act_slope >= 0.0f && p.act_slope <= 1.0f)) return EDTR_E_SHAPE;
     if (p.rowvec && p.rows_per_image <= 0) return EDTR_E_SHAPE;
     // 16-byte rule
     if ((p.K & 7) || (p.N & 7) || (p.C1 & 7) || (p.C2 & 7) || (p.ld1 & 7) || (p.C2 && (p.ld2 & 7)) || (p.ldw & 7))

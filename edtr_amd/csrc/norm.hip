@@ -143,14 +143,16 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
 // LayerNorm: one wave per row, row held in registers (up to 4 vectors of 8 per lane: C <= 2048),
 // mean / variance by wavefront shuffles.
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* x, int64_t rows, int C, int ldx,
+// PADDED: only the first c_valid (< C) columns are real; the rest are excluded from the statistics and written as zeros.
+template <typename T, bool PADDED>
+__global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* x, int64_t rows, int C, int c_valid, int ldx,
                                                        const float* gamma, const float* beta, float eps,
                                                        uint16_t* y, int ldy) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int CV = C >> 3;
+    const float n_cols = (float)(PADDED ? c_valid : C);
     float f[4][8];
     float sum = 0.0f;
 #pragma unroll
@@ -159,27 +161,36 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* x, int64
         if (cv < CV) {
             unpack8<T>(ldg16(x + row * ldx + cv * 8), f[s]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += f[s][j];
+            for (int j = 0; j < 8; ++j) {
+                if (PADDED && cv * 8 + j >= c_valid) f[s][j] = 0.0f;
+                sum += f[s][j];
+            }
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
+    const float mean = wave_sum(sum) / n_cols;
     float sq = 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int cv = lane + 64 * s;
         if (cv < CV) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = f[s][j] - mean; sq += d * d; }
+            for (int j = 0; j < 8; ++j) {
+                const float d = f[s][j] - mean;
+                if (!PADDED || cv * 8 + j < c_valid) sq += d * d;
+            }
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = rsqrtf(wave_sum(sq) / n_cols + eps);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int cv = lane + 64 * s;
         if (cv < CV) {
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f[s][j] - mean) * rstd * gamma[cv * 8 + j] + beta[cv * 8 + j];
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (f[s][j] - mean) * rstd * gamma[cv * 8 + j] + beta[cv * 8 + j];
+                if (PADDED && cv * 8 + j >= c_valid) o[j] = 0.0f;
+            }
             stg16(y + row * ldy + cv * 8, pack8<T>(o));
         }
     }
@@ -328,21 +339,25 @@ extern "C" int edtr_gn_pool(double* sums, const float* weights, const float* cou
     return EDTR_OK;
 }
 
-extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int ldx, const float* gamma,
+extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int c_valid, int ldx, const float* gamma,
                               const float* beta, float eps, void* y, int ldy, edtr_stream_t stream) {
     if (!x || !y || !gamma || !beta) return EDTR_E_NULL;
     if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
-    if (rows <= 0 || C <= 0) return EDTR_E_SHAPE;
+    if (rows <= 0 || C <= 0 || c_valid < 0 || c_valid > C) return EDTR_E_SHAPE;
     if (C > 2048) return EDTR_E_UNSUPPORTED;
     if ((C & 7) || (ldx & 7) || (ldy & 7) || !aligned16(x) || !aligned16(y)) return EDTR_E_ALIGN;
+    if (c_valid == 0) c_valid = C;
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (dtype == EDTR_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<BF16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(x), rows, C,
-                           ldx, gamma, beta, eps, static_cast<uint16_t*>(y), ldy);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<F16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(x), rows, C,
-                           ldx, gamma, beta, eps, static_cast<uint16_t*>(y), ldy);
+    const uint16_t* xp = static_cast<const uint16_t*>(x);
+    uint16_t* yp = static_cast<uint16_t*>(y);
+    if (dtype == EDTR_BF16) {
+        if (c_valid == C) hipLaunchKernelGGL((layernorm_kernel<BF16, false>), grid, dim3(256), 0, s, xp, rows, C, C, ldx, gamma, beta, eps, yp, ldy);
+        else hipLaunchKernelGGL((layernorm_kernel<BF16, true>), grid, dim3(256), 0, s, xp, rows, C, c_valid, ldx, gamma, beta, eps, yp, ldy);
+    } else {
+        if (c_valid == C) hipLaunchKernelGGL((layernorm_kernel<F16, false>), grid, dim3(256), 0, s, xp, rows, C, C, ldx, gamma, beta, eps, yp, ldy);
+        else hipLaunchKernelGGL((layernorm_kernel<F16, true>), grid, dim3(256), 0, s, xp, rows, C, c_valid, ldx, gamma, beta, eps, yp, ldy);
+    }
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

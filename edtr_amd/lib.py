@@ -10,14 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
 
 BF16, F16 = 0, 1
-ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3, 4
 
 DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
     "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
-    "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens",
+    "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle",
 ]
 
 
@@ -42,6 +42,7 @@ class IgemmParams(C.Structure):
         ("tile", C.c_int32), ("splitk", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("gn_partial", C.c_void_p),
+        ("act_slope", C.c_float),
     ]
 
 
@@ -54,6 +55,17 @@ class AttnParams(C.Structure):
         ("out", C.c_void_p), ("o_bs", C.c_int64), ("o_ld", C.c_int32),
         ("scale", C.c_float),
         ("causal", C.c_int32),
+    ]
+
+
+class WindowAttnParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("heads", C.c_int32), ("head_dim", C.c_int32), ("shift", C.c_int32),
+        ("qkv", C.c_void_p), ("ld_qkv", C.c_int32),
+        ("out", C.c_void_p), ("ld_out", C.c_int32), ("c_pad", C.c_int32),
+        ("bias", C.c_void_p), ("labels", C.c_void_p),
+        ("scale", C.c_float),
     ]
 
 
@@ -95,7 +107,7 @@ def load() -> C.CDLL:
     lib.edtr_gn_stats.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_apply.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_finalize.argtypes = [vp, i32, i32, i32, i32, vp, vp]
-    lib.edtr_layernorm.argtypes = [i32, vp, i64, i32, i32, vp, vp, f32, vp, i32, vp]
+    lib.edtr_layernorm.argtypes = [i32, vp, i64, i32, i32, i32, vp, vp, f32, vp, i32, vp]
     lib.edtr_softmax_rows.argtypes = [i32, vp, i64, i32, i64, vp, i64, i32, vp]
     lib.edtr_nchw_to_nhwc.argtypes = [i32, vp, i32, i32, i64, vp, i32, i32, i32, f32, f32, vp]
     lib.edtr_nhwc_to_nchw.argtypes = [i32, vp, i32, i32, i32, i64, i32, vp, f32, vp]
@@ -118,7 +130,9 @@ def load() -> C.CDLL:
             fn.restype = i32
     lib.edtr_zero_bytes.argtypes = [vp, i64, vp]
     lib.edtr_embed_tokens.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
-    if lib.edtr_abi_version() != 3:
+    lib.edtr_window_attn.argtypes = [C.POINTER(WindowAttnParams), vp]
+    lib.edtr_pixel_unshuffle.argtypes = [i32, vp, i32, i32, i32, i32, i32, vp, f32, vp, i32, i32, vp]
+    if lib.edtr_abi_version() != 4:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1,0 +1,337 @@
+"""SwinIR pre-restoration network on libedtr_hip: the step in front of the ControlLDM path on every
+reference script (`pre_res = swinir(img)`, reference demo.py:99; model/swinir.py:624-905, configs/det/demo.yaml:2-18).
+
+Same constructor arguments, state-dict keys (parameters AND the two registered buffers) and call convention as the
+reference class, so `swinir.load_state_dict(torch.load("swinir_last.pt"), strict=True)` and `swinir(img)` work unchanged.
+Only the shipped structure is implemented on the device: pixel-unshuffle front end, `1conv` residual connection,
+`nearest+conv` upsampler; anything else raises NotImplementedError at construction.
+
+MI355X mapping ("SwinIR"): tokens are pixel-major rows of CP = roundup64(embed_dim) 16-bit channels whose pad
+columns are kept exactly zero, so every linear / 3x3 convolution is an edtr_igemm on the LDS-DMA path (K a multiple of
+64); heads are widened to 32 columns inside the fused qkv projection (zero weight rows), and the shifted-window attention —
+cyclic shift, window gather, relative-position bias, region mask, softmax, PV, scatter back — is ONE kernel
+(edtr_window_attn) that keeps the 64 x 64 scores of a (window, head) in registers.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import lib as L
+from .. import ops as ops_mod
+from ..engine import Act, Arena, Emitter, Program, WeightStore
+from ..ops import round_up
+from .params import ParamTree, params_fingerprint
+
+RGB_MEAN = (0.4488, 0.4371, 0.4040)      # model/swinir.py:691
+HEAD_PAD = 32                            # device head width (edtr_window_attn); real head width <= 32
+
+
+def swinir_state_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(key, shape, kind) in the reference's state-dict order; kind is "param", "index" (int64 buffer) or "mask" (fp32 buffer)."""
+    C, ws = cfg["embed_dim"], cfg["window_size"]
+    hidden = int(C * cfg["mlp_ratio"])
+    res = cfg["img_size"] // cfg.get("patch_size", 1)
+    n_win = (res // ws) ** 2
+    cin = cfg["in_chans"] * (cfg["unshuffle_scale"] ** 2 if cfg.get("unshuffle") else 1)
+    spec: List[Tuple[str, Tuple[int, ...], str]] = []
+
+    def wb(prefix: str, *wshape: int):
+        spec.append((prefix + "weight", tuple(wshape), "param"))
+        spec.append((prefix + "bias", (wshape[0],), "param"))
+
+    wb("conv_first.1." if cfg.get("unshuffle") else "conv_first.", C, cin, 3, 3)
+    if cfg.get("patch_norm", True):
+        wb("patch_embed.norm.", C)
+    for i, (depth, heads) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+        for j in range(depth):
+            p = f"layers.{i}.residual_group.blocks.{j}."
+            if j % 2 == 1:
+                spec.append((p + "attn_mask", (n_win, ws * ws, ws * ws), "mask"))
+            wb(p + "norm1.", C)
+            spec.append((p + "attn.relative_position_bias_table", ((2 * ws - 1) ** 2, heads), "param"))
+            spec.append((p + "attn.relative_position_index", (ws * ws, ws * ws), "index"))
+            wb(p + "attn.qkv.", 3 * C, C)
+            wb(p + "attn.proj.", C, C)
+            wb(p + "norm2.", C)
+            wb(p + "mlp.fc1.", hidden, C)
+            wb(p + "mlp.fc2.", C, hidden)
+        wb(f"layers.{i}.conv.", C, C, 3, 3)
+    wb("norm.", C)
+    wb("conv_after_body.", C, C, 3, 3)
+    wb("conv_before_upsample.0.", 64, C, 3, 3)
+    for name in ("conv_up1.", "conv_up2.", "conv_up3.")[: int(math.log2(cfg["sf"]))]:
+        wb(name, 64, 64, 3, 3)
+    wb("conv_hr.", 64, 64, 3, 3)
+    wb("conv_last.", cfg["in_chans"], 64, 3, 3)
+    return spec
+
+
+def relative_position_index(ws: int) -> np.ndarray:
+    """bias-table row for (query i, key j) of a ws x ws window (model/swinir.py:96-108)."""
+    ys, xs = np.divmod(np.arange(ws * ws), ws)
+    return ((ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1)).astype(np.int64)
+
+
+def region_labels(H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    """uint8 [H, W]: the image region (3 bands per axis) a pixel of the cyclically SHIFTED frame belongs to; two tokens of a
+    window attend to each other only when their labels agree (model/swinir.py:222-243 builds the equivalent -100 mask)."""
+    def band(n):
+        i = np.arange(n)
+        return np.where(i < n - ws, 0, np.where(i < n - shift, 1, 2))
+    return (band(H)[:, None] * 3 + band(W)[None, :]).astype(np.uint8)
+
+
+def shift_mask(H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    """The reference's attn_mask buffer, [nW, ws*ws, ws*ws] of 0 / -100."""
+    win = region_labels(H, W, ws, shift).reshape(H // ws, ws, W // ws, ws).transpose(0, 2, 1, 3).reshape(-1, ws * ws)
+    return np.where(win[:, None, :] != win[:, :, None], -100.0, 0.0).astype(np.float32)
+
+
+def pack_qkv(w: torch.Tensor, b: torch.Tensor, heads: int, cp: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[3C, C] / [3C] of nn.Linear(dim, 3*dim) -> fp32 [3*heads*HEAD_PAD, cp] / [3*heads*HEAD_PAD]: output row
+    (s, h, e) = s*heads*HEAD_PAD + h*HEAD_PAD + e holds reference row s*C + h*d + e for e < d, zeros otherwise."""
+    C = w.shape[1]
+    d = C // heads
+    wo = torch.zeros((3, heads, HEAD_PAD, cp), dtype=torch.float32, device=w.device)
+    bo = torch.zeros((3, heads, HEAD_PAD), dtype=torch.float32, device=w.device)
+    wo[:, :, :d, :C] = w.reshape(3, heads, d, C)
+    bo[:, :, :d] = b.reshape(3, heads, d)
+    return wo.reshape(-1, cp), bo.reshape(-1)
+
+
+def expand_bias(table: torch.Tensor, ws: int) -> torch.Tensor:
+    """[(2ws-1)^2, heads] -> fp32 [heads, N, N] (query-major), the tensor added to the scores (model/swinir.py:133-136)."""
+    idx = torch.from_numpy(relative_position_index(ws)).to(table.device)
+    return table[idx.reshape(-1)].reshape(ws * ws, ws * ws, -1).permute(2, 0, 1).contiguous().float()
+
+
+class _SwinEngine:
+    """The whole network for one input shape [B, 3, H, W] (H, W multiples of 8 * window): static fp32 input / output
+    tensors, one launch program, optionally one hipGraph."""
+
+    def __init__(self, owner: "SwinIR", B: int, H: int, W: int, graph: bool = True):
+        cfg = owner.cfg
+        dev = owner._device()
+        dt = owner.compute_dtype
+        C, ws, sf = cfg["embed_dim"], cfg["window_size"], cfg["sf"]
+        us = cfg["unshuffle_scale"]
+        CP = round_up(C, 64)
+        hidden = int(C * cfg["mlp_ratio"])
+        HP = round_up(hidden, 64)
+        th, tw = H // us, W // us
+        if th % ws or tw % ws:
+            raise ValueError(f"SwinIR: input {H}x{W} must be a multiple of {us * ws} (callers pad: demo.py:89-90)")
+        rows = B * th * tw
+        self.x = torch.zeros((B, 3, H, W), dtype=torch.float32, device=dev)
+        oh, ow = th * sf, tw * sf
+        self.y = torch.zeros((B, 3, oh, ow), dtype=torch.float32, device=dev)
+        self.arena = Arena(dev)
+        params = owner.flat_params("")
+        store = WeightStore(params, dt, dev)
+        self.prog = Program("swinir")
+        em = Emitter(self.prog, self.arena, store, dt)
+        rng = float(cfg["img_range"])
+        mean = torch.tensor(RGB_MEAN if cfg["in_chans"] == 3 else (0.0,) * cfg["in_chans"], dtype=torch.float32, device=dev)
+
+        # ---- front end: (x - mean) * range, pixel-unshuffle, NHWC 16-bit with 3*us*us channels (model/swinir.py:700-704,861)
+        cin = 3 * us * us
+        f_in = em.new(rows, round_up(cin, 64))
+        self.prog.add(ops_mod.make_pixel_unshuffle(dtype=dt, src=self.x, B=B, C=3, H=H, W=W, r=us, dst=f_in, ld=f_in.stride(0),
+                                                    sub=mean, scale=rng, zero_pad_to=f_in.shape[1]))
+        self._keep = [mean]
+
+        def conv_w(prefix: str, cin_pad: int, cout_pad: int, extra_bias: Optional[torch.Tensor] = None, bscale: float = 1.0):
+            key = ("swin_conv", prefix, cin_pad, cout_pad)
+            if key not in store.cache:
+                w = ops_mod.pack_conv_weight(store._p(prefix + "weight"), dt, cin_pad=cin_pad, cout_pad=cout_pad)
+                b = ops_mod.pad_bias(store._p(prefix + "bias") * bscale, cout_pad)
+                if extra_bias is not None:
+                    b[: extra_bias.numel()] += extra_bias
+                store.cache[key] = (w, b)
+            return store.cache[key]
+
+        def conv3(x: Act, prefix: str, cout_pad: int, *, ups=False, act=0, slope=0.0, residual=None, out_f32=False, alpha=1.0,
+                  extra_bias=None, name="swin.conv3x3") -> Act:
+            w, b = conv_w(prefix, x.C, cout_pad, extra_bias, alpha)
+            LH, LW = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
+            M = x.B * LH * LW
+            out = em.new(M, cout_pad, torch.float32 if out_f32 else None)
+            tile, splitk = ops_mod.choose_splitk(M, cout_pad, 9 * x.C)
+            wsp = self.arena.alloc((splitk * M * cout_pad,), torch.float32) if splitk > 1 else None
+            self.prog.add(ops_mod.make_igemm(
+                dtype=dt, a1=x.t, w=w, out=out, taps=9, M=M, N=cout_pad, C1=x.C, ld1=x.ld, ldw=w.stride(0), ldc=out.stride(0),
+                spatial=(x.H, x.W, LH, LW, 1, 1, 1, int(ups)), bias_n=b, act=act, act_slope=slope, residual=residual,
+                ldr=residual.stride(0) if residual is not None else 0, out_f32=out_f32, alpha=alpha, tile=tile, splitk=splitk,
+                workspace=wsp, name=name))
+            self.arena.free(wsp)
+            return Act(out, x.B, LH, LW, cout_pad)
+
+        def ln(x: torch.Tensor, prefix: str) -> torch.Tensor:
+            y = em.new(rows, CP)
+            self.prog.add(ops_mod.make_layernorm(dtype=dt, x=x, rows=rows, C=CP, ldx=x.stride(0), gamma=store.vec(prefix + "weight", CP),
+                                                 beta=store.vec(prefix + "bias", CP), eps=1e-5, y=y, ldy=CP, c_valid=C,
+                                                 name="swin.layernorm"))
+            return y
+
+        def linear(prefix: str, k_pad: int, n_pad: int):
+            key = ("swin_linear", prefix, k_pad, n_pad)
+            if key not in store.cache:
+                w = store._p(prefix + "weight")
+                wp = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=dev)
+                wp[: w.shape[0], : w.shape[1]] = w
+                store.cache[key] = (wp.to(dt).contiguous(), ops_mod.pad_bias(store._p(prefix + "bias"), n_pad))
+            return store.cache[key]
+
+        f0 = conv3(Act(f_in, B, th, tw, f_in.shape[1]), "conv_first.1.", CP, name="swin.conv_first")
+        em.free(f_in)
+        t = ln(f0.t, "patch_embed.norm.") if cfg.get("patch_norm", True) else f0.t
+        labels: Dict[int, torch.Tensor] = {}
+        for i, (depth, heads) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+            d = C // heads
+            if d > HEAD_PAD:
+                raise NotImplementedError(f"SwinIR head width {d} > {HEAD_PAD}")
+            QW = heads * HEAD_PAD
+            r = t
+            for j in range(depth):
+                p = f"layers.{i}.residual_group.blocks.{j}."
+                shift = 0 if j % 2 == 0 else ws // 2
+                h = ln(r, p + "norm1.")
+                key = ("swin_qkv", p)
+                if key not in store.cache:
+                    wq, bq = pack_qkv(store._p(p + "attn.qkv.weight"), store._p(p + "attn.qkv.bias"), heads, CP)
+                    store.cache[key] = (wq.to(dt).contiguous(), bq.contiguous(),
+                                        expand_bias(store._p(p + "attn.relative_position_bias_table"), ws))
+                wq, bq, bias = store.cache[key]
+                qkv = em.gemm(h, wq, rows, 3 * QW, CP, bias=bq, name="swin.qkv")
+                em.free(h)
+                lab = None
+                if shift:
+                    if shift not in labels:
+                        labels[shift] = torch.from_numpy(region_labels(th, tw, ws, shift)).to(dev).contiguous()
+                    lab = labels[shift]
+                o = em.new(rows, CP)
+                self.prog.add(ops_mod.make_window_attn(dtype=dt, qkv=qkv, ld_qkv=qkv.stride(0), out=o, ld_out=CP, B=B, H=th, W=tw,
+                                                       heads=heads, head_dim=d, c_pad=CP, shift=shift, bias=bias, labels=lab,
+                                                       scale=d ** -0.5))
+                em.free(qkv)
+                wp, bp = linear(p + "attn.proj.", CP, CP)
+                x1 = em.gemm(o, wp, rows, CP, CP, bias=bp, residual=r, name="swin.proj")
+                em.free(o)
+                if r is not t:
+                    em.free(r)
+                h2 = ln(x1, p + "norm2.")
+                w1, b1 = linear(p + "mlp.fc1.", CP, HP)
+                g = em.gemm(h2, w1, rows, HP, CP, bias=b1, act=L.ACT_GELU, name="swin.fc1")
+                em.free(h2)
+                w2, b2 = linear(p + "mlp.fc2.", HP, CP)
+                r = em.gemm(g, w2, rows, CP, HP, bias=b2, residual=x1, name="swin.fc2")
+                em.free(g, x1)
+            t2 = conv3(Act(r, B, th, tw, CP), f"layers.{i}.conv.", CP, residual=t, name="swin.rstb_conv")
+            em.free(r)
+            if t is not f0.t:
+                em.free(t)
+            t = t2.t
+        tn = ln(t, "norm.")
+        f = conv3(Act(tn, B, th, tw, CP), "conv_after_body.", CP, residual=f0.t, name="swin.conv_after_body")
+        em.free(tn, t, f0)
+        # ---- reconstruction: conv + LeakyReLU(0.01), three (nearest x2 -> conv -> LeakyReLU(0.2)), conv_hr, conv_last (:776-787,878-886)
+        u = conv3(f, "conv_before_upsample.0.", 64, act=L.ACT_LRELU, slope=0.01, name="swin.conv_before_upsample")
+        em.free(f)
+        for name in ("conv_up1.", "conv_up2.", "conv_up3.")[: int(math.log2(sf))]:
+            u2 = conv3(u, name, 64, ups=True, act=L.ACT_LRELU, slope=0.2, name="swin.conv_up")
+            em.free(u)
+            u = u2
+        hr = conv3(u, "conv_hr.", 64, act=L.ACT_LRELU, slope=0.2, name="swin.conv_hr")
+        em.free(u)
+        # x / range + mean folded into the last convolution's epilogue: alpha = 1/range, bias' = bias/range + mean
+        last = conv3(hr, "conv_last.", 8, out_f32=True, alpha=1.0 / rng, extra_bias=mean, name="swin.conv_last")
+        em.free(hr)
+        em.to_nchw(last.t, B, 3, oh * ow, self.y)
+        self.graphed = False
+        if graph:
+            self.prog.run()                      # warm-up outside capture
+            torch.cuda.synchronize()
+            self.prog.capture()
+            self.graphed = True
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        self.x.copy_(x)
+        self.prog.run()
+        return self.y.clone()
+
+
+class SwinIR(ParamTree):
+    """reference model/swinir.py:624-905 (constructor keywords as in configs/det/demo.yaml:2-18)."""
+
+    def __init__(self, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6),
+                 window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.1, norm_layer=None, ape=False, patch_norm=True, use_checkpoint=False, sf=4, img_range=1.0,
+                 upsampler="", resi_connection="1conv", unshuffle=False, unshuffle_scale=None, hq_key="jpg", lq_key="hint",
+                 learning_rate=None, weight_decay=None):
+        cfg = dict(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, depths=list(depths),
+                   num_heads=list(num_heads), window_size=window_size, mlp_ratio=mlp_ratio, sf=sf, img_range=img_range,
+                   upsampler=upsampler, resi_connection=resi_connection, unshuffle=unshuffle, unshuffle_scale=unshuffle_scale,
+                   patch_norm=patch_norm)
+        unsupported = []
+        if upsampler != "nearest+conv":
+            unsupported.append(f"upsampler={upsampler!r}")
+        if resi_connection != "1conv":
+            unsupported.append(f"resi_connection={resi_connection!r}")
+        if not unshuffle or unshuffle_scale != sf:
+            unsupported.append("unshuffle=False or unshuffle_scale != sf")
+        if ape or not qkv_bias or qk_scale is not None or patch_size != 1 or in_chans != 3 or sf not in (2, 4, 8):
+            unsupported.append("ape / qkv_bias=False / qk_scale / patch_size != 1 / in_chans != 3 / sf not in {2,4,8}")
+        if unsupported:
+            raise NotImplementedError("edtr_amd SwinIR implements the shipped pre-restoration structure only "
+                                      "(configs/det/demo.yaml:2-18); got " + ", ".join(unsupported))
+        self.cfg = cfg
+        spec = swinir_state_spec(cfg)
+        super().__init__([(k, s) for k, s, kind in spec if kind == "param"], unet_like=False)
+        # the two buffers the reference registers (so strict loads of its checkpoints succeed); the device path derives the
+        # same information itself (relative_position_index / region_labels) and never reads them
+        ws, res = window_size, img_size // patch_size
+        for key, shape, kind in spec:
+            if kind == "param":
+                continue
+            node = self
+            parts = key.split(".")
+            for part in parts[:-1]:
+                node = node._modules[part]
+            val = (torch.from_numpy(relative_position_index(ws)) if kind == "index"
+                   else torch.from_numpy(shift_mask(res, res, ws, ws // 2)))
+            node.register_buffer(parts[-1], val)
+        self.upscale, self.upsampler, self.window_size = sf, upsampler, window_size
+        self.unshuffle, self.unshuffle_scale, self.img_range = unshuffle, unshuffle_scale, img_range
+        self.embed_dim, self.hq_key, self.lq_key = embed_dim, hq_key, lq_key
+        self.compute_dtype: Optional[torch.dtype] = None
+        self.use_graph = True
+        self._engines: Dict[Tuple[int, int, int], _SwinEngine] = {}
+        self._fingerprint = None
+
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.device.type != "cuda":
+            raise RuntimeError("SwinIR: the MI355X path runs only on a ROCm GPU; there is no CPU fallback")
+        if self.compute_dtype is None:
+            import os
+            self.compute_dtype = torch.float16 if os.environ.get("EDTR_AMD_DTYPE", "bf16") == "fp16" else torch.bfloat16
+        fp = (params_fingerprint(self), self.compute_dtype)
+        if fp != self._fingerprint:
+            self._engines.clear()
+            self._fingerprint = fp
+        B, _, H0, W0 = x.shape
+        ws = self.window_size
+        ph, pw = (-H0) % ws, (-W0) % ws
+        if ph or pw:                                   # check_image_size (model/swinir.py:834-839): image-space reflect pad
+            x = torch.nn.functional.pad(x, (0, pw, 0, ph), mode="reflect")
+        key = (B, x.shape[2], x.shape[3])
+        if key not in self._engines:
+            self._engines[key] = _SwinEngine(self, *key, graph=self.use_graph)
+        y = self._engines[key].run(x.float())
+        return y[:, :, : H0 * self.upscale, : W0 * self.upscale]

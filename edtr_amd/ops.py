@@ -61,7 +61,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                rowvec: Optional[torch.Tensor] = None, rowvec_ld: int = 0, rows_per_image: int = 0, act: int = 0,
                residual: Optional[torch.Tensor] = None, ldr: int = 0, out_f32: bool = False, n_valid: int = 0,
                tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None,
-               gn_partial: Optional[torch.Tensor] = None, name: str = "igemm") -> Rec:
+               gn_partial: Optional[torch.Tensor] = None, act_slope: float = 0.0, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -82,6 +82,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     if splitk > 1:
         p.workspace, p.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     p.gn_partial = ptr(gn_partial)
+    p.act_slope = act_slope
     flops = 2.0 * M * N * p.K * Z
     # algorithmic HBM bytes: every operand once (a conv reads its input image once, not once per tap)
     a_rows = (M // (p.OH * p.OW)) * p.IH * p.IW if spatial else M
@@ -131,6 +132,19 @@ def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_l
     return Rec(L.load().edtr_flash_attn64, (ct.byref(p),), (p, q, k, vt, out), name, flops)
 
 
+def make_window_attn(*, dtype, qkv, ld_qkv, out, ld_out, B, H, W, heads, head_dim, c_pad, shift, bias, labels, scale,
+                     name: str = "window_attn") -> Rec:
+    """SwinIR shifted-window attention (edtr_hip.h: edtr_window_attn): qkv [B*H*W, 3*heads*32] -> out [B*H*W, c_pad]."""
+    p = L.WindowAttnParams()
+    p.dtype, p.B, p.H, p.W, p.heads, p.head_dim, p.shift = dt_code(dtype), B, H, W, heads, head_dim, shift
+    p.qkv, p.ld_qkv, p.out, p.ld_out, p.c_pad = ptr(qkv), ld_qkv, ptr(out), ld_out, c_pad
+    p.bias, p.labels, p.scale = ptr(bias), ptr(labels), scale
+    tokens = B * H * W
+    flops = 4.0 * tokens * 64 * heads * head_dim
+    nbytes = 2.0 * tokens * (3 * heads * 32 + heads * head_dim)
+    return Rec(L.load().edtr_window_attn, (ct.byref(p),), (p, qkv, out, bias, labels), name, flops, nbytes)
+
+
 # --------------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------------
@@ -173,8 +187,9 @@ def gn_fusable(M: int, N: int, C1: int, hw: int, taps: int = 1, C2: int = 0, spl
     return dma_ok or big >= 200
 
 
-def make_layernorm(*, dtype, x, rows, C, ldx, gamma, beta, eps, y, ldy, name="layernorm") -> Rec:
-    args = (dt_code(dtype), ptr(x), rows, C, ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy)
+def make_layernorm(*, dtype, x, rows, C, ldx, gamma, beta, eps, y, ldy, c_valid: int = 0, name="layernorm") -> Rec:
+    """c_valid (0 = C): statistics over the first c_valid columns only; the remaining columns of y are written as zeros."""
+    args = (dt_code(dtype), ptr(x), rows, C, c_valid, ldx, ptr(gamma), ptr(beta), eps, ptr(y), ldy)
     return Rec(L.load().edtr_layernorm, args, (x, gamma, beta, y), name, 0.0, 4.0 * rows * C)
 
 
@@ -190,6 +205,12 @@ def make_nchw_to_nhwc(*, dtype, src, B, C, HW, dst, ld, coff=0, zero_pad_to=0, s
                       name="nchw_to_nhwc") -> Rec:
     args = (dt_code(dtype), ptr(src), B, C, HW, ptr(dst), ld, coff, zero_pad_to, scale, shift)
     return Rec(L.load().edtr_nchw_to_nhwc, args, (src, dst), name, 0.0, 6.0 * B * C * HW)
+
+
+def make_pixel_unshuffle(*, dtype, src, B, C, H, W, r, dst, ld, sub=None, scale=1.0, zero_pad_to=0,
+                         name="pixel_unshuffle") -> Rec:
+    args = (dt_code(dtype), ptr(src), B, C, H, W, r, ptr(sub), scale, ptr(dst), ld, zero_pad_to)
+    return Rec(L.load().edtr_pixel_unshuffle, args, (src, sub, dst), name, 0.0, 6.0 * B * C * H * W)
 
 
 def make_nhwc_to_nchw(*, dtype, src, src_f32, B, C, HW, ld, dst, scale=1.0, name="nhwc_to_nchw") -> Rec:

@@ -132,6 +132,20 @@ def tiny_config() -> dict:
     return cfg
 
 
+def swinir_config() -> dict:
+    """SwinIR pre-restoration network of reference configs/det/demo.yaml:2-18."""
+    return dict(img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8,
+                mlp_ratio=2, sf=8, img_range=1.0, upsampler="nearest+conv", resi_connection="1conv", unshuffle=True,
+                unshuffle_scale=8)
+
+
+def swinir_small_config() -> dict:
+    """Same structure, 2 groups of 2 layers, 2 heads of the SAME head width (30) as the shipped network."""
+    cfg = swinir_config()
+    cfg.update(embed_dim=60, depths=[2, 2], num_heads=[2, 2])
+    return cfg
+
+
 def clip_small_config() -> dict:
     """Reduced text tower for the CLIP goldens: head width 64 like ViT-H (2 heads x 64), 3 layers."""
     return dict(embed_dim=128, vision_cfg=dict(image_size=32, layers=1, width=64, head_width=32, patch_size=16),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 3
+#define EDTR_ABI_VERSION 4
 
 enum edtr_dtype { EDTR_BF16 = 0, EDTR_F16 = 1 };
 
@@ -44,7 +44,8 @@ enum edtr_error {
     EDTR_E_UNSUPPORTED = -5
 };
 
-enum edtr_act { EDTR_ACT_NONE = 0, EDTR_ACT_GEGLU = 1, EDTR_ACT_SILU = 2, EDTR_ACT_GELU = 3 /* exact erf GELU: the CLIP text MLP, model/open_clip/transformer.py:220-224 */ };
+enum edtr_act { EDTR_ACT_NONE = 0, EDTR_ACT_GEGLU = 1, EDTR_ACT_SILU = 2, EDTR_ACT_GELU = 3 /* exact erf GELU: the CLIP text MLP, model/open_clip/transformer.py:220-224; SwinIR Mlp, model/swinir.py:28-34 */,
+                EDTR_ACT_LRELU = 4 /* x > 0 ? x : act_slope * x — SwinIR reconstruction convs, model/swinir.py:776,787,878-886 */ };
 
 typedef void* edtr_stream_t; /* hipStream_t */
 
@@ -76,7 +77,7 @@ int edtr_device_info(int* compute_units, int64_t* hbm_bytes, char* arch_name, in
  * z (grid.z) offsets: operand_offset = (z / zdiv) * zs_outer + (z % zdiv) * zs_inner (elements).
  * Epilogue order: *alpha, +bias_n[n], +bias_m[m], GEGLU (value/gate column blocks of 32
  *   interleaved by the weight packer; output has N/2 columns), +rowvec[(m / rows_per_image)][n],
- *   SiLU, +residual[m][n], then store as 16-bit or fp32 at out[m*ldc + n].
+ *   SiLU / GELU / LeakyReLU, +residual[m][n], then store as 16-bit or fp32 at out[m*ldc + n].
  * ---------------------------------------------------------------------------------------- */
 typedef struct edtr_igemm_params {
     int32_t dtype;          /* edtr_dtype of a1/a2/w/residual and of a 16-bit output */
@@ -113,6 +114,7 @@ typedef struct edtr_igemm_params {
      * the fp64 sums edtr_gn_apply consumes, so the separate statistics pass over the tensor (edtr_gn_stats) disappears.
      * Needs M % 128 == 0, 16-bit output, no GEGLU / split-K / z-batching, tile 0/1/3. */
     float* gn_partial;
+    float act_slope;        /* negative-side slope of EDTR_ACT_LRELU (0 <= slope <= 1) */
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -170,10 +172,42 @@ int edtr_gn_finalize(const float* partial, int tiles_per_image, int B, int C, in
                      edtr_stream_t stream);
 int edtr_gn_apply(const edtr_gn_params* p, edtr_stream_t stream);
 
-/* LayerNorm over the last dimension, rows x C (C <= 2048), fp32 math, 16-bit in/out.
- * replaces: nn.LayerNorm, reference model/attention.py:222-224. */
-int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int ldx, const float* gamma,
+/* LayerNorm over the last dimension, rows x C (C <= 2048, multiple of 8), fp32 math, 16-bit in/out.
+ * c_valid (0 = C): only the first c_valid columns are real — the statistics run over them, and columns c_valid..C-1 of y are
+ * written as zeros (SwinIR keeps its 180 channels in rows of 192 so that every GEMM has K % 64 == 0; gamma / beta hold C entries).
+ * replaces: nn.LayerNorm, reference model/attention.py:222-224; model/swinir.py:208,215,753 (norm1 / norm2 / norm). */
+int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int c_valid, int ldx, const float* gamma,
                    const float* beta, float eps, void* y, int ldy, edtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Shifted-window multi-head attention of SwinIR, window 8 x 8 (64 tokens), head width <= 32, one launch per layer:
+ * cyclic shift, window partition, q k^T * scale + relative-position bias + region mask, softmax, P v, window merge and
+ * reverse shift.  One wavefront per (window, head); the 64 x 64 scores never leave registers.
+ * replaces: torch.roll + window_partition + WindowAttention.forward (up to, not including, `proj`) + window_reverse +
+ *           torch.roll, reference model/swinir.py:254-279 and :120-148.
+ *   qkv    : [B*H*W][ld_qkv] 16-bit, token (b, y, x) at row (b*H + y)*W + x of the UNSHIFTED image; columns
+ *            s*heads*32 + h*32 + e  (s = 0/1/2 for q/k/v, e < 32; e >= head_dim must be zero — the packed projection
+ *            has zero weight rows there)
+ *   out    : [B*H*W][ld_out] 16-bit; head h writes columns h*head_dim .. h*head_dim+head_dim-1, and columns
+ *            heads*head_dim .. c_pad-1 are written as zeros
+ *   bias   : fp32 [heads][64][64], bias[h][i][j] added to the score of query i and key j (the gathered
+ *            relative_position_bias_table)
+ *   labels : NULL when shift == 0; else uint8 [H][W], the image region of each pixel of the SHIFTED frame; a pair whose
+ *            labels differ gets -100 added (the reference's attn_mask values, model/swinir.py:241)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct edtr_window_attn_params {
+    int32_t dtype;
+    int32_t B, H, W;                /* token grid; H % 8 == 0, W % 8 == 0 */
+    int32_t heads, head_dim;        /* head_dim even, <= 32 */
+    int32_t shift;                  /* 0 <= shift < 8: window (wy, wx) token (ty, tx) is pixel ((8wy+ty+shift) % H, (8wx+tx+shift) % W) */
+    const void* qkv; int32_t ld_qkv;
+    void* out; int32_t ld_out; int32_t c_pad;
+    const float* bias;
+    const uint8_t* labels;
+    float scale;
+} edtr_window_attn_params;
+
+int edtr_window_attn(const edtr_window_attn_params* p, edtr_stream_t stream);
 
 /* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p); columns cols..cols_pad-1
  * of every output row are written as zeros (so the row can feed a GEMM whose K is padded to a multiple of 8).
@@ -194,6 +228,13 @@ int edtr_embed_tokens(int dtype, const int64_t* tokens, const float* table, cons
  * node inside a hipGraph).  replaces: the implicit zero-initialisation of the reduction buffers that torch's
  * native_group_norm allocates per call (reference model/util.py:146-163 via nn.GroupNorm). */
 int edtr_zero_bytes(void* ptr, int64_t bytes, edtr_stream_t stream);
+/* Pixel-unshuffle front end of SwinIR: NCHW fp32 image [B][C][H][W] -> NHWC 16-bit tokens [B*(H/r)*(W/r)][ld] with
+ * dst[row(b, y, x)][c*r*r + dy*r + dx] = (src[b][c][y*r+dy][x*r+dx] - sub[c]) * scale   (sub == NULL: 0);
+ * columns C*r*r .. zero_pad_to-1 are written as zeros.  r in 1..8, H % r == 0, W % r == 0.
+ * replaces: `(x - self.mean) * self.img_range` and nn.PixelUnshuffle (channel order c*r*r + dy*r + dx), reference
+ * model/swinir.py:861 and :700-704. */
+int edtr_pixel_unshuffle(int dtype, const float* src, int B, int C, int H, int W, int r, const float* sub, float scale,
+                         void* dst, int ld, int zero_pad_to, edtr_stream_t stream);
 /* NCHW fp32 [B][C][HW] -> NHWC 16-bit: dst[(b*HW+p)*ld + coff + c] = scale*src + shift; when
  * zero_pad_to > C the channels C..zero_pad_to-1 (relative to coff) are written as 0.
  * replaces: `.type(self.dtype)` + rearranges (model/controlnet.py:266-269; model/attention.py:292)

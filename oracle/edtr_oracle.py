@@ -668,3 +668,100 @@ def clip_text_forward(sd: SD, text_cfg: dict, tokens: torch.Tensor, layer_idx: i
         h = F.gelu(F.linear(h, sd[q + "mlp.c_fc.weight"], sd[q + "mlp.c_fc.bias"]))
         x = x + F.linear(h, sd[q + "mlp.c_proj.weight"], sd[q + "mlp.c_proj.bias"])
     return F.layer_norm(x, (W,), sd[p + "model.ln_final.weight"], sd[p + "model.ln_final.bias"], 1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# SwinIR pre-restoration (SURVEY.md §8f rank 3): the network that produces `pre_res`, the input of the path
+# ------------------------------------------------------------------------------------------
+
+def swin_relative_index(ws: int) -> np.ndarray:
+    """[ws*ws, ws*ws] row of the (2ws-1)^2 bias table used for the pair (query i, key j): (dy+ws-1)*(2ws-1) + dx+ws-1
+    with (dy, dx) = position(i) - position(j).  model/swinir.py:96-108."""
+    ys, xs = np.divmod(np.arange(ws * ws), ws)
+    return (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1)
+
+
+def swin_shift_mask(H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    """[nW, ws*ws, ws*ws] additive mask of the shifted-window attention: after the cyclic shift a window may hold pixels
+    of up to 3 x 3 disjoint image regions (bands [0, n-ws), [n-ws, n-shift), [n-shift, n) per axis); pairs from different
+    regions get -100.  model/swinir.py:222-243."""
+    def band(n):
+        i = np.arange(n)
+        return np.where(i < n - ws, 0, np.where(i < n - shift, 1, 2))
+    label = band(H)[:, None] * 3 + band(W)[None, :]
+    win = label.reshape(H // ws, ws, W // ws, ws).transpose(0, 2, 1, 3).reshape(-1, ws * ws)
+    return np.where(win[:, None, :] != win[:, :, None], -100.0, 0.0).astype(np.float32)
+
+
+def _windows(x: torch.Tensor, ws: int) -> torch.Tensor:
+    """[B, H, W, C] -> [B * nW, ws*ws, C], windows in row-major order.  model/swinir.py:37-49."""
+    B, H, W, C = x.shape
+    return x.reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+
+
+def _unwindows(w: torch.Tensor, ws: int, B: int, H: int, W: int) -> torch.Tensor:
+    """inverse of _windows.  model/swinir.py:52-66."""
+    return w.reshape(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+def swin_block(sd: SD, p: str, x: torch.Tensor, H: int, W: int, heads: int, ws: int, shift: int) -> torch.Tensor:
+    """One Swin transformer layer on tokens [B, H*W, C]: x += proj(window-attention(LN(x))) ; x += MLP(LN(x)).
+    model/swinir.py:245-285 (block), :120-151 (attention), :28-34 (MLP)."""
+    B, _, C = x.shape
+    d = C // heads
+    h = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5).reshape(B, H, W, C)
+    if shift:
+        h = torch.roll(h, (-shift, -shift), (1, 2))
+    win = _windows(h, ws)                                                    # [B*nW, N, C]
+    qkv = F.linear(win, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+    q, k, v = qkv.reshape(-1, ws * ws, 3, heads, d).permute(2, 0, 3, 1, 4)    # each [B*nW, heads, N, d]
+    att = (q * d ** -0.5) @ k.transpose(-1, -2)
+    table = sd[p + "attn.relative_position_bias_table"]                     # [(2ws-1)^2, heads]
+    att = att + table[torch.from_numpy(swin_relative_index(ws))].permute(2, 0, 1)
+    if shift:
+        m = torch.from_numpy(swin_shift_mask(H, W, ws, shift))               # [nW, N, N]
+        att = (att.reshape(B, -1, heads, ws * ws, ws * ws) + m[None, :, None]).reshape(-1, heads, ws * ws, ws * ws)
+    o = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(-1, ws * ws, C)
+    o = _unwindows(F.linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]), ws, B, H, W)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    x = x + o.reshape(B, H * W, C)
+    h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+SWINIR_RGB_MEAN = (0.4488, 0.4371, 0.4040)
+
+
+def swinir_forward(sd: SD, cfg: dict, x: torch.Tensor, p: str = "swinir.") -> torch.Tensor:
+    """image [B, 3, H, W] in [0, 1] -> pre-restored image, same size: the configuration of configs/det/demo.yaml:2-18
+    (pixel-unshuffle by `sf` in front, 1conv residual connection, "nearest+conv" upsampler back to full size).
+    model/swinir.py:856-894 (forward), :841-854 (features), :487-488 (RSTB)."""
+    if cfg.get("upsampler") != "nearest+conv" or not cfg.get("unshuffle") or cfg.get("resi_connection", "1conv") != "1conv":
+        raise NotImplementedError("oracle covers the shipped SwinIR configuration only")
+    ws, sf, C = cfg["window_size"], cfg["sf"], cfg["embed_dim"]
+    rng = float(cfg.get("img_range", 1.0))
+    H0, W0 = x.shape[2:]
+    x = F.pad(x, (0, (-W0) % ws, 0, (-H0) % ws), mode="reflect")            # check_image_size (:834-839), image space
+    mean = torch.tensor(SWINIR_RGB_MEAN if cfg.get("in_chans", 3) == 3 else (0.0,)).view(1, -1, 1, 1)
+    x = (x - mean) * rng
+    f0 = conv(sd, p + "conv_first.1.", F.pixel_unshuffle(x, cfg["unshuffle_scale"]))
+    B, _, H, W = f0.shape
+    t = f0.flatten(2).transpose(1, 2)                                           # tokens [B, H*W, C]
+    if cfg.get("patch_norm", True):
+        t = F.layer_norm(t, (C,), sd[p + "patch_embed.norm.weight"], sd[p + "patch_embed.norm.bias"], 1e-5)
+    for i, (depth, heads) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+        r = t
+        for j in range(depth):
+            r = swin_block(sd, f"{p}layers.{i}.residual_group.blocks.{j}.", r, H, W, heads, ws, 0 if j % 2 == 0 else ws // 2)
+        r = conv(sd, f"{p}layers.{i}.conv.", r.transpose(1, 2).reshape(B, C, H, W))
+        t = t + r.flatten(2).transpose(1, 2)
+    t = F.layer_norm(t, (C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+    f = conv(sd, p + "conv_after_body.", t.transpose(1, 2).reshape(B, C, H, W)) + f0
+    f = F.leaky_relu(conv(sd, p + "conv_before_upsample.0.", f), 0.01)       # nn.LeakyReLU() default slope (:776)
+    ups = {2: ["conv_up1."], 4: ["conv_up1.", "conv_up2."], 8: ["conv_up1.", "conv_up2.", "conv_up3."]}[sf]
+    for name in ups:
+        f = F.leaky_relu(conv(sd, p + name, F.interpolate(f, scale_factor=2, mode="nearest")), 0.2)
+    f = conv(sd, p + "conv_last.", F.leaky_relu(conv(sd, p + "conv_hr.", f), 0.2))
+    return (f / rng + mean)[:, :, :H0 * sf, :W0 * sf]

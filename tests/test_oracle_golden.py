@@ -218,3 +218,39 @@ def test_clip_text_vith(golden_dir):
         z = O.clip_text_forward(_clip_sd("vith", cfg), cfg["text_cfg"], tokens[:2], layer_idx=1)
     assert rel_err(z, g["z_vith"].astype(np.float32)) < 1e-3          # golden stored as fp16
     np.testing.assert_allclose([float(z.abs().mean())], [g["stats_vith"][1]], rtol=2e-2)
+
+
+def _swinir_sd(tag, cfg):
+    from edtr_amd.model.swinir import swinir_state_spec
+    return {"swinir." + k: synth.synth_param(f"swinir{tag}." + k, shp) for k, shp, kind in swinir_state_spec(cfg) if kind == "param"}
+
+
+def test_swinir_small(golden_dir):
+    """SwinIR restatement vs the reference class on a 2x2-layer network, non-square input (2 x 3 windows: every shifted-window
+    mask case), plus the relative-position index and shift masks against the reference's own buffers."""
+    g = np.load(os.path.join(golden_dir, "swinir.npz"))
+    cfg = synth.swinir_small_config()
+    np.testing.assert_array_equal(O.swin_relative_index(8), g["rel_index"].astype(np.int64))
+    for name, (h, w) in (("mask_64x64", (64, 64)), ("mask_16x24", (16, 24))):
+        m = O.swin_shift_mask(h, w, 8, 4)
+        np.testing.assert_array_equal(np.packbits(m != 0), g[name])
+        assert set(np.unique(m)) == {0.0, float(g["mask_value"][0])}
+    x = synth.synth_input("swinir:small", (2, 3, 128, 192), 0.0, 1.0)
+    with torch.no_grad():
+        y = O.swinir_forward(_swinir_sd("small", cfg), cfg, x)
+    assert y.shape == (2, 3, 128, 192)
+    assert rel_err(y, g["y_small"]) < 2e-5
+
+
+def test_swinir_full(golden_dir):
+    """The shipped 8 x 6-layer, 180-channel network of configs/det/demo.yaml at 256^2 (full output) and 512^2 (samples)."""
+    g = np.load(os.path.join(golden_dir, "swinir.npz"))
+    cfg = synth.swinir_config()
+    sd = _swinir_sd("full", cfg)
+    with torch.no_grad():
+        y256 = O.swinir_forward(sd, cfg, synth.synth_input("swinir:256", (1, 3, 256, 256), 0.0, 1.0))
+        y512 = O.swinir_forward(sd, cfg, synth.synth_input("swinir:512", (1, 3, 512, 512), 0.0, 1.0))
+    assert rel_err(y256, g["y_256"].astype(np.float32)) < 1e-3            # golden stored as fp16
+    assert rel_err(y512[:, :, 3::8, 5::8], g["y_512_stride8"]) < 5e-5
+    np.testing.assert_allclose([float(y512.mean()), float(y512.abs().mean()), float(y512.abs().max()), float(y512.std())],
+                               g["y_512_stats"], rtol=1e-4)

@@ -4,7 +4,7 @@
 
 Run in the build container only (the reference does not exist on the GPU box):
 
-    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,wavelet]
+    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,wavelet,clip,psnr,swinir]
 
 Fixtures are data (inputs are regenerated from edtr_amd.synth formulas, expected outputs
 are stored); nothing from the reference's source travels.
@@ -315,16 +315,62 @@ def gen_psnr():
     print("psnr.npz written")
 
 
+def build_reference_swinir(tag: str, cfg: dict):
+    ref_import.install_stubs()
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    from model.swinir import SwinIR
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = SwinIR(**cfg).eval()
+    with torch.no_grad():
+        for key, val in m.state_dict().items():
+            if val.dtype.is_floating_point and not key.endswith("attn_mask"):     # buffers keep the reference's own values
+                val.copy_(synth.synth_param(f"swinir{tag}." + key, tuple(val.shape)))
+    return m
+
+
+def gen_swinir():
+    """The reference SwinIR (model/swinir.py) on synthetic weights: a 2x2-layer network on a non-square input (every
+    window / shift-mask case), the shipped 8x6-layer network at 256^2 (full output) and 512^2 (statistics + samples),
+    its relative-position index and shift masks, and the state-dict key manifest."""
+    out, man = {}, {}
+    small = build_reference_swinir("small", synth.swinir_small_config())
+    man["small"] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in small.state_dict().items()]
+    x = synth.synth_input("swinir:small", (2, 3, 128, 192), 0.0, 1.0)
+    with torch.no_grad():
+        out["y_small"] = small(x).numpy()
+    blk = small.layers[0].residual_group.blocks[1]
+    out["rel_index"] = blk.attn.relative_position_index.numpy().astype(np.int16)
+    out["mask_64x64"] = np.packbits(blk.attn_mask.numpy() != 0)
+    out["mask_16x24"] = np.packbits(blk.calculate_mask((16, 24)).numpy() != 0)
+    out["mask_value"] = np.array([float(blk.attn_mask.min())])
+    full = build_reference_swinir("full", synth.swinir_config())
+    man["full"] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in full.state_dict().items()]
+    with torch.no_grad():
+        t0 = time.time()
+        y256 = full(synth.synth_input("swinir:256", (1, 3, 256, 256), 0.0, 1.0))
+        y512 = full(synth.synth_input("swinir:512", (1, 3, 512, 512), 0.0, 1.0))
+        print(f"full SwinIR 256^2 + 512^2 on CPU: {time.time() - t0:.1f} s")
+    out["y_256"] = y256.numpy().astype(np.float16)
+    out["y_512_stride8"] = y512[:, :, 3::8, 5::8].numpy()
+    out["y_512_stats"] = np.array([float(y512.mean()), float(y512.abs().mean()), float(y512.abs().max()), float(y512.std())])
+    print("small", float(out["y_small"].mean()), float(np.abs(out["y_small"]).max()), "full stats", out["y_512_stats"])
+    np.savez_compressed(os.path.join(GOLD, "swinir.npz"), **out)
+    with open(os.path.join(GOLD, "manifest_swinir.json"), "w") as f:
+        json.dump(man, f)
+    print("swinir.npz written")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr,swinir")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr}[name]()
+         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir}[name]()
 
 
 if __name__ == "__main__":
