@@ -53,11 +53,13 @@ def calculate_psnr_pt(img: torch.Tensor, img2: torch.Tensor, crop_border: int, t
 @torch.no_grad()
 def restore_dataset(cldm, diffusion, sampler, pre_restored: Sequence[torch.Tensor], gts: Optional[Sequence[torch.Tensor]] = None,
                     img_size: int = 512, batch_size: int = 8, used_timesteps=(50, 100, 150, 200), start_timestep: int = 200,
-                    colour_fix: bool = True) -> Tuple[List[torch.Tensor], Optional[torch.Tensor]]:
+                    colour_fix: bool = True, swinir=None) -> Tuple[List[torch.Tensor], Optional[torch.Tensor]]:
     """The restoration loop of main/det/test_edtr.py:121-135 without accelerate: this rank's shard of the
     (C, h, w <= img_size) pre-restored images is padded, pushed through vae_encode -> q_sample(t) -> spaced sampler ->
     vae_decode (-> wavelet colour fix), cropped back, and — when ground truth is given — scored with PSNR; the scalar
-    PSNR sums are all-reduced, nothing else crosses ranks.  Returns (restored images of this shard, mean PSNR or None)."""
+    PSNR sums are all-reduced, nothing else crosses ranks.  With ``swinir`` (an edtr_amd.model.SwinIR) the inputs are the
+    low-quality images themselves and the pre-restoration runs on the padded batch first (`cfg.model.pre_restoration`,
+    main/det/test_edtr.py:118).  Returns (restored images of this shard, mean PSNR or None)."""
     import torch.distributed as dist
     from .wavelet import wavelet_reconstruction
     dev = next(cldm.unet.parameters()).device
@@ -69,6 +71,8 @@ def restore_dataset(cldm, diffusion, sampler, pre_restored: Sequence[torch.Tenso
     for i in range(0, len(mine), batch_size):
         chunk = mine[i:i + batch_size]
         pre = list_to_batch(chunk, img_size, dev).float()
+        if swinir is not None:
+            pre = swinir(pre)
         cond = cldm.prepare_condition(pre, [""] * pre.size(0))
         t = torch.full((pre.size(0),), start_timestep, dtype=torch.int64)
         x_T = diffusion.q_sample(cond["c_img"], t, torch.randn_like(cond["c_img"]))

@@ -325,3 +325,83 @@ def test_full_size_batch_invariance_and_determinism():
     print(f"\n[full size] batch-3 vs batch-1: latent {ez:.2e}, image {ei:.2e}")
     assert ez < 2e-2 and ei < 3e-2
     assert torch.isfinite(img3).all() and float(img3.abs().max()) < 50.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_swinir_vs_reference_golden(golden_dir, tag, dtype):
+    """SwinIR pre-restoration (edtr_pixel_unshuffle, padded edtr_layernorm, edtr_igemm incl. the LeakyReLU epilogue and the
+    fused nearest-x2 convs, edtr_window_attn) against the reference class's output on the same synthetic weights: a 2 x 2-layer
+    network on a non-square batch (eager launch list AND hipGraph replay), and the shipped 8 x 6-layer network at 256^2 / 512^2.
+    Stated tolerance (relative L2 of the output image): fp16 3e-3, bf16 2e-2 — measured 7e-4 / 5e-3."""
+    from edtr_amd import synth
+    from edtr_amd.model.swinir import SwinIR
+    from edtr_amd.testing import rel_err
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "swinir.npz"))
+    cfg = synth.swinir_small_config() if tag == "small" else synth.swinir_config()
+    m = SwinIR(**cfg)
+    sd = m.state_dict()
+    m.load_state_dict({k: (synth.synth_param(f"swinir{tag}." + k, tuple(v.shape)) if v.dtype.is_floating_point and not k.endswith("attn_mask") else v)
+                       for k, v in sd.items()}, strict=True)
+    m = m.eval().to(dev)
+    m.compute_dtype = dtype
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    if tag == "small":
+        x = synth.synth_input("swinir:small", (2, 3, 128, 192), 0.0, 1.0).to(dev)
+        outs = []
+        for graph in (False, True):
+            m.use_graph = graph
+            m._engines.clear()
+            y = m(x)
+            torch.cuda.synchronize()
+            outs.append(y)
+            err = rel_err(y, g["y_small"])
+            print(f"\n[swinir small {dtype} graph={graph}] rel err {err:.2e}")
+            assert y.shape == (2, 3, 128, 192) and err < tol
+        assert torch.equal(outs[0], outs[1])                       # graph replay == eager launch list, bit for bit
+        # an image of a batch does not depend on its batch mates
+        y1 = m(x[1:])
+        assert rel_err(y1, outs[1][1:]) < 1e-6
+    else:
+        y = m(synth.synth_input("swinir:256", (1, 3, 256, 256), 0.0, 1.0).to(dev))
+        err = rel_err(y, g["y_256"].astype(np.float32))
+        y5 = m(synth.synth_input("swinir:512", (1, 3, 512, 512), 0.0, 1.0).to(dev))
+        err5 = rel_err(y5[:, :, 3::8, 5::8], g["y_512_stride8"])
+        print(f"\n[swinir full {dtype}] rel err 256^2 {err:.2e}, 512^2 (stride-8 samples) {err5:.2e}")
+        assert err < tol and err5 < tol
+        np.testing.assert_allclose(float(y5.mean()), g["y_512_stats"][0], rtol=5e-3)
+
+
+def test_restore_dataset_with_pre_restoration():
+    """The whole demo.py:89-124 chain on the device: low-quality images -> SwinIR -> vae_encode -> q_sample -> 4 steps ->
+    vae_decode -> colour fix, through evalutil.restore_dataset(swinir=...).  The pre-restoration stage must be what the
+    driver feeds the path: the result equals running SwinIR by hand and passing its output as `pre_restored`."""
+    from edtr_amd import evalutil, synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.model.swinir import SwinIR
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, rel_err
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    cldm = build_synthetic_cldm(synth.tiny_config(), dev, torch.float16)
+    cldm.clip.set_embedding(synth.synth_input("drv:c_txt", (1, 77, 64), -1.0, 1.0).to(dev))
+    swinir = SwinIR(**synth.swinir_small_config())
+    sd = swinir.state_dict()
+    swinir.load_state_dict({k: (synth.synth_param("swinirsmall." + k, tuple(v.shape)) if v.dtype.is_floating_point and not k.endswith("attn_mask") else v)
+                            for k, v in sd.items()}, strict=True)
+    swinir = swinir.eval().to(dev)
+    swinir.compute_dtype = torch.float16
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
+    sampler = SpacedSampler(diffusion.betas)
+    imgs = [synth.synth_input(f"drv2:img{i}", (3, 128, 128), 0.0, 1.0) for i in range(3)]
+    torch.manual_seed(0)
+    outs, _ = evalutil.restore_dataset(cldm, diffusion, sampler, imgs, img_size=128, batch_size=2, swinir=swinir)
+    by_hand = [swinir(i[None].to(dev))[0] for i in imgs]
+    torch.manual_seed(0)
+    outs2, _ = evalutil.restore_dataset(cldm, diffusion, sampler, by_hand, img_size=128, batch_size=2)
+    assert all(tuple(o.shape) == (3, 128, 128) and torch.isfinite(o).all() for o in outs)
+    assert all(rel_err(a, b) < 2e-3 for a, b in zip(outs, outs2))

@@ -594,3 +594,116 @@ def test_embed_tokens_and_zero_bytes(dtype):
     ops.launch(ops.make_zero(buf[2:2 + 4096]))
     torch.cuda.synchronize()
     assert float(buf[2:2 + 4096].abs().max()) == 0.0 and float(buf[:2].min()) == 3.0 and float(buf[2 + 4096:].min()) == 3.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SwinIR kernels
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("r,H,W,ld", [(8, 64, 96, 200), (4, 32, 40, 56), (2, 6, 8, 16)])
+def test_pixel_unshuffle(dtype, r, H, W, ld):
+    """(x - mean) * range + nn.PixelUnshuffle(r) into NHWC 16-bit rows with zeroed pad columns (model/swinir.py:861,700-704)."""
+    ops = _ops()
+    d = dev()
+    B, C = 2, 3
+    x = torch.rand((B, C, H, W), generator=torch.Generator().manual_seed(160))
+    sub = torch.tensor([0.4488, 0.4371, 0.4040])
+    out = torch.full((B * (H // r) * (W // r), ld), float("nan"), dtype=dtype, device=d)
+    ops.launch(ops.make_pixel_unshuffle(dtype=dtype, src=x.to(d), B=B, C=C, H=H, W=W, r=r, dst=out, ld=ld, sub=sub.to(d), scale=2.0,
+                                        zero_pad_to=ld))
+    torch.cuda.synchronize()
+    ref = F.pixel_unshuffle((x - sub.view(1, 3, 1, 1)) * 2.0, r).permute(0, 2, 3, 1).reshape(-1, C * r * r)
+    got = out.float().cpu()
+    assert torch.equal(got[:, :C * r * r], ref.to(dtype).float()) and float(got[:, C * r * r:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C,cv", [(1000, 192, 180), (37, 64, 60), (5, 256, 255)])
+def test_layernorm_padded_columns(dtype, rows, C, cv):
+    """c_valid < C: statistics over the real columns only (garbage in the pad columns is ignored), pad columns of y zeroed."""
+    ops = _ops()
+    d = dev()
+    x = (rnd((rows, C), 161) * 2 + 0.5).to(dtype)
+    x[:, cv:] = 7.0
+    gamma, beta = torch.zeros(C), torch.zeros(C)
+    gamma[:cv], beta[:cv] = 1 + 0.1 * rnd((cv,), 162), 0.1 * rnd((cv,), 163)
+    y = torch.full((rows, C), float("nan"), dtype=dtype, device=d)
+    ops.launch(ops.make_layernorm(dtype=dtype, x=x.to(d), rows=rows, C=C, ldx=C, gamma=gamma.to(d), beta=beta.to(d), eps=1e-5,
+                                  y=y, ldy=C, c_valid=cv))
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert rel(got[:, :cv], F.layer_norm(x.float()[:, :cv], (cv,), gamma[:cv], beta[:cv], 1e-5)) < TOL[dtype]
+    assert float(got[:, cv:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 6, 8])
+def test_gemm_leaky_relu_epilogue(dtype, tile):
+    """LeakyReLU epilogue (act = 4, SwinIR reconstruction convs) on every main-loop family and through the split-K reducer."""
+    ops = _ops()
+    d = dev()
+    M, N, K = 308, 320, 256
+    a = rnd((M, K), 164).to(dtype)
+    w = rnd((N, K), 165, 1 / math.sqrt(K)).to(dtype)
+    b = rnd((N,), 166)
+    for slope in (0.2, 0.01):
+        ref = F.leaky_relu(a.float() @ w.float().t() + b, slope)
+        out = torch.empty((M, N), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=a.to(d), w=w.to(d), out=out, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N,
+                                  bias_n=b.to(d), act=4, act_slope=slope, tile=tile))
+        torch.cuda.synchronize()
+        assert rel(out.float().cpu(), ref) < TOL[dtype]
+    if tile in (0, 3):
+        ws = torch.empty(2 * M * N, dtype=torch.float32, device=d)
+        out2 = torch.empty((M, N), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=a.to(d), w=w.to(d), out=out2, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N,
+                                  bias_n=b.to(d), act=4, act_slope=0.01, tile=tile, splitk=2, workspace=ws))
+        torch.cuda.synchronize()
+        assert rel(out2.float().cpu(), ref) < TOL[dtype]
+    p_bad = ops.make_igemm(dtype=dtype, a1=a.to(d), w=w.to(d), out=out, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N, act=4, act_slope=1.5)
+    with pytest.raises(RuntimeError):
+        ops.launch(p_bad)
+
+
+def _window_attn_reference(qkv, table_bias, H, W, heads, d, shift):
+    """plain torch fp32 restatement of model/swinir.py:254-279 + :120-148 without the two linears: qkv [B, H, W, 3, heads, d]."""
+    from edtr_amd.model import swinir as S
+    B = qkv.shape[0]
+    C = heads * d
+    h = qkv.reshape(B, H, W, 3 * C)
+    if shift:
+        h = torch.roll(h, (-shift, -shift), (1, 2))
+    win = h.reshape(B, H // 8, 8, W // 8, 8, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64, 3, heads, d)
+    q, k, v = win.permute(2, 0, 3, 1, 4)
+    att = (q * d ** -0.5) @ k.transpose(-1, -2) + table_bias
+    if shift:
+        m = torch.from_numpy(S.shift_mask(H, W, 8, shift))
+        att = (att.reshape(B, -1, heads, 64, 64) + m[None, :, None]).reshape(-1, heads, 64, 64)
+    o = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B, H // 8, W // 8, 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    return torch.roll(o, (shift, shift), (1, 2)) if shift else o
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,heads,d,cp,shift", [(2, 16, 24, 6, 30, 192, 0), (2, 16, 24, 6, 30, 192, 4), (1, 8, 8, 2, 30, 64, 4),
+                                                    (3, 24, 8, 4, 32, 128, 3), (1, 64, 64, 6, 30, 192, 4), (1, 16, 16, 3, 8, 64, 0)])
+def test_window_attention(dtype, B, H, W, heads, d, cp, shift):
+    """edtr_window_attn vs the windowed / shifted / masked / biased softmax attention written out in torch fp32: non-square
+    token grids, one-window images (every region label inside one window), head widths 8 / 30 / 32, odd shift."""
+    from edtr_amd.model import swinir as S
+    ops = _ops()
+    dv = dev()
+    qkv = (rnd((B, H, W, 3, heads, d), 170) * 1.5).to(dtype)
+    table = rnd((225, heads), 171, 0.7)
+    bias = S.expand_bias(table, 8)
+    packed = torch.zeros((B * H * W, 3, heads, 32), dtype=dtype)
+    packed[..., :d] = qkv.reshape(B * H * W, 3, heads, d)
+    out = torch.full((B * H * W, cp), float("nan"), dtype=dtype, device=dv)
+    lab = torch.from_numpy(S.region_labels(H, W, 8, shift)).to(dv) if shift else None
+    ops.launch(ops.make_window_attn(dtype=dtype, qkv=packed.reshape(B * H * W, -1).to(dv), ld_qkv=3 * heads * 32, out=out, ld_out=cp,
+                                    B=B, H=H, W=W, heads=heads, head_dim=d, c_pad=cp, shift=shift, bias=bias.to(dv), labels=lab,
+                                    scale=d ** -0.5))
+    torch.cuda.synchronize()
+    ref = _window_attn_reference(qkv.float(), bias, H, W, heads, d, shift).reshape(B * H * W, heads * d)
+    got = out.float().cpu()
+    assert rel(got[:, :heads * d], ref) < TOL[dtype]
+    assert float(got[:, heads * d:].abs().max()) == 0.0 if cp > heads * d else True

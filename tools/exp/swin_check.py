@@ -66,6 +66,22 @@ for what in todo:
             ms = (time.time() - t1) * 100
             print(f"full B=8 512^2 bf16: {ms:.2f} ms per batch ({8000 / ms:.1f} images/s), {eng.prog.total_flops() / 1e12:.3f} TFLOP per batch, "
                   f"{eng.prog.total_flops() / ms / 1e9:.1f} TFLOP/s, {len(eng.prog.recs)} launches", flush=True)
+        elif what == "breakdown":
+            m = build("full", synth.swinir_config(), torch.bfloat16)
+            m.use_graph = False
+            m(torch.rand(8, 3, 512, 512, device="cuda"))
+            eng = next(iter(m._engines.values()))
+            eng.prog.run_timed()
+            rows = {}
+            for _ in range(3):
+                for name, ms, fl, nb, tag in eng.prog.run_timed():
+                    r = rows.setdefault((name, tag), [0, 0.0, 0.0, 0.0])
+                    r[0] += 1; r[1] += ms; r[2] += fl; r[3] += nb
+            tot = sum(r[1] for r in rows.values()) / 3
+            print(f"eager per-launch timing, B=8 512^2 bf16: {tot:.2f} ms per batch (event-bracketed launches, no graph)")
+            for (name, tag), r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+                ms = r[1] / 3
+                print(f"  {name:28s} {tag:44s} n={r[0] // 3:3d}  {ms:7.3f} ms  {r[2] / 3 / ms / 1e9 if ms else 0:7.1f} TFLOP/s  {r[3] / 3 / ms / 1e6 if ms else 0:7.1f} GB/s")
         print(f"{what}: {time.time() - t0:.1f} s", flush=True)
     except Exception as e:
         import traceback
