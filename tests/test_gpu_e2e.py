@@ -405,3 +405,32 @@ def test_restore_dataset_with_pre_restoration():
     outs2, _ = evalutil.restore_dataset(cldm, diffusion, sampler, by_hand, img_size=128, batch_size=2)
     assert all(tuple(o.shape) == (3, 128, 128) and torch.isfinite(o).all() for o in outs)
     assert all(rel_err(a, b) < 2e-3 for a, b in zip(outs, outs2))
+
+
+def test_tiled_pre_restoration():
+    """demo.py:96-98 (`--pre-res-tiled`): make_tiled_fn(swinir, size, stride) = SwinIR per sliding window + Gaussian-weighted
+    overlap-add, against the same overlap-add done by hand in torch from the per-window outputs."""
+    from edtr_amd import synth
+    from edtr_amd.model.swinir import SwinIR
+    from edtr_amd.testing import rel_err
+    from edtr_amd.tiling import gaussian_weights, make_tiled_fn, sliding_windows
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    swinir = SwinIR(**synth.swinir_small_config())
+    sd = swinir.state_dict()
+    swinir.load_state_dict({k: (synth.synth_param("swinirsmall." + k, tuple(v.shape)) if v.dtype.is_floating_point and not k.endswith("attn_mask") else v)
+                            for k, v in sd.items()}, strict=True)
+    swinir = swinir.eval().to(dev)
+    swinir.compute_dtype = torch.float16
+    x = synth.synth_input("swinir:tiled", (1, 3, 128, 192), 0.0, 1.0).to(dev)
+    y = make_tiled_fn(swinir, size=64, stride=32)(x)
+    torch.cuda.synchronize()
+    w = torch.tensor(gaussian_weights(64, 64), dtype=torch.float32)
+    num, den = torch.zeros(1, 3, 128, 192), torch.zeros(1, 3, 128, 192)
+    wins = sliding_windows(128, 192, 64, 32)
+    assert len(wins) == 15
+    for hi, he, wi, we in wins:
+        num[..., hi:he, wi:we] += swinir(x[..., hi:he, wi:we].contiguous()).cpu() * w
+        den[..., hi:he, wi:we] += w
+    assert y.shape == x.shape and rel_err(y, num / den) < 1e-5
