@@ -9,8 +9,10 @@ PyTorch operator on the data path.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as ct
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -86,6 +88,37 @@ class Arena:
 
     def total_bytes(self) -> int:
         return sum(c.numel() for c in self.chunks)
+
+
+class EngineCache(collections.OrderedDict):
+    """Shape-keyed engines (static buffers + launch programs + hipGraphs) with least-recently-used eviction: a dataset of
+    many distinct image sizes must not pin one arena per size for ever.  ``EDTR_ENGINE_CACHE`` overrides the capacity."""
+
+    def __init__(self, release=None, capacity: Optional[int] = None):
+        super().__init__()
+        self.capacity = max(1, capacity if capacity is not None else int(os.environ.get("EDTR_ENGINE_CACHE", "16")))
+        self.release = release
+
+    def fetch(self, key, build):
+        if key in self:
+            self.move_to_end(key)
+            return self[key]
+        eng = build()
+        self[key] = eng
+        while len(self) > self.capacity:
+            old_key = next(iter(self))
+            old = self.pop(old_key)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()          # nothing may still be replaying the evicted engine's graph
+            if self.release is not None:
+                self.release(old)
+        return eng
+
+    def drop_all(self) -> None:
+        for eng in list(self.values()):
+            if self.release is not None:
+                self.release(eng)
+        self.clear()
 
 
 # ----------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import arch, nets
 from .. import ops as ops_mod
-from ..engine import Act, Arena, Emitter, Program, WeightStore
+from ..engine import Act, Arena, Emitter, EngineCache, Program, WeightStore
 from .clip import FrozenOpenCLIPEmbedder
 from .params import ParamTree, params_fingerprint
 
@@ -268,8 +268,8 @@ class ControlLDM(nn.Module):
         self.engine_slot = 0
         self._weights = None
         self._fingerprint = None
-        self._cldm_engines: Dict[tuple, CldmEngine] = {}
-        self._vae_engines: Dict[tuple, VaeEngine] = {}
+        self._cldm_engines = EngineCache(lambda e: (e.step_prog.release_graph(), e.ctx_prog.release_graph()))
+        self._vae_engines = EngineCache(lambda e: e.prog.release_graph())
 
     # -- engine plumbing ---------------------------------------------------------------------
     def _device(self) -> torch.device:
@@ -283,13 +283,8 @@ class ControlLDM(nn.Module):
             self._fingerprint = fp
 
     def release_engines(self) -> None:
-        for e in list(self._cldm_engines.values()):
-            e.step_prog.release_graph()
-            e.ctx_prog.release_graph()
-        for e in list(self._vae_engines.values()):
-            e.prog.release_graph()
-        self._cldm_engines.clear()
-        self._vae_engines.clear()
+        self._cldm_engines.drop_all()
+        self._vae_engines.drop_all()
         self._weights = None
 
     def _store(self) -> WeightStore:
@@ -304,16 +299,12 @@ class ControlLDM(nn.Module):
     def cldm_engine(self, B: int, h: int, w: int, nctx: int = 77) -> CldmEngine:
         self._check_fresh()
         key = (B, h, w, nctx, self.engine_slot)
-        if key not in self._cldm_engines:
-            self._cldm_engines[key] = CldmEngine(self, B, h, w, nctx)
-        return self._cldm_engines[key]
+        return self._cldm_engines.fetch(key, lambda: CldmEngine(self, B, h, w, nctx))
 
     def vae_engine(self, kind: str, B: int, H: int, W: int, tile_size: int = 0) -> VaeEngine:
         self._check_fresh()
         key = (kind, B, H, W, tile_size, self.engine_slot)
-        if key not in self._vae_engines:
-            self._vae_engines[key] = VaeEngine(self, kind, B, H, W, tile_size)
-        return self._vae_engines[key]
+        return self._vae_engines.fetch(key, lambda: VaeEngine(self, kind, B, H, W, tile_size))
 
     # -- checkpoint ingestion (reference model/cldm.py:46-105) -----------------------------------
     @torch.no_grad()

@@ -22,7 +22,7 @@ import torch
 
 from .. import lib as L
 from .. import ops as ops_mod
-from ..engine import Act, Arena, Emitter, Program, WeightStore
+from ..engine import Act, Arena, Emitter, EngineCache, Program, WeightStore
 from ..ops import round_up
 from .params import ParamTree, params_fingerprint
 
@@ -130,8 +130,7 @@ class _SwinEngine:
         oh, ow = th * sf, tw * sf
         self.y = torch.zeros((B, 3, oh, ow), dtype=torch.float32, device=dev)
         self.arena = Arena(dev)
-        params = owner.flat_params("")
-        store = WeightStore(params, dt, dev)
+        store = owner._store()                  # packed weights are shared by the engines of every input shape
         self.prog = Program("swinir")
         em = Emitter(self.prog, self.arena, store, dt)
         rng = float(cfg["img_range"])
@@ -309,11 +308,17 @@ class SwinIR(ParamTree):
         self.embed_dim, self.hq_key, self.lq_key = embed_dim, hq_key, lq_key
         self.compute_dtype: Optional[torch.dtype] = None
         self.use_graph = True
-        self._engines: Dict[Tuple[int, int, int], _SwinEngine] = {}
+        self._engines = EngineCache(lambda e: e.prog.release_graph())      # keyed by (B, H, W)
+        self._weights: Optional[WeightStore] = None
         self._fingerprint = None
 
     def _device(self) -> torch.device:
         return next(self.parameters()).device
+
+    def _store(self) -> WeightStore:
+        if self._weights is None:
+            self._weights = WeightStore(self.flat_params(""), self.compute_dtype, self._device())
+        return self._weights
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.device.type != "cuda":
@@ -323,7 +328,8 @@ class SwinIR(ParamTree):
             self.compute_dtype = torch.float16 if os.environ.get("EDTR_AMD_DTYPE", "bf16") == "fp16" else torch.bfloat16
         fp = (params_fingerprint(self), self.compute_dtype)
         if fp != self._fingerprint:
-            self._engines.clear()
+            self._engines.drop_all()
+            self._weights = None
             self._fingerprint = fp
         B, _, H0, W0 = x.shape
         ws = self.window_size
@@ -331,7 +337,5 @@ class SwinIR(ParamTree):
         if ph or pw:                                   # check_image_size (model/swinir.py:834-839): image-space reflect pad
             x = torch.nn.functional.pad(x, (0, pw, 0, ph), mode="reflect")
         key = (B, x.shape[2], x.shape[3])
-        if key not in self._engines:
-            self._engines[key] = _SwinEngine(self, *key, graph=self.use_graph)
-        y = self._engines[key].run(x.float())
+        y = self._engines.fetch(key, lambda: _SwinEngine(self, *key, graph=self.use_graph)).run(x.float())
         return y[:, :, : H0 * self.upscale, : W0 * self.upscale]

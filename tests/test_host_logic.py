@@ -268,3 +268,21 @@ def test_swinir_packing_helpers(golden_dir):
     bias = S.expand_bias(table, 8)
     idx = torch.from_numpy(S.relative_position_index(8))
     assert bias.shape == (heads, 64, 64) and float(bias[3, 10, 50]) == float(table[idx[10, 50], 3])
+
+
+def test_engine_cache_lru():
+    """Shape-keyed engine cache: hits refresh recency, the least recently used entry is evicted and released past capacity."""
+    from edtr_amd.engine import EngineCache
+    released, built = [], []
+    cache = EngineCache(release=released.append, capacity=2)
+
+    def build(tag):
+        built.append(tag)
+        return tag
+    assert cache.fetch("a", lambda: build("A")) == "A"
+    assert cache.fetch("b", lambda: build("B")) == "B"
+    assert cache.fetch("a", lambda: build("A2")) == "A" and built == ["A", "B"]        # hit: nothing rebuilt
+    assert cache.fetch("c", lambda: build("C")) == "C"
+    assert list(cache) == ["a", "c"] and released == ["B"]                              # b was the least recently used
+    cache.drop_all()
+    assert len(cache) == 0 and sorted(released) == ["A", "B", "C"]
