@@ -39,20 +39,23 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, bucket_bytes: in
     """Broadcast every parameter/buffer of `module` from rank `src` (torch.distributed must be initialised; backend
     'nccl' == RCCL on ROCm, 'gloo' in the CPU tests).  Returns (number of collectives, bytes moved)."""
     import torch.distributed as dist
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b is not None]
+    # the parameters themselves (not .data): the in-place copy must bump their version counters, which is what
+    # params_fingerprint() watches to invalidate packed weights / engines built before the broadcast
+    tensors = list(module.parameters()) + [b for b in module.buffers() if b is not None]
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
     calls = nbytes = 0
-    for group in by_dtype.values():
-        for bucket in bucketize(group, bucket_bytes):
-            flat = torch.cat([t.reshape(-1) for t in bucket])
-            dist.broadcast(flat, src=src)
-            off = 0
-            for t in bucket:
-                n = t.numel()
-                t.copy_(flat[off:off + n].view_as(t))
-                off += n
-            calls += 1
-            nbytes += flat.numel() * flat.element_size()
+    with torch.no_grad():
+        for group in by_dtype.values():
+            for bucket in bucketize(group, bucket_bytes):
+                flat = torch.cat([t.detach().reshape(-1) for t in bucket])
+                dist.broadcast(flat, src=src)
+                off = 0
+                for t in bucket:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t))
+                    off += n
+                calls += 1
+                nbytes += flat.numel() * flat.element_size()
     return calls, nbytes

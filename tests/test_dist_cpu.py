@@ -32,7 +32,10 @@ def _worker(rank: int, world: int, port: int, q):
         m.unet.load_state_dict(sds["unet"])
         m.load_controlnet_from_ckpt(sds["controlnet"])
         m.vae.load_state_dict(sds["vae"])
+    from edtr_amd.model.params import params_fingerprint
+    fp_before = params_fingerprint(m.unet)
     calls, nbytes = broadcast_parameters(m, src=0, bucket_bytes=1 << 24)
+    assert params_fingerprint(m.unet) != fp_before, "the broadcast must invalidate anything packed from the old weights"
     checksum = sum(float(p.double().sum()) for p in m.parameters())
     sl = shard_slice(rank, world, 6)
     noise = synth.synth_normal("dist:noise", (6, 4, 8, 8))[sl]
