@@ -57,6 +57,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-name time table to stderr")
+    ap.add_argument("--swinir", action="store_true",
+                    help="also time the SwinIR pre-restoration in front of the path (excluded from the metric, SURVEY.md §8d) and "
+                         "report it separately as \"pre_restoration\"")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,6 +220,11 @@ def main() -> None:
         "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE / (world * PEAK_TFLOPS * 1e12), 4) if S == 512 and args.config == "sd21" else None,
     }
 
+    if rank == 0 and args.swinir:
+        try:
+            result["pre_restoration"] = swinir_leg(dev, dtype, B, S, args.steps)
+        except Exception as e:       # reported separately: must never take the headline line down with it
+            result["pre_restoration"] = {"error": repr(e)}
     if rank == 0 and not args.no_roofline:
         result.update(roofline_pass(cldm, args))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -226,6 +234,30 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def swinir_leg(dev, dtype, B, S, steps) -> dict:
+    """SwinIR (configs/det/demo.yaml:2-18) on a batch of synthetic low-quality images: hipGraph replay, wall clock over
+    `steps` forwards.  Not part of `value`."""
+    from edtr_amd import synth
+    from edtr_amd.model.swinir import SwinIR
+    m = SwinIR(**synth.swinir_config())
+    sd = m.state_dict()
+    m.load_state_dict({k: (synth.synth_param("swinirfull." + k, tuple(v.shape)) if v.dtype.is_floating_point and not k.endswith("attn_mask") else v)
+                       for k, v in sd.items()}, strict=True)
+    m = m.eval().to(dev)
+    m.compute_dtype = dtype
+    x = synth.synth_input("bench:lq", (B, 3, S, S), 0.0, 1.0).to(dev)
+    m(x)
+    eng = next(iter(m._engines.values()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.prog.run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"network": "SwinIR 8x6 layers, 180 channels, window 8 (pixel-unshuffle 8, nearest+conv)", "ms_per_batch": round(ms, 3),
+            "images_per_s": round(B / ms * 1e3, 2), "tflops": round(eng.prog.total_flops() / ms / 1e9, 1), "launches": len(eng.prog.recs)}
 
 
 def roofline_pass(cldm, args) -> dict:
