@@ -509,7 +509,10 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
 // multiplied: counted s_waitcnt vmcnt(8) + raw s_barrier (a __syncthreads() would drain the prefetch).
 // Requires (C1 % 64 == 0, C2 == 0): every 64-wide K-tile lies inside one filter tap.
 // ------------------------------------------------------------------------------------------------------
-template <typename T, bool SPATIAL, bool FAST>
+// NST = LDS stages.  2 (default): tile t+1 in flight while tile t is multiplied, two workgroups per CU hide each other's
+// waits.  4 (tile 11, experiment): three tiles in flight, 128 KiB of LDS, one workgroup per CU — for grids below one
+// resident round, where nobody else covers the HBM latency of the next weight tile.
+template <typename T, bool SPATIAL, bool FAST, int NST = 2>
 __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm_params p) {
     EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
     constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
@@ -737,15 +740,23 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     }
     EDTR_STAMP(1);
     if (nkt > 0) issue_tile(kt0, 0);
+    if constexpr (NST > 2) {
+#pragma unroll
+        for (int t = 1; t < NST - 1; ++t)
+            if (t < nkt) issue_tile(kt0 + t, t);
+    }
 
 #ifdef EDTR_STAMPS
     uint64_t stamp_acc[4] = {0, 0, 0, 0};
 #endif
+    int ring_cur = 0, ring_next = NST - 1;      // NST > 2: LDS slot of tile kt / of the tile issued in iteration kt
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
+        int cur;
+        if constexpr (NST == 2) cur = kt & 1; else cur = ring_cur;
 #ifdef EDTR_STAMPS
         const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (NST == 2) {
         if (kt + 1 < nkt) {
             issue_tile(kt0 + kt + 1, cur ^ 1);
 #ifdef EDTR_STAMPS
@@ -754,6 +765,17 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMAs of tile kt have landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        } else {
+            // slot ring_next held tile kt-1, whose readers passed the closing barrier of the previous iteration
+            if (kt + NST - 1 < nkt) issue_tile(kt0 + kt + NST - 1, ring_next);
+            const int ahead = min(NST - 1, nkt - 1 - kt);      // tiles issued after tile kt that may still be in flight
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ring_cur = ring_cur + 1 == NST ? 0 : ring_cur + 1;
+            ring_next = ring_next + 1 == NST ? 0 : ring_next + 1;
         }
 #ifdef EDTR_STAMPS
         const uint64_t ts1 = __builtin_amdgcn_s_memtime();
@@ -812,18 +834,18 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     EDTR_STAMP(4); EDTR_STAMP(7);
 }
 
-template <typename T, bool SPATIAL, bool FAST>
+template <typename T, bool SPATIAL, bool FAST, int NST = 2>
 int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 2 * (128 + 128) * BK * 2;
+    constexpr int lds = NST * (128 + 128) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST, NST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
-    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST>), grid, dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST, NST>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
     if (p.splitk > 1) {
         const int64_t nvec = (int64_t)p.M * (p.N >> 3);
@@ -2183,9 +2205,13 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 10) {
+    if (tile >= 3 && tile <= 11) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
+        if (tile == 11) {  // tile 3 with a 4-deep LDS ring (experiment, not yet validated on hardware: opt-in only)
+            if (!fast) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_dma<T, true, true, 4>(p, s) : launch_dma<T, false, true, 4>(p, s);
+        }
         if (tile == 4) {
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_p3<T, true>(p, s) : launch_p3<T, false>(p, s);
@@ -2340,7 +2366,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 10) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 11) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""torch-free A/B of two edtr_igemm tile variants on ONE device: same random operands through tile A (reference, default 3) and
+tile B, outputs compared (bit-exact expected when both walk K in the same order, e.g. 3 vs 11; otherwise a tolerance), both timed.
+
+    python3 tools/exp/hw_ab_tiles.py --a 3 --b 11 [--tol 0] [--dt bf16]
+
+Cases cover 1..40 K-tiles, M / N tails, 3x3 convs with halo (stride 1, nearest-x2), residual + bias + GroupNorm partials and
+split-K, i.e. every path the variant shares with tile 3.  Writes gpurun_out/hw_ab_tiles.json."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hipfree as H  # noqa: E402
+from hipfree import C, L  # noqa: E402
+
+GEMMS = [(256, 128, 64), (300, 72, 192), (4096, 320, 320), (130, 136, 128), (77, 640, 1024), (8, 1280, 320), (2048, 1280, 1280),
+         (512, 1280, 1280), (8192, 640, 640), (2048, 1280, 2560)]
+CONVS = [(2, 16, 24, 64, 96, 0), (1, 32, 32, 128, 128, 0), (2, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 64, 1), (8, 16, 16, 1280, 1280, 0)]
+
+
+def run(dt, tile, *, M, N, K, taps, spatial, C1, a, w, bias, res, splitk=1, gnp=False):
+    out = H.Dev(nbytes=M * N * 2, fill=0xFF)
+    p = L.IgemmParams()
+    p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = dt, taps, M, N, K, 1, 1
+    p.a1, p.C1, p.ld1, p.w, p.ldw = a.p, C1, C1, w.p, K
+    if spatial:
+        p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l, p.upsample2x = spatial
+    p.alpha, p.bias_n, p.residual, p.ldr = 1.0, bias.p, res.p, N
+    p.out, p.ldc, p.tile, p.splitk = out.p, N, tile, splitk
+    keep = [out]
+    if splitk > 1:
+        ws = H.Dev(nbytes=splitk * M * N * 4)
+        p.workspace, p.workspace_bytes = ws.p, splitk * M * N * 4
+        keep.append(ws)
+    g = None
+    if gnp:
+        g = H.Dev(nbytes=(M // 128) * N * 2 * 4, fill=0)
+        p.gn_partial = g.p
+    code = H.edtr.edtr_igemm(C.byref(p), H.stream())
+    if code != 0 and not H.DRY:
+        return None, None, None, code
+    ms = H.time_launches([lambda s: H.chk(H.edtr.edtr_igemm(C.byref(p), s), "igemm")], iters=10, warm=2)
+    got = out.get(np.uint16, (M, N))
+    gp = g.get(np.float32, ((M // 128), N, 2)) if gnp else None
+    return got, gp, ms, 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--a", type=int, default=3)
+    ap.add_argument("--b", type=int, default=11)
+    ap.add_argument("--tol", type=float, default=0.0, help="0 = bit-exact; else max |a-b| / max|a|")
+    ap.add_argument("--dt", default="bf16", choices=["bf16", "fp16"])
+    args = ap.parse_args()
+    dt = 0 if args.dt == "bf16" else 1
+    rng = np.random.default_rng(0)
+    rows, bad = [], 0
+    cases = [("gemm", g, 1) for g in GEMMS] + [("gemm", (2048, 1280, 5120), 3), ("gemm", (512, 1280, 1280), 2)]
+    cases += [("conv", c, 1) for c in CONVS] + [("conv", (8, 8, 8, 1280, 1280, 0), 6)]
+    for kind, shp, splitk in cases:
+        if kind == "gemm":
+            M, N, K = shp
+            taps, spatial, C1, rows_in = 1, None, K, M
+        else:
+            B, Hh, Ww, Cin, Cout, up = shp
+            OH, OW = (Hh * 2, Ww * 2) if up else (Hh, Ww)
+            M, N, K, taps, C1, rows_in = B * OH * OW, Cout, 9 * Cin, 9, Cin, B * Hh * Ww
+            spatial = (Hh, Ww, OH, OW, 1, 1, 1, up)
+        a = H.Dev(H.rand16(rng, (rows_in, C1), dt))
+        w = H.Dev(H.rand16(rng, (N, K), dt, 1.0 / np.sqrt(K)))
+        bias = H.Dev(rng.standard_normal(N, dtype=np.float32))
+        res = H.Dev(H.rand16(rng, (M, N), dt))
+        gnp = splitk == 1 and M % 128 == 0 and N % 32 == 0
+        kw = dict(M=M, N=N, K=K, taps=taps, spatial=spatial, C1=C1, a=a, w=w, bias=bias, res=res, splitk=splitk, gnp=gnp)
+        ya, ga, ta, ca = run(dt, args.a, **kw)
+        yb, gb, tb, cb = run(dt, args.b, **kw)
+        name = f"{kind}{shp} sk{splitk}{' gnp' if gnp else ''}"
+        if ca or cb:
+            print(f"SKIP  {name}: tile {args.a} rc {ca}, tile {args.b} rc {cb}", flush=True)
+            rows.append({"case": name, "rc": [ca, cb]})
+            continue
+        fa, fb = H.from16(ya, dt), H.from16(yb, dt)
+        err = float(np.abs(fa - fb).max() / max(np.abs(fa).max(), 1e-30))
+        gerr = float(np.abs(ga - gb).max() / max(np.abs(ga).max(), 1e-30)) if gnp else 0.0
+        ok = (np.array_equal(ya, yb) if args.tol == 0 else err <= args.tol) and (gerr <= max(args.tol, 1e-6))
+        bad += not ok
+        print(f"{'PASS' if ok else 'FAIL'}  {name:44s} err {err:.2e} gnp {gerr:.1e}   tile {args.a}: {ta * 1e3:8.1f} us   tile {args.b}: {tb * 1e3:8.1f} us  ({ta / tb:4.2f}x)", flush=True)
+        rows.append({"case": name, "ok": bool(ok), "err": err, "us_a": ta * 1e3, "us_b": tb * 1e3})
+    os.makedirs(os.path.join(H.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(H.ROOT, "gpurun_out", "hw_ab_tiles.json"), "w") as f:
+        json.dump({"a": args.a, "b": args.b, "rows": rows}, f, indent=1)
+    print("ALL PASS" if not bad else f"{bad} FAILED")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
