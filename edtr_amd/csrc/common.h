@@ -18,6 +18,7 @@ struct alignas(16) U4 { uint32_t x, y, z, w; };
 // 16-bit storage traits: conversions + the matching MFMA.
 struct BF16 {
     using vec8 = bf16x8_t;
+    static constexpr uint32_t kOnePair = 0x3F803F80u;    // two 1.0 values
     static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
     static __device__ __forceinline__ uint16_t from_f32(float f) {
         __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
@@ -37,6 +38,7 @@ struct BF16 {
 };
 struct F16 {
     using vec8 = f16x8_t;
+    static constexpr uint32_t kOnePair = 0x3C003C00u;
     static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
     static __device__ __forceinline__ uint16_t from_f32(float f) {
         _Float16 h = (_Float16)f;

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""torch-free check + timing of edtr_flash_attn64 (numpy reference on the same 16-bit-rounded operands).  The staged variant is
+selected by the environment (read once per process), so an A/B is two runs in one gpurun call:
+
+    python3 tools/exp/hw_check_attn.py; EDTR_ATTN_LSUM_MFMA=1 python3 tools/exp/hw_check_attn.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hipfree as H  # noqa: E402
+from hipfree import C, L  # noqa: E402
+
+CHECK = [(2, 5, 256, 256, 0), (1, 3, 100, 77, 0), (2, 2, 130, 130, 1), (1, 5, 4096, 4096, 0), (3, 10, 64, 77, 0), (1, 1, 77, 77, 1)]
+TIME = [(8, 5, 4096, 4096, 0), (8, 10, 1024, 1024, 0), (8, 20, 256, 256, 0), (8, 5, 4096, 77, 0)]
+
+
+def run(dt, B, heads, Nq, Nk, causal, rng, check):
+    Cc = heads * 64
+    ldv = (Nk + 7) // 8 * 8
+    q = H.rand16(rng, (B, Nq, heads, 64), dt)
+    k = H.rand16(rng, (B, Nk, heads, 64), dt)
+    v = H.rand16(rng, (B, Nk, heads, 64), dt)
+    vt = np.zeros((B, heads, 64, ldv), np.uint16)
+    vt[..., :Nk] = v.transpose(0, 2, 3, 1)
+    dq, dk, dvt = H.Dev(q), H.Dev(k), H.Dev(vt)
+    do = H.Dev(nbytes=B * Nq * Cc * 2, fill=0xFF)
+    p = L.AttnParams()
+    p.dtype, p.B, p.H, p.Nq, p.Nk = dt, B, heads, Nq, Nk
+    p.q, p.q_bs, p.q_ld, p.k, p.k_bs, p.k_ld = dq.p, Nq * Cc, Cc, dk.p, Nk * Cc, Cc
+    p.vt, p.vt_bs, p.vt_ld, p.out, p.o_bs, p.o_ld = dvt.p, Cc * ldv, ldv, do.p, Nq * Cc, Cc
+    p.scale, p.causal = 0.125, causal
+    ms = H.time_launches([lambda s: H.chk(H.edtr.edtr_flash_attn64(C.byref(p), s), "flash_attn64")], iters=10, warm=2)
+    err = float("nan")
+    if check:
+        got = H.from16(do.get(np.uint16, (B, Nq, heads, 64)), dt)
+        qf, kf, vf = (H.from16(t, dt).astype(np.float64).transpose(0, 2, 1, 3) for t in (q, k, v))
+        sc = qf @ kf.transpose(0, 1, 3, 2) * 0.125
+        if causal:
+            sc = sc + np.triu(np.full((Nq, Nk), -np.inf), 1)
+        sc = np.exp(sc - sc.max(-1, keepdims=True))
+        ref = ((sc / sc.sum(-1, keepdims=True)) @ vf).transpose(0, 2, 1, 3)
+        err = float(np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()))
+    return ms, err, 4.0 * B * heads * Nq * Nk * 64
+
+
+def main():
+    variant = "lsum_mfma" if os.environ.get("EDTR_ATTN_LSUM_MFMA") == "1" else "default"
+    rng = np.random.default_rng(0)
+    rows, bad = [], 0
+    for dt in (0, 1):
+        tol = 6e-3 if dt == 0 else 1e-3
+        for case in CHECK:
+            ms, err, fl = run(dt, *case, rng, True)
+            ok = bool(err <= tol) or H.DRY
+            bad += not ok
+            print(f"{'PASS' if ok else 'FAIL'}  [{variant}] dt{dt} B,H,Nq,Nk,causal={case}: rel err {err:.2e} (tol {tol:.0e})", flush=True)
+            rows.append({"variant": variant, "dt": dt, "case": case, "err": err, "ok": ok})
+    for case in TIME:
+        ms, _, fl = run(0, *case, rng, False)
+        print(f"TIME  [{variant}] bf16 {case}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+        rows.append({"variant": variant, "case": case, "us": ms * 1e3, "tflops": fl / ms / 1e9})
+    os.makedirs(os.path.join(H.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(H.ROOT, "gpurun_out", f"hw_check_attn_{variant}.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print("ALL PASS" if not bad else f"{bad} FAILED")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
