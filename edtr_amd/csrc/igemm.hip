@@ -2205,12 +2205,16 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 11) {
+    if (tile >= 3 && tile <= 12) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 11) {  // tile 3 with a 4-deep LDS ring (experiment, not yet validated on hardware: opt-in only)
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_dma<T, true, true, 4>(p, s) : launch_dma<T, false, true, 4>(p, s);
+        }
+        if (tile == 12) {  // the same with a 3-deep ring (96 KiB of LDS; same status)
+            if (!fast) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_dma<T, true, true, 3>(p, s) : launch_dma<T, false, true, 3>(p, s);
         }
         if (tile == 4) {
             if (!fast) return EDTR_E_UNSUPPORTED;
@@ -2366,7 +2370,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 11) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 12) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }
