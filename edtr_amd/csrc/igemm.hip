@@ -119,9 +119,29 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // loaded once, and the ITER residual vectors are requested up front — before the barrier that publishes the staged
 // tile — so that their L2/HBM latency overlaps the staging instead of serialising ITER dependent round trips
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
-template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256>
+// SWZ (staged experiment, tile 13; BNO == 128 only): the staged tile is bank-swizzled — row ml keeps its 32-column halves
+// swapped when bit 2 of ml is set (the two lane halves of an accumulator store then hit disjoint banks), and the two float4
+// halves of a row vector are fetched in opposite order by the threads with n8 >= 8 (one ds_read_b128 of 16 lanes then covers
+// all 64 banks once instead of half of them twice).
+template <bool SWZ>
+__device__ __forceinline__ void read_staged8(const float* stage, int ml, int pitch, int n8, f32x4& s0, f32x4& s1) {
+    if constexpr (SWZ) {
+        const float* row = stage + ml * pitch + ((n8 ^ (((ml >> 2) & 1) << 2)) << 3);
+        const int h = (n8 >> 3) & 1;
+        const f32x4 first = *reinterpret_cast<const f32x4*>(row + 4 * h);
+        const f32x4 second = *reinterpret_cast<const f32x4*>(row + 4 * (1 - h));
+        s0 = h ? second : first;
+        s1 = h ? first : second;
+    } else {
+        s0 = *reinterpret_cast<const f32x4*>(stage + ml * pitch + n8 * 8);
+        s1 = *reinterpret_cast<const f32x4*>(stage + ml * pitch + n8 * 8 + 4);
+    }
+}
+
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool SWZ = false>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8]) {
+    static_assert(!SWZ || (BNO == 128 && !GEGLU), "swizzled staging is defined for the 128-column tile only");
     // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
     constexpr int VPR = BNO / 8, RPI = THREADS / VPR, ITER = (BM + RPI - 1) / RPI;
     constexpr bool EXACT = (THREADS % VPR == 0) && (BM % RPI == 0);
@@ -136,8 +156,13 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         for (int it = 0; it < ITER; ++it) {
             const int ml = r0 + RPI * it, m = m0 + ml;
             if (m < p.M && n_ok && (EXACT || ml < BM)) {
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+                f32x4 s0, s1;
+                if constexpr (SWZ) {
+                    read_staged8<true>(stage, ml, BNO, n8, s0, s1);
+                } else {
+                    s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+                    s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+                }
                 float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
                 *reinterpret_cast<f32x4*>(o) = s0;
                 *reinterpret_cast<f32x4*>(o + 4) = s1;
@@ -180,8 +205,13 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     for (int it = 0; it < ITER; ++it) {
         const int ml = r0 + RPI * it, m = m0 + ml;
         if (m < p.M && n_ok && (EXACT || ml < BM)) {
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-            const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+            f32x4 s0, s1;
+            if constexpr (SWZ) {
+                read_staged8<true>(stage, ml, BNO, n8, s0, s1);
+            } else {
+                s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+                s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+            }
             float f[8];
             f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
 #pragma unroll
@@ -232,9 +262,10 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 }
 
 // Tile epilogue shared by both main-loop variants: accumulators -> LDS (fp32) -> row vectors of 8 columns.
-template <typename T, int MI, int NI>
+template <typename T, int MI, int NI, bool SWZ = false>
 __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16 (&acc)[MI][NI], char* smem, int m0, int n0,
                                               int64_t o_zoff) {
+    static_assert(!SWZ || (MI == 2 && NI == 2), "swizzled staging is defined for the 128 x 128 tile only");
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -265,7 +296,8 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
+                    if constexpr (SWZ) stage[ml * BNO + ((wn * 32 * NI + ni * 32 + l31) ^ (lh << 5))] = acc[mi][ni][r];   // bit 2 of ml == lh
+                    else stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
                 }
     }
     const int n_out = geglu ? p.N / 2 : p.N;
@@ -277,7 +309,7 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
     if (geglu) rows_phase<T, BM, BN / 2, true>(p, stage, m0, no0, n_out, o_zoff, false, gs, gq);
-    else rows_phase<T, BM, BN, false>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
+    else rows_phase<T, BM, BN, false, 256, SWZ>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
     if (gn_acc) {
         // lanes l, l+16, l+32, l+48 of a wave own the same columns: fold them, then fold the 4 waves through LDS
 #pragma unroll
@@ -512,7 +544,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
 // NST = LDS stages.  2 (default): tile t+1 in flight while tile t is multiplied, two workgroups per CU hide each other's
 // waits.  4 (tile 11, experiment): three tiles in flight, 128 KiB of LDS, one workgroup per CU — for grids below one
 // resident round, where nobody else covers the HBM latency of the next weight tile.
-template <typename T, bool SPATIAL, bool FAST, int NST = 2>
+template <typename T, bool SPATIAL, bool FAST, int NST = 2, bool SWZ = false>
 __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm_params p) {
     EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
     constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
@@ -830,22 +862,22 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
 #undef STAMP_VALUE
 #define STAMP_VALUE 0
 #endif
-    tile_epilogue<T, MI, NI>(p, acc, smem, m0, n0, o_zoff);
+    tile_epilogue<T, MI, NI, SWZ>(p, acc, smem, m0, n0, o_zoff);
     EDTR_STAMP(4); EDTR_STAMP(7);
 }
 
-template <typename T, bool SPATIAL, bool FAST, int NST = 2>
+template <typename T, bool SPATIAL, bool FAST, int NST = 2, bool SWZ = false>
 int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int lds = NST * (128 + 128) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST, NST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST, NST, SWZ>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
-    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST, NST>), grid, dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST, NST, SWZ>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
     if (p.splitk > 1) {
         const int64_t nvec = (int64_t)p.M * (p.N >> 3);
@@ -2205,12 +2237,16 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 12) {
+    if (tile >= 3 && tile <= 13) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 11) {  // tile 3 with a 4-deep LDS ring (experiment, not yet validated on hardware: opt-in only)
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_dma<T, true, true, 4>(p, s) : launch_dma<T, false, true, 4>(p, s);
+        }
+        if (tile == 13) {  // tile 3 with the bank-swizzled epilogue staging (experiment, same status; GEGLU keeps the plain staging)
+            if (!fast) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_dma<T, true, true, 2, true>(p, s) : launch_dma<T, false, true, 2, true>(p, s);
         }
         if (tile == 12) {  // the same with a 3-deep ring (96 KiB of LDS; same status)
             if (!fast) return EDTR_E_UNSUPPORTED;
@@ -2370,7 +2406,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 12) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 13) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }
