@@ -38,9 +38,11 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_ctypes_structs_match_the_c_layout(tmp_path):
     from edtr_amd import lib
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "edtr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "edtr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(edtr_igemm_params),sizeof(edtr_attn_params),sizeof(edtr_gn_params),'
-                   'offsetof(edtr_igemm_params,workspace),offsetof(edtr_igemm_params,out));return 0;}\n')
+                   'offsetof(edtr_igemm_params,workspace),offsetof(edtr_igemm_params,out),'
+                   'sizeof(edtr_window_attn_params),offsetof(edtr_window_attn_params,labels),offsetof(edtr_window_attn_params,scale),'
+                   'offsetof(edtr_igemm_params,act_slope));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
@@ -49,7 +51,10 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     assert int(out[2]) == ctypes.sizeof(lib.GnParams)
     assert int(out[3]) == lib.IgemmParams.workspace.offset
     assert int(out[4]) == lib.IgemmParams.out.offset
-
+    assert int(out[5]) == ctypes.sizeof(lib.WindowAttnParams)
+    assert int(out[6]) == lib.WindowAttnParams.labels.offset
+    assert int(out[7]) == lib.WindowAttnParams.scale.offset
+    assert int(out[8]) == lib.IgemmParams.act_slope.offset
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from edtr_amd import lib
