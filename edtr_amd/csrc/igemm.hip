@@ -2397,6 +2397,22 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             tile = 8;
         else if (pp_ok && !(no_auto & (1 << 6)) && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4)
             tile = 6;
+        // Staged experiments, default off (A/B switches for a whole-path run on ONE device):
+        //   EDTR_IGEMM_DEEP=<max workgroups>  a tile-3 launch whose grid has at most that many workgroups (i.e. about one per
+        //                                     CU or fewer: nobody hides the DMA latency) runs the 4-deep-ring tile 11 instead
+        //   EDTR_IGEMM_SWZ=1                  every remaining tile-3 launch runs tile 13 (bank-swizzled epilogue staging)
+        static int deep_max = -1, swz = -1;
+        if (deep_max < 0) {
+            const char* e = getenv("EDTR_IGEMM_DEEP");
+            deep_max = e ? atoi(e) : 0;
+            const char* e2 = getenv("EDTR_IGEMM_SWZ");
+            swz = (e2 && e2[0] == '1') ? 1 : 0;
+        }
+        if (tile == 3 && (deep_max > 0 || swz) && (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial)) {
+            const int64_t wgs = big * (p.splitk > 1 ? p.splitk : 1);
+            if (deep_max > 0 && wgs <= deep_max && p.K / 64 / (p.splitk > 1 ? p.splitk : 1) >= 4) tile = 11;
+            else if (swz) tile = 13;
+        }
         // (tile 10 — the same 128x128 geometry with 16x16x32 MFMAs — is +9 % in isolation on the 512x512-level N = 128 VAE
         //  convolutions but -0.5..-1 % on the whole path in the same A/B; opt-in)
         // (the 64x128 tile 9 wins 10-30 % in isolation on the short-K GEMMs of the 16x16 / 8x8 latent levels but cost 1 % of
