@@ -365,6 +365,9 @@ def test_swinir_vs_reference_golden(golden_dir, tag, dtype):
         # an image of a batch does not depend on its batch mates
         y1 = m(x[1:])
         assert rel_err(y1, outs[1][1:]) < 1e-6
+        # input that is not a multiple of the window: reflect pad, padded size returned (reference quirk, model/swinir.py:834-839,894)
+        yp = m(synth.synth_input("swinir:odd", (1, 3, 60, 124), 0.0, 1.0).to(dev))
+        assert yp.shape == (1, 3, 64, 128) and rel_err(yp, g["y_small_padded"]) < tol
     else:
         y = m(synth.synth_input("swinir:256", (1, 3, 256, 256), 0.0, 1.0).to(dev))
         err = rel_err(y, g["y_256"].astype(np.float32))

@@ -240,6 +240,10 @@ def test_swinir_small(golden_dir):
         y = O.swinir_forward(_swinir_sd("small", cfg), cfg, x)
     assert y.shape == (2, 3, 128, 192)
     assert rel_err(y, g["y_small"]) < 2e-5
+    # not a multiple of the window: reflect pad in image space, and the PADDED size comes back (model/swinir.py:834-839,894)
+    with torch.no_grad():
+        yp = O.swinir_forward(_swinir_sd("small", cfg), cfg, synth.synth_input("swinir:odd", (1, 3, 60, 124), 0.0, 1.0))
+    assert yp.shape == (1, 3, 64, 128) and rel_err(yp, g["y_small_padded"]) < 2e-5
 
 
 def test_swinir_full(golden_dir):

@@ -339,6 +339,10 @@ def gen_swinir():
     x = synth.synth_input("swinir:small", (2, 3, 128, 192), 0.0, 1.0)
     with torch.no_grad():
         out["y_small"] = small(x).numpy()
+    # an input that is not a multiple of the window: check_image_size reflect-pads it in image space and the final crop
+    # `[:H*sf, :W*sf]` is a no-op for the pixel-unshuffle configuration, i.e. the PADDED size comes back (model/swinir.py:834-839,894)
+    with torch.no_grad():
+        out["y_small_padded"] = small(synth.synth_input("swinir:odd", (1, 3, 60, 124), 0.0, 1.0)).numpy()
     blk = small.layers[0].residual_group.blocks[1]
     out["rel_index"] = blk.attn.relative_position_index.numpy().astype(np.int16)
     out["mask_64x64"] = np.packbits(blk.attn_mask.numpy() != 0)
