@@ -9,7 +9,7 @@ Reference constructors being described: model/unet.py:391-685 (UNetModel), model
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Tuple
+from typing import List, Tuple
 
 Shape = Tuple[int, ...]
 

@@ -4,7 +4,7 @@ data-parallel driver that shards a list of pre-restored images over the ranks of
 edtr_amd path on each shard and reports PSNR.  Plain tensor bookkeeping: no kernels of their own."""
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 

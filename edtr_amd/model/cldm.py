@@ -7,7 +7,7 @@ There is no CPU / PyTorch-operator fallback: calling a forward on a CPU-resident
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional, Set, Tuple
+from typing import Dict, List, Set, Tuple
 
 import torch
 from torch import nn

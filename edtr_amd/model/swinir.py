@@ -15,7 +15,7 @@ cyclic shift, window gather, relative-position bias, region mask, softmax, PV, s
 from __future__ import annotations
 
 import math
-from typing import Dict, Iterable, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch

@@ -3,7 +3,7 @@ same constructor, buffers, method names and argument meaning.  The per-step late
 (edtr_sampler_update) instead of ~10 elementwise ATen ops; the network evaluation is ControlLDM.forward."""
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 import torch

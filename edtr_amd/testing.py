@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 import contextlib
-from typing import Dict, Iterable, List
+from typing import Dict, Iterable
 
 import torch
 
