@@ -2237,12 +2237,17 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile >= 3 && tile <= 13) {
+    if (tile >= 3 && tile <= 14) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
         if (tile == 11) {  // tile 3 with a 4-deep LDS ring (experiment, not yet validated on hardware: opt-in only)
             if (!fast) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_dma<T, true, true, 4>(p, s) : launch_dma<T, false, true, 4>(p, s);
+        }
+        if (tile == 14) {  // 256 x 32 tile for skinny-N convolutions (N <= 32: the decoder's 3-channel output conv wastes 94 % of a
+                           // 128-wide tile); an instantiation of the 16x16x32 template, experiment, same status
+            if (!fast || p.act == EDTR_ACT_GEGLU || p.gn_partial) return EDTR_E_UNSUPPORTED;
+            return spatial ? launch_n160<T, true, 8, 1>(p, s) : launch_n160<T, false, 8, 1>(p, s);
         }
         if (tile == 13) {  // tile 3 with the bank-swizzled epilogue staging (experiment, same status; GEGLU keeps the plain staging)
             if (!fast) return EDTR_E_UNSUPPORTED;
@@ -2408,6 +2413,14 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             const char* e2 = getenv("EDTR_IGEMM_SWZ");
             swz = (e2 && e2[0] == '1') ? 1 : 0;
         }
+        static int skinny = -1;
+        if (skinny < 0) {
+            const char* e3 = getenv("EDTR_IGEMM_SKINNY");      //   EDTR_IGEMM_SKINNY=1: automatic N <= 32 launches run tile 14
+            skinny = (e3 && e3[0] == '1') ? 1 : 0;
+        }
+        if (skinny && tile == 3 && p.N <= 32 && p.splitk <= 1 && !p.gn_partial && p.act != EDTR_ACT_GEGLU &&
+            (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
+            tile = 14;
         if (tile == 3 && (deep_max > 0 || swz) && (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial)) {
             const int64_t wgs = big * (p.splitk > 1 ? p.splitk : 1);
             if (deep_max > 0 && wgs <= deep_max && p.K / 64 / (p.splitk > 1 ? p.splitk : 1) >= 4) tile = 11;
@@ -2422,7 +2435,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 13) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 14) return EDTR_E_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

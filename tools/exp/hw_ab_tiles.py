@@ -3,6 +3,7 @@
 tile B, outputs compared (bit-exact expected when both walk K in the same order, e.g. 3 vs 11; otherwise a tolerance), both timed.
 
     python3 tools/exp/hw_ab_tiles.py --a 3 --b 11 [--tol 0] [--dt bf16]
+    python3 tools/exp/hw_ab_tiles.py --a 3 --b 14 --tol 4e-3      # other MFMA shape: not bit-exact
 
 Cases cover 1..40 K-tiles, M / N tails, 3x3 convs with halo (stride 1, nearest-x2), residual + bias + GroupNorm partials and
 split-K, i.e. every path the variant shares with tile 3.  Writes gpurun_out/hw_ab_tiles.json."""
@@ -19,7 +20,7 @@ from hipfree import C, L  # noqa: E402
 
 GEMMS = [(256, 128, 64), (300, 72, 192), (4096, 320, 320), (130, 136, 128), (77, 640, 1024), (8, 1280, 320), (2048, 1280, 1280),
          (512, 1280, 1280), (8192, 640, 640), (2048, 1280, 2560)]
-CONVS = [(2, 16, 24, 64, 96, 0), (1, 32, 32, 128, 128, 0), (2, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 64, 1), (8, 16, 16, 1280, 1280, 0)]
+CONVS = [(2, 64, 64, 128, 8, 0), (1, 32, 32, 64, 64, 0), (2, 16, 24, 64, 96, 0), (1, 32, 32, 128, 128, 0), (2, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 64, 1), (8, 16, 16, 1280, 1280, 0)]
 
 
 def run(dt, tile, *, M, N, K, taps, spatial, C1, a, w, bias, res, splitk=1, gnp=False):
