@@ -88,7 +88,7 @@ def main() -> None:
     from edtr_amd.model.params import skip_init
     from edtr_amd.parallel import broadcast_parameters, shard_slice
     from edtr_amd.sampler import SpacedSampler
-    from edtr_amd.testing import flat_oracle_sd, injected_noise, rel_err, synthetic_state_dicts
+    from edtr_amd.testing import injected_noise, rel_err, synthetic_state_dicts
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     cfg = synth.CONFIGS[args.config]()
@@ -356,8 +356,9 @@ def _cpu_worker(q_in, q_out, cfg_name, S, threads):
     import torch as th
     th.set_num_threads(threads)
     from edtr_amd import synth as sy
-    from edtr_amd.testing import flat_oracle_sd, synthetic_state_dicts
+    from edtr_amd.testing import synthetic_state_dicts
     from oracle import edtr_oracle as O
+    from oracle import flat_sd as flat_oracle_sd
     cfg = sy.CONFIGS[cfg_name]()
     sd = flat_oracle_sd(synthetic_state_dicts(cfg))
     q_out.put(("ready", None))

@@ -106,6 +106,16 @@ __global__ void __launch_bounds__(256) axpby_kernel(const float* x, const float*
         out[i] = a * x[i] + b * y[i];
 }
 
+// q_sample with the timestep read on the device: out[b] = tab_a[t[b]] * x[b] + tab_b[t[b]] * noise[b]
+__global__ void __launch_bounds__(256) q_sample_kernel(const float* x, const float* noise, const int64_t* t, const float* tab_a,
+                                                      const float* tab_b, int n_tab, float* out, int64_t per_image, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int64_t ti = t[i / per_image];
+        ti = ti < 0 ? 0 : (ti >= n_tab ? n_tab - 1 : ti);
+        out[i] = tab_a[ti] * x[i] + tab_b[ti] * noise[i];
+    }
+}
+
 __global__ void __launch_bounds__(256) divide_kernel(const float* num, const float* den, float* out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         out[i] = num[i] / den[i];
@@ -302,6 +312,17 @@ extern "C" int edtr_axpby(const float* x, const float* y, float a, float b, floa
     if (n <= 0) return EDTR_E_SHAPE;
     hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, a, b, out,
                        n);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_q_sample(const float* x, const float* noise, const int64_t* t, const float* tab_a, const float* tab_b,
+                             int n_tab, float* out, int B, int64_t per_image, edtr_stream_t stream) {
+    if (!x || !noise || !t || !tab_a || !tab_b || !out) return EDTR_E_NULL;
+    if (B <= 0 || per_image <= 0 || n_tab <= 0) return EDTR_E_SHAPE;
+    const int64_t n = (int64_t)B * per_image;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, noise, t, tab_a,
+                       tab_b, n_tab, out, per_image, n);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

@@ -55,14 +55,22 @@ class Diffusion(nn.Module):
         self.register_buffer(name, torch.tensor(value, dtype=torch.float32))
 
     def q_sample(self, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
-        """sqrt(ac_t) x0 + sqrt(1 - ac_t) noise.  One libedtr_hip launch when t is uniform over the batch (every
-        caller: demo.py:108, main/*/test_edtr.py); per-sample t falls back to B launches."""
+        """sqrt(ac_t) x0 + sqrt(1 - ac_t) noise, one libedtr_hip launch.  A GPU-resident ``t`` (every reference call
+        site: demo.py:107-108, main/*/test_edtr.py) is read ON the device by edtr_q_sample — no ``.tolist()`` / host
+        round trip; a host ``t`` is turned into scalars for edtr_axpby (per-sample launches when it is not uniform)."""
         if x_start.device.type != "cuda":
             raise RuntimeError("Diffusion.q_sample: GPU tensors required (no CPU fallback on the EDTR MI355X path)")
         x_start = x_start.contiguous().float()
         noise = noise.contiguous().float()
         out = torch.empty_like(x_start)
-        tl = t.tolist()      # pass a host tensor to avoid a device sync
+        if t.device.type == "cuda":
+            if self.sqrt_alphas_cumprod.device != x_start.device:
+                raise RuntimeError("Diffusion.q_sample: call diffusion.to(device) first (the schedule tables are on "
+                                   f"{self.sqrt_alphas_cumprod.device})")
+            ops.launch(ops.make_q_sample(x=x_start, noise=noise, t=t.to(torch.int64).contiguous(),
+                                         tab_a=self.sqrt_alphas_cumprod, tab_b=self.sqrt_one_minus_alphas_cumprod, out=out))
+            return out
+        tl = t.tolist()
         a_tab, b_tab = self._host_sqrt_ac, self._host_sqrt_1mac
         if len(set(tl)) == 1:
             ops.launch(ops.make_axpby(x=x_start, y=noise, a=a_tab[tl[0]], b=b_tab[tl[0]], out=out, n=x_start.numel()))

@@ -115,6 +115,8 @@ class EngineCache(collections.OrderedDict):
         return eng
 
     def drop_all(self) -> None:
+        if len(self) and torch.cuda.is_available():
+            torch.cuda.synchronize()              # a replay of one of these graphs may still be queued on another stream
         for eng in list(self.values()):
             if self.release is not None:
                 self.release(eng)

@@ -15,7 +15,7 @@ ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3, 4
 DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
     "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
-    "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby",
+    "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle",
 ]
@@ -115,6 +115,7 @@ def load() -> C.CDLL:
     lib.edtr_timestep_embedding.argtypes = [i32, vp, i32, i32, vp, i32, vp]
     lib.edtr_sampler_update.argtypes = [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]
     lib.edtr_axpby.argtypes = [vp, vp, f32, f32, vp, i64, vp]
+    lib.edtr_q_sample.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
     lib.edtr_tile_accumulate.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.edtr_divide.argtypes = [vp, vp, vp, i64, vp]
     lib.edtr_wavelet_level.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
@@ -132,7 +133,7 @@ def load() -> C.CDLL:
     lib.edtr_embed_tokens.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.edtr_window_attn.argtypes = [C.POINTER(WindowAttnParams), vp]
     lib.edtr_pixel_unshuffle.argtypes = [i32, vp, i32, i32, i32, i32, i32, vp, f32, vp, i32, i32, vp]
-    if lib.edtr_abi_version() != 4:
+    if lib.edtr_abi_version() != 5:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

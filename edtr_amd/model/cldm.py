@@ -31,6 +31,10 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
                            "there is no CPU fallback. Move the module and inputs to 'cuda'.")
 
 
+class NansException(Exception):
+    """Raised by the tiled VAE when a tile came out NaN (reference utils/tilevae/tilevae.py:62-69,435,548)."""
+
+
 def disabled_train(self: nn.Module, mode: bool = True) -> nn.Module:
     return self
 
@@ -135,14 +139,16 @@ class CldmEngine:
         em.to_nchw(eps, B, ua.out_channels, hw, self.eps_out)
 
     def set_context(self, c_txt: torch.Tensor) -> None:
-        key = (c_txt.data_ptr(), c_txt._version, tuple(c_txt.shape))
-        if key == self.ctx_key:
+        """Re-run the context program unless ``c_txt`` is the very tensor OBJECT (same version) the cached K / V^T came
+        from.  The cache holds a reference to that tensor, so its storage cannot be recycled for another prompt's
+        embedding while the entry is alive (an address/version key alone would alias a new same-shaped tensor)."""
+        held = self.ctx_key
+        if held is not None and held[0] is c_txt and held[1] == c_txt._version:
             return
-        if c_txt.shape[0] == 1 and self.B > 1:
-            c_txt = c_txt.expand(self.B, -1, -1)
-        self.ctx_in.copy_(c_txt)
+        src = c_txt.expand(self.B, -1, -1) if (c_txt.shape[0] == 1 and self.B > 1) else c_txt
+        self.ctx_in.copy_(src)
         self.ctx_prog.run()
-        self.ctx_key = key
+        self.ctx_key = (c_txt, c_txt._version)
 
     def step(self, x: torch.Tensor, t: torch.Tensor, c_txt: torch.Tensor, c_img: torch.Tensor) -> torch.Tensor:
         self.set_context(c_txt)
@@ -170,6 +176,7 @@ class VaeEngine:
         dd = owner.vae.cfg["ddconfig"]
         f32 = torch.float32
         self.prog = Program(f"vae.{kind}" + (".tiled" if tile_size else ""))
+        self.nan_probe = None      # tiled form: (row, col) of the first output pixel of every tile
         em = Emitter(self.prog, self.arena, store, dt)
         sf = owner.scale_factor
         nlev = len(dd["ch_mult"])
@@ -188,6 +195,7 @@ class VaeEngine:
                 y = nets.emit_vae_net(em, "vae.encoder.", layers, Act(x, B, H, W, cp), final_f32=False)
             else:
                 y = self._tiled(em, "vae.encoder.", layers, x, B, H, W, cp, tile_size, False, h, w)
+                self.nan_probe = [(ob[2], ob[0]) for ob in nets.split_tiles(H, W, tile_size, False)[1]]
             # quant_conv 1x1 (model/vae.py:727) then DiagonalGaussianDistribution.mode() = first half (distributions.py:30,64)
             m = em.conv(y, "vae.quant_conv.", taps=1, out_f32=True, name="vae.quant_conv")
             em.free(y)
@@ -206,6 +214,7 @@ class VaeEngine:
                 y = nets.emit_vae_net(em, "vae.decoder.", layers, z2, final_f32=True)
             else:
                 y = self._tiled(em, "vae.decoder.", layers, z2.t, B, H, W, z2.C, tile_size, True, H * up, W * up)
+                self.nan_probe = [(ob[2], ob[0]) for ob in nets.split_tiles(H, W, tile_size, True)[1]]
             em.to_nchw(y.t, B, dd["out_ch"], y.H * y.W, self.out)
 
     @staticmethod
@@ -243,6 +252,13 @@ class VaeEngine:
     def run(self, x: torch.Tensor) -> torch.Tensor:
         self.inp.copy_(x)
         self.prog.run()
+        if self.nan_probe and not torch.cuda.is_current_stream_capturing():
+            # test_for_nans(tile, "vae") of the reference (utils/tilevae/tilevae.py:66-69,435,548): one element per tile is
+            # looked at; like there, this costs a device round trip per call (tiled VAE only)
+            rows = torch.tensor([r for r, _ in self.nan_probe], device=self.out.device)
+            cols = torch.tensor([c for _, c in self.nan_probe], device=self.out.device)
+            if bool(torch.isnan(self.out[0, 0, rows, cols]).any()):
+                raise NansException("vae")
         return self.out
 
 

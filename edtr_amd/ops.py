@@ -237,6 +237,13 @@ def make_axpby(*, x, y, a, b, out, n, name="axpby") -> Rec:
     return Rec(L.load().edtr_axpby, (ptr(x), ptr(y), float(a), float(b), ptr(out), n), (x, y, out), name, 0.0, 12.0 * n)
 
 
+def make_q_sample(*, x, noise, t, tab_a, tab_b, out, name="q_sample") -> Rec:
+    B = x.shape[0]
+    per = x.numel() // B
+    args = (ptr(x), ptr(noise), ptr(t), ptr(tab_a), ptr(tab_b), tab_a.numel(), ptr(out), B, per)
+    return Rec(L.load().edtr_q_sample, args, (x, noise, t, tab_a, tab_b, out), name, 0.0, 12.0 * x.numel())
+
+
 def make_tile_accumulate(*, tile, wts, out, count, B, C, H, W, th, tw, hi, wi, name="tile_accumulate") -> Rec:
     args = (ptr(tile), ptr(wts), ptr(out), ptr(count), B, C, H, W, th, tw, hi, wi)
     return Rec(L.load().edtr_tile_accumulate, args, (tile, wts, out, count), name)

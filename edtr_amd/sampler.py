@@ -126,12 +126,18 @@ class SpacedSampler(nn.Module):
     def _install_tiling(self, model, tile_size: int, tile_stride: int) -> None:
         # NB: like the reference (:288-303) the patched forward is never restored.
         forward = model.forward
+        ctx_rep = {}      # (n) -> (source c_txt, its version, repeated copy): the SAME tensor object goes to every step, so the
+        #                   engine's context cache (keyed on tensor identity) hits instead of re-projecting K / V^T per step
 
         def batched(x_tiles, windows, t, cond):
             # the windows of one latent stacked on the batch axis (window-major, like torch.cat of the per-window batches)
             n = len(windows)
             c_img = torch.cat([cond["c_img"][..., hi:he, wi:we] for hi, he, wi, we in windows], dim=0)
-            return forward(x_tiles, t.repeat(n), {"c_txt": cond["c_txt"].repeat(n, 1, 1), "c_img": c_img})
+            c_txt = cond["c_txt"]
+            hit = ctx_rep.get(n)
+            if hit is None or hit[0] is not c_txt or hit[1] != c_txt._version:
+                hit = ctx_rep[n] = (c_txt, c_txt._version, c_txt.repeat(n, 1, 1))
+            return forward(x_tiles, t.repeat(n), {"c_txt": hit[2], "c_img": c_img})
 
         model.forward = make_tiled_fn(
             lambda x_tile, t, cond, hi, hi_end, wi, wi_end: forward(

@@ -1,4 +1,5 @@
-"""Helpers shared by tests / smoke / bench: build a ControlLDM with the synthetic weights of edtr_amd.synth."""
+"""Helpers shared by tests / smoke / bench: build a ControlLDM with the synthetic weights of edtr_amd.synth.
+Nothing here touches the CPU oracle (oracle/ is imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline only)."""
 from __future__ import annotations
 
 import contextlib
@@ -19,10 +20,6 @@ def synthetic_state_dicts(cfg: dict) -> Dict[str, Dict[str, torch.Tensor]]:
         "vae": arch.vae_param_spec(cfg["vae_cfg"]),
     }
     return {part: {k: synth.synth_param(f"{part}.{k}", shp) for k, shp in spec} for part, spec in specs.items()}
-
-
-def flat_oracle_sd(sds: Dict[str, Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
-    return {f"{part}.{k}": v for part, sd in sds.items() for k, v in sd.items()}
 
 
 def build_synthetic_cldm(cfg: dict, device, dtype=None, sds=None) -> ControlLDM:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 4
+#define EDTR_ABI_VERSION 5
 
 enum edtr_dtype { EDTR_BF16 = 0, EDTR_F16 = 1 };
 
@@ -265,6 +265,12 @@ int edtr_sampler_update(const float* x, const float* eps, const float* noise, fl
 /* out = a*x + b*y (fp32).  replaces: Diffusion.q_sample, model/gaussian_diffusion.py:80-84. */
 int edtr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n,
                edtr_stream_t stream);
+/* Diffusion.q_sample with per-image timesteps read on the device (no host round trip for a GPU-resident `t`):
+ *   out[b][i] = tab_a[t[b]] * x[b][i] + tab_b[t[b]] * noise[b][i],  tab_a = sqrt_alphas_cumprod, tab_b = sqrt_one_minus_alphas_cumprod
+ * (fp32 tables of n_tab entries, t clamped into the table).  replaces: extract_into_tensor + the two multiplies and the add,
+ * reference model/gaussian_diffusion.py:34-37,80-84 as called with a device `t` at demo.py:107-108, main/det/test_edtr.py:127-128. */
+int edtr_q_sample(const float* x, const float* noise, const int64_t* t, const float* tab_a, const float* tab_b,
+                  int n_tab, float* out, int B, int64_t per_image, edtr_stream_t stream);
 /* Gaussian-weighted overlap-add of one latent tile (fp32 NCHW):
  *   out[b][c][hi+y][wi+x] += tile[b][c][y][x] * wts[y][x];  count[...] += wts[y][x]
  * replaces: utils/common.py:415-424 (make_tiled_fn accumulation). */

@@ -1,4 +1,5 @@
-"""smoke(): one small restoration (tiny config, B=1, 64x64 image, 4 denoise steps) through the HIP path on cuda:0,
+"""Checker behind __graft_entry__.smoke() (lives under tests/ because it imports the CPU oracle; the product package
+edtr_amd/ never does).  smoke(): one small restoration (tiny config, B=1, 64x64 image, 4 denoise steps) through the HIP path on cuda:0,
 checked against the CPU oracle on the same weights / inputs / noise."""
 from __future__ import annotations
 
@@ -15,8 +16,9 @@ def smoke(verbose: bool = True) -> dict:
     from edtr_amd import synth
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.sampler import SpacedSampler
-    from edtr_amd.testing import build_synthetic_cldm, flat_oracle_sd, injected_noise, rel_err, synthetic_state_dicts
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise, rel_err, synthetic_state_dicts
     from oracle import edtr_oracle as O   # checker only
+    from oracle import flat_sd as flat_oracle_sd
 
     if not torch.cuda.is_available():
         raise RuntimeError("smoke() needs cuda:0 (the HIP path has no CPU fallback)")

@@ -121,8 +121,9 @@ def test_sample_api_and_cfg_vs_oracle():
     from edtr_amd import synth
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.sampler import SpacedSampler, space_timesteps
-    from edtr_amd.testing import (build_synthetic_cldm, flat_oracle_sd, injected_noise, rel_err, synthetic_state_dicts)
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise, rel_err, synthetic_state_dicts
     from oracle import edtr_oracle as O
+    from oracle import flat_sd as flat_oracle_sd
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")

@@ -4,7 +4,7 @@
 
 Run in the build container only (the reference does not exist on the GPU box):
 
-    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,wavelet,clip,psnr,swinir]
+    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,wavelet,clip,psnr,swinir,full]
 
 Fixtures are data (inputs are regenerated from edtr_amd.synth formulas, expected outputs
 are stored); nothing from the reference's source travels.
@@ -365,16 +365,112 @@ def gen_swinir():
     print("swinir.npz written")
 
 
+def _img_digest(img: torch.Tensor) -> dict:
+    """Compact pin of a large image tensor: stride-4 samples (fp16) + global statistics."""
+    return {"samples": img[:, :, 1::4, 2::4].numpy().astype(np.float16),
+            "stats": np.array([float(img.mean()), float(img.abs().mean()), float(img.abs().max()), float(img.std())])}
+
+
+def gen_full():
+    """The BASELINE.json configurations at FULL size on the reference (SD-2.1 widths, CPU fp32), on exactly the synthetic
+    inputs bench.py feeds its workloads (`bench:*` names), so that the -m gpu tests compare bench.py's own code paths:
+      * configs[1] det512: images 3 and 7 of the batch of 8 (512x512, 4 steps)               -> full_det512.npz
+      * configs[3] seg1024tiled: one 1024x1024 image, tiled VAE encoder (256-px tiles), latent-tiled sampler (64/32),
+        untiled decoder (demo.py:96-124)                                                      -> full_seg1024.npz
+      * configs[4] det512s50: image 0, 50-step `sample` from pure noise (utils/sampler.py:206-265) -> full_s50.npz"""
+    ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
+    t0 = time.time()
+    cldm, cfg = build_reference_cldm("sd21")
+    print(f"sd21 reference built + synthetic weights in {time.time() - t0:.1f}s", flush=True)
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    c_txt = synth.synth_normal("bench:c_txt", (1, 77, 1024))
+    eps_list = []
+    hook = cldm.register_forward_hook(lambda m, i, o: eps_list.append(o.detach().clone()))
+
+    # ---- configs[1]: images 3 and 7 of the bench batch
+    GB, S, h = 8, 512, 64
+    sel = [3, 7]
+    pre = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)[sel]
+    noises = [synth.synth_normal(f"bench:noise{i}", (GB, 4, h, h))[sel] for i in range(5)]
+    out = {"images": np.array(sel)}
+    with torch.no_grad():
+        t0 = time.time()
+        z_pre = cldm.vae_encode(pre * 2 - 1, sample=False)
+        x_T = diffusion.q_sample(z_pre, torch.full((len(sel),), 200, dtype=torch.int64), noises[0])
+        sampler = SpacedSampler(diffusion.betas)
+        eps_list.clear()
+        with injected_noise(noises[1:]):
+            z = sampler.manual_sample_with_timesteps(
+                model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=len(sel),
+                cond={"c_txt": c_txt.expand(len(sel), -1, -1), "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+        img = cldm.vae_decode(z)
+        print(f"det512 x{len(sel)}: {time.time() - t0:.1f}s", flush=True)
+    out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
+    for i, e in enumerate(eps_list):
+        out[f"eps{i}"] = e.numpy()
+    np.savez_compressed(os.path.join(GOLD, "full_det512.npz"), **out)
+    print("full_det512.npz written", flush=True)
+
+    # ---- configs[4]: image 0 of the batch of 4, 50 spaced steps from pure noise
+    GB = 4
+    pre = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)[:1]
+    x_T = synth.synth_normal("bench:noise0", (GB, 4, h, h))[:1]
+    step_noise = [synth.synth_normal(f"bench:s50noise{i}", (GB, 4, h, h))[:1] for i in range(50)]
+    out = {}
+    with torch.no_grad():
+        t0 = time.time()
+        z_pre = cldm.vae_encode(pre * 2 - 1, sample=False)
+        sampler = SpacedSampler(diffusion.betas)
+        eps_list.clear()
+        with injected_noise(step_noise):
+            z, inter = sampler.sample(model=cldm, device="cpu", steps=50, batch_size=1, x_size=(4, h, h),
+                                      cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, x_T=x_T,
+                                      progress=False, return_intermediates=True)
+        img = cldm.vae_decode(z)
+        print(f"det512s50 x1: {time.time() - t0:.1f}s", flush=True)
+    out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
+    for i in (0, 9, 24, 39, 49):
+        out[f"pred_x0_{i}"] = inter[i].numpy()
+        out[f"eps{i}"] = eps_list[i].numpy()
+    np.savez_compressed(os.path.join(GOLD, "full_s50.npz"), **out)
+    print("full_s50.npz written", flush=True)
+
+    # ---- configs[3]: 1024x1024, tiled encoder / latent-tiled sampler / untiled decoder
+    S, h = 1024, 128
+    pre = synth.synth_input("bench:pre_res", (1, 3, S, S), 0.0, 1.0)
+    noises = [synth.synth_normal(f"bench:noise{i}", (1, 4, h, h)) for i in range(5)]
+    out = {}
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.time()
+        z_pre = cldm.vae_encode(pre * 2 - 1, sample=False, tiled=True, tile_size=256)
+        t_enc = time.time() - t0
+        x_T = diffusion.q_sample(z_pre, torch.full((1,), 200, dtype=torch.int64), noises[0])
+        sampler = SpacedSampler(diffusion.betas)
+        eps_list.clear()
+        with injected_noise(noises[1:]):
+            z = sampler.manual_sample_with_timesteps(
+                model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=1,
+                cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False,
+                tiled=True, tile_size=64, tile_stride=32)
+        t_smp = time.time() - t0 - t_enc
+        img = cldm.vae_decode(z)
+    print(f"seg1024tiled: enc {t_enc:.1f}s sampler {t_smp:.1f}s total {time.time() - t0:.1f}s", flush=True)
+    out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
+    hook.remove()
+    np.savez_compressed(os.path.join(GOLD, "full_seg1024.npz"), **out)
+    print("full_seg1024.npz written", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr,swinir")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr,swinir,full")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir}[name]()
+         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full}[name]()
 
 
 if __name__ == "__main__":
