@@ -31,6 +31,8 @@ if ROOT not in sys.path:
 USED_TIMESTEPS = [50, 100, 150, 200]
 PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md chip table
 FLOP_PER_IMAGE = 7.925e12  # VAE-enc 1.1167 + 4 x 1.0734 + VAE-dec 2.5145 TFLOP per 512x512 image
+# 50-step variant 57.30 TFLOP/image; tiled 1024^2 = 38.6 (9 windows x 4 steps) + 6.2 (tiled encoder) + 10.5 (untiled decoder)
+FLOP_PER_IMAGE_BY_WORKLOAD = {"det512": FLOP_PER_IMAGE, "det512s50": 57.30e12, "seg1024tiled": 55.4e12}
 
 
 def log(*a):
@@ -82,13 +84,13 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_handle = start_cpu_baseline(args.config, args.size)
 
-    from edtr_amd import synth
+    from edtr_amd import synth, workloads
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.model import ControlLDM
     from edtr_amd.model.params import skip_init
-    from edtr_amd.parallel import broadcast_parameters, shard_slice
+    from edtr_amd.parallel import broadcast_parameters
     from edtr_amd.sampler import SpacedSampler
-    from edtr_amd.testing import injected_noise, rel_err, synthetic_state_dicts
+    from edtr_amd.testing import rel_err, synthetic_state_dicts
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     cfg = synth.CONFIGS[args.config]()
@@ -96,10 +98,10 @@ def main() -> None:
     s50 = args.workload == "det512s50"
     if tiled:
         args.batch, args.size, args.inflight = 1, 1024, 1
-        args.no_cpu_baseline = args.no_roofline = True
+        args.no_cpu_baseline = True
     if s50:
         args.batch, args.size = 4, 512
-        args.no_cpu_baseline = args.no_roofline = True
+        args.no_cpu_baseline = True
     B, S = args.batch, args.size
     h = S // 8
     ctx_dim = cfg["unet_cfg"]["context_dim"]
@@ -130,34 +132,12 @@ def main() -> None:
 
     # ---- synthetic inputs for the GLOBAL batch, sliced per rank (results independent of the GPU count)
     GB = B * world
-    sl = shard_slice(rank, world, GB)
-    pre_res_g = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)
-    c_txt1 = synth.synth_normal("bench:c_txt", (1, 77, ctx_dim))
-    noises_g = [synth.synth_normal(f"bench:noise{i}", (GB, 4, h, h)) for i in range(5)]
-    pre_res = pre_res_g[sl].to(dev)
-    c_txt = c_txt1.expand(B, -1, -1).contiguous().to(dev)
-    noises = [n[sl].to(dev) for n in noises_g]
-    t200 = torch.full((B,), 200, dtype=torch.int64)   # host tensor: q_sample reads it without a device sync
-
+    inp = workloads.make_inputs(args.workload, ctx_dim, dev, B, S, rank, world)
     untiled_forward = cldm.forward
 
     def one_pass():
-        if tiled:   # the reference never restores the patched forward (sampler.py:288-303): re-arm it per pass
-            cldm.forward = untiled_forward
-            z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False, tiled=True, tile_size=256)
-        else:
-            z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
-        if s50:     # DiffBIR-style: 50 spaced steps from pure noise, fresh noise every step (torch.randn_like on the GPU)
-            z = sampler.sample(model=cldm, device=dev, steps=50, batch_size=B, x_size=(4, h, h),
-                               cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, x_T=noises[0], progress=False)
-            return cldm.vae_decode(z), z
-        x_T = diffusion.q_sample(z_pre, t200, noises[0])
-        with injected_noise(noises[1:]):
-            z = sampler.manual_sample_with_timesteps(
-                model=cldm, device=dev, x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=B,
-                cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False,
-                tiled=tiled, tile_size=64, tile_stride=32)
-        return cldm.vae_decode(z), z
+        img, z, _ = workloads.restore_pass(cldm, diffusion, sampler, inp, args.workload, untiled_forward)
+        return img, z
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,7 +197,7 @@ def main() -> None:
                                f"vae_decode, batch {B}/GPU of {S}x{S}", "global_batch": GB, "image_size": S,
                    "denoise_steps": 50 if s50 else 4, "parallelism": f"batch-sharded x{world}", "graphs": not args.no_graph,
                    "batches_in_flight": args.inflight},
-        "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE / (world * PEAK_TFLOPS * 1e12), 4) if S == 512 and args.config == "sd21" else None,
+        "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE_BY_WORKLOAD[args.workload] / (world * PEAK_TFLOPS * 1e12), 4) if args.config == "sd21" else None,
     }
 
     if rank == 0 and args.swinir:
@@ -228,7 +208,9 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         result.update(roofline_pass(cldm, args))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result.update(finish_cpu_baseline(cpu_handle, pre_res_g, c_txt1, noises_g, img.cpu(), z.cpu(), S, rel_err))
+        result.update(finish_cpu_baseline(cpu_handle, inp, img.cpu(), z.cpu(), S, rel_err, args.dtype))
+    if rank == 0 and world == 1 and args.config == "sd21":
+        result.update(golden_parity(args.workload, img, z, rel_err, args.dtype))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
@@ -267,7 +249,7 @@ def roofline_pass(cldm, args) -> dict:
     progs = []
     for key, e in cldm._cldm_engines.items():
         if key[-1] == 0:            # one buffer slot is enough: the slots run identical programs
-            progs.append((e.step_prog, 4))
+            progs.append((e.step_prog, 50 if args.workload == "det512s50" else 4))
     for key, e in cldm._vae_engines.items():
         if key[-1] == 0:
             progs.append((e.prog, 1))
@@ -351,8 +333,13 @@ def kernel_of(name: str) -> str:
     return "igemm_kernel"
 
 
+# relative-L2 tolerances of the 16-bit storage modes against the fp32 reference at full size (measured values and the error
+# budget are in DESIGN.md §5; the north-star 1e-3 is asserted for the parity mode, EDTR_AMD_PRECISION=high)
+TOLERANCE = {"bf16": {"latent": 2e-2, "image": 3e-2}, "fp16": {"latent": 3e-3, "image": 5e-3}}
+
+
 def _cpu_worker(q_in, q_out, cfg_name, S, threads):
-    """Child process: the oracle (CPU fp32 restatement pinned to the reference) on image 0 of the bench batch."""
+    """Child process: the oracle (CPU fp32 restatement pinned to the reference) on samples of the bench batch."""
     import torch as th
     th.set_num_threads(threads)
     from edtr_amd import synth as sy
@@ -362,21 +349,36 @@ def _cpu_worker(q_in, q_out, cfg_name, S, threads):
     cfg = sy.CONFIGS[cfg_name]()
     sd = flat_oracle_sd(synthetic_state_dicts(cfg))
     q_out.put(("ready", None))
-    pre_res, c_txt, noises = q_in.get()          # numpy arrays (pickled by value, no shared-memory handles)
-    pre_res, c_txt, noises = th.from_numpy(pre_res), th.from_numpy(c_txt), [th.from_numpy(n) for n in noises]
-    with th.no_grad():
-        t0 = time.perf_counter()
-        img, tr = O.restore(sd, cfg, O.make_betas(), pre_res, c_txt, noises, USED_TIMESTEPS, 200, return_trace=True)
-        dt = time.perf_counter() - t0
-    q_out.put(("done", (dt, img.numpy(), tr["z"].numpy())))
+    while True:
+        job = q_in.get()          # numpy arrays (pickled by value, no shared-memory handles); None = stop
+        if job is None:
+            return
+        pre_res, c_txt, noises = job
+        pre_res, c_txt, noises = th.from_numpy(pre_res), th.from_numpy(c_txt), [th.from_numpy(n) for n in noises]
+        with th.no_grad():
+            t0 = time.perf_counter()
+            img, tr = O.restore(sd, cfg, O.make_betas(), pre_res, c_txt, noises, USED_TIMESTEPS, 200, return_trace=True)
+            dt = time.perf_counter() - t0
+        q_out.put(("done", (dt, img.numpy(), tr["z"].numpy())))
+
+
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def start_cpu_baseline(cfg_name, S):
-    """Spawn the oracle process early: it builds its fp32 weights while the GPU side builds its own, then idles
-    until the timed GPU region is over (so neither measurement perturbs the other)."""
+    """Spawn the oracle process early (before this process touches the GPU): it builds its fp32 weights while the GPU side
+    builds its own, then idles until the timed GPU region is over (so neither measurement perturbs the other)."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
-    threads = int(os.environ.get("EDTR_CPU_THREADS", str(min(cores, 32))))
+    threads = int(os.environ.get("EDTR_CPU_THREADS", str(cores)))      # BASELINE.md §3: os.cpu_count() threads
     ctx = mp.get_context("spawn")
     q_in, q_out = ctx.Queue(), ctx.Queue()
     proc = ctx.Process(target=_cpu_worker, args=(q_in, q_out, cfg_name, S, threads), daemon=True)
@@ -384,37 +386,88 @@ def start_cpu_baseline(cfg_name, S):
     return proc, q_in, q_out, threads, cores
 
 
-def finish_cpu_baseline(handle, pre_res_g, c_txt1, noises_g, img, z, S, rel_err, budget_s=420.0) -> dict:
+def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=420.0) -> dict:
+    """CPU points of BASELINE.md §3 on a bounded sample: the FIRST and the LAST image of the batch as two B=1 runs (both also
+    give the live GPU-vs-oracle parity), then — if the B=1 runs were fast enough to leave room in the budget — the whole
+    batch as one B=8 run."""
     proc, q_in, q_out, threads, cores = handle
-    res = None
+    B = inp.pre_res.shape[0]
+    pre, ctx, noises = inp.pre_res.cpu(), inp.c_txt[:1].cpu(), [n.cpu() for n in inp.noises]
+    runs = {}
+    t_begin = time.perf_counter()
+
+    def job(sel):
+        q_in.put((pre[sel].numpy().copy(), ctx.numpy().copy(), [n[sel].numpy().copy() for n in noises]))
+        _, res = q_out.get(timeout=max(10.0, budget_s - (time.perf_counter() - t_begin)))
+        return res
+
     try:
         q_out.get(timeout=budget_s)                       # "ready"
-        q_in.put((pre_res_g[:1].numpy().copy(), c_txt1.numpy().copy(), [n[:1].numpy().copy() for n in noises_g]))
-        _, res = q_out.get(timeout=budget_s)
+        runs["first"] = (slice(0, 1), job(slice(0, 1)))
+        if B > 1:
+            runs["last"] = (slice(B - 1, B), job(slice(B - 1, B)))
+            if runs["first"][1][0] * B * 0.6 < budget_s - (time.perf_counter() - t_begin) and not os.environ.get("EDTR_CPU_NO_B8"):
+                runs["batch"] = (slice(0, B), job(slice(0, B)))
+        q_in.put(None)
     except Exception:
-        res = None
+        pass
     finally:
         if proc.is_alive():
             proc.kill()
         proc.join(timeout=10)
-    if res is None:
+    cpu = _cpu_model()
+    if "first" not in runs:
         return {"cpu_baseline": {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
-                                 "sample": f"1 image {S}x{S}, 4 steps: exceeded the {budget_s:.0f}s budget"}}
-    dt, ref_img, ref_z = res
-    ez, ei = rel_err(z[:1], ref_z), rel_err(img[:1], ref_img)
-    tol = 5e-2 if img.dtype == torch.float32 else 5e-2
-    ok = bool(ez == ez and ei == ei and ez < tol and ei < tol)          # NaN-safe
+                                 "sample": f"1 image {S}x{S}, 4 steps: exceeded the {budget_s:.0f}s budget ({cpu})"}}
+    tol = TOLERANCE[dtype_name]
+    parity, ok = {}, True
+    for name in ("first", "last"):
+        if name in runs:
+            sel, (dt, ref_img, ref_z) = runs[name]
+            ez, ei = rel_err(z[sel], ref_z), rel_err(img[sel], ref_img)
+            good = bool(ez == ez and ei == ei and ez < tol["latent"] and ei < tol["image"])          # NaN-safe
+            ok = ok and good
+            parity[f"{name}_image"] = {"index": sel.start, "rel_err_latent_vs_oracle": float(f"{ez:.3e}"),
+                                       "rel_err_image_vs_oracle": float(f"{ei:.3e}"), "ok": good}
+    if "batch" in runs:
+        sel, (dt8, ref_img, ref_z) = runs["batch"]
+        worst = max(max(rel_err(z[k:k + 1], ref_z[k:k + 1]), rel_err(img[k:k + 1], ref_img[k:k + 1])) for k in range(B))
+        parity["whole_batch_worst_image_rel_err"] = float(f"{worst:.3e}")
+        ok = ok and bool(worst == worst and worst < tol["image"])
     if not ok:
-        log(f"!!! PARITY FAILURE: GPU vs CPU oracle rel err latent {ez:.3e}, image {ei:.3e} (tolerance {tol:.0e}) — the "
-            "throughput above is NOT a valid result")
-    return {
-        "cpu_baseline": {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": threads, "kind": "port",
-                         "sample": f"1 image {S}x{S}, 4 steps, fp32 oracle on torch CPU kernels, {threads} threads "
-                                   f"of {cores} host cores ({dt:.1f} s)"},
-        "parity": {"rel_err_latent_vs_oracle": float(f"{rel_err(z[:1], ref_z):.3e}"),
-                   "rel_err_image_vs_oracle": float(f"{rel_err(img[:1], ref_img):.3e}"), "sample": "image 0 of the batch",
-                   "ok": ok, "tolerance": tol},
-    }
+        log(f"!!! PARITY FAILURE: GPU vs CPU oracle {parity} (tolerance {tol}) — the throughput above is NOT a valid result")
+    dt1 = runs["first"][1][0]
+    b1 = 1.0 / dt1
+    out = {"value": round(b1, 5), "unit": "images/s", "cores": threads, "kind": "port", "cpu_model": cpu,
+           "sample": f"B=1: image 0 of the batch, {S}x{S}, 4 steps, fp32 oracle on torch CPU kernels, {threads} threads of "
+                     f"{cores} host cores ({dt1:.1f} s)", "b1_images_per_s": round(b1, 5)}
+    if "batch" in runs:
+        dt8 = runs["batch"][1][0]
+        out["b8_images_per_s"] = round(B / dt8, 5)
+        out["value"] = round(max(b1, B / dt8), 5)
+        out["sample"] += f"; B={B}: the whole batch in one oracle call ({dt8:.1f} s); value = the faster of the two"
+    return {"cpu_baseline": out, "parity": dict(parity, ok=ok, tolerance=tol, against="CPU oracle (fp32, pinned to the reference)")}
+
+
+def golden_parity(workload, img, z, rel_err, dtype_name) -> dict:
+    """Live check of the timed workload's result against the REFERENCE's own output on the same inputs
+    (tests/golden/full_*.npz, tools/make_goldens.py gen_full): latents in full, images at stride-4 samples."""
+    name = {"det512": "full_det512.npz", "seg1024tiled": "full_seg1024.npz", "det512s50": None}[workload]
+    path = os.path.join(ROOT, "tests", "golden", name) if name else None
+    if not path or not os.path.exists(path):
+        return {}
+    g = np.load(path)
+    sel = [int(k) for k in g["images"]] if "images" in g.files else [0]
+    if max(sel) >= z.shape[0]:
+        return {}
+    zc, ic = z.cpu()[sel], img.cpu()[sel][:, :, 1::4, 2::4]
+    ez, ei = rel_err(zc, g["z"]), rel_err(ic, g["img_samples"].astype(np.float32))
+    tol = TOLERANCE[dtype_name]
+    ok = bool(ez == ez and ei == ei and ez < tol["latent"] and ei < tol["image"])
+    if not ok:
+        log(f"!!! PARITY FAILURE vs the reference golden {name}: latent {ez:.3e}, image {ei:.3e} (tolerance {tol})")
+    return {"parity_vs_reference_golden": {"fixture": f"tests/golden/{name}", "images": sel, "rel_err_latent": float(f"{ez:.3e}"),
+                                           "rel_err_image_samples": float(f"{ei:.3e}"), "ok": ok, "tolerance": tol}}
 
 
 if __name__ == "__main__":

@@ -49,6 +49,18 @@ class UNetArch:
         return out
 
 
+def control_shapes(a: UNetArch, h: int, w: int) -> List[Tuple[int, int, int]]:
+    """(channels, height, width) of the 13 control tensors / skip activations for a latent of h x w: one per input block,
+    then the middle block (reference model/controlnet.py:263-277)."""
+    out = []
+    for blk, ch in zip(a.input_blocks, a.skip_channels):
+        if any(l.kind == "down" for l in blk):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        out.append((ch, h, w))
+    out.append((a.skip_channels[-1], h, w))
+    return out
+
+
 def _check_supported(cfg: dict) -> None:
     if not cfg.get("use_spatial_transformer", False) or not cfg.get("use_linear_in_transformer", False):
         raise NotImplementedError("only the SD-2.x layout (spatial transformer with linear projections) is built")

@@ -18,6 +18,7 @@ struct alignas(16) U4 { uint32_t x, y, z, w; };
 // 16-bit storage traits: conversions + the matching MFMA.
 struct BF16 {
     using vec8 = bf16x8_t;
+    using elem = uint16_t;
     static constexpr uint32_t kOnePair = 0x3F803F80u;    // two 1.0 values
     static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
     static __device__ __forceinline__ uint16_t from_f32(float f) {
@@ -38,6 +39,7 @@ struct BF16 {
 };
 struct F16 {
     using vec8 = f16x8_t;
+    using elem = uint16_t;
     static constexpr uint32_t kOnePair = 0x3C003C00u;
     static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
     static __device__ __forceinline__ uint16_t from_f32(float f) {
@@ -54,6 +56,12 @@ struct F16 {
     static __device__ __forceinline__ f32x4 mfma16(const U4& a, const U4& b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
+};
+
+// fp32 "storage" for the elementwise kernels' high-precision (EDTR_F32_SPLIT) variants
+struct F32E {
+    using elem = float;
+    static __device__ __forceinline__ float from_f32(float f) { return f; }
 };
 
 template <typename T>

@@ -7,7 +7,7 @@ namespace {
 // NCHW fp32 -> NHWC 16-bit through an LDS transpose tile: reads are contiguous along pixels,
 // writes are contiguous along channels.  grid (ceil(HW/64), B), 256 threads.
 template <typename T>
-__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* src, int C, int64_t HW, uint16_t* dst, int ld,
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* src, int C, int64_t HW, typename T::elem* dst, int ld,
                                                           int coff, int cpad, float scale, float shift) {
     __shared__ float tile[64][65];
     const int b = blockIdx.y;
@@ -75,8 +75,67 @@ __global__ void __launch_bounds__(256) add_kernel(const uint16_t* a, int lda, co
     }
 }
 
+// fp32 a (+ b) -> fp32 out, row-strided (high-precision activation stream)
+__global__ void __launch_bounds__(256) add_f32_kernel(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
+                                                     int64_t rows, int CV4) {
+    const int64_t total = rows * CV4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / CV4;
+        const int cv = (int)(i - r * CV4);
+        f32x4 va = *reinterpret_cast<const f32x4*>(a + r * lda + cv * 4);
+        if (b) va += *reinterpret_cast<const f32x4*>(b + r * ldb + cv * 4);
+        *reinterpret_cast<f32x4*>(out + r * ldo + cv * 4) = va;
+    }
+}
+
+// [rows][C] (fp32 or 16-bit) -> bf16 [rows][3C]: hi | lo | hi (pattern 0) or hi | hi | lo (pattern 1)
+template <typename SRC>
+__global__ void __launch_bounds__(256) split3_kernel(const void* src, int64_t rows, int CV, int C, int64_t ld_src, int pattern,
+                                                    uint16_t* dst, int64_t ld_dst) {
+    const int64_t total = rows * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / CV;
+        const int cv = (int)(i - r * CV);
+        float f[8], back[8], lo[8];
+        if constexpr (sizeof(typename SRC::elem) == 4) {
+            const float* sp = static_cast<const float*>(src) + r * ld_src + cv * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[j + 4] = b[j]; }
+        } else {
+            unpack8<SRC>(ldg16(static_cast<const uint16_t*>(src) + r * ld_src + cv * 8), f);
+        }
+        const U4 hi = pack8<BF16>(f);
+        unpack8<BF16>(hi, back);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo[j] = f[j] - back[j];
+        const U4 lov = pack8<BF16>(lo);
+        uint16_t* dp = dst + r * ld_dst + cv * 8;
+        stg16(dp, hi);
+        stg16(dp + C, pattern ? hi : lov);
+        stg16(dp + 2 * C, pattern ? lov : hi);
+    }
+}
+
+// fp32 [rows][C] (row stride ld_src) -> 16-bit [rows][C] (row stride ld_dst)
 template <typename T>
-__global__ void temb_kernel(const int64_t* t, int dim, uint16_t* out, int ld) {
+__global__ void __launch_bounds__(256) cast16_kernel(const float* src, int64_t rows, int CV, int64_t ld_src, uint16_t* dst,
+                                                    int64_t ld_dst) {
+    const int64_t total = rows * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / CV;
+        const int cv = (int)(i - r * CV);
+        const float* sp = src + r * ld_src + cv * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[j + 4] = b[j]; }
+        stg16(dst + r * ld_dst + cv * 8, pack8<T>(f));
+    }
+}
+
+template <typename T>
+__global__ void temb_kernel(const int64_t* t, int dim, typename T::elem* out, int ld) {
     const int b = blockIdx.x, half = dim >> 1;
     const float tv = (float)t[b];
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
@@ -193,13 +252,16 @@ extern "C" int edtr_device_info(int* compute_units, int64_t* hbm_bytes, char* ar
 extern "C" int edtr_nchw_to_nhwc(int dtype, const float* src, int B, int C, int64_t HW, void* dst, int ld, int coff,
                                  int zero_pad_to, float scale, float shift, edtr_stream_t stream) {
     if (!src || !dst) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
     if (B <= 0 || C <= 0 || HW <= 0 || ld <= 0 || coff < 0) return EDTR_E_SHAPE;
     const int cpad = zero_pad_to > C ? zero_pad_to : C;
     if (coff + cpad > ld) return EDTR_E_SHAPE;
     dim3 grid((unsigned)((HW + 63) / 64), B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == EDTR_BF16)
+    if (dtype == EDTR_F32_SPLIT)       // high-precision mode: the NHWC activation stays fp32
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32E>, grid, dim3(256), 0, s, src, C, HW, static_cast<float*>(dst), ld, coff,
+                           cpad, scale, shift);
+    else if (dtype == EDTR_BF16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<BF16>, grid, dim3(256), 0, s, src, C, HW, static_cast<uint16_t*>(dst), ld,
                            coff, cpad, scale, shift);
     else
@@ -227,8 +289,17 @@ extern "C" int edtr_nhwc_to_nchw(int dtype, const void* src, int src_f32, int B,
 extern "C" int edtr_add(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,
                         int C, edtr_stream_t stream) {
     if (!a || !out) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
     if (rows <= 0 || C <= 0) return EDTR_E_SHAPE;
+    if (dtype == EDTR_F32_SPLIT) {     // fp32 in / out
+        if ((C & 3) || (lda & 3) || (ldo & 3) || (b && (ldb & 3)) || !aligned16(a) || (b && !aligned16(b)) || !aligned16(out))
+            return EDTR_E_ALIGN;
+        hipLaunchKernelGGL(add_f32_kernel, dim3(blocks_for(rows * (C >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const float*>(a), lda, static_cast<const float*>(b), ldb, static_cast<float*>(out), ldo,
+                           rows, C >> 2);
+        EDTR_LAUNCH_CHECK();
+        return EDTR_OK;
+    }
     if ((C & 7) || (lda & 7) || (ldo & 7) || (b && (ldb & 7)) || !aligned16(a) || (b && !aligned16(b)) || !aligned16(out))
         return EDTR_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -285,10 +356,12 @@ extern "C" int edtr_embed_tokens(int dtype, const int64_t* tokens, const float* 
 extern "C" int edtr_timestep_embedding(int dtype, const int64_t* t, int B, int dim, void* out, int ld,
                                        edtr_stream_t stream) {
     if (!t || !out) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
     if (B <= 0 || dim <= 0 || (dim & 1) || ld < dim) return EDTR_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == EDTR_BF16)
+    if (dtype == EDTR_F32_SPLIT)
+        hipLaunchKernelGGL(temb_kernel<F32E>, dim3(B), dim3(256), 0, s, t, dim, static_cast<float*>(out), ld);
+    else if (dtype == EDTR_BF16)
         hipLaunchKernelGGL(temb_kernel<BF16>, dim3(B), dim3(256), 0, s, t, dim, static_cast<uint16_t*>(out), ld);
     else
         hipLaunchKernelGGL(temb_kernel<F16>, dim3(B), dim3(256), 0, s, t, dim, static_cast<uint16_t*>(out), ld);
@@ -312,6 +385,37 @@ extern "C" int edtr_axpby(const float* x, const float* y, float a, float b, floa
     if (n <= 0) return EDTR_E_SHAPE;
     hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, a, b, out,
                        n);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_split3(int src_dtype, const void* src, int64_t rows, int C, int64_t ld_src, int pattern, void* dst,
+                           int64_t ld_dst, edtr_stream_t stream) {
+    if (!src || !dst) return EDTR_E_NULL;
+    if (src_dtype != EDTR_BF16 && src_dtype != EDTR_F16 && src_dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
+    if (rows <= 0 || C <= 0 || ld_dst < 3 * (int64_t)C || ld_src < C || (pattern != 0 && pattern != 1)) return EDTR_E_SHAPE;
+    if ((C & 7) || (ld_src & 7) || (ld_dst & 7) || !aligned16(src) || !aligned16(dst)) return EDTR_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int CV = C >> 3;
+    const unsigned blocks = blocks_for(rows * CV);
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    if (src_dtype == EDTR_F32_SPLIT) hipLaunchKernelGGL(split3_kernel<F32E>, dim3(blocks), dim3(256), 0, s, src, rows, CV, C, ld_src, pattern, d, ld_dst);
+    else if (src_dtype == EDTR_BF16) hipLaunchKernelGGL(split3_kernel<BF16>, dim3(blocks), dim3(256), 0, s, src, rows, CV, C, ld_src, pattern, d, ld_dst);
+    else hipLaunchKernelGGL(split3_kernel<F16>, dim3(blocks), dim3(256), 0, s, src, rows, CV, C, ld_src, pattern, d, ld_dst);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_cast16(int dst_dtype, const float* src, int64_t rows, int C, int64_t ld_src, void* dst, int64_t ld_dst,
+                           edtr_stream_t stream) {
+    if (!src || !dst) return EDTR_E_NULL;
+    if (dst_dtype != EDTR_BF16 && dst_dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (rows <= 0 || C <= 0 || ld_src < C || ld_dst < C) return EDTR_E_SHAPE;
+    if ((C & 7) || (ld_src & 3) || (ld_dst & 7) || !aligned16(src) || !aligned16(dst)) return EDTR_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int CV = C >> 3;
+    if (dst_dtype == EDTR_BF16) hipLaunchKernelGGL(cast16_kernel<BF16>, dim3(blocks_for(rows * CV)), dim3(256), 0, s, src, rows, CV, ld_src, static_cast<uint16_t*>(dst), ld_dst);
+    else hipLaunchKernelGGL(cast16_kernel<F16>, dim3(blocks_for(rows * CV)), dim3(256), 0, s, src, rows, CV, ld_src, static_cast<uint16_t*>(dst), ld_dst);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

@@ -5,6 +5,38 @@
 
 namespace {
 
+// Storage traits of the normalisation kernels.  IO16<T>: 16-bit in, 16-bit out (the throughput modes).  IOF32S: the
+// high-precision mode (EDTR_F32_SPLIT) — the activation stream is fp32 and the normalised tensor is written as the bf16
+// "split-3" GEMM operand  [hi | lo | hi]  (3*C columns: hi = bf16(x), lo = bf16(x - hi)), which the implicit GEMM
+// multiplies with weights packed [Wh | Wh | Wl]:  hi*Wh + lo*Wh + hi*Wl = x*W to ~16 mantissa bits with fp32 accumulation.
+template <typename T>
+struct IO16 {
+    using in_t = uint16_t;
+    using out_t = uint16_t;
+    static __device__ __forceinline__ void load8(const in_t* p, float (&f)[8]) { unpack8<T>(ldg16(p), f); }
+    static __device__ __forceinline__ void store8(out_t* p, int, const float (&f)[8]) { stg16(p, pack8<T>(f)); }
+};
+struct IOF32S {
+    using in_t = float;
+    using out_t = uint16_t;
+    static __device__ __forceinline__ void load8(const in_t* p, float (&f)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[j + 4] = b[j]; }
+    }
+    static __device__ __forceinline__ void store8(out_t* p, int C, const float (&f)[8]) {
+        float lo[8];
+        const U4 hi = pack8<BF16>(f);
+        float back[8];
+        unpack8<BF16>(hi, back);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo[j] = f[j] - back[j];
+        stg16(p, hi);
+        stg16(p + C, pack8<BF16>(lo));
+        stg16(p + 2 * C, hi);
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // GroupNorm statistics.  grid (pixel chunks <= 64 per image, B); block = CV * R threads (CV = C/8 channel
 // vectors, R pixel rows in flight).  Each thread accumulates 8 channel sums / squares over its pixels in
@@ -12,8 +44,9 @@ namespace {
 // groups by 32 threads, and each workgroup issues ONE fp64 atomic pair per group (<= 64 arrivals per
 // address per image, so the atomics never become the bottleneck).
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename IO>
 __global__ void gn_stats_kernel(const edtr_gn_params p, int CV, int R, int ppb) {
+    using in_t = typename IO::in_t;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);   // [2][R][C]
     const int tid = threadIdx.x;
@@ -22,7 +55,7 @@ __global__ void gn_stats_kernel(const edtr_gn_params p, int CV, int R, int ppb) 
     const int cpg = C / p.groups;
     const int64_t pix0 = (int64_t)blockIdx.x * ppb;
     const int npix = (int)min((int64_t)ppb, (int64_t)p.HW - pix0);
-    const uint16_t* xb = static_cast<const uint16_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx;
+    const in_t* xb = static_cast<const in_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx;
     const int nslots = (CV + blockDim.x - 1) / blockDim.x;  // > 1 only when CV > blockDim (then R == 1)
     for (int slot = 0; slot < nslots; ++slot) {
         const int cv = R > 1 ? tid % CV : tid + slot * (int)blockDim.x;
@@ -31,23 +64,21 @@ __global__ void gn_stats_kernel(const edtr_gn_params p, int CV, int R, int ppb) 
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-        const uint16_t* xp = xb + cv * 8;
+        const in_t* xp = xb + cv * 8;
         int pi = r;
         for (; pi + 3 * R < npix; pi += 4 * R) {
-            U4 v[4];
+            float fv[4][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ldg16(xp + (int64_t)(pi + u * R) * p.ldx);
+            for (int u = 0; u < 4; ++u) IO::load8(xp + (int64_t)(pi + u * R) * p.ldx, fv[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                float f[8];
-                unpack8<T>(v[u], f);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+                for (int j = 0; j < 8; ++j) { s[j] += fv[u][j]; q[j] += fv[u][j] * fv[u][j]; }
             }
         }
         for (; pi < npix; pi += R) {
             float f[8];
-            unpack8<T>(ldg16(xp + (int64_t)pi * p.ldx), f);
+            IO::load8(xp + (int64_t)pi * p.ldx, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
         }
@@ -82,8 +113,10 @@ __global__ void gn_stats_kernel(const edtr_gn_params p, int CV, int R, int ppb) 
 // ------------------------------------------------------------------------------------------
 constexpr int GN_CC = 256;  // channels per workgroup in the apply kernel
 
-template <typename T>
+template <typename IO>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, int ppb) {
+    using in_t = typename IO::in_t;
+    using out_t = typename IO::out_t;
     __shared__ __attribute__((aligned(16))) float sc[GN_CC];
     __shared__ __attribute__((aligned(16))) float sh[GN_CC];
     const int tid = threadIdx.x, b = blockIdx.z;
@@ -105,24 +138,23 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
     const int ncv = cc >> 3;
     const int64_t pix0 = (int64_t)blockIdx.x * ppb;
     const int npix = (int)min((int64_t)ppb, (int64_t)p.HW - pix0);
-    const uint16_t* xb = static_cast<const uint16_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx + c0;
-    uint16_t* yb = static_cast<uint16_t*>(p.y) + ((int64_t)b * p.HW + pix0) * p.ldy + c0;
+    const in_t* xb = static_cast<const in_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx + c0;
+    out_t* yb = static_cast<out_t*>(p.y) + ((int64_t)b * p.HW + pix0) * p.ldy + c0;
     const int total = npix * ncv;
     for (int i0 = tid; i0 < total; i0 += 4 * 256) {
-        U4 v[4];
+        float fv[4][8];
         int pi[4], cv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * 256;
             pi[u] = i / ncv;
             cv[u] = i - pi[u] * ncv;
-            if (i < total) v[u] = ldg16(xb + (int64_t)pi[u] * p.ldx + cv[u] * 8);
+            if (i < total) IO::load8(xb + (int64_t)pi[u] * p.ldx + cv[u] * 8, fv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (i0 + u * 256 >= total) continue;
-            float f[8];
-            unpack8<T>(v[u], f);
+            float (&f)[8] = fv[u];
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + cv[u] * 8), a1 = *reinterpret_cast<const f32x4*>(sc + cv[u] * 8 + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh + cv[u] * 8), b1 = *reinterpret_cast<const f32x4*>(sh + cv[u] * 8 + 4);
 #pragma unroll
@@ -134,7 +166,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
             }
-            stg16(yb + (int64_t)pi[u] * p.ldy + cv[u] * 8, pack8<T>(f));
+            IO::store8(yb + (int64_t)pi[u] * p.ldy + cv[u] * 8, p.C, f);
         }
     }
 }
@@ -144,10 +176,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
 // mean / variance by wavefront shuffles.
 // ------------------------------------------------------------------------------------------
 // PADDED: only the first c_valid (< C) columns are real; the rest are excluded from the statistics and written as zeros.
-template <typename T, bool PADDED>
-__global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* x, int64_t rows, int C, int c_valid, int ldx,
+template <typename IO, bool PADDED>
+__global__ void __launch_bounds__(256) layernorm_kernel(const typename IO::in_t* x, int64_t rows, int C, int c_valid, int ldx,
                                                        const float* gamma, const float* beta, float eps,
-                                                       uint16_t* y, int ldy) {
+                                                       typename IO::out_t* y, int ldy) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -159,7 +191,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* x, int64
     for (int s = 0; s < 4; ++s) {
         const int cv = lane + 64 * s;
         if (cv < CV) {
-            unpack8<T>(ldg16(x + row * ldx + cv * 8), f[s]);
+            IO::load8(x + row * ldx + cv * 8, f[s]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (PADDED && cv * 8 + j >= c_valid) f[s][j] = 0.0f;
@@ -191,7 +223,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* x, int64
                 o[j] = (f[s][j] - mean) * rstd * gamma[cv * 8 + j] + beta[cv * 8 + j];
                 if (PADDED && cv * 8 + j >= c_valid) o[j] = 0.0f;
             }
-            stg16(y + row * ldy + cv * 8, pack8<T>(o));
+            IO::store8(y + row * ldy + cv * 8, C, o);
         }
     }
 }
@@ -237,7 +269,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* s, int c
 int check_gn(const edtr_gn_params& p, bool apply) {
     if (!p.x || !p.sums) return EDTR_E_NULL;
     if (apply && (!p.y || !p.gamma || !p.beta)) return EDTR_E_NULL;
-    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16 && p.dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
     if (p.B <= 0 || p.HW <= 0 || p.C <= 0 || p.groups <= 0 || p.groups > 64) return EDTR_E_SHAPE;
     if (p.C % p.groups) return EDTR_E_SHAPE;
     if ((p.C & 7) || (p.ldx & 7) || (apply && (p.ldy & 7))) return EDTR_E_ALIGN;
@@ -276,9 +308,11 @@ extern "C" int edtr_gn_stats(const edtr_gn_params* pp, edtr_stream_t stream) {
     dim3 grid((unsigned)((p.HW + ppb - 1) / ppb), p.B);
     const size_t lds = sizeof(float) * 2 * R * p.C;
     if (p.dtype == EDTR_BF16)
-        hipLaunchKernelGGL(gn_stats_kernel<BF16>, grid, dim3(threads), lds, s, p, CV, R, ppb);
+        hipLaunchKernelGGL(gn_stats_kernel<IO16<BF16>>, grid, dim3(threads), lds, s, p, CV, R, ppb);
+    else if (p.dtype == EDTR_F16)
+        hipLaunchKernelGGL(gn_stats_kernel<IO16<F16>>, grid, dim3(threads), lds, s, p, CV, R, ppb);
     else
-        hipLaunchKernelGGL(gn_stats_kernel<F16>, grid, dim3(threads), lds, s, p, CV, R, ppb);
+        hipLaunchKernelGGL(gn_stats_kernel<IOF32S>, grid, dim3(threads), lds, s, p, CV, R, ppb);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }
@@ -297,9 +331,11 @@ extern "C" int edtr_gn_apply(const edtr_gn_params* pp, edtr_stream_t stream) {
     if (ppb > 256) ppb = 256;
     dim3 grid((unsigned)((p.HW + ppb - 1) / ppb), nchunk_c, p.B);
     if (p.dtype == EDTR_BF16)
-        hipLaunchKernelGGL(gn_apply_kernel<BF16>, grid, dim3(256), 0, s, p, (int)ppb);
+        hipLaunchKernelGGL(gn_apply_kernel<IO16<BF16>>, grid, dim3(256), 0, s, p, (int)ppb);
+    else if (p.dtype == EDTR_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<IO16<F16>>, grid, dim3(256), 0, s, p, (int)ppb);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<F16>, grid, dim3(256), 0, s, p, (int)ppb);
+        hipLaunchKernelGGL(gn_apply_kernel<IOF32S>, grid, dim3(256), 0, s, p, (int)ppb);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }
@@ -342,7 +378,7 @@ extern "C" int edtr_gn_pool(double* sums, const float* weights, const float* cou
 extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int c_valid, int ldx, const float* gamma,
                               const float* beta, float eps, void* y, int ldy, edtr_stream_t stream) {
     if (!x || !y || !gamma || !beta) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
     if (rows <= 0 || C <= 0 || c_valid < 0 || c_valid > C) return EDTR_E_SHAPE;
     if (C > 2048) return EDTR_E_UNSUPPORTED;
     if ((C & 7) || (ldx & 7) || (ldy & 7) || !aligned16(x) || !aligned16(y)) return EDTR_E_ALIGN;
@@ -351,12 +387,15 @@ extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int
     dim3 grid((unsigned)((rows + 3) / 4));
     const uint16_t* xp = static_cast<const uint16_t*>(x);
     uint16_t* yp = static_cast<uint16_t*>(y);
-    if (dtype == EDTR_BF16) {
-        if (c_valid == C) hipLaunchKernelGGL((layernorm_kernel<BF16, false>), grid, dim3(256), 0, s, xp, rows, C, C, ldx, gamma, beta, eps, yp, ldy);
-        else hipLaunchKernelGGL((layernorm_kernel<BF16, true>), grid, dim3(256), 0, s, xp, rows, C, c_valid, ldx, gamma, beta, eps, yp, ldy);
+    if (dtype == EDTR_F32_SPLIT) {       // fp32 rows in, bf16 [hi | lo | hi] GEMM operand out (3*C columns)
+        if (c_valid != C) return EDTR_E_UNSUPPORTED;
+        hipLaunchKernelGGL((layernorm_kernel<IOF32S, false>), grid, dim3(256), 0, s, static_cast<const float*>(x), rows, C, C, ldx, gamma, beta, eps, yp, ldy);
+    } else if (dtype == EDTR_BF16) {
+        if (c_valid == C) hipLaunchKernelGGL((layernorm_kernel<IO16<BF16>, false>), grid, dim3(256), 0, s, xp, rows, C, C, ldx, gamma, beta, eps, yp, ldy);
+        else hipLaunchKernelGGL((layernorm_kernel<IO16<BF16>, true>), grid, dim3(256), 0, s, xp, rows, C, c_valid, ldx, gamma, beta, eps, yp, ldy);
     } else {
-        if (c_valid == C) hipLaunchKernelGGL((layernorm_kernel<F16, false>), grid, dim3(256), 0, s, xp, rows, C, C, ldx, gamma, beta, eps, yp, ldy);
-        else hipLaunchKernelGGL((layernorm_kernel<F16, true>), grid, dim3(256), 0, s, xp, rows, C, c_valid, ldx, gamma, beta, eps, yp, ldy);
+        if (c_valid == C) hipLaunchKernelGGL((layernorm_kernel<IO16<F16>, false>), grid, dim3(256), 0, s, xp, rows, C, C, ldx, gamma, beta, eps, yp, ldy);
+        else hipLaunchKernelGGL((layernorm_kernel<IO16<F16>, true>), grid, dim3(256), 0, s, xp, rows, C, c_valid, ldx, gamma, beta, eps, yp, ldy);
     }
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;

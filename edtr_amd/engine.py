@@ -130,7 +130,9 @@ class WeightStore:
     """fp32 parameters (reference names/shapes) -> device-resident packed 16-bit matrices + fp32 vectors.
     Packs lazily, caches per (kind, names); ``invalidate()`` after the parameters change."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], dtype: torch.dtype, device: torch.device):
+    def __init__(self, params: Dict[str, torch.Tensor], dtype, device: torch.device):
+        """``dtype``: torch.bfloat16 / torch.float16, or ops.F32S for the high-precision mode (bf16 matrices whose K axis is
+        the split [hi | hi | lo], three times as wide; see include/edtr_hip.h EDTR_F32_SPLIT)."""
         self.params, self.dtype, self.device = params, dtype, device
         self.cache: Dict[tuple, object] = {}
 
@@ -321,10 +323,21 @@ class Program:
 # ----------------------------------------------------------------------------------------------
 # activations + primitive emitters
 # ----------------------------------------------------------------------------------------------
+class Op3:
+    """High-precision GEMM operand: bf16 ``t3`` [rows, 3*C] = [hi | lo | hi] of an fp32 [rows, C] activation."""
+
+    def __init__(self, t3: torch.Tensor, C: int):
+        self.t3, self.C = t3, C
+
+    def stride(self, dim: int) -> int:
+        return self.t3.stride(dim)
+
+
 @dataclass
 class Act:
-    """NHWC activation: ``t`` is a 2-D view [B*H*W, C] (row stride ``ld`` >= C) of 16-bit storage."""
-    t: torch.Tensor
+    """NHWC activation: ``t`` is a 2-D view [B*H*W, C] (row stride ``ld`` >= C) of 16-bit storage — fp32 storage, or an Op3
+    (the output of a normalisation, which only ever feeds a GEMM) in the high-precision mode."""
+    t: object
     B: int
     H: int
     W: int
@@ -341,31 +354,73 @@ class Act:
 
 
 class Emitter:
-    def __init__(self, prog: Program, arena: Arena, store: WeightStore, dtype: torch.dtype):
-        self.prog, self.arena, self.store, self.dtype = prog, arena, store, dtype
+    """Primitive emitters.  ``precision="high"`` selects the parity mode: fp32 activation stream, every GEMM / convolution
+    as a bf16 split-3 product (3x the K, fp32 out), residual adds as fp32 launches, attention operands in fp16."""
+
+    def __init__(self, prog: Program, arena: Arena, store: WeightStore, dtype: torch.dtype, precision: str = "fast"):
+        self.prog, self.arena, self.store = prog, arena, store
+        self.hp = precision == "high"
+        if self.hp != (store.dtype == ops.F32S):
+            raise ValueError("the weight store and the emitter must agree on the precision mode")
+        self.dtype = torch.bfloat16 if self.hp else dtype          # MFMA operand type of edtr_igemm
+        self.attn_dtype = torch.float16 if self.hp else dtype      # q / k / v^T / P of the attention kernels
+        self.act_dtype = torch.float32 if self.hp else dtype       # storage of the activation stream
+        self.io = ops.F32S if self.hp else dtype                    # dtype code of the norm / layout / elementwise launches
+        self.last_gnp = None
 
     # -- memory
     def new(self, rows: int, cols: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        return self.arena.alloc((rows, cols), dtype or self.dtype)
+        return self.arena.alloc((rows, cols), dtype or self.act_dtype)
 
     def free(self, *ts) -> None:
         for t in ts:
             if isinstance(t, Act):
                 self.arena.free(t.gnp)
                 t = t.t
+            if isinstance(t, Op3):
+                t = t.t3
             self.arena.free(t)
 
+    # -- high-precision operands ------------------------------------------------------------------
+    def _operand(self, a, rows: int, C: int, pattern: int = 0):
+        """(bf16 [rows, 3C] operand, temporary to free or None) of an fp32 / fp16 activation or of a ready Op3."""
+        if isinstance(a, Op3):
+            if a.C != C or pattern != 0:
+                raise ValueError("Op3 operand does not match the GEMM")
+            return a.t3, None
+        t3 = self.arena.alloc((rows, 3 * C), torch.bfloat16)
+        self.prog.add(ops.make_split3(src=a, rows=rows, C=C, dst=t3, pattern=pattern))
+        return t3, t3
+
+    def to16(self, x: torch.Tensor, rows: int, C: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """High-precision mode: a 16-bit copy (attention operand) of an fp32 [rows, C] view."""
+        y = self.arena.alloc((rows, C), dtype or self.attn_dtype)
+        self.prog.add(ops.make_cast16(dtype=dtype or self.attn_dtype, src=x, rows=rows, C=C, dst=y))
+        return y
+
     # -- GEMM family ------------------------------------------------------------------------
-    def gemm(self, a: torch.Tensor, w: torch.Tensor, M: int, N: int, K: int, *, bias=None, out=None, act=0,
+    def gemm(self, a, w: torch.Tensor, M: int, N: int, K: int, *, bias=None, out=None, act=0,
              residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,
              **kw) -> torch.Tensor:
         """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld)."""
         n_out = N // 2 if act == L.ACT_GEGLU else N
+        self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
+        if self.hp:
+            if out is None:
+                out = self.new(M, n_out, torch.float32)
+            a3, tmp = self._operand(a, M, K)
+            self.prog.add(ops.make_igemm(
+                dtype=self.dtype, a1=a3, w=w, out=out, M=M, N=N, C1=3 * K, ld1=a3.stride(0), ldw=w.stride(0),
+                ldc=out.stride(0), bias_n=bias, act=act, rowvec=rowvec, rowvec_ld=rowvec.stride(0) if rowvec is not None else 0,
+                rows_per_image=rows_per_image, out_f32=True, alpha=alpha, name=name, **kw))
+            self.arena.free(tmp)
+            if residual is not None:
+                self.add(out, residual, M, n_out, out=out)
+            return out
         if out is None:
             out = self.new(M, n_out, torch.float32 if out_f32 else None)
         tile, splitk = ops.choose_splitk(M, N, K, kw.get("Z", 1), act) if "tile" not in kw else (kw.pop("tile"), 1)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
-        self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
         if (stats_hw and act == 0 and not out_f32 and out.stride(0) == N and "Z" not in kw
                 and ops.gn_fusable(M, N, K, stats_hw, splitk=splitk)):
             self.last_gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
@@ -392,10 +447,23 @@ class Emitter:
         else:
             OH, OW, spatial = x.H, x.W, None
         M = x.B * OH * OW
-        if out is None:
-            out = self.new(M, N, torch.float32 if out_f32 else None)
         if alpha != 1.0:
             bias = bias * alpha  # epilogue applies alpha before the bias
+        if self.hp:
+            if out is None:
+                out = self.new(M, N, torch.float32)
+            a3, tmp = self._operand(x.t, x.rows, x.C)
+            self.prog.add(ops.make_igemm(
+                dtype=self.dtype, a1=a3, w=w, out=out, taps=taps, M=M, N=N, C1=3 * x.C, ld1=a3.stride(0), ldw=w.stride(0),
+                ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
+                rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, out_f32=True, alpha=alpha,
+                name=name or ("conv3x3" if taps == 9 else "conv1x1")))
+            self.arena.free(tmp)
+            if residual is not None:
+                self.add(out, residual, M, N, out=out)
+            return Act(out, x.B, OH, OW, N, None)
+        if out is None:
+            out = self.new(M, N, torch.float32 if out_f32 else None)
         tile, splitk = ops.choose_splitk(M, N, taps * x.C)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
@@ -417,11 +485,22 @@ class Emitter:
         c_real = self.store.params[prefix + "weight"].numel()
         if c_real != x.C:
             raise ValueError(f"GroupNorm {prefix}: activation has {x.C} channels, parameter has {c_real}")
-        return ops.make_gn(dtype=self.dtype, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C, sums=sums, gamma=gamma,
+        return ops.make_gn(dtype=self.io, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C, sums=sums, gamma=gamma,
                            beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed)
 
+    def _gn_out(self, x: Act):
+        """(buffer the apply launch writes, what the Act carries): high-precision mode = the split-3 operand itself."""
+        if self.hp:
+            y3 = self.arena.alloc((x.rows, 3 * x.C), torch.bfloat16)
+            return y3, Op3(y3, x.C)
+        y = self.new(x.rows, x.C)
+        return y, y
+
     def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None) -> Act:
-        y = out if out is not None else self.new(x.rows, x.C)
+        if out is not None:
+            y, carried = out, out
+        else:
+            y, carried = self._gn_out(x)
         if x.gnp is not None:    # the producer's epilogue already reduced this tensor per 128-row tile
             sums = self.arena.alloc((x.B, 32, 2), torch.float64)
             _, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
@@ -433,12 +512,12 @@ class Emitter:
         self.prog.add(ap)
         if x.gnp is not None:
             self.arena.free(sums)
-        return Act(y, x.B, x.H, x.W, x.C)
+        return Act(carried, x.B, x.H, x.W, x.C)
 
     def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor):
         """Statistics half only (tiled VAE: the caller pools `sums` across tiles before the apply half).
         Returns a closure that emits the apply half and yields the normalised activation."""
-        y = self.new(x.rows, x.C)
+        y, carried = self._gn_out(x)
         st, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
         if x.gnp is not None:
             st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
@@ -446,27 +525,31 @@ class Emitter:
 
         def apply() -> Act:
             self.prog.add(ap)
-            return Act(y, x.B, x.H, x.W, x.C)
+            return Act(carried, x.B, x.H, x.W, x.C)
         return apply
 
-    def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str) -> torch.Tensor:
-        y = self.new(rows, C)
-        self.prog.add(ops.make_layernorm(dtype=self.dtype, x=x, rows=rows, C=C, ldx=x.stride(0),
+    def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str):
+        if self.hp:
+            y3 = self.arena.alloc((rows, 3 * C), torch.bfloat16)
+            y, carried = y3, Op3(y3, C)
+        else:
+            y = carried = self.new(rows, C)
+        self.prog.add(ops.make_layernorm(dtype=self.io, x=x, rows=rows, C=C, ldx=x.stride(0),
                                          gamma=self.store.vec(prefix + "weight"), beta=self.store.vec(prefix + "bias"),
-                                         eps=1e-5, y=y, ldy=C))
-        return y
+                                         eps=1e-5, y=y, ldy=y.stride(0)))
+        return carried
 
     # -- elementwise --------------------------------------------------------------------------
     def add(self, a: torch.Tensor, b: Optional[torch.Tensor], rows: int, C: int, out=None) -> torch.Tensor:
         if out is None:
             out = self.new(rows, C)
-        self.prog.add(ops.make_add(dtype=self.dtype, a=a, lda=a.stride(0), b=b, ldb=b.stride(0) if b is not None else 0,
+        self.prog.add(ops.make_add(dtype=self.io, a=a, lda=a.stride(0), b=b, ldb=b.stride(0) if b is not None else 0,
                                    out=out, ldo=out.stride(0), rows=rows, C=C))
         return out
 
     def to_nhwc(self, src: torch.Tensor, B: int, C: int, HW: int, dst: torch.Tensor, coff=0, pad_to=0, scale=1.0,
                 shift=0.0) -> None:
-        self.prog.add(ops.make_nchw_to_nhwc(dtype=self.dtype, src=src, B=B, C=C, HW=HW, dst=dst, ld=dst.stride(0),
+        self.prog.add(ops.make_nchw_to_nhwc(dtype=self.io, src=src, B=B, C=C, HW=HW, dst=dst, ld=dst.stride(0),
                                             coff=coff, zero_pad_to=pad_to, scale=scale, shift=shift))
 
     def to_nchw(self, src: torch.Tensor, B: int, C: int, HW: int, dst: torch.Tensor, scale=1.0) -> None:
@@ -474,29 +557,54 @@ class Emitter:
                                             HW=HW, ld=src.stride(0), dst=dst, scale=scale))
 
     def cast_flat(self, src_f32: torch.Tensor, n: int) -> torch.Tensor:
-        """fp32 -> 16-bit cast of n contiguous elements (inputs such as c_txt)."""
+        """fp32 -> 16-bit cast of n contiguous elements (inputs such as c_txt); the high-precision mode keeps fp32."""
+        if self.hp:
+            return src_f32.reshape(n, 1)
         dst = self.new(n, 1)
         self.prog.add(ops.make_nchw_to_nhwc(dtype=self.dtype, src=src_f32, B=1, C=1, HW=n, dst=dst, ld=1, name="cast16"))
         return dst
 
     # -- attention ------------------------------------------------------------------------------
     def flash(self, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B, H, Nq, Nk, k_bs, vt_bs, vt_ld,
-              out=None, causal: bool = False) -> torch.Tensor:
+              out=None, causal: bool = False, prescaled: bool = False) -> torch.Tensor:
         C = H * 64
+        tmp = []
+        if self.hp:      # fp32 projections -> fp16 operands (k / v^T of the context arrive already cast)
+            if q.dtype == torch.float32:
+                q = self.to16(q, B * Nq, C)
+                tmp.append(q)
+            if k.dtype == torch.float32:
+                k = self.to16(k, B * Nk, C)
+                tmp.append(k)
+                k_bs = Nk * C
+            if vt.dtype == torch.float32:
+                vt = self.to16(vt, B * C, vt_ld)
+                tmp.append(vt)
+                vt_bs = C * vt_ld
         if out is None:
-            out = self.new(B * Nq, C)
-        self.prog.add(ops.make_flash_attn(dtype=self.dtype, q=q, k=k, vt=vt, out=out, B=B, H=H, Nq=Nq, Nk=Nk,
+            out = self.arena.alloc((B * Nq, C), self.attn_dtype)
+        self.prog.add(ops.make_flash_attn(dtype=self.attn_dtype, q=q, k=k, vt=vt, out=out, B=B, H=H, Nq=Nq, Nk=Nk,
                                           q_bs=Nq * q.stride(0), q_ld=q.stride(0), k_bs=k_bs, k_ld=k.stride(0),
                                           vt_bs=vt_bs, vt_ld=vt_ld, o_bs=Nq * out.stride(0), o_ld=out.stride(0),
-                                          scale=1.0 / math.sqrt(64.0), causal=causal))
+                                          scale=1.0 / math.sqrt(64.0), causal=causal, prescaled=prescaled))
+        self.free(*tmp)
         return out
 
-    def vt_gemm(self, wv: torch.Tensor, x: torch.Tensor, *, B, Ntok, Cin, bias_m=None, name="v_transposed") -> Tuple[torch.Tensor, int]:
+    def vt_gemm(self, wv: torch.Tensor, x, *, B, Ntok, Cin, bias_m=None, name="v_transposed", alpha=1.0) -> Tuple[torch.Tensor, int]:
         """V^T[b] = Wv @ x[b]^T  ->  [B, Cout, roundup8(Ntok)] (padding keys exactly zero when bias_m is None)."""
         Cout = wv.shape[0]
         ldv = round_up(Ntok, 8)
+        if self.hp:      # A = [Wh | Wh | Wl] (the packed weight), B operand = x as [hi | lo | hi]: wh*xh + wh*xl + wl*xh
+            vt = self.arena.alloc((B * Cout, ldv), torch.float32)
+            x3, tmp = self._operand(x, B * Ntok, Cin)
+            self.prog.add(ops.make_igemm(dtype=self.dtype, a1=wv, w=x3, out=vt, M=Cout, N=ldv, n_valid=Ntok, C1=3 * Cin,
+                                         ld1=wv.stride(0), ldw=x3.stride(0), ldc=ldv, Z=B, a_zs=(0, 0),
+                                         w_zs=(Ntok * x3.stride(0), 0), o_zs=(Cout * ldv, 0), bias_m=bias_m, out_f32=True,
+                                         alpha=alpha, name=name))
+            self.arena.free(tmp)
+            return vt, ldv
         vt = self.arena.alloc((B * Cout, ldv), self.dtype)
         self.prog.add(ops.make_igemm(dtype=self.dtype, a1=wv, w=x, out=vt, M=Cout, N=ldv, n_valid=Ntok, C1=Cin,
                                      ld1=wv.stride(0), ldw=x.stride(0), ldc=ldv, Z=B, a_zs=(0, 0),
-                                     w_zs=(Ntok * x.stride(0), 0), o_zs=(Cout * ldv, 0), bias_m=bias_m, name=name))
+                                     w_zs=(Ntok * x.stride(0), 0), o_zs=(Cout * ldv, 0), bias_m=bias_m, alpha=alpha, name=name))
         return vt, ldv

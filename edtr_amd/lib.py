@@ -9,13 +9,13 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
 
-BF16, F16 = 0, 1
+BF16, F16, F32_SPLIT = 0, 1, 2
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3, 4
 
 DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
     "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
-    "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample",
+    "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample", "edtr_split3", "edtr_cast16",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle",
 ]
@@ -55,6 +55,7 @@ class AttnParams(C.Structure):
         ("out", C.c_void_p), ("o_bs", C.c_int64), ("o_ld", C.c_int32),
         ("scale", C.c_float),
         ("causal", C.c_int32),
+        ("q_prescaled", C.c_int32),
     ]
 
 
@@ -116,6 +117,8 @@ def load() -> C.CDLL:
     lib.edtr_sampler_update.argtypes = [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]
     lib.edtr_axpby.argtypes = [vp, vp, f32, f32, vp, i64, vp]
     lib.edtr_q_sample.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
+    lib.edtr_split3.argtypes = [i32, vp, i64, i32, i64, i32, vp, i64, vp]
+    lib.edtr_cast16.argtypes = [i32, vp, i64, i32, i64, vp, i64, vp]
     lib.edtr_tile_accumulate.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.edtr_divide.argtypes = [vp, vp, vp, i64, vp]
     lib.edtr_wavelet_level.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]

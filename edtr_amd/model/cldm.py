@@ -7,7 +7,7 @@ There is no CPU / PyTorch-operator fallback: calling a forward on a CPU-resident
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Set, Tuple
+from typing import Dict, List, Optional, Set, Tuple
 
 import torch
 from torch import nn
@@ -23,6 +23,20 @@ _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.flo
 
 def default_compute_dtype() -> torch.dtype:
     return _DTYPES[os.environ.get("EDTR_AMD_DTYPE", "bf16").lower()]
+
+
+def default_precision() -> str:
+    """"fast": 16-bit activation storage in `compute_dtype` (the throughput modes).  "high": the parity mode — fp32
+    activation stream, every convolution / linear as a bf16 split-3 product with fp32 accumulation (~16 mantissa bits per
+    operand), fp16 attention operands; `compute_dtype` is ignored.  EDTR_AMD_PRECISION selects the default."""
+    p = os.environ.get("EDTR_AMD_PRECISION", "fast").lower()
+    if p not in ("fast", "high"):
+        raise ValueError(f"EDTR_AMD_PRECISION must be 'fast' or 'high', got {p!r}")
+    return p
+
+
+def _store_dtype(precision: str, compute_dtype):
+    return ops_mod.F32S if precision == "high" else compute_dtype
 
 
 def _require_gpu(t: torch.Tensor, what: str) -> None:
@@ -42,8 +56,39 @@ def disabled_train(self: nn.Module, mode: bool = True) -> nn.Module:
 # ----------------------------------------------------------------------------------------------
 # parameter-holding modules (reference class names; forward() of the parts is not on the hot path)
 # ----------------------------------------------------------------------------------------------
-class ControlledUnetModel(ParamTree):
+class _NetPart(ParamTree):
+    """A ControlNet / ControlledUnetModel parameter tree that can also run on its own (the reference calls the two nets
+    as separate modules, model/cldm.py:169-193; ControlLDM.forward here fuses them into one program and does not come
+    through these forwards).  The standalone programs re-project the context every call: they exist for API parity and
+    for checking the 13 control tensors, not for speed."""
+
+    _prefix = ""
+
+    def _init_part(self) -> None:
+        self.compute_dtype = default_compute_dtype()
+        self.precision = default_precision()
+        self._part_store = None
+        self._part_fp = None
+        self._part_engines = EngineCache(lambda e: e.prog.release_graph())
+
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def _store(self) -> WeightStore:
+        fp = (params_fingerprint(self), self.compute_dtype, self.precision)
+        if fp != self._part_fp:
+            self._part_engines.drop_all()
+            self._part_store, self._part_fp = None, fp
+        if self._part_store is None:
+            self._part_store = WeightStore(self.flat_params(self._prefix), _store_dtype(self.precision, self.compute_dtype),
+                                           self._device())
+        return self._part_store
+
+
+class ControlledUnetModel(_NetPart):
     """Parameters of reference model/controlnet.py:18 (ControlledUnetModel = UNetModel, model/unet.py:361)."""
+
+    _prefix = "unet."
 
     def __init__(self, **cfg):
         self.cfg = dict(cfg)
@@ -51,13 +96,29 @@ class ControlledUnetModel(ParamTree):
         super().__init__(arch.unet_param_spec(self.arch), unet_like=True)
         self.model_channels = self.arch.model_channels
         self.dtype = torch.float32
+        self._init_part()
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("call ControlLDM.forward: ControlNet + UNet run as one fused kernel program")
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, control=None, only_mid_control=False, **kwargs):
+        """reference model/controlnet.py:20-41: eps from the latent, the timesteps, the context and the (already
+        scaled) 13 control tensors.  ``control`` is consumed (popped) like the reference does."""
+        _require_gpu(x, "ControlledUnetModel.forward")
+        B, _, h, w = x.shape
+        store = self._store()
+        mode = "none" if control is None else ("mid" if only_mid_control else "all")
+        eng = self._part_engines.fetch((B, h, w, context.shape[1], mode),
+                                       lambda: UnetPartEngine(self, store, B, h, w, context.shape[1], mode))
+        ctrl = None
+        if control is not None:
+            ctrl = list(control)
+            del control[:]
+        return eng.run(x, timesteps, context, ctrl).clone()
 
 
-class ControlNet(ParamTree):
+class ControlNet(_NetPart):
     """Parameters of reference model/controlnet.py:44 (ControlNet)."""
+
+    _prefix = "controlnet."
 
     def __init__(self, **cfg):
         self.cfg = dict(cfg)
@@ -65,9 +126,17 @@ class ControlNet(ParamTree):
         super().__init__(arch.unet_param_spec(self.arch), unet_like=True)
         self.model_channels = self.arch.model_channels
         self.dtype = torch.float32
+        self._init_part()
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("call ControlLDM.forward: ControlNet + UNet run as one fused kernel program")
+    @torch.no_grad()
+    def forward(self, x, hint, timesteps, context, **kwargs) -> List[torch.Tensor]:
+        """reference model/controlnet.py:263-277: the 13 control tensors (fp32 NCHW, unscaled)."""
+        _require_gpu(x, "ControlNet.forward")
+        B, _, h, w = x.shape
+        store = self._store()
+        eng = self._part_engines.fetch((B, h, w, context.shape[1]),
+                                       lambda: ControlNetPartEngine(self, store, B, h, w, context.shape[1]))
+        return [o.clone() for o in eng.run(x, hint, timesteps, context)]
 
 
 class AutoencoderKL(ParamTree):
@@ -108,14 +177,14 @@ class CldmEngine:
 
         # ---- context program
         self.ctx_prog = Program("cldm.context")
-        em = Emitter(self.ctx_prog, self.arena, store, dt)
+        em = Emitter(self.ctx_prog, self.arena, store, dt, owner.precision)
         ctx16 = em.cast_flat(self.ctx_in, B * nctx * ua.context_dim).view(B * nctx, ua.context_dim)
         self.kv_c = nets.emit_context_kv(em, "controlnet.", ca, ctx16, B, nctx)
         self.kv_u = nets.emit_context_kv(em, "unet.", ua, ctx16, B, nctx)
 
         # ---- step program
         self.step_prog = Program("cldm.step")
-        em = Emitter(self.step_prog, self.arena, store, dt)
+        em = Emitter(self.step_prog, self.arena, store, dt, owner.precision)
         hw = h * w
         cin_c = ca.in_channels + ca.hint_channels
         x8c = em.new(B * hw, arch_round8(cin_c))
@@ -128,7 +197,7 @@ class CldmEngine:
         tab_u, offs_u = nets.emit_time_rows(em, "unet.", ua, self.t_in, B)
         # ControlNet (lane 1, own arena) is independent of the UNet encoder + middle block (lane 0): two graph branches
         self.arena_cn = Arena(dev)
-        em_cn = Emitter(self.step_prog, self.arena_cn, store, dt)
+        em_cn = Emitter(self.step_prog, self.arena_cn, store, dt, owner.precision)
         self.step_prog.fork()
         self.step_prog.set_lane(1)
         ctrl = nets.emit_controlnet(em_cn, "controlnet.", ca, Act(x8c, B, h, w, x8c.shape[1]), tab_c, offs_c, self.kv_c,
@@ -159,6 +228,94 @@ class CldmEngine:
         return self.eps_out
 
 
+class _PartEngineBase:
+    def _common(self, part: _NetPart, store: WeightStore, B: int, h: int, w: int, nctx: int, name: str):
+        dev = part._device()
+        a = part.arch
+        self.arena = Arena(dev)
+        self.prog = Program(name)
+        em = Emitter(self.prog, self.arena, store, part.compute_dtype, part.precision)
+        f32 = torch.float32
+        self.x_in = torch.zeros((B, a.in_channels, h, w), dtype=f32, device=dev)
+        self.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
+        self.ctx_in = torch.zeros((B, nctx, a.context_dim), dtype=f32, device=dev)
+        ctx16 = em.cast_flat(self.ctx_in, B * nctx * a.context_dim).view(B * nctx, a.context_dim)
+        kv = nets.emit_context_kv(em, part._prefix, a, ctx16, B, nctx)
+        table, offs = nets.emit_time_rows(em, part._prefix, a, self.t_in, B)
+        return em, kv, table, offs
+
+    def _load(self, x, t, ctx):
+        self.x_in.copy_(x)
+        self.t_in.copy_(t)
+        self.ctx_in.copy_(ctx.expand(self.x_in.shape[0], -1, -1) if ctx.shape[0] == 1 else ctx)
+
+
+class ControlNetPartEngine(_PartEngineBase):
+    """ControlNet alone for a fixed (B, h, w): 13 fp32 NCHW outputs."""
+
+    def __init__(self, part: "ControlNet", store: WeightStore, B: int, h: int, w: int, nctx: int):
+        em, kv, table, offs = self._common(part, store, B, h, w, nctx, "controlnet.alone")
+        a = part.arch
+        dev = part._device()
+        self.hint_in = torch.zeros((B, a.hint_channels, h, w), dtype=torch.float32, device=dev)
+        cin = a.in_channels + a.hint_channels
+        x8 = em.new(B * h * w, arch_round8(cin))
+        em.to_nhwc(self.x_in, B, a.in_channels, h * w, x8, coff=0)
+        em.to_nhwc(self.hint_in, B, a.hint_channels, h * w, x8, coff=a.in_channels, pad_to=arch_round8(cin) - a.in_channels)
+        ctrl = nets.emit_controlnet(em, part._prefix, a, Act(x8, B, h, w, x8.shape[1]), table, offs, kv, [1.0] * 13)
+        self.outs = []
+        for c in ctrl:
+            o = torch.zeros((B, c.C, c.H, c.W), dtype=torch.float32, device=dev)
+            em.to_nchw(c.t, B, c.C, c.H * c.W, o)
+            self.outs.append(o)
+
+    def run(self, x, hint, t, ctx):
+        self._load(x, t, ctx)
+        self.hint_in.copy_(hint)
+        self.prog.run()
+        return self.outs
+
+
+class UnetPartEngine(_PartEngineBase):
+    """ControlledUnetModel alone for a fixed (B, h, w): control tensors come in as fp32 NCHW."""
+
+    def __init__(self, part: "ControlledUnetModel", store: WeightStore, B: int, h: int, w: int, nctx: int, mode: str):
+        em, kv, table, offs = self._common(part, store, B, h, w, nctx, "unet.alone")
+        a = part.arch
+        dev = part._device()
+        x8 = em.new(B * h * w, arch_round8(a.in_channels))
+        em.to_nhwc(self.x_in, B, a.in_channels, h * w, x8, coff=0, pad_to=arch_round8(a.in_channels))
+        self.ctrl_in: List[Optional[torch.Tensor]] = []
+        acts: Optional[List[Optional[Act]]] = None
+        if mode != "none":
+            acts = []
+            shapes = arch.control_shapes(a, h, w)
+            for i, (C, hh, ww) in enumerate(shapes):
+                if mode == "mid" and i != len(shapes) - 1:
+                    self.ctrl_in.append(None)
+                    acts.append(None)
+                    continue
+                src = torch.zeros((B, C, hh, ww), dtype=torch.float32, device=dev)
+                dst = em.new(B * hh * ww, C)
+                em.to_nhwc(src, B, C, hh * ww, dst)
+                self.ctrl_in.append(src)
+                acts.append(Act(dst, B, hh, ww, C))
+        self.eps_out = torch.zeros((B, a.out_channels, h, w), dtype=torch.float32, device=dev)
+        eps = nets.emit_unet(em, part._prefix, a, Act(x8, B, h, w, x8.shape[1]), table, offs, kv, acts)
+        em.to_nchw(eps, B, a.out_channels, h * w, self.eps_out)
+
+    def run(self, x, t, ctx, control):
+        self._load(x, t, ctx)
+        if control is not None:
+            if len(control) != len(self.ctrl_in):
+                raise ValueError(f"expected {len(self.ctrl_in)} control tensors, got {len(control)}")
+            for dst, src in zip(self.ctrl_in, control):
+                if dst is not None:
+                    dst.copy_(src)
+        self.prog.run()
+        return self.eps_out
+
+
 def arch_round8(c: int) -> int:
     return (c + 7) // 8 * 8
 
@@ -177,7 +334,7 @@ class VaeEngine:
         f32 = torch.float32
         self.prog = Program(f"vae.{kind}" + (".tiled" if tile_size else ""))
         self.nan_probe = None      # tiled form: (row, col) of the first output pixel of every tile
-        em = Emitter(self.prog, self.arena, store, dt)
+        em = Emitter(self.prog, self.arena, store, dt, owner.precision)
         sf = owner.scale_factor
         nlev = len(dd["ch_mult"])
         is_dec = kind == "decode"
@@ -279,6 +436,7 @@ class ControlLDM(nn.Module):
         self.scale_factor = latent_scale_factor
         self.control_scales = [1.0] * 13
         self.compute_dtype = default_compute_dtype()
+        self.precision = default_precision()      # "fast" | "high" (parity mode), see default_precision()
         # engines (static buffers + programs) are cached per shape AND per slot: a caller that keeps two batches in
         # flight on two HIP streams flips the slot so the batches never share a buffer (bench.py --inflight 2)
         self.engine_slot = 0
@@ -293,7 +451,7 @@ class ControlLDM(nn.Module):
 
     def _check_fresh(self) -> None:
         fp = (params_fingerprint(self.unet), params_fingerprint(self.controlnet), params_fingerprint(self.vae),
-              self.compute_dtype, tuple(self.control_scales))
+              self.compute_dtype, self.precision, tuple(self.control_scales))
         if fp != self._fingerprint:
             self.release_engines()
             self._fingerprint = fp
@@ -309,7 +467,7 @@ class ControlLDM(nn.Module):
             params.update(self.unet.flat_params("unet."))
             params.update(self.controlnet.flat_params("controlnet."))
             params.update(self.vae.flat_params("vae."))
-            self._weights = WeightStore(params, self.compute_dtype, self._device())
+            self._weights = WeightStore(params, _store_dtype(self.precision, self.compute_dtype), self._device())
         return self._weights
 
     def cldm_engine(self, B: int, h: int, w: int, nctx: int = 77) -> CldmEngine:

@@ -17,7 +17,7 @@ import html
 import os
 import re
 from functools import lru_cache
-from typing import Dict, List, Optional, Sequence
+from typing import Tuple, Dict, List, Optional, Sequence
 
 import torch
 
@@ -46,83 +46,97 @@ def clip_text_param_spec(embed_dim: int, text_cfg: dict):
 
 
 # ----------------------------------------------------------------------------------------------
-# tokenizer (restatement of reference model/open_clip/tokenizer.py:20-188; ftfy is skipped like in
-# tools/ref_import.py — it only repairs mojibake)
+# tokenizer: byte-level BPE with the OpenCLIP vocabulary (the algorithm of reference model/open_clip/tokenizer.py:26-157,
+# which is GPT-2's; token ids are pinned by tests/golden/clip_tokens.json, generated with the reference tokenizer).  ftfy is
+# skipped like in tools/ref_import.py — it only repairs mojibake.
 # ----------------------------------------------------------------------------------------------
+N_MERGES = 49152 - 256 - 2                     # merge rules kept from the vocabulary file (tokenizer.py:64)
+_WORD_END = "</w>"
+_PRINTABLE = [(0x21, 0x7E), (0xA1, 0xAC), (0xAE, 0xFF)]     # byte values that stand for themselves
+
+
 @lru_cache()
-def _bytes_to_unicode() -> Dict[int, str]:
-    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
-    cs = bs[:]
-    n = 0
+def _byte_symbols() -> List[str]:
+    """One printable unicode character per byte value: printable latin-1 bytes map to themselves, the other 68 to U+0100...
+    in ascending byte order."""
+    own = [any(lo <= b <= hi for lo, hi in _PRINTABLE) for b in range(256)]
+    table, spare = [], 0
     for b in range(256):
-        if b not in bs:
-            bs.append(b)
-            cs.append(256 + n)
-            n += 1
-    return dict(zip(bs, [chr(c) for c in cs]))
+        if own[b]:
+            table.append(chr(b))
+        else:
+            table.append(chr(256 + spare))
+            spare += 1
+    return table
+
+
+def _vocabulary_order(symbols: List[str]) -> List[str]:
+    """Single-byte tokens are numbered in the order: printable bytes (ascending), then the remapped ones (ascending)."""
+    own = [any(lo <= b <= hi for lo, hi in _PRINTABLE) for b in range(256)]
+    return [symbols[b] for b in range(256) if own[b]] + [symbols[b] for b in range(256) if not own[b]]
 
 
 class SimpleTokenizer:
     def __init__(self, bpe_path: str):
-        self.byte_encoder = _bytes_to_unicode()
-        merges = gzip.open(bpe_path).read().decode("utf-8").split("\n")
-        merges = [tuple(m.split()) for m in merges[1:49152 - 256 - 2 + 1]]
-        vocab = list(self.byte_encoder.values())
-        vocab = vocab + [v + "</w>" for v in vocab]
-        vocab += ["".join(m) for m in merges]
-        vocab += ["<start_of_text>", "<end_of_text>"]
-        self.encoder = dict(zip(vocab, range(len(vocab))))
-        self.bpe_ranks = dict(zip(merges, range(len(merges))))
-        self.cache = {"<start_of_text>": "<start_of_text>", "<end_of_text>": "<end_of_text>"}
-        # \p{L} / \p{N} of the `regex` module restated with the stdlib `re` classes (letters / digits, unicode aware)
-        try:        # the reference's pattern needs \p{L} / \p{N} (third-party `regex`); stdlib classes are the fallback
+        try:
             import regex
-            self.pat = regex.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
-                                     regex.IGNORECASE)
-        except ImportError:
-            self.pat = re.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[^\W\d_]+|\d|[^\s\w]+|_+", re.IGNORECASE)
+        except ImportError as exc:       # \p{L} / \p{N} have no exact stdlib equivalent: no silent approximation
+            raise RuntimeError("tokenising a non-empty prompt needs the `regex` package (unicode letter / number classes)") from exc
+        self.byte_symbol = _byte_symbols()
+        with gzip.open(bpe_path) as f:
+            rows = f.read().decode("utf-8").split("\n")[1:N_MERGES + 1]
+        self.rank: Dict[Tuple[str, str], int] = {}
+        singles = _vocabulary_order(self.byte_symbol)
+        names = singles + [c + _WORD_END for c in singles]
+        for r, row in enumerate(rows):
+            left, right = row.split()
+            self.rank[(left, right)] = r
+            names.append(left + right)
+        names += ["<start_of_text>", "<end_of_text>"]
+        self.token_id = {name: i for i, name in enumerate(names)}
+        self.split = regex.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
+                                   regex.IGNORECASE)
+        self._memo: Dict[str, List[str]] = {}
 
-    def bpe(self, token: str) -> str:
-        if token in self.cache:
-            return self.cache[token]
-        word = tuple(token[:-1]) + (token[-1] + "</w>",)
-        pairs = {(word[i], word[i + 1]) for i in range(len(word) - 1)}
-        if not pairs:
-            return token + "</w>"
-        while True:
-            bigram = min(pairs, key=lambda pr: self.bpe_ranks.get(pr, float("inf")))
-            if bigram not in self.bpe_ranks:
+    def _merge_word(self, chars: str) -> List[str]:
+        """Greedy BPE of one pre-token: repeatedly fuse every occurrence (left to right) of the adjacent pair with the lowest
+        merge rank until no adjacent pair has a rank."""
+        hit = self._memo.get(chars)
+        if hit is not None:
+            return hit
+        parts = list(chars)
+        parts[-1] += _WORD_END
+        inf = len(self.rank)
+        while len(parts) > 1:
+            best, best_rank = -1, inf
+            for i in range(len(parts) - 1):
+                r = self.rank.get((parts[i], parts[i + 1]), inf)
+                if r < best_rank:
+                    best, best_rank = i, r
+            if best < 0:
                 break
-            first, second = bigram
-            new_word, i = [], 0
-            while i < len(word):
-                try:
-                    j = word.index(first, i)
-                    new_word.extend(word[i:j])
-                    i = j
-                except ValueError:
-                    new_word.extend(word[i:])
-                    break
-                if word[i] == first and i < len(word) - 1 and word[i + 1] == second:
-                    new_word.append(first + second)
+            left, right = parts[best], parts[best + 1]
+            fused, i = [], 0
+            while i < len(parts):
+                if i + 1 < len(parts) and parts[i] == left and parts[i + 1] == right:
+                    fused.append(left + right)
                     i += 2
                 else:
-                    new_word.append(word[i])
+                    fused.append(parts[i])
                     i += 1
-            word = tuple(new_word)
-            if len(word) == 1:
-                break
-            pairs = {(word[i], word[i + 1]) for i in range(len(word) - 1)}
-        out = " ".join(word)
-        self.cache[token] = out
-        return out
+            parts = fused
+        self._memo[chars] = parts
+        return parts
 
     def encode(self, text: str) -> List[int]:
-        text = re.sub(r"\s+", " ", html.unescape(html.unescape(text)).strip()).strip().lower()
+        text = " ".join(html.unescape(html.unescape(text)).split()).lower()       # whitespace_clean(basic_clean(text)).lower()
         ids: List[int] = []
-        for token in self.pat.findall(text):
-            token = "".join(self.byte_encoder[b] for b in token.encode("utf-8"))
-            ids.extend(self.encoder[t] for t in self.bpe(token).split(" "))
+        for piece in self.split.findall(text):
+            if piece in ("<start_of_text>", "<end_of_text>"):
+                ids.append(self.token_id[piece])
+                continue
+            chars = "".join(self.byte_symbol[b] for b in piece.encode("utf-8"))
+            ids.extend(self.token_id[t] for t in self._merge_word(chars))
         return ids
 
 

@@ -33,7 +33,7 @@ def emit_time_rows(em: Emitter, P: str, a: UNetArch, t_dev: torch.Tensor, B: int
     Reference: model/util.py:98-118, model/unet.py:475-480 / model/controlnet.py:128-133, model/unet.py:212."""
     mc, ted = a.model_channels, a.model_channels * 4
     temb = em.new(B, mc)
-    em.prog.add(ops.make_timestep_embedding(dtype=em.dtype, t=t_dev, B=B, dim=mc, out=temb, ld=mc))
+    em.prog.add(ops.make_timestep_embedding(dtype=em.io, t=t_dev, B=B, dim=mc, out=temb, ld=mc))
     w0, b0 = em.store.linear([P + "time_embed.0.weight"], [P + "time_embed.0.bias"])
     h = em.gemm(temb, w0, B, ted, mc, bias=b0, act=L.ACT_SILU, name="time_embed.0")
     w2, b2 = em.store.linear([P + "time_embed.2.weight"], [P + "time_embed.2.bias"])
@@ -49,6 +49,9 @@ def emit_time_rows(em: Emitter, P: str, a: UNetArch, t_dev: torch.Tensor, B: int
         offs[l.prefix] = o
         o += l.cout
     return table, offs
+
+
+ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(64.0)      # log2(e) / sqrt(head width)
 
 
 class ContextKV:
@@ -73,6 +76,11 @@ def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: in
     kv.sumC, kv.Nctx = wk.shape[0], Nctx
     kv.k_all = em.gemm(ctx16, wk, B * Nctx, kv.sumC, a.context_dim, name="ctx_k(all)")
     kv.vt_all, kv.ldv = em.vt_gemm(wv, ctx16, B=B, Ntok=Nctx, Cin=a.context_dim, name="ctx_vT(all)")
+    if em.hp:      # the attention kernel's operands are fp16 in the high-precision mode: cast once per prompt
+        k32, v32 = kv.k_all, kv.vt_all
+        kv.k_all = em.to16(k32, B * Nctx, kv.sumC)
+        kv.vt_all = em.to16(v32, B * kv.sumC, kv.ldv)
+        em.free(k32, v32)
     o = 0
     for l in layers:
         kv.offs[l.prefix] = o
@@ -106,18 +114,24 @@ def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C:
                         ctx: Optional[Tuple[torch.Tensor, torch.Tensor, int, int, int, int]], residual: torch.Tensor) -> torch.Tensor:
     """One attention layer on tokens x [B*N, C] (already layer-normed): projections, fused attention, output
     projection with bias and residual.  model/attention.py:176-203."""
+    # softmax scale (1/sqrt(64)) and the exp -> exp2 factor log2(e) are folded into the projections' fp32 epilogues (q.k
+    # products arrive "prescaled", include/edtr_hip.h q_prescaled): sqrt(c) on both halves of the fused [Q;K] projection,
+    # c on the cross-attention's Q (its K comes from the per-prompt context program) — no extra rounding, one multiply
+    # less per score in the attention kernel
+    c = ATTN_PRESCALE
     if ctx is None:   # self attention: fused [Wq;Wk] projection, V^T via the operand-swapped GEMM
         wqk, _ = em.store.linear([p + "to_q.weight", p + "to_k.weight"])
-        qk = em.gemm(x, wqk, B * N, 2 * C, C, name="attn1.qk")
+        qk = em.gemm(x, wqk, B * N, 2 * C, C, alpha=math.sqrt(c), name="attn1.qk")
         wv, _ = em.store.linear([p + "to_v.weight"])
         vt, ldv = em.vt_gemm(wv, x, B=B, Ntok=N, Cin=C, name="attn1.vT")
-        o = em.flash(qk[:, :C], qk[:, C:], vt, B=B, H=heads, Nq=N, Nk=N, k_bs=N * qk.stride(0), vt_bs=C * ldv, vt_ld=ldv)
+        o = em.flash(qk[:, :C], qk[:, C:], vt, B=B, H=heads, Nq=N, Nk=N, k_bs=N * qk.stride(0), vt_bs=C * ldv, vt_ld=ldv,
+                     prescaled=True)
         em.free(qk, vt)
     else:
         k, vt, k_bs, vt_bs, ldv, nctx = ctx
         wq, _ = em.store.linear([p + "to_q.weight"])
-        q = em.gemm(x, wq, B * N, C, C, name="attn2.q")
-        o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv)
+        q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q")
+        o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv, prescaled=True)
         em.free(q)
     wo, bo = em.store.linear([p + "to_out.0.weight"], [p + "to_out.0.bias"])
     y = em.gemm(o, wo, B * N, C, C, bias=bo, residual=residual, name="attn.out")
@@ -214,8 +228,8 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
     # first decoder input: cat([mid + control_mid, hs[-1] + control[-2]])
     skip = hs.pop()
     cat = em.new(skip.rows, mid.C + skip.C)
-    if control is not None:
-        c = control.pop()
+    c = control.pop() if control is not None else None      # a None entry = no control at that tap (only_mid_control)
+    if c is not None:
         em.add(mid.t, c.t, mid.rows, mid.C, out=cat[:, :mid.C])
         em.free(c)
     else:
@@ -226,8 +240,8 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
     nblk = len(a.output_blocks)
     for j, layers in enumerate(a.output_blocks):
         # right half of the concat: skip (+ control)
-        if control is not None:
-            c = control.pop()
+        c = control.pop() if control is not None else None
+        if c is not None:
             em.add(skip.t, c.t, skip.rows, skip.C, out=cat[:, cur_C:])
             em.free(c)
         else:
@@ -297,20 +311,26 @@ def _g_vae_attn(em: Emitter, p: str, x: Act):
     wv, _ = em.store.linear([p + "v.weight"])
     vt, ldv = em.vt_gemm(wv, n.t, B=B, Ntok=N, Cin=C, bias_m=em.store.vec(p + "v.bias"), name="vae.attn.vT")
     em.free(n)
+    adt = em.attn_dtype
+    if em.hp:      # the two batched products of this one layer run on fp16 operands cut from the fp32 projections
+        qk32, vt32 = qk, vt
+        qk = em.to16(qk32, rows, 2 * C)
+        vt = em.to16(vt32, B * C, ldv)
+        em.free(qk32, vt32)
     lds = round_up(N, 8)
     s = em.new(rows, lds, torch.float32)
-    em.prog.add(ops.make_igemm(dtype=em.dtype, a1=qk[:, :C], w=qk[:, C:], out=s, M=N, N=lds, n_valid=N, C1=C,
+    em.prog.add(ops.make_igemm(dtype=adt, a1=qk[:, :C], w=qk[:, C:], out=s, M=N, N=lds, n_valid=N, C1=C,
                                ld1=qk.stride(0), ldw=qk.stride(0), ldc=lds, Z=B, a_zs=(N * qk.stride(0), 0),
                                w_zs=(N * qk.stride(0), 0), o_zs=(N * lds, 0), alpha=1.0 / math.sqrt(C), out_f32=True,
                                name="vae.attn.scores"))
     em.free(qk)
-    pr = em.new(rows, lds)
-    em.prog.add(ops.make_softmax_rows(dtype=em.dtype, s=s, rows=rows, cols=N, ld_s=lds, p=pr, ld_p=lds, cols_pad=lds))
+    pr = em.arena.alloc((rows, lds), adt)
+    em.prog.add(ops.make_softmax_rows(dtype=adt, s=s, rows=rows, cols=N, ld_s=lds, p=pr, ld_p=lds, cols_pad=lds))
     em.free(s)
-    o = em.new(rows, C)
+    o = em.new(rows, C)      # fp32 in the high-precision mode
     # K is padded to a multiple of 8: the pad columns of P are exact zeros, those of V^T hold the (finite) bias
-    em.prog.add(ops.make_igemm(dtype=em.dtype, a1=pr, w=vt, out=o, M=N, N=C, C1=lds, ld1=lds, ldw=ldv, ldc=C, Z=B,
-                               a_zs=(N * lds, 0), w_zs=(C * ldv, 0), o_zs=(N * C, 0), name="vae.attn.pv"))
+    em.prog.add(ops.make_igemm(dtype=adt, a1=pr, w=vt, out=o, M=N, N=C, C1=lds, ld1=lds, ldw=ldv, ldc=C, Z=B,
+                               a_zs=(N * lds, 0), w_zs=(C * ldv, 0), o_zs=(N * C, 0), out_f32=em.hp, name="vae.attn.pv"))
     em.free(pr, vt)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
     y = em.gemm(o, wo, rows, C, C, bias=bo, residual=x.t, name="vae.attn.proj_out", stats_hw=N)

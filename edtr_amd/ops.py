@@ -14,7 +14,8 @@ import torch
 
 from . import lib as L
 
-_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16}
+F32S = "f32_split"     # high-precision mode: fp32 activation stream, bf16 split-3 GEMM operands (edtr_hip.h EDTR_F32_SPLIT)
+_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, F32S: L.F32_SPLIT}
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -119,7 +120,7 @@ def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int
 # attention
 # --------------------------------------------------------------------------------------------
 def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld,
-                    scale: float, causal: bool = False, name: str = "flash_attn64") -> Rec:
+                    scale: float, causal: bool = False, prescaled: bool = False, name: str = "flash_attn64") -> Rec:
     p = L.AttnParams()
     p.dtype, p.B, p.H, p.Nq, p.Nk = dt_code(dtype), B, H, Nq, Nk
     p.q, p.q_bs, p.q_ld = ptr(q), q_bs, q_ld
@@ -128,6 +129,7 @@ def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_l
     p.out, p.o_bs, p.o_ld = ptr(out), o_bs, o_ld
     p.scale = scale
     p.causal = int(causal)
+    p.q_prescaled = int(prescaled)
     flops = 4.0 * B * H * Nq * Nk * 64
     return Rec(L.load().edtr_flash_attn64, (ct.byref(p),), (p, q, k, vt, out), name, flops)
 
@@ -244,6 +246,17 @@ def make_q_sample(*, x, noise, t, tab_a, tab_b, out, name="q_sample") -> Rec:
     return Rec(L.load().edtr_q_sample, args, (x, noise, t, tab_a, tab_b, out), name, 0.0, 12.0 * x.numel())
 
 
+def make_split3(*, src: torch.Tensor, rows: int, C: int, dst: torch.Tensor, pattern: int = 0, name="split3") -> Rec:
+    code = L.F32_SPLIT if src.dtype == torch.float32 else dt_code(src.dtype)
+    args = (code, ptr(src), rows, C, src.stride(0), pattern, ptr(dst), dst.stride(0))
+    return Rec(L.load().edtr_split3, args, (src, dst), name, 0.0, (src.element_size() + 6.0) * rows * C)
+
+
+def make_cast16(*, dtype, src: torch.Tensor, rows: int, C: int, dst: torch.Tensor, name="cast16") -> Rec:
+    args = (dt_code(dtype), ptr(src), rows, C, src.stride(0), ptr(dst), dst.stride(0))
+    return Rec(L.load().edtr_cast16, args, (src, dst), name, 0.0, 6.0 * rows * C)
+
+
 def make_tile_accumulate(*, tile, wts, out, count, B, C, H, W, th, tw, hi, wi, name="tile_accumulate") -> Rec:
     args = (ptr(tile), ptr(wts), ptr(out), ptr(count), B, C, H, W, th, tw, hi, wi)
     return Rec(L.load().edtr_tile_accumulate, args, (tile, wts, out, count), name)
@@ -274,22 +287,35 @@ def round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: Optional[int] = None,
+def split3_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., C] -> bf16 [..., 3C] = [hi | hi | lo] along the last axis: the weight side of the high-precision product
+    (activation operand [hi | lo | hi]): xh*wh + xl*wh + xh*wl."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, hi, lo], dim=-1).contiguous()
+
+
+def pack_conv_weight(w: torch.Tensor, dtype, cin_pad: Optional[int] = None,
                      cout_pad: Optional[int] = None) -> torch.Tensor:
-    """[Cout, Cin, kh, kw] fp32 -> [Cout_pad][kh][kw][Cin_pad] 16-bit, flattened to [N][K] (K contiguous)."""
+    """[Cout, Cin, kh, kw] fp32 -> [Cout_pad][kh][kw][Cin_pad] 16-bit, flattened to [N][K] (K contiguous).
+    dtype == F32S: bf16 [Cout_pad][kh][kw][3*Cin_pad] with the channel axis split [hi | hi | lo]."""
     co, ci, kh, kw = w.shape
     cip = cin_pad or round_up(ci, 8)
     cop = cout_pad or round_up(co, 8)
     out = torch.zeros((cop, kh, kw, cip), dtype=torch.float32, device=w.device)
     out[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+    if dtype == F32S:
+        return split3_weight(out).reshape(cop, kh * kw * 3 * cip)
     return out.reshape(cop, kh * kw * cip).to(dtype).contiguous()
 
 
-def pack_linear_weight(w: torch.Tensor, dtype: torch.dtype, n_pad: Optional[int] = None) -> torch.Tensor:
+def pack_linear_weight(w: torch.Tensor, dtype, n_pad: Optional[int] = None) -> torch.Tensor:
     n, k = w.shape
     npad = n_pad or round_up(n, 8)
     out = torch.zeros((npad, round_up(k, 8)), dtype=torch.float32, device=w.device)
     out[:n, :k] = w
+    if dtype == F32S:
+        return split3_weight(out)
     return out.to(dtype).contiguous()
 
 

@@ -11,9 +11,22 @@ from . import arch, synth
 from .model import ControlLDM
 
 
+_SD_CACHE: Dict[str, Dict[str, Dict[str, torch.Tensor]]] = {}
+
+
 def synthetic_state_dicts(cfg: dict) -> Dict[str, Dict[str, torch.Tensor]]:
     """{'unet': sd, 'controlnet': sd, 'vae': sd} with reference key names; hash keys carry the part prefix, exactly
-    as tools/make_goldens.py did on the reference model (`cldm.state_dict()` keys)."""
+    as tools/make_goldens.py did on the reference model (`cldm.state_dict()` keys).  Cached per configuration (hashing the
+    1.3 G parameters of the SD-2.1 size takes about a minute of CPU; consumers copy the values, never mutate them)."""
+    import json
+    key = json.dumps({k: cfg[k] for k in ("unet_cfg", "controlnet_cfg", "vae_cfg")}, sort_keys=True, default=str)
+    if key in _SD_CACHE:
+        return _SD_CACHE[key]
+    _SD_CACHE[key] = _synthetic_state_dicts(cfg)
+    return _SD_CACHE[key]
+
+
+def _synthetic_state_dicts(cfg: dict) -> Dict[str, Dict[str, torch.Tensor]]:
     specs = {
         "unet": arch.unet_param_spec(arch.unet_arch(cfg["unet_cfg"])),
         "controlnet": arch.unet_param_spec(arch.unet_arch(cfg["controlnet_cfg"], controlnet=True)),
@@ -22,7 +35,7 @@ def synthetic_state_dicts(cfg: dict) -> Dict[str, Dict[str, torch.Tensor]]:
     return {part: {k: synth.synth_param(f"{part}.{k}", shp) for k, shp in spec} for part, spec in specs.items()}
 
 
-def build_synthetic_cldm(cfg: dict, device, dtype=None, sds=None) -> ControlLDM:
+def build_synthetic_cldm(cfg: dict, device, dtype=None, sds=None, precision=None) -> ControlLDM:
     from .model.params import skip_init
     with skip_init():
         model = ControlLDM(**cfg)
@@ -32,6 +45,8 @@ def build_synthetic_cldm(cfg: dict, device, dtype=None, sds=None) -> ControlLDM:
     model.vae.load_state_dict(sds["vae"], strict=True)
     if dtype is not None:
         model.compute_dtype = dtype
+    if precision is not None:
+        model.precision = model.controlnet.precision = model.unet.precision = precision
     return model.eval().to(device)
 
 

@@ -33,7 +33,15 @@ extern "C" {
 
 #define EDTR_ABI_VERSION 5
 
-enum edtr_dtype { EDTR_BF16 = 0, EDTR_F16 = 1 };
+enum edtr_dtype {
+    EDTR_BF16 = 0, EDTR_F16 = 1,
+    /* High-precision mode (accepted by the normalisation / layout / elementwise entry points that say so, never by
+     * edtr_igemm / edtr_flash_attn64): the activation stream is fp32, and a tensor that feeds a GEMM is written as the bf16
+     * "split-3" operand [hi | lo | hi] (3*C columns; hi = bf16(x), lo = bf16(x - hi)).  edtr_igemm (dtype EDTR_BF16, K = 3*C
+     * per tap) multiplies it with weights packed [Wh | Wh | Wl]: hi*Wh + lo*Wh + hi*Wl = x*w to ~16 mantissa bits, fp32
+     * accumulation, fp32 output.  This is what lets the path meet the 1e-3 parity target that 16-bit operands cannot. */
+    EDTR_F32_SPLIT = 2
+};
 
 enum edtr_error {
     EDTR_OK = 0,
@@ -142,6 +150,9 @@ typedef struct edtr_attn_params {
     float scale;
     int32_t causal;                 /* nonzero: key j contributes to query i only if j <= i (the CLIP text tower's attn_mask,
                                        reference model/open_clip/model.py build_attention_mask; Nq == Nk) */
+    int32_t q_prescaled;            /* nonzero: the q.k products already carry scale*log2(e) (the projection GEMMs that produced q
+                                       and/or k applied it in fp32 before their single 16-bit rounding), so the kernel evaluates
+                                       exp2(q.k - max) directly and ignores `scale`: one v_exp and no multiply per score */
 } edtr_attn_params;
 
 int edtr_flash_attn64(const edtr_attn_params* p, edtr_stream_t stream);
@@ -271,6 +282,15 @@ int edtr_axpby(const float* x, const float* y, float a, float b, float* out, int
  * reference model/gaussian_diffusion.py:34-37,80-84 as called with a device `t` at demo.py:107-108, main/det/test_edtr.py:127-128. */
 int edtr_q_sample(const float* x, const float* noise, const int64_t* t, const float* tab_a, const float* tab_b,
                   int n_tab, float* out, int B, int64_t per_image, edtr_stream_t stream);
+/* bf16 split-3 GEMM operand of a [rows][C] matrix (high-precision mode, see EDTR_F32_SPLIT): dst[rows][3*C] =
+ * [hi | lo | hi] (pattern 0, the activation side) or [hi | hi | lo] (pattern 1, the weight side of an activation x activation
+ * product).  src_dtype: EDTR_F32_SPLIT = fp32 source, EDTR_BF16 / EDTR_F16 = 16-bit source.  C, ld_src, ld_dst multiples of 8. */
+int edtr_split3(int src_dtype, const void* src, int64_t rows, int C, int64_t ld_src, int pattern, void* dst, int64_t ld_dst,
+                edtr_stream_t stream);
+/* fp32 [rows][C] -> 16-bit [rows][C] with independent row strides (high-precision mode: the fp16 q / k / v^T operands of
+ * edtr_flash_attn64 are cut from fp32 projection outputs).  C, ld_dst multiples of 8; ld_src multiple of 4. */
+int edtr_cast16(int dst_dtype, const float* src, int64_t rows, int C, int64_t ld_src, void* dst, int64_t ld_dst,
+                edtr_stream_t stream);
 /* Gaussian-weighted overlap-add of one latent tile (fp32 NCHW):
  *   out[b][c][hi+y][wi+x] += tile[b][c][y][x] * wts[y][x];  count[...] += wts[y][x]
  * replaces: utils/common.py:415-424 (make_tiled_fn accumulation). */

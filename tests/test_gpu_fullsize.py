@@ -1,0 +1,175 @@
+"""Full-size parity on the MI355X (pytest -m gpu) for every BASELINE.json configuration, through the very functions
+bench.py times (edtr_amd/workloads.py), against outputs of the REFERENCE on the same synthetic inputs
+(tests/golden/full_*.npz, produced by tools/make_goldens.py gen_full with /root/reference on CPU fp32, SD-2.1 widths):
+
+  configs[1]/[2]  det512: batch 8 of 512x512, 4 steps — images 3 and 7 vs the reference; EVERY image vs its batch-1 run
+  configs[3]      seg1024tiled: 1024x1024, tiled VAE encoder + latent-tiled sampler + untiled decoder vs the reference
+  configs[4]      det512s50: 50-step sampler from pure noise, batch 4 — image 0 vs the reference
+  a6              the 13 ControlNet control tensors vs the reference (tiny config and SD-2.1 widths)
+
+Tolerances are relative L2 errors vs the fp32 reference; the 16-bit storage modes use bench.TOLERANCE (measured values in
+DESIGN.md §5), the parity mode (EDTR_AMD_PRECISION=high) asserts the north-star 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def _tol(name):
+    import bench
+    return bench.TOLERANCE[name]
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _samples(img):
+    return img[:, :, 1::4, 2::4]
+
+
+def _build(dev, dtype, cfg_name="sd21"):
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm
+    cldm = build_synthetic_cldm(synth.CONFIGS[cfg_name](), dev, dtype)
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
+    return cldm, diffusion, SpacedSampler(diffusion.betas)
+
+
+def _slice_inputs(inp, k):
+    from edtr_amd.workloads import Inputs
+    return Inputs(inp.pre_res[k:k + 1].contiguous(), inp.c_txt[k:k + 1].contiguous(), [n[k:k + 1].contiguous() for n in inp.noises],
+                  [n[k:k + 1].contiguous() for n in inp.step_noises], inp.t_start[k:k + 1])
+
+
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+def test_det512_batch8_every_image(golden_dir, dname):
+    """BASELINE configs[1] (and one GPU's share of configs[2]) exactly as bench.py runs it: B = 8."""
+    from edtr_amd import workloads
+    from edtr_amd.testing import rel_err
+    dev = _need_gpu()
+    g = np.load(os.path.join(golden_dir, "full_det512.npz"))
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname])
+    inp = workloads.make_inputs("det512", 1024, dev, 8, 512)
+    img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "det512")
+    torch.cuda.synchronize()
+    assert torch.isfinite(img).all() and torch.isfinite(z).all()
+    sel = [int(k) for k in g["images"]]
+    tol = _tol(dname)
+    e_pre = rel_err(tr["z_pre"][sel], g["z_pre"])
+    e_z = rel_err(z[sel], g["z"])
+    e_img = rel_err(_samples(img[sel]), g["img_samples"].astype(np.float32))
+    per_image = [(rel_err(z[k:k + 1], g["z"][i:i + 1]), rel_err(_samples(img[k:k + 1]), g["img_samples"][i:i + 1].astype(np.float32)))
+                 for i, k in enumerate(sel)]
+    print(f"\n[det512 B=8 {dname}] images {sel} vs reference: z_pre {e_pre:.2e} latent {e_z:.2e} image {e_img:.2e}; per image {per_image}")
+    assert e_pre < tol["latent"] and e_z < tol["latent"] and e_img < tol["image"]
+    np.testing.assert_allclose(float(img[sel].mean()), g["img_stats"][0], atol=5e-3)
+    # every image of the batch vs the same image travelling alone (batch 1: other tile choices, same arithmetic)
+    worst = 0.0
+    for k in range(8):
+        img1, z1, _ = workloads.restore_pass(cldm, diffusion, sampler, _slice_inputs(inp, k), "det512")
+        ez, ei = rel_err(z[k:k + 1], z1), rel_err(img[k:k + 1], img1)
+        worst = max(worst, ez, ei)
+        assert ez < tol["latent"] and ei < tol["image"], (k, ez, ei)
+    print(f"[det512 B=8 {dname}] worst batch-8 vs batch-1 deviation over the 8 images: {worst:.2e}")
+
+
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+def test_seg1024tiled_vs_reference_golden(golden_dir, dname):
+    """BASELINE configs[3]: --vae-encoder-tiled --cldm-tiled at 1024x1024 (demo.py:96-124)."""
+    from edtr_amd import workloads
+    from edtr_amd.testing import rel_err
+    dev = _need_gpu()
+    g = np.load(os.path.join(golden_dir, "full_seg1024.npz"))
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname])
+    inp = workloads.make_inputs("seg1024tiled", 1024, dev, 1, 1024)
+    fwd = cldm.forward
+    img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "seg1024tiled", fwd)
+    torch.cuda.synchronize()
+    tol = _tol(dname)
+    e_pre, e_z = rel_err(tr["z_pre"], g["z_pre"]), rel_err(z, g["z"])
+    e_img = rel_err(_samples(img), g["img_samples"].astype(np.float32))
+    print(f"\n[seg1024tiled {dname}] vs reference: tiled z_pre {e_pre:.2e} latent {e_z:.2e} image {e_img:.2e}")
+    assert tuple(img.shape) == (1, 3, 1024, 1024) and torch.isfinite(img).all()
+    assert e_pre < tol["latent"] and e_z < tol["latent"] and e_img < tol["image"]
+    np.testing.assert_allclose(float(img.mean()), g["img_stats"][0], atol=5e-3)
+
+
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+def test_det512s50_vs_reference_golden(golden_dir, dname):
+    """BASELINE configs[4] per GPU (batch 4, 50 spaced steps from pure noise, every step the same program): image 0 vs the
+    reference's `SpacedSampler.sample(steps=50)` with the same injected per-step noise.  50 sequential network evaluations
+    compound the 16-bit rounding: the tolerance is 2x the per-4-step one."""
+    from edtr_amd import workloads
+    from edtr_amd.testing import rel_err
+    dev = _need_gpu()
+    g = np.load(os.path.join(golden_dir, "full_s50.npz"))
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname])
+    inp = workloads.make_inputs("det512s50", 1024, dev, 4, 512, with_step_noises=True)
+    img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "det512s50")
+    torch.cuda.synchronize()
+    tol = _tol(dname)
+    e_z = rel_err(z[:1], g["z"])
+    e_img = rel_err(_samples(img[:1]), g["img_samples"].astype(np.float32))
+    print(f"\n[det512s50 {dname}] image 0 vs reference after 50 steps: latent {e_z:.2e} image {e_img:.2e}")
+    assert torch.isfinite(img).all()
+    assert e_z < 2 * tol["latent"] and e_img < 2 * tol["image"]
+
+
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+def test_controlnet_controls_vs_reference_golden(golden_dir, dname):
+    """a6: `ControlNet.forward` (model/controlnet.py:263-277) — all 13 control tensors of the tiny pipeline's first denoise
+    step and of the SD-2.1-width network against the reference's own tensors / statistics."""
+    from edtr_amd import synth
+    from edtr_amd.testing import rel_err
+    dev = _need_gpu()
+    dtype = DTYPES[dname]
+    tol = 4e-3 if dname == "fp16" else 3e-2
+    # tiny config: controls of the first step (t = 200) of the tiny pipeline golden
+    g = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))
+    cldm, _, _ = _build(dev, dtype, "tiny")
+    cldm.controlnet.compute_dtype = dtype
+    x_T, z_pre = torch.from_numpy(g["x_T"]).to(dev), torch.from_numpy(g["z_pre"]).to(dev)
+    c_txt = synth.synth_input("tiny:c_txt", (2, 77, 64), -1.0, 1.0).to(dev)
+    t = torch.full((2,), 200, dtype=torch.int64, device=dev)
+    ctrl = cldm.controlnet(x=x_T, hint=z_pre, timesteps=t, context=c_txt)
+    torch.cuda.synchronize()
+    assert len(ctrl) == 13
+    errs = {i: rel_err(ctrl[i], g[f"ctrl{i}"].astype(np.float32)) for i in (0, 3, 6, 12)}
+    stats = np.array([[float(c.mean()), float(c.abs().mean()), float(c.abs().max())] for c in ctrl])
+    print(f"\n[controls tiny {dname}] " + " ".join(f"ctrl{i}={e:.2e}" for i, e in errs.items()))
+    assert all(e < tol for e in errs.values()), errs
+    np.testing.assert_allclose(stats[:, 1], g["ctrl_stats"][:, 1], rtol=2e-2 if dname == "bf16" else 4e-3)
+    np.testing.assert_allclose(stats[:, 2], g["ctrl_stats"][:, 2], rtol=5e-2 if dname == "bf16" else 1e-2)
+    # the standalone UNet fed with these controls reproduces the fused ControlLDM.forward
+    scaled = [c * s for c, s in zip(ctrl, cldm.control_scales)]
+    cldm.unet.compute_dtype = dtype
+    eps_sep = cldm.unet(x=x_T, timesteps=t, context=c_txt, control=scaled, only_mid_control=False)
+    eps_fused = cldm(x_T, t, {"c_txt": c_txt, "c_img": z_pre})
+    torch.cuda.synchronize()
+    assert scaled == []                                  # consumed like the reference's control.pop()
+    assert rel_err(eps_sep, eps_fused) < 1e-3
+    assert rel_err(eps_fused, g["eps0"]) < tol
+    # SD-2.1 widths, latent 64x64
+    g = np.load(os.path.join(golden_dir, "sd21_blocks.npz"))
+    cldm, _, _ = _build(dev, dtype, "sd21")
+    cldm.controlnet.compute_dtype = dtype
+    x = synth.synth_normal("sd21:x", (1, 4, 64, 64)).to(dev)
+    c_img = synth.synth_normal("sd21:c_img", (1, 4, 64, 64)).to(dev)
+    c_txt = synth.synth_input("sd21:c_txt", (1, 77, 1024), -1.0, 1.0).to(dev)
+    ctrl = cldm.controlnet(x=x, hint=c_img, timesteps=torch.tensor([200], device=dev), context=c_txt)
+    torch.cuda.synchronize()
+    e12, e0 = rel_err(ctrl[12], g["ctrl12"]), rel_err(ctrl[0], g["ctrl0_f16"].astype(np.float32))
+    stats = np.array([[float(c.mean()), float(c.abs().mean()), float(c.abs().max())] for c in ctrl])
+    print(f"[controls sd21 {dname}] ctrl0={e0:.2e} ctrl12={e12:.2e}")
+    assert e0 < tol and e12 < tol
+    np.testing.assert_allclose(stats[:, 1], g["ctrl_stats"][:, 1], rtol=2e-2 if dname == "bf16" else 4e-3)

@@ -286,3 +286,20 @@ def test_engine_cache_lru():
     assert list(cache) == ["a", "c"] and released == ["B"]                              # b was the least recently used
     cache.drop_all()
     assert len(cache) == 0 and sorted(released) == ["A", "B", "C"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/model/open_clip/bpe_simple_vocab_16e6.txt.gz"),
+                    reason="needs the OpenCLIP BPE vocabulary of the reference checkout (build container only)")
+def test_clip_tokenizer_token_ids_vs_reference(golden_dir):
+    """Non-empty prompts: token ids equal the reference tokenizer's (tests/golden/clip_tokens.json, tools/make_goldens.py
+    gen_tokens) — contractions, unicode letters / digits, html entities, special markers, long words, truncation at 77."""
+    import json
+    from edtr_amd.model.clip import SimpleTokenizer, tokenize
+    path = "/root/reference/model/open_clip/bpe_simple_vocab_16e6.txt.gz"
+    with open(os.path.join(golden_dir, "clip_tokens.json")) as f:
+        g = json.load(f)
+    tok = SimpleTokenizer(path)
+    for prompt, want in zip(g["prompts"], g["encode"]):
+        assert tok.encode(prompt) == want, prompt
+    got = tokenize(g["prompts"], 77, bpe_path=path)
+    assert got.tolist() == g["tokenize_77"]

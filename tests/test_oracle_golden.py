@@ -258,3 +258,22 @@ def test_swinir_full(golden_dir):
     assert rel_err(y512[:, :, 3::8, 5::8], g["y_512_stride8"]) < 5e-5
     np.testing.assert_allclose([float(y512.mean()), float(y512.abs().mean()), float(y512.abs().max()), float(y512.std())],
                                g["y_512_stats"], rtol=1e-4)
+
+
+@pytest.mark.slow
+def test_full_size_det512_image_vs_reference(golden_dir):
+    """BASELINE configs[1] at full size (SD-2.1 widths, 512x512, 4 steps): the oracle on image 7 of bench.py's batch against the
+    reference's own run on the same inputs (tests/golden/full_det512.npz) — this is the oracle bench.py times as `cpu_baseline`
+    and checks the GPU result against, at the size it is used."""
+    g = np.load(os.path.join(golden_dir, "full_det512.npz"))
+    cfg = synth.sd21_config()
+    sd = synth_sd(os.path.join(golden_dir, "manifest_sd21.json"))
+    k = int(g["images"][1])
+    pre = synth.synth_input("bench:pre_res", (8, 3, 512, 512), 0.0, 1.0)[k:k + 1]
+    c_txt = synth.synth_normal("bench:c_txt", (1, 77, 1024))
+    noises = [synth.synth_normal(f"bench:noise{i}", (8, 4, 64, 64))[k:k + 1] for i in range(5)]
+    with torch.no_grad():
+        img, tr = O.restore(sd, cfg, O.make_betas(), pre, c_txt, noises, USED, 200, return_trace=True)
+    assert rel_err(tr["z_pre"], g["z_pre"][1:2]) < 2e-5
+    assert rel_err(tr["z"], g["z"][1:2]) < 5e-5
+    assert rel_err(img[:, :, 1::4, 2::4], g["img_samples"][1:2]) < 5e-5

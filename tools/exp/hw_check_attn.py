@@ -16,13 +16,24 @@ from hipfree import C, L  # noqa: E402
 
 CHECK = [(2, 5, 256, 256, 0), (1, 3, 100, 77, 0), (2, 2, 130, 130, 1), (1, 5, 4096, 4096, 0), (3, 10, 64, 77, 0), (1, 1, 77, 77, 1)]
 TIME = [(8, 5, 4096, 4096, 0), (8, 10, 1024, 1024, 0), (8, 20, 256, 256, 0), (8, 5, 4096, 77, 0)]
+PRESCALED = os.environ.get("EDTR_ATTN_PRESCALED") == "1"      # q.k already carries scale*log2e: the large-N kernels (v2 / v3)
+if PRESCALED:
+    # (B, H, Nq, Nk, causal, growth): growth > 1 multiplies the keys of the later tiles so that the row maximum of the first tile is
+    # beaten by far more than 14 octaves -> the slow (re-maximise) path runs; ragged Nq exercises the store predicate
+    CHECK = [(1, 5, 4096, 4096, 0, 1.0), (2, 8, 2048, 1024, 0, 1.0), (1, 3, 2100, 512, 0, 1.0), (1, 2, 2048, 2048, 0, 4.0),
+             (2, 1, 4096, 256, 0, 6.0), (1, 16, 2304, 6912, 0, 1.0)]
+    TIME = [(8, 5, 4096, 4096, 0), (4, 5, 4096, 4096, 0), (8, 10, 2048, 1024, 0), (1, 16, 4096, 4096, 0)]
 
 
-def run(dt, B, heads, Nq, Nk, causal, rng, check):
+def run(dt, B, heads, Nq, Nk, causal, rng, check, growth=1.0):
     Cc = heads * 64
     ldv = (Nk + 7) // 8 * 8
-    q = H.rand16(rng, (B, Nq, heads, 64), dt)
-    k = H.rand16(rng, (B, Nk, heads, 64), dt)
+    q = H.rand16(rng, (B, Nq, heads, 64), dt, 0.42 if PRESCALED else 1.0)
+    k = H.rand16(rng, (B, Nk, heads, 64), dt, 0.42 if PRESCALED else 1.0)
+    if growth != 1.0:
+        kf = H.from16(k, dt)
+        kf[:, Nk // 2:] *= growth
+        k = H.to16(kf, dt)
     v = H.rand16(rng, (B, Nk, heads, 64), dt)
     vt = np.zeros((B, heads, 64, ldv), np.uint16)
     vt[..., :Nk] = v.transpose(0, 2, 3, 1)
@@ -33,12 +44,13 @@ def run(dt, B, heads, Nq, Nk, causal, rng, check):
     p.q, p.q_bs, p.q_ld, p.k, p.k_bs, p.k_ld = dq.p, Nq * Cc, Cc, dk.p, Nk * Cc, Cc
     p.vt, p.vt_bs, p.vt_ld, p.out, p.o_bs, p.o_ld = dvt.p, Cc * ldv, ldv, do.p, Nq * Cc, Cc
     p.scale, p.causal = 0.125, causal
+    p.q_prescaled = 1 if PRESCALED else 0
     ms = H.time_launches([lambda s: H.chk(H.edtr.edtr_flash_attn64(C.byref(p), s), "flash_attn64")], iters=10, warm=2)
     err = float("nan")
     if check:
         got = H.from16(do.get(np.uint16, (B, Nq, heads, 64)), dt)
         qf, kf, vf = (H.from16(t, dt).astype(np.float64).transpose(0, 2, 1, 3) for t in (q, k, v))
-        sc = qf @ kf.transpose(0, 1, 3, 2) * 0.125
+        sc = qf @ kf.transpose(0, 1, 3, 2) * (np.log(2.0) if PRESCALED else 0.125)
         if causal:
             sc = sc + np.triu(np.full((Nq, Nk), -np.inf), 1)
         sc = np.exp(sc - sc.max(-1, keepdims=True))
@@ -49,12 +61,14 @@ def run(dt, B, heads, Nq, Nk, causal, rng, check):
 
 def main():
     variant = "lsum_mfma" if os.environ.get("EDTR_ATTN_LSUM_MFMA") == "1" else "default"
+    if PRESCALED:
+        variant = "prescaled_" + ("v2cpp" if os.environ.get("EDTR_ATTN_V3") == "0" else "v3asm")
     rng = np.random.default_rng(0)
     rows, bad = [], 0
     for dt in (0, 1):
         tol = 6e-3 if dt == 0 else 1e-3
         for case in CHECK:
-            ms, err, fl = run(dt, *case, rng, True)
+            ms, err, fl = run(dt, *case[:5], rng, True, *case[5:])
             ok = bool(err <= tol) or H.DRY
             bad += not ok
             print(f"{'PASS' if ok else 'FAIL'}  [{variant}] dt{dt} B,H,Nq,Nk,causal={case}: rel err {err:.2e} (tol {tol:.0e})", flush=True)

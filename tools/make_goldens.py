@@ -365,9 +365,34 @@ def gen_swinir():
     print("swinir.npz written")
 
 
+TOKEN_PROMPTS = [
+    "", "a cat", "A photo of a DOG, running fast!", "remove dense noise", "high quality, 8k, ultra-detailed",
+    "it's the artist's best work; they've said so", "  multiple   spaces\tand\nnewlines  ", "naïve café — déjà vu",
+    "日本語のテキスト", "emoji 😀 test", "numbers 12345 and 3.14159", "under_score and-hyphen/slash",
+    "&amp;lt;escaped&amp;gt; html &quot;entities&quot;", "<start_of_text> literal marker <end_of_text>", "ALL CAPS SHOUTING",
+    "supercalifragilisticexpialidocious antidisestablishmentarianism", "don't won't can't I'll we'd she'm",
+    "a " * 100, "x" * 300, "mixed123abc456 !!! ??? ...", "Ünïcödé ẞharp ǅ",
+]
+
+
+def gen_tokens():
+    """Token ids of the reference tokenizer (model/open_clip/tokenizer.py) for prompts covering contractions, unicode, html
+    entities, digits, long words and truncation -> tests/golden/clip_tokens.json."""
+    ref_import.install_stubs()
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    from model.open_clip import tokenizer as T
+    toks = T.tokenize(TOKEN_PROMPTS)
+    tok = T.SimpleTokenizer()
+    raw = [tok.encode(p) for p in TOKEN_PROMPTS]
+    with open(os.path.join(GOLD, "clip_tokens.json"), "w") as f:
+        json.dump({"prompts": TOKEN_PROMPTS, "tokenize_77": toks.tolist(), "encode": raw}, f)
+    print("clip_tokens.json written:", [len(r) for r in raw])
+
+
 def _img_digest(img: torch.Tensor) -> dict:
     """Compact pin of a large image tensor: stride-4 samples (fp16) + global statistics."""
-    return {"samples": img[:, :, 1::4, 2::4].numpy().astype(np.float16),
+    return {"samples": img[:, :, 1::4, 2::4].numpy().astype(np.float32),
             "stats": np.array([float(img.mean()), float(img.abs().mean()), float(img.abs().max()), float(img.std())])}
 
 
@@ -387,90 +412,94 @@ def gen_full():
     eps_list = []
     hook = cldm.register_forward_hook(lambda m, i, o: eps_list.append(o.detach().clone()))
 
-    # ---- configs[1]: images 3 and 7 of the bench batch
-    GB, S, h = 8, 512, 64
-    sel = [3, 7]
-    pre = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)[sel]
-    noises = [synth.synth_normal(f"bench:noise{i}", (GB, 4, h, h))[sel] for i in range(5)]
-    out = {"images": np.array(sel)}
-    with torch.no_grad():
-        t0 = time.time()
-        z_pre = cldm.vae_encode(pre * 2 - 1, sample=False)
-        x_T = diffusion.q_sample(z_pre, torch.full((len(sel),), 200, dtype=torch.int64), noises[0])
-        sampler = SpacedSampler(diffusion.betas)
-        eps_list.clear()
-        with injected_noise(noises[1:]):
-            z = sampler.manual_sample_with_timesteps(
-                model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=len(sel),
-                cond={"c_txt": c_txt.expand(len(sel), -1, -1), "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
-        img = cldm.vae_decode(z)
-        print(f"det512 x{len(sel)}: {time.time() - t0:.1f}s", flush=True)
-    out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
-    for i, e in enumerate(eps_list):
-        out[f"eps{i}"] = e.numpy()
-    np.savez_compressed(os.path.join(GOLD, "full_det512.npz"), **out)
-    print("full_det512.npz written", flush=True)
+    only = os.environ.get("EDTR_GOLD_FULL_ONLY", "det512,s50,seg1024").split(",")
+    if "det512" in only:
+        # ---- configs[1]: images 3 and 7 of the bench batch
+        GB, S, h = 8, 512, 64
+        sel = [3, 7]
+        pre = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)[sel]
+        noises = [synth.synth_normal(f"bench:noise{i}", (GB, 4, h, h))[sel] for i in range(5)]
+        out = {"images": np.array(sel)}
+        with torch.no_grad():
+            t0 = time.time()
+            z_pre = cldm.vae_encode(pre * 2 - 1, sample=False)
+            x_T = diffusion.q_sample(z_pre, torch.full((len(sel),), 200, dtype=torch.int64), noises[0])
+            sampler = SpacedSampler(diffusion.betas)
+            eps_list.clear()
+            with injected_noise(noises[1:]):
+                z = sampler.manual_sample_with_timesteps(
+                    model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=len(sel),
+                    cond={"c_txt": c_txt.expand(len(sel), -1, -1), "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+            img = cldm.vae_decode(z)
+            print(f"det512 x{len(sel)}: {time.time() - t0:.1f}s", flush=True)
+        out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
+        for i, e in enumerate(eps_list):
+            out[f"eps{i}"] = e.numpy()
+        np.savez_compressed(os.path.join(GOLD, "full_det512.npz"), **out)
+        print("full_det512.npz written", flush=True)
 
-    # ---- configs[4]: image 0 of the batch of 4, 50 spaced steps from pure noise
-    GB = 4
-    pre = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)[:1]
-    x_T = synth.synth_normal("bench:noise0", (GB, 4, h, h))[:1]
-    step_noise = [synth.synth_normal(f"bench:s50noise{i}", (GB, 4, h, h))[:1] for i in range(50)]
-    out = {}
-    with torch.no_grad():
-        t0 = time.time()
-        z_pre = cldm.vae_encode(pre * 2 - 1, sample=False)
-        sampler = SpacedSampler(diffusion.betas)
-        eps_list.clear()
-        with injected_noise(step_noise):
-            z, inter = sampler.sample(model=cldm, device="cpu", steps=50, batch_size=1, x_size=(4, h, h),
-                                      cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, x_T=x_T,
-                                      progress=False, return_intermediates=True)
-        img = cldm.vae_decode(z)
-        print(f"det512s50 x1: {time.time() - t0:.1f}s", flush=True)
-    out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
-    for i in (0, 9, 24, 39, 49):
-        out[f"pred_x0_{i}"] = inter[i].numpy()
-        out[f"eps{i}"] = eps_list[i].numpy()
-    np.savez_compressed(os.path.join(GOLD, "full_s50.npz"), **out)
-    print("full_s50.npz written", flush=True)
+    if "s50" in only:
+        # ---- configs[4]: image 0 of the batch of 4, 50 spaced steps from pure noise
+        GB = 4
+        pre = synth.synth_input("bench:pre_res", (GB, 3, S, S), 0.0, 1.0)[:1]
+        x_T = synth.synth_normal("bench:noise0", (GB, 4, h, h))[:1]
+        step_noise = [synth.synth_normal(f"bench:s50noise{i}", (GB, 4, h, h))[:1] for i in range(50)]
+        out = {}
+        with torch.no_grad():
+            t0 = time.time()
+            z_pre = cldm.vae_encode(pre * 2 - 1, sample=False)
+            sampler = SpacedSampler(diffusion.betas)
+            eps_list.clear()
+            with injected_noise(step_noise):
+                z, inter = sampler.sample(model=cldm, device="cpu", steps=50, batch_size=1, x_size=(4, h, h),
+                                          cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, x_T=x_T,
+                                          progress=False, return_intermediates=True)
+            img = cldm.vae_decode(z)
+            print(f"det512s50 x1: {time.time() - t0:.1f}s", flush=True)
+        out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
+        for i in (0, 9, 24, 39, 49):
+            out[f"pred_x0_{i}"] = inter[i].numpy()
+            out[f"eps{i}"] = eps_list[i].numpy()
+        np.savez_compressed(os.path.join(GOLD, "full_s50.npz"), **out)
+        print("full_s50.npz written", flush=True)
 
-    # ---- configs[3]: 1024x1024, tiled encoder / latent-tiled sampler / untiled decoder
-    S, h = 1024, 128
-    pre = synth.synth_input("bench:pre_res", (1, 3, S, S), 0.0, 1.0)
-    noises = [synth.synth_normal(f"bench:noise{i}", (1, 4, h, h)) for i in range(5)]
-    out = {}
-    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
-        t0 = time.time()
-        z_pre = cldm.vae_encode(pre * 2 - 1, sample=False, tiled=True, tile_size=256)
-        t_enc = time.time() - t0
-        x_T = diffusion.q_sample(z_pre, torch.full((1,), 200, dtype=torch.int64), noises[0])
-        sampler = SpacedSampler(diffusion.betas)
-        eps_list.clear()
-        with injected_noise(noises[1:]):
-            z = sampler.manual_sample_with_timesteps(
-                model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=1,
-                cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False,
-                tiled=True, tile_size=64, tile_stride=32)
-        t_smp = time.time() - t0 - t_enc
-        img = cldm.vae_decode(z)
-    print(f"seg1024tiled: enc {t_enc:.1f}s sampler {t_smp:.1f}s total {time.time() - t0:.1f}s", flush=True)
-    out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
-    hook.remove()
-    np.savez_compressed(os.path.join(GOLD, "full_seg1024.npz"), **out)
-    print("full_seg1024.npz written", flush=True)
+    if "seg1024" in only:
+        # ---- configs[3]: 1024x1024, tiled encoder / latent-tiled sampler / untiled decoder
+        S, h = 1024, 128
+        pre = synth.synth_input("bench:pre_res", (1, 3, S, S), 0.0, 1.0)
+        noises = [synth.synth_normal(f"bench:noise{i}", (1, 4, h, h)) for i in range(5)]
+        out = {}
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.time()
+            z_pre = cldm.vae_encode(pre * 2 - 1, sample=False, tiled=True, tile_size=256)
+            t_enc = time.time() - t0
+            x_T = diffusion.q_sample(z_pre, torch.full((1,), 200, dtype=torch.int64), noises[0])
+            sampler = SpacedSampler(diffusion.betas)
+            eps_list.clear()
+            with injected_noise(noises[1:]):
+                z = sampler.manual_sample_with_timesteps(
+                    model=cldm, device="cpu", x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=1,
+                    cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False,
+                    tiled=True, tile_size=64, tile_stride=32)
+            t_smp = time.time() - t0 - t_enc
+            img = cldm.vae_decode(z)
+        print(f"seg1024tiled: enc {t_enc:.1f}s sampler {t_smp:.1f}s total {time.time() - t0:.1f}s", flush=True)
+        out.update(z_pre=z_pre.numpy(), z=z.numpy(), img_samples=_img_digest(img)["samples"], img_stats=_img_digest(img)["stats"])
+        hook.remove()
+        np.savez_compressed(os.path.join(GOLD, "full_seg1024.npz"), **out)
+        print("full_seg1024.npz written", flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr,swinir,full")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr,swinir,full,tokens")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full}[name]()
+         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens}[name]()
 
 
 if __name__ == "__main__":
