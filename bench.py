@@ -48,6 +48,9 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
+    ap.add_argument("--precision", default="fast", choices=["fast", "high"],
+                    help="fast = 16-bit activation storage in --dtype (headline); high = the parity mode (fp32 stream, bf16 split-3 "
+                         "products, fp16 attention) that meets the 1e-3 north-star tolerance")
     ap.add_argument("--workload", default="det512", choices=["det512", "seg1024tiled", "det512s50"],
                     help="det512 = BASELINE configs[1] (default); seg1024tiled = configs[3]: one 1024x1024 image, tiled VAE encoder "
                          "(256-px tiles), latent-tiled denoiser (64/32 latent tiles), untiled decoder (demo.py:99-124); det512s50 = configs[4] per GPU: batch 4 of 512x512, 50-step sampler from pure noise")
@@ -67,6 +70,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    tiled = args.workload == "seg1024tiled"
+    s50 = args.workload == "det512s50"
+    if tiled:
+        args.batch, args.size, args.inflight = 1, 1024, 1
+        args.no_cpu_baseline = True
+    if s50:
+        args.batch, args.size = 4, 512
+        args.no_cpu_baseline = True
+    # ---- the CPU-baseline child is spawned before this process makes any HIP call; it builds its fp32 weights, reports "ready"
+    #      and idles.  The GPU side waits for that "ready" before its warm-up, so the two never compete for the host cores.
+    cpu_handle = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_handle = start_cpu_baseline(args.config, args.size)
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
@@ -80,28 +96,17 @@ def main() -> None:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
 
-    cpu_handle = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_handle = start_cpu_baseline(args.config, args.size)
 
     from edtr_amd import synth, workloads
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.model import ControlLDM
     from edtr_amd.model.params import skip_init
-    from edtr_amd.parallel import broadcast_parameters
+    from edtr_amd.parallel import broadcast_packed
     from edtr_amd.sampler import SpacedSampler
     from edtr_amd.testing import rel_err, synthetic_state_dicts
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     cfg = synth.CONFIGS[args.config]()
-    tiled = args.workload == "seg1024tiled"
-    s50 = args.workload == "det512s50"
-    if tiled:
-        args.batch, args.size, args.inflight = 1, 1024, 1
-        args.no_cpu_baseline = True
-    if s50:
-        args.batch, args.size = 4, 512
-        args.no_cpu_baseline = True
     B, S = args.batch, args.size
     h = S // 8
     ctx_dim = cfg["unet_cfg"]["context_dim"]
@@ -109,22 +114,20 @@ def main() -> None:
     # ---- model: rank 0 materialises the synthetic checkpoint, the other ranks receive it by ONE bucketed RCCL
     #      broadcast over xGMI (start-up only; the denoise loop has no collective)
     t0 = time.time()
-    with skip_init():
+    with skip_init(), torch.device(dev):          # parameters are born on the device
         cldm = ControlLDM(**cfg)
     cldm.compute_dtype = dtype
-    sds = None
-    if rank == 0:
-        sds = synthetic_state_dicts(cfg)
+    cldm.precision = args.precision
+    if rank == 0:                                  # the "checkpoint" lives on rank 0 only (hashed on the device: bit-identical to the host)
+        sds = synthetic_state_dicts(cfg, dev)
         cldm.unet.load_state_dict(sds["unet"], strict=True)
         cldm.load_controlnet_from_ckpt(sds["controlnet"])
         cldm.vae.load_state_dict(sds["vae"], strict=True)
+    else:
+        with torch.no_grad():
+            for p_ in cldm.parameters():
+                p_.zero_()
     cldm = cldm.eval().to(dev)
-    if use_dist:
-        calls = nbytes = 0
-        for part in (cldm.unet, cldm.controlnet, cldm.vae):      # the CLIP tower is not on this path: c_txt is an input
-            c_, n_ = broadcast_parameters(part, src=0)
-            calls, nbytes = calls + c_, nbytes + n_
-        log(f"[rank {rank}] weights broadcast over RCCL: {calls} collectives, {nbytes / 2**30:.2f} GiB")
     log(f"[rank {rank}] model ready in {time.time() - t0:.1f}s")
 
     diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
@@ -145,6 +148,8 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if cpu_handle is not None:
+        wait_cpu_ready(cpu_handle)
     # ---- warm-up (builds the kernel programs on the first pass), optional hipGraph capture
     slots = list(range(args.inflight))
     streams = [torch.cuda.Stream() for _ in slots]
@@ -154,6 +159,19 @@ def main() -> None:
         img, z = one_pass()
     torch.cuda.synchronize()
     log(f"[rank {rank}] first pass (program build + weight packing) {time.time() - t0:.1f}s")
+    bcast = None
+    if use_dist:
+        # ---- ONE bucketed RCCL broadcast of the PACKED weights over xGMI (start-up only; the denoise loop has no collective):
+        #      every rank has built the same programs, the packed tensors are overwritten in place
+        t0 = time.time()
+        calls, nbytes = broadcast_packed(cldm, src=0)
+        torch.cuda.synchronize()
+        bcast = {"collectives": calls, "GiB": round(nbytes / 2**30, 3), "seconds": round(time.time() - t0, 2)}
+        log(f"[rank {rank}] packed weights broadcast over RCCL: {bcast}")
+        for sl_ in slots:                          # results of the warm-up pass on the receiving ranks were computed from zeros
+            cldm.engine_slot = sl_
+            img, z = one_pass()
+        torch.cuda.synchronize()
     if not args.no_graph:
         for e in cldm._cldm_engines.values():
             e.step_prog.capture(parallel_lanes=not args.serial_lanes)
@@ -186,17 +204,22 @@ def main() -> None:
     ms_per_step = elapsed / args.steps * 1e3
     value = GB * args.steps / elapsed
 
+    tol_key = "high" if args.precision == "high" else args.dtype
     result = {
         "metric": f"restored {S}x{S} images/sec @ {50 if s50 else 4} denoise steps",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": "bf16 split-3 products over an fp32 stream (precision=high)" if args.precision == "high" else args.dtype,
+        "data": "synthetic",
         "config": {"workload": (f"EDTR-seg s4 ({args.config}), configs[3]: tiled vae_encode (256-px tiles) + q_sample(t=200) + 4 x latent-tiled "
                                 f"(64/32) ControlNet+UNet + untiled vae_decode, batch {B}/GPU of {S}x{S}") if tiled else
+                               (f"EDTR-det s50 ({args.config}), configs[4] per GPU: vae_encode + 50-step spaced sampler from pure noise "
+                                f"(50 x (ControlNet+UNet)) + vae_decode, batch {B}/GPU of {S}x{S}") if s50 else
                                f"EDTR-det s4 ({args.config}): vae_encode + q_sample(t=200) + 4 x (ControlNet+UNet) + "
                                f"vae_decode, batch {B}/GPU of {S}x{S}", "global_batch": GB, "image_size": S,
                    "denoise_steps": 50 if s50 else 4, "parallelism": f"batch-sharded x{world}", "graphs": not args.no_graph,
                    "batches_in_flight": args.inflight},
+        "weight_broadcast": bcast,
         "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE_BY_WORKLOAD[args.workload] / (world * PEAK_TFLOPS * 1e12), 4) if args.config == "sd21" else None,
     }
 
@@ -208,9 +231,9 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         result.update(roofline_pass(cldm, args))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result.update(finish_cpu_baseline(cpu_handle, inp, img.cpu(), z.cpu(), S, rel_err, args.dtype))
+        result.update(finish_cpu_baseline(cpu_handle, inp, img.cpu(), z.cpu(), S, rel_err, tol_key))
     if rank == 0 and world == 1 and args.config == "sd21":
-        result.update(golden_parity(args.workload, img, z, rel_err, args.dtype))
+        result.update(golden_parity(args.workload, img, z, rel_err, tol_key))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
@@ -335,7 +358,8 @@ def kernel_of(name: str) -> str:
 
 # relative-L2 tolerances of the 16-bit storage modes against the fp32 reference at full size (measured values and the error
 # budget are in DESIGN.md §5; the north-star 1e-3 is asserted for the parity mode, EDTR_AMD_PRECISION=high)
-TOLERANCE = {"bf16": {"latent": 2e-2, "image": 3e-2}, "fp16": {"latent": 3e-3, "image": 5e-3}}
+TOLERANCE = {"bf16": {"latent": 2e-2, "image": 3e-2}, "fp16": {"latent": 3e-3, "image": 5e-3},
+             "high": {"latent": 1e-3, "image": 1e-3}}
 
 
 def _cpu_worker(q_in, q_out, cfg_name, S, threads):
@@ -383,14 +407,24 @@ def start_cpu_baseline(cfg_name, S):
     q_in, q_out = ctx.Queue(), ctx.Queue()
     proc = ctx.Process(target=_cpu_worker, args=(q_in, q_out, cfg_name, S, threads), daemon=True)
     proc.start()
-    return proc, q_in, q_out, threads, cores
+    return [proc, q_in, q_out, threads, cores, {"ready": False}]
+
+
+def wait_cpu_ready(handle, budget_s=600.0) -> None:
+    """Block until the oracle child has built its weights (so it is idle during the GPU warm-up and the timed region)."""
+    proc, q_in, q_out, threads, cores, state = handle
+    try:
+        q_out.get(timeout=budget_s)
+        state["ready"] = True
+    except Exception:
+        log("cpu baseline child did not become ready in time")
 
 
 def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=420.0) -> dict:
     """CPU points of BASELINE.md §3 on a bounded sample: the FIRST and the LAST image of the batch as two B=1 runs (both also
     give the live GPU-vs-oracle parity), then — if the B=1 runs were fast enough to leave room in the budget — the whole
     batch as one B=8 run."""
-    proc, q_in, q_out, threads, cores = handle
+    proc, q_in, q_out, threads, cores, state = handle
     B = inp.pre_res.shape[0]
     pre, ctx, noises = inp.pre_res.cpu(), inp.c_txt[:1].cpu(), [n.cpu() for n in inp.noises]
     runs = {}
@@ -402,7 +436,8 @@ def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=42
         return res
 
     try:
-        q_out.get(timeout=budget_s)                       # "ready"
+        if not state["ready"]:
+            q_out.get(timeout=budget_s)                   # "ready"
         runs["first"] = (slice(0, 1), job(slice(0, 1)))
         if B > 1:
             runs["last"] = (slice(B - 1, B), job(slice(B - 1, B)))

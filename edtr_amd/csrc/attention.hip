@@ -238,269 +238,40 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
 }
 
 
-// =====================================================================================================================
-// v2: the large-N self-attention kernel (64x64 / 32x32 latents: N = 4096 / 1024 keys).
-//
-// The softmax at head width 64 needs more vector-ISSUE cycles than the two matrix products need matrix-pipe cycles
-// (per score: v_exp 8 + v_add 4 + half a v_cvt_pk ~2.3 against 2 x 4 MFMA-pipe cycles), so the structure is chosen to
-// delete issue slots, not to re-order them:
-//   * one workgroup = 4 waves = 256 queries of one (image, head); a wave owns TWO 32-query blocks (A, B) and the whole
-//     512-entry register file (one wave per SIMD).  A K / V^T tile staged in LDS by 4 LDS-DMA pieces per wave feeds 32 MFMAs
-//     per wave instead of 16, and every K / V fragment read from LDS is used by both blocks' products.
-//   * the scores arrive pre-scaled (q_prescaled: the projection GEMM multiplied by scale*log2e in fp32 before its
-//     single rounding) and the running maximum enters through the MFMA's C operand (a register vector holding -m), so the
-//     exponent's argument leaves the matrix core ready: ONE v_exp per score, no v_fma.
-//   * no per-score maximum: the row max is taken on the first tile only.  Afterwards a tile's probabilities are formed
-//     against the old maximum and the tile's row sum is compared with 2^14 (one wave vote); only if some row exceeds it
-//     (a later key beats the first tile's best by > 14 octaves) the slow path raises the maximum, rescales O and l and
-//     re-forms the tile.  fp32 accumulators and the 8-bit (bf16) / 5-bit (fp16, max 2^16) exponents of P make 2^14 safe.
-//   * the two blocks are software-pipelined against each other inside the one instruction stream:
-//        phase 1:  softmax(A, t)   beside  O_B += V(t-1) P_B(t-1)   and  S_B(t)   = K(t)   Q_B
-//        phase 2:  softmax(B, t)   beside  O_A += V(t)   P_A(t)     and  S_A(t+1) = K(t+1) Q_A
-//     so every MFMA has about six vector instructions of the other block next to it, and every operand is produced a
-//     whole phase before its use.  One s_barrier per tile; K/V tiles travel two tiles ahead through a 4-stage LDS ring.
-// =====================================================================================================================
-constexpr int QB2 = 256;                  // queries per workgroup (v2)
+constexpr int QB2 = 256;                  // queries per workgroup of the large-N kernel
 constexpr int NSTAGE = 4;
-constexpr float kSumLimit = 16384.0f;     // 2^14: a half-row tile sum above this takes the slow (re-maximise) path
-
-template <typename T>
-__global__ void __launch_bounds__(kThreads, 1) flash_attn64_v2_kernel(const edtr_attn_params p) {
-    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * 2 * TILE_BYTES];  // [stage][K tile | V^T tile] = 64 KiB
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5;
-    // ---- workgroup -> (image, head, query block): the query blocks of one (image, head) share K / V, so they are dealt to ONE
-    //      XCD (blockIdx % 8 under round-robin placement; speed only) when the pair count allows a bijective map
-    const int nqb = (p.Nq + QB2 - 1) / QB2;
-    const int BH = p.B * p.H;
-    int bh, qb;
-    {
-        const int bid = blockIdx.x;
-        if ((BH & 7) == 0) {
-            const int xcd = bid & 7, j = bid >> 3;
-            bh = xcd + 8 * (j / nqb);
-            qb = j % nqb;
-        } else {
-            bh = bid / nqb;
-            qb = bid % nqb;
-        }
-    }
-    const int b = bh / p.H, h = bh - b * p.H;
-    const int q_rowA = qb * QB2 + wave * 64 + l31, q_rowB = q_rowA + 32;
-
-    const uint16_t* qp = static_cast<const uint16_t*>(p.q) + b * p.q_bs + h * 64;
-    const uint16_t* kp = static_cast<const uint16_t*>(p.k) + b * p.k_bs + h * 64;
-    const uint16_t* vp = static_cast<const uint16_t*>(p.vt) + b * p.vt_bs + (int64_t)h * 64 * p.vt_ld;
-
-    U4 qA[4], qB[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qA[ks] = zero16();
-        qB[ks] = zero16();
-        if (q_rowA < p.Nq) qA[ks] = ldg16(qp + (int64_t)q_rowA * p.q_ld + ks * 16 + lh * 8);
-        if (q_rowB < p.Nq) qB[ks] = ldg16(qp + (int64_t)q_rowB * p.q_ld + ks * 16 + lh * 8);
-    }
-
-    // ---- tile staging (as v1): one LDS-DMA = 8 tile rows of 128 bytes; a wave owns rows wave*16 + 8j + (lane>>3)
-    const u32x4 srd_k = srd_of(kp), srd_v = srd_of(vp);
-    const uint32_t smem_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem));
-    const int rsub = lane >> 3, slot = lane & 7;
-    uint32_t koff[2], voff[2];
-    int vkey[2], krow[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = wave * 16 + 8 * j + rsub;
-        const int chunk = slot ^ ((row >> 1) & 7);
-        krow[j] = row;
-        koff[j] = (uint32_t)(((int64_t)row * p.k_ld + chunk * 8) * 2);
-        vkey[j] = chunk * 8;
-        voff[j] = (uint32_t)(((int64_t)row * p.vt_ld + chunk * 8) * 2);
-    }
-    auto issue_tile = [&](int t) {
-        const int kv0 = t * KV;
-        const uint32_t sk = smem_base + (t & (NSTAGE - 1)) * 2 * TILE_BYTES + wave * (16 * 128);
-        const uint32_t sv = sk + TILE_BYTES;
-        const uint32_t soff_k = (uint32_t)kv0 * (uint32_t)p.k_ld * 2u, soff_v = (uint32_t)kv0 * 2u;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            dma16(kv0 + krow[j] < p.Nk ? koff[j] : kOob, srd_k, soff_k, sk + j * 1024);
-            dma16(kv0 + vkey[j] < p.Nk ? voff[j] : kOob, srd_v, soff_v, sv + j * 1024);
-        }
-    };
-
-    // ---- per-block state
-    f32x16 oA[2], oB[2], sA[2], sB[2], nmA, nmB;      // O^T accumulators, score tiles, -max vectors (MFMA C operands)
-    U4 pA[2][2], pB[2][2];                             // packed probabilities: B operands of O^T += V^T P^T
-    float lA = 0.0f, lB = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oA[0][r] = oA[1][r] = oB[0][r] = oB[1][r] = 0.0f; nmA[r] = nmB[r] = 0.0f; }
-
-    const int krd = swap23(l31);
-    const int nt = (p.Nk + KV - 1) / KV;
-    const bool ragged = (p.Nk & (KV - 1)) != 0;
-
-    // LDS fragment addresses inside a stage (tile_off is lane-constant)
-    int kaddr[2][4], vaddr[2][2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kaddr[kb][ks] = tile_off(kb * 32 + krd, 2 * ks + lh);
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) vaddr[db][kb][st] = TILE_BYTES + tile_off(db * 32 + l31, kb * 4 + 2 * st + lh);
-
-    auto stage_ptr = [&](int t) -> const char* { return smem + (t & (NSTAGE - 1)) * 2 * TILE_BYTES; };
-
-    // S^T block = K(tile) Q^T, accumulated on top of the -max vector
-    auto qk = [&](const char* st, const U4 (&qf)[4], const f32x16& nm, f32x16 (&s)[2]) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const U4 kf = *reinterpret_cast<const U4*>(st + kaddr[kb][ks]);
-                s[kb] = T::mfma(kf, qf[ks], ks == 0 ? nm : s[kb]);
-            }
-        }
-    };
-    auto pv = [&](const char* st, const U4 (&pf)[2][2], f32x16 (&o)[2]) {
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const U4 vf = *reinterpret_cast<const U4*>(st + vaddr[db][kb][s2]);
-                    o[db] = T::mfma(vf, pf[kb][s2], o[db]);
-                }
-    };
-    // keys past Nk in the last tile: -inf scores (their K rows landed as zeros)
-    auto mask_tail = [&](int t, f32x16 (&s)[2]) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * KV + kb * 32 + 16 * (r >> 3) + 8 * lh + (r & 7);
-                if (key >= p.Nk) s[kb][r] = -1e30f;
-            }
-    };
-    // probabilities of one tile against the current maximum: P packed, returns this lane's half-row sum
-    auto expo = [&](const f32x16 (&s)[2], U4 (&pf)[2][2]) -> float {
-        float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            float pr[16];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                pr[r] = __builtin_amdgcn_exp2f(s[kb][r]);
-                pr[r + 1] = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                a0 += pr[r];
-                a1 += pr[r + 1];
-            }
-            pf[kb][0].x = pack2<T>(pr[0], pr[1]);   pf[kb][0].y = pack2<T>(pr[2], pr[3]);
-            pf[kb][0].z = pack2<T>(pr[4], pr[5]);   pf[kb][0].w = pack2<T>(pr[6], pr[7]);
-            pf[kb][1].x = pack2<T>(pr[8], pr[9]);   pf[kb][1].y = pack2<T>(pr[10], pr[11]);
-            pf[kb][1].z = pack2<T>(pr[12], pr[13]); pf[kb][1].w = pack2<T>(pr[14], pr[15]);
-        }
-        return a0 + a1;
-    };
-    // raise the maximum by the tile's row maximum (first tile: set it), rescale O / l, shift the tile's scores
-    auto remax = [&](bool first, f32x16 (&s)[2], f32x16& nm, f32x16 (&o)[2], float& l) {
-        float mt = s[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        if (!first) mt = fmaxf(mt, 0.0f);            // never lower an established maximum
-        mt = fmaxf(mt, -1e30f) ;                     // a fully masked row keeps finite arithmetic
-        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-mt);
-        l *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[0][r] -= mt;
-            s[1][r] -= mt;
-            nm[r] -= mt;
-            o[0][r] *= alpha;
-            o[1][r] *= alpha;
-        }
-    };
-    // softmax of one block's tile: FIRST sets the maximum up front, later tiles verify the row sums afterwards
-    auto softmax_tile = [&](bool first, f32x16 (&s)[2], f32x16& nm, f32x16 (&o)[2], float& l, U4 (&pf)[2][2]) {
-        if (first) remax(true, s, nm, o, l);
-        float ps = expo(s, pf);
-        if (!first && !__all(ps <= kSumLimit)) {
-            remax(false, s, nm, o, l);
-            ps = expo(s, pf);
-        }
-        l += ps;
-    };
-
-    // ---- prologue: tiles 0 and 1 in flight, S_A(0)
-    issue_tile(0);
-    if (nt > 1) {
-        issue_tile(1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    qk(stage_ptr(0), qA, nmA, sA);
-    if (ragged && nt == 1) mask_tail(0, sA);
-
-    for (int t = 0; t < nt; ++t) {
-        // tile t+1 has landed in every wave's view; the stage of tile t-2 is free for tile t+2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < nt) issue_tile(t + 2);
-        const bool first = (t == 0), last = (t + 1 == nt);
-        const char* st_cur = stage_ptr(t);
-        // ---- phase 1: softmax(A, t)  |  O_B += V(t-1) P_B(t-1),  S_B(t) = K(t) Q_B
-        if (!first) pv(stage_ptr(t - 1), pB, oB);
-        qk(st_cur, qB, nmB, sB);
-        if (ragged && last) mask_tail(t, sB);
-        softmax_tile(first, sA, nmA, oA, lA, pA);
-        // ---- phase 2: softmax(B, t)  |  O_A += V(t) P_A(t),  S_A(t+1) = K(t+1) Q_A
-        pv(st_cur, pA, oA);
-        if (!last) {
-            qk(stage_ptr(t + 1), qA, nmA, sA);
-            if (ragged && t + 2 == nt) mask_tail(t + 1, sA);
-        }
-        softmax_tile(first, sB, nmB, oB, lB, pB);
-    }
-    pv(stage_ptr(nt - 1), pB, oB);
-
-    // ---- normalise and store (lane (q, half) holds d = db*32 + 8g + 4*half + (0..3) in regs 4g..4g+3)
-    const float invA = 1.0f / (lA + __shfl_xor(lA, 32, 64)), invB = 1.0f / (lB + __shfl_xor(lB, 32, 64));
-    uint16_t* ob = static_cast<uint16_t*>(p.out) + b * p.o_bs + h * 64;
-    auto store = [&](int q_row, const f32x16 (&o)[2], float inv) {
-        if (q_row >= p.Nq) return;
-        uint16_t* op = ob + (int64_t)q_row * p.o_ld;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v;
-                v.x = pack2<T>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
-                v.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = v;
-            }
-    };
-    store(q_rowA, oA, invA);
-    store(q_rowB, oB, invB);
-}
 
 // =====================================================================================================================
-// v3: the algorithm of v2 with the whole tile loop as ONE generated inline-asm statement (tools/gen_attn_v2.py ->
-// attn_v3_loop.inc): registers owned by the stream, every vector instruction placed in an MFMA gap.  The C++ around it only
-// computes addresses, loads Q and stores O.  Needs Nk % 256 == 0 (4 tiles per unrolled trip, no key masking).
+// v3: the large-N self-attention kernel (64x64 latents: N = 4096 keys; any Nq >= 2048 with Nk % 256 == 0).
+//
+// At head width 64 the softmax needs more vector-ISSUE cycles than the two matrix products need matrix-pipe cycles, so the
+// structure deletes issue slots instead of re-ordering them:
+//   * one workgroup = 4 waves = 256 queries of one (image, head); a wave owns TWO 32-query blocks (A, B) and the whole
+//     512-entry register file (one wave per SIMD): a K / V^T tile staged by 4 LDS-DMA pieces per wave feeds 32 MFMAs per wave
+//     (16 in v1), and every K / V fragment read from LDS serves both blocks' products;
+//   * scores arrive pre-scaled (q_prescaled) and the running maximum enters through the MFMA's C operand (a register vector
+//     holding -max): ONE v_exp per score, no v_fma, and no per-score maximum — the row max is taken on the first tile; later
+//     a half-row tile sum above 2^14 (one wave vote per block and tile) sends the block through an out-of-line path that
+//     raises the maximum, rescales O and l and re-forms the tile (fp32 accumulators and the exponent range of bf16 / fp16 P
+//     make 2^14 safe);
+//   * the blocks are software-pipelined against each other in ONE instruction stream:
+//        phase 1:  softmax(A, t)  beside  S_B(t) = K(t) Q_B      and  O_B += V(t-1) P_B(t-1)   (fragments kept in registers)
+//        phase 2:  softmax(B, t)  beside  S_A(t+1) = K(t+1) Q_A  and  O_A += V(t) P_A(t)       (16 ds_read_b128)
+//     one s_barrier per tile, tiles travel two ahead through a 4-stage LDS ring.
+// hipcc's scheduler clusters the MFMAs of such a loop, shuttles accumulators between the register files around every branch
+// and packs the f32 adds (the C++ form of this algorithm ran at 447 TFLOP/s where v1 runs at 711), so the whole tile loop is
+// ONE generated inline-asm statement (tools/gen_attn_v2.py -> attn_v3_loop.inc) that owns its registers; the C++ around it
+// computes addresses, loads Q and stores O.  Measured (MI355X, B 8 x 5 heads x 4096^2, bf16): 201 us = 854 TFLOP/s;
+// in-kernel stamps (tools/exp/attn_variants.py): ~2010 cycles per tile and wave = 32 MFMA slots of ~44 issue cycles (v_exp
+// ~13 each), 255 for the 4 LDS-DMA pieces, 95 at the barrier — the wave is ISSUE-bound, the matrix pipe is busy 51 %.
 // =====================================================================================================================
-#include "attn_v3_loop.inc"
+#ifndef EDTR_ATTN_V3_INC
+#define EDTR_ATTN_V3_INC "attn_v3_loop.inc"
+#endif
+#include EDTR_ATTN_V3_INC
+#ifdef EDTR_STAMPS      // diagnostic build (tools/exp/attn_variants.py): per-wave cycle sums of the loop's segments
+__device__ unsigned g_attn_stamps[1 << 16];
+#endif
 
 template <typename T>
 __global__ void __launch_bounds__(kThreads, 1) flash_attn64_v3_kernel(const edtr_attn_params p) {
@@ -565,12 +336,21 @@ __global__ void __launch_bounds__(kThreads, 1) flash_attn64_v3_kernel(const edtr
         for (int st = 0; st < 2; ++st) vad[kb * 2 + st] = (int)smem_base + tile_off(l31, kb * 4 + 2 * st + lh);
 
     float oa0[16], oa1[16], ob0[16], ob1[16], la, lb;
+#ifdef EDTR_STAMPS
+    unsigned stamps[4];
+#endif
     if constexpr (__is_same(T, BF16)) {
         asm volatile(EDTR_ATTN_V3_ASM("v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32") : EDTR_ATTN_V3_OUTS : EDTR_ATTN_V3_INS : EDTR_ATTN_V3_CLOBBERS);
     } else {
         asm volatile(EDTR_ATTN_V3_ASM("v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32") : EDTR_ATTN_V3_OUTS : EDTR_ATTN_V3_INS : EDTR_ATTN_V3_CLOBBERS);
     }
 
+#ifdef EDTR_STAMPS
+    if (lane == 0 && blockIdx.x < 4096) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g_attn_stamps[(blockIdx.x * 4 + wave) * 4 + i] = stamps[i];
+    }
+#endif
     const float invA = 1.0f / (la + __shfl_xor(la, 32, 64)), invB = 1.0f / (lb + __shfl_xor(lb, 32, 64));
     uint16_t* ob = static_cast<uint16_t*>(p.out) + b * p.o_bs + h * 64;
     auto store = [&](int q_row, const float (&o0)[16], const float (&o1)[16], float inv) {
@@ -593,6 +373,12 @@ __global__ void __launch_bounds__(kThreads, 1) flash_attn64_v3_kernel(const edtr
 
 }  // namespace
 
+#ifdef EDTR_STAMPS
+extern "C" int edtr_attn_stamps_read(unsigned* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_stamps), (size_t)n * 4);
+}
+#endif
+
 extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t stream) {
     if (!pp) return EDTR_E_NULL;
     const edtr_attn_params& p = *pp;
@@ -608,12 +394,12 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
     // 32-bit byte offsets inside one (image, head) slice of K and of V^T (buffer addressing)
     if ((int64_t)(p.Nk + 64) * p.k_ld * 2 >= 0xF0000000LL || (int64_t)64 * p.vt_ld * 2 >= 0xF0000000LL) return EDTR_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static int v2_min_nq = -1;      // the large-N kernel takes over at this many queries (EDTR_ATTN_V2_MIN_NQ, 0 = never)
+    static int v2_min_nq = -1;      // the large-N kernel takes over at this many queries (EDTR_ATTN_V3_MIN_NQ, 0 = never)
     if (v2_min_nq < 0) {
-        const char* e = getenv("EDTR_ATTN_V2_MIN_NQ");
+        const char* e = getenv("EDTR_ATTN_V3_MIN_NQ");
         v2_min_nq = e ? atoi(e) : 2048;
     }
-    static int v3_on = -1;          // EDTR_ATTN_V3=0 keeps the C++ form (v2) of the large-N kernel
+    static int v3_on = -1;          // EDTR_ATTN_V3=0: every shape runs the v1 kernel (A/B runs on one device)
     if (v3_on < 0) {
         const char* e = getenv("EDTR_ATTN_V3");
         v3_on = (e && e[0] == '0') ? 0 : 1;
@@ -622,13 +408,6 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
         dim3 grid3(((p.Nq + QB2 - 1) / QB2) * p.H * p.B);
         if (p.dtype == EDTR_BF16) hipLaunchKernelGGL((flash_attn64_v3_kernel<BF16>), grid3, dim3(kThreads), 0, s, p);
         else hipLaunchKernelGGL((flash_attn64_v3_kernel<F16>), grid3, dim3(kThreads), 0, s, p);
-        EDTR_LAUNCH_CHECK();
-        return EDTR_OK;
-    }
-    if (p.q_prescaled && !p.causal && v2_min_nq > 0 && p.Nq >= v2_min_nq && p.Nk >= 256) {
-        dim3 grid2(((p.Nq + QB2 - 1) / QB2) * p.H * p.B);
-        if (p.dtype == EDTR_BF16) hipLaunchKernelGGL((flash_attn64_v2_kernel<BF16>), grid2, dim3(kThreads), 0, s, p);
-        else hipLaunchKernelGGL((flash_attn64_v2_kernel<F16>), grid2, dim3(kThreads), 0, s, p);
         EDTR_LAUNCH_CHECK();
         return EDTR_OK;
     }

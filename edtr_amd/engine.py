@@ -221,11 +221,12 @@ class Program:
         self.sums_pool: Optional[torch.Tensor] = None   # GroupNorm [B][32][2] fp64 accumulators, zeroed by ONE launch
         self.sums_used = 0
 
-    SUMS_SLOTS = 384
+    SUMS_SLOTS = 4096
 
-    def sums_slot(self, arena: "Arena", B: int) -> torch.Tensor:
-        """A never-reused [B, 32, 2] fp64 GroupNorm accumulator out of a pool that the program's FIRST launch zeroes
-        (a hipMemsetAsync per edtr_gn_stats call costs two extra tiny kernels per node inside the hipGraph)."""
+    def sums_slot(self, arena: "Arena", B: int, count: int = 1) -> torch.Tensor:
+        """A never-reused [B, 32, 2] fp64 GroupNorm accumulator ([count, B, 32, 2] for count > 1: the tiled VAE's per-tile
+        sums of one GroupNorm) out of a pool that the program's FIRST launch zeroes (a hipMemsetAsync per edtr_gn_stats call
+        costs two extra tiny kernels per node inside a hipGraph and far more in eager replay)."""
         if self.sums_pool is None:
             # Its OWN allocation, never arena memory: the pool is live from the program's first launch (which zeroes it), i.e.
             # earlier than the build-time point of this call — an arena hole freed by launches that precede the first
@@ -236,10 +237,10 @@ class Program:
             self.recs.insert(0, rec)
             self.lanes.insert(0, 0)
             self.marks = {k + 1: v for k, v in self.marks.items()}
-        if self.sums_used >= self.SUMS_SLOTS or self.sums_pool.shape[1] != B:
+        if self.sums_used + count > self.SUMS_SLOTS or self.sums_pool.shape[1] != B:
             raise RuntimeError("GroupNorm accumulator pool exhausted")
-        t = self.sums_pool[self.sums_used]
-        self.sums_used += 1
+        t = self.sums_pool[self.sums_used] if count == 1 else self.sums_pool[self.sums_used:self.sums_used + count]
+        self.sums_used += count
         return t
 
     def add(self, rec: Rec) -> Rec:
@@ -514,11 +515,11 @@ class Emitter:
             self.arena.free(sums)
         return Act(carried, x.B, x.H, x.W, x.C)
 
-    def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor):
+    def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, sums_zeroed: bool = False):
         """Statistics half only (tiled VAE: the caller pools `sums` across tiles before the apply half).
         Returns a closure that emits the apply half and yields the normalised activation."""
         y, carried = self._gn_out(x)
-        st, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
+        st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=sums_zeroed)
         if x.gnp is not None:
             st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
         self.prog.add(st)

@@ -461,6 +461,12 @@ class ControlLDM(nn.Module):
         self._vae_engines.drop_all()
         self._weights = None
 
+    def weights_updated_in_place(self) -> None:
+        """The packed weight tensors were overwritten in place (edtr_amd.parallel.broadcast_packed): programs and hipGraphs
+        stay valid, but everything DERIVED from the old values — the cached cross-attention K / V^T of each engine — is stale."""
+        for eng in self._cldm_engines.values():
+            eng.ctx_key = None
+
     def _store(self) -> WeightStore:
         if self._weights is None:
             params: Dict[str, torch.Tensor] = {}

@@ -274,7 +274,7 @@ def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool):
     fp64 sums slice to fill), emits the statistics launch, yields again (the driver may pool the sums across tiles),
     then emits the apply launch.  Plain and tiled VAE share every other line of emission code."""
     sums = yield x
-    apply = em.gn_stats_into(x, prefix, 1e-6, silu, sums)
+    apply = em.gn_stats_into(x, prefix, 1e-6, silu, sums, sums_zeroed=True)     # slots of the program's pre-zeroed pool
     yield None
     return apply()
 
@@ -374,13 +374,10 @@ def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32:
     try:
         req = next(gen)
         while True:
-            sums = em.arena.alloc((req.B, 32, 2), torch.float64)
+            sums = em.prog.sums_slot(em.arena, req.B)
             gen.send(sums)            # statistics launch emitted
-            prev = sums
             req = gen.send(None)      # apply launch emitted, emission continues up to the next GroupNorm
-            em.arena.free(prev)
     except StopIteration as done:
-        em.arena.free(sums)
         return done.value
 
 
@@ -398,7 +395,7 @@ def emit_vae_net_tiled(em: Emitter, P: str, layers: List[VaeLayer], tiles: List[
         pix = [float(r.H * r.W) for r in reqs]
         weights = torch.tensor([v / sum(pix) for v in pix], dtype=torch.float32, device=dev)
         counts = torch.tensor([v * (reqs[0].C // 32) for v in pix], dtype=torch.float32, device=dev)
-        sums = em.arena.alloc((T, BG, 2), torch.float64)
+        sums = em.prog.sums_slot(em.arena, reqs[0].B, count=T).view(T, BG, 2)
         for k, g in enumerate(gens):
             g.send(sums[k])
         em.prog.add(ops.make_gn_pool(sums=sums, weights=weights, counts=counts, T=T, BG=BG))
@@ -407,7 +404,6 @@ def emit_vae_net_tiled(em: Emitter, P: str, layers: List[VaeLayer], tiles: List[
                 reqs[k] = g.send(None)
             except StopIteration as done:
                 results[k] = done.value
-        em.arena.free(sums)
     return results
 
 

@@ -59,3 +59,42 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, bucket_bytes: in
                 calls += 1
                 nbytes += flat.numel() * flat.element_size()
     return calls, nbytes
+
+
+def broadcast_packed(model, src: int = 0, bucket_bytes: int = 1 << 29) -> Tuple[int, int]:
+    """Start-up weight distribution as SURVEY.md §8(e) specifies it: ONE bucketed broadcast of the PACKED 16-bit weight store
+    (plus its small fp32 bias / norm vectors) from rank `src`, in place.  Every rank has already built the same kernel
+    programs (a warm-up pass packs whatever its parameters hold — zeros on the receiving ranks), so the packed tensors exist
+    at fixed addresses inside the launch records and hipGraphs; overwriting them in place needs no re-packing and no
+    re-capture.  About half the bytes of the fp32 parameters and no per-rank packing work.  Returns (collectives, bytes)."""
+    import torch.distributed as dist
+    store = model._store()
+    tensors: List[torch.Tensor] = []
+    for key in sorted(store.cache, key=repr):          # identical order on every rank (same programs -> same keys)
+        val = store.cache[key]
+        for t in (val if isinstance(val, (tuple, list)) else (val,)):
+            if isinstance(t, torch.Tensor):
+                tensors.append(t)
+    seen, uniq = set(), []
+    for t in tensors:                                   # a bias vector can be shared by two cache entries
+        if t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            uniq.append(t)
+    by_dtype = {}
+    for t in uniq:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    calls = nbytes = 0
+    with torch.no_grad():
+        for dt in sorted(by_dtype, key=str):
+            for bucket in bucketize(by_dtype[dt], bucket_bytes):
+                flat = torch.cat([t.reshape(-1) for t in bucket])
+                dist.broadcast(flat, src=src)
+                off = 0
+                for t in bucket:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t))
+                    off += n
+                calls += 1
+                nbytes += flat.numel() * flat.element_size()
+    model.weights_updated_in_place()
+    return calls, nbytes

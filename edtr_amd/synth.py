@@ -33,20 +33,22 @@ def _hash_u32(idx: torch.Tensor, seed: int) -> torch.Tensor:
     return x
 
 
-def hashed_uniform(key: str, numel: int, chunk: int = 1 << 24) -> torch.Tensor:
-    """fp32 tensor of ``numel`` values, uniform in [-1, 1), fully determined by ``key``."""
+def hashed_uniform(key: str, numel: int, chunk: int = 1 << 24, device=None) -> torch.Tensor:
+    """fp32 tensor of ``numel`` values, uniform in [-1, 1), fully determined by ``key``.  ``device``: where the integer hash
+    runs — int64 arithmetic and exactly representable fp32 results, so a GPU produces the same bits as the CPU (the 1.3 G
+    parameters of the SD-2.1 size take about a minute on the host cores and about a second on the device)."""
     seed = zlib.crc32(key.encode("utf-8")) & _M32
-    out = torch.empty(numel, dtype=torch.float32)
+    out = torch.empty(numel, dtype=torch.float32, device=device)
     for s in range(0, numel, chunk):
         e = min(numel, s + chunk)
-        idx = torch.arange(s, e, dtype=torch.int64)
+        idx = torch.arange(s, e, dtype=torch.int64, device=device)
         h = _hash_u32(idx, seed)
         # 24 random bits -> exactly representable fp32 in [-1, 1)
         out[s:e] = ((h >> 8).to(torch.float32) * (2.0 / (1 << 24))) - 1.0
     return out
 
 
-def synth_param(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
+def synth_param(key: str, shape: Tuple[int, ...], device=None) -> torch.Tensor:
     """Synthetic value for one state-dict entry.
 
     * norm scales (GroupNorm / LayerNorm ``weight``, 1-D, not a bias):  1 + 0.1 u
@@ -55,7 +57,7 @@ def synth_param(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
     """
     shape = tuple(int(s) for s in shape)
     numel = int(np.prod(shape)) if len(shape) else 1
-    u = hashed_uniform(key, numel).reshape(shape)
+    u = hashed_uniform(key, numel, device=device).reshape(shape)
     if len(shape) <= 1:
         if key.endswith("bias"):
             return 0.05 * u

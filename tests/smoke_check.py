@@ -34,8 +34,10 @@ def smoke(verbose: bool = True) -> dict:
         ref_img, tr = O.restore(flat_oracle_sd(sds), cfg, O.make_betas(), pre_res, c_txt, noises, used, 200,
                                 return_trace=True)
     out = {}
-    for dtype, tol in ((torch.float16, 8e-3), (torch.bfloat16, 5e-2)):
-        cldm = build_synthetic_cldm(cfg, dev, dtype, sds)
+    # the parity mode ("high": fp32 stream, bf16 split-3 products, fp16 attention) must meet the north-star 1e-3; the two
+    # 16-bit storage modes are held to their measured envelopes
+    for mode, dtype, tol in (("high", None, 1e-3), ("fast", torch.float16, 8e-3), ("fast", torch.bfloat16, 5e-2)):
+        cldm = build_synthetic_cldm(cfg, dev, dtype, sds, precision=mode)
         diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
         sampler = SpacedSampler(diffusion.betas)
         z_pre = cldm.vae_encode(pre_res.to(dev) * 2 - 1, sample=False)
@@ -47,11 +49,12 @@ def smoke(verbose: bool = True) -> dict:
         img = cldm.vae_decode(z)
         torch.cuda.synchronize()
         e_z, e_img = rel_err(z, tr["z"]), rel_err(img, ref_img)
-        out[str(dtype)] = (e_z, e_img)
+        tag = "precision=high" if mode == "high" else str(dtype)
+        out[tag] = (e_z, e_img)
         if verbose:
-            print(f"smoke[{dtype}]: rel err latent {e_z:.2e}, image {e_img:.2e} (tolerance {tol:.0e})")
+            print(f"smoke[{tag}]: rel err latent {e_z:.2e}, image {e_img:.2e} (tolerance {tol:.0e})")
         if not (e_img < tol and e_z < tol):
-            raise AssertionError(f"smoke parity failed for {dtype}: latent {e_z:.3e}, image {e_img:.3e}")
+            raise AssertionError(f"smoke parity failed for {tag}: latent {e_z:.3e}, image {e_img:.3e}")
     return out
 
 

@@ -201,3 +201,41 @@ def test_tiled_vae_nan_guard():
     img[0, 0, 3, 5] = float("nan")
     with pytest.raises(NansException):
         cldm.vae_encode(img, sample=False, tiled=True, tile_size=64)
+
+
+@pytest.mark.gpu
+def test_synthetic_weights_hashed_on_the_device_equal_the_host():
+    """edtr_amd.synth on the GPU (int64 hash + exactly representable fp32 results) reproduces the host bits: the goldens
+    were generated from host-hashed weights, the GPU tests and bench.py hash on the device."""
+    from edtr_amd import synth
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    for key, shape in (("unet.input_blocks.1.0.in_layers.2.weight", (320, 320, 3, 3)), ("vae.decoder.norm_out.weight", (128,)),
+                       ("controlnet.time_embed.0.bias", (1280,)), ("unet.out.2.weight", (4, 320, 3, 3))):
+        assert torch.equal(synth.synth_param(key, shape, device=dev).cpu(), synth.synth_param(key, shape))
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_on_one_rank():
+    """bench.py with EDTR_BENCH_DIST=1 in a fresh child process: RCCL (backend "nccl") initialises on one rank, the packed
+    weight store is broadcast in place, the timed region uses the barrier / all-reduce path, and ONE JSON line comes out."""
+    import json
+    import socket
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EDTR_BENCH_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--size", "128", "--batch", "2",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["weight_broadcast"]["collectives"] >= 2 and out["weight_broadcast"]["GiB"] > 0
+    assert "packed weights broadcast over RCCL" in res.stderr

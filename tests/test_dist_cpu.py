@@ -63,3 +63,118 @@ def test_two_rank_broadcast_and_sharding():
     assert bytes0 == bytes1 > 50e6 * 4 * 0.9
     assert sum0 == sum1, "rank 1 must hold rank 0's weights bit for bit"
     assert gap0 == 0.0 and gap1 == 0.0, "per-rank slices tile the global batch"
+
+
+def _worker_packed(rank: int, world: int, port: int, q):
+    """broadcast_packed: both ranks pack the same store entries (rank 1 from zeros), one bucketed broadcast overwrites rank 1's
+    packed tensors IN PLACE (same addresses: launch records / hipGraphs built on them stay valid)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from edtr_amd import synth
+    from edtr_amd.model import ControlLDM
+    from edtr_amd.model.params import skip_init
+    from edtr_amd.parallel import broadcast_packed
+    from edtr_amd.testing import synthetic_state_dicts
+    cfg = synth.tiny_config()
+    with skip_init():
+        m = ControlLDM(**cfg)
+    m.compute_dtype = torch.bfloat16
+    for p in m.parameters():
+        p.data.zero_()
+    if rank == 0:
+        sds = synthetic_state_dicts(cfg)
+        m.unet.load_state_dict(sds["unet"])
+        m.load_controlnet_from_ckpt(sds["controlnet"])
+        m.vae.load_state_dict(sds["vae"])
+    store = m._store()
+    w, b = store.conv("unet.input_blocks.1.0.in_layers.2.", cin_pad=64)
+    wl, _ = store.linear(["unet.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight",
+                          "unet.input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight"])
+    g = store.vec("vae.encoder.norm_out.weight")
+    wg, bg = store.geglu("unet.input_blocks.1.1.transformer_blocks.0.ff.net.0.proj.weight",
+                         "unet.input_blocks.1.1.transformer_blocks.0.ff.net.0.proj.bias")
+    ptrs = [t.data_ptr() for t in (w, b, wl, g, wg, bg)]
+    calls, nbytes = broadcast_packed(m, src=0, bucket_bytes=1 << 20)
+    assert ptrs == [t.data_ptr() for t in (w, b, wl, g, wg, bg)]
+    q.put((rank, calls, nbytes, [float(t.double().abs().sum()) for t in (w, b, wl, g, wg, bg)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_packed_broadcast_in_place():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, c0, n0, s0), (_, c1, n1, s1) = res
+    assert c0 == c1 >= 2 and n0 == n1 > 0          # one bucket per dtype (16-bit matrices, fp32 vectors)
+    assert s0 == s1 and all(v > 0 for v in s0), "rank 1 must hold rank 0's packed weights bit for bit"
+
+
+class _StubCldm(torch.nn.Module):
+    """Identity restoration: prepare_condition hands the image through as the 'latent', vae_decode maps it back to [-1, 1]."""
+
+    def __init__(self):
+        super().__init__()
+        self.unet = torch.nn.Linear(1, 1)
+
+    def prepare_condition(self, clean, prompt):
+        return {"c_txt": torch.zeros(clean.size(0), 77, 4), "c_img": clean}
+
+    def vae_decode(self, z):
+        return z * 2 - 1
+
+
+class _StubDiffusion:
+    def q_sample(self, x_start, t, noise):
+        return x_start
+
+
+class _StubSampler:
+    def manual_sample_with_timesteps(self, model, device, x_T, **kw):
+        return x_T
+
+
+def _worker_dataset(rank: int, world: int, port: int, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from edtr_amd import evalutil, synth
+    sizes = [(40, 56), (64, 64), (33, 47), (64, 20), (50, 50)]
+    imgs = [synth.synth_input(f"ds:img{i}", (3, h, w), 0.0, 1.0) for i, (h, w) in enumerate(sizes)]
+    gts = [(im + 0.03 * synth.synth_normal(f"ds:n{i}", tuple(im.shape))).clamp(0, 1) for i, im in enumerate(imgs)]
+    outs, psnr = evalutil.restore_dataset(_StubCldm(), _StubDiffusion(), _StubSampler(), imgs, gts=gts, img_size=64, batch_size=2,
+                                          colour_fix=False)
+    q.put((rank, [tuple(o.shape) for o in outs], [float((o - imgs[i]).abs().max()) for o, i in zip(outs, range(*evalutil.shard_slice(rank, world, len(imgs)).indices(len(imgs))))],
+           float(psnr)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_restore_dataset_sharding_and_metric():
+    """evalutil.restore_dataset on 2 gloo ranks (stub networks: the restoration is the identity): the ragged image list is
+    sharded 3 + 2 without overlap, padded / cropped per image, and the PSNR all-reduce gives every rank the dataset mean."""
+    from edtr_amd import evalutil, synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dataset, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = [(40, 56), (64, 64), (33, 47), (64, 20), (50, 50)]
+    (_, shp0, gap0, ps0), (_, shp1, gap1, ps1) = res
+    assert shp0 == [(3, h, w) for h, w in sizes[:3]] and shp1 == [(3, h, w) for h, w in sizes[3:]]
+    assert max(gap0 + gap1) == 0.0
+    imgs = [synth.synth_input(f"ds:img{i}", (3, h, w), 0.0, 1.0) for i, (h, w) in enumerate(sizes)]
+    gts = [(im + 0.03 * synth.synth_normal(f"ds:n{i}", tuple(im.shape))).clamp(0, 1) for i, im in enumerate(imgs)]
+    want = sum(float(evalutil.calculate_psnr_pt(a[None], b[None], 0)[0]) for a, b in zip(imgs, gts)) / len(imgs)
+    assert abs(ps0 - want) < 1e-6 and abs(ps1 - want) < 1e-6

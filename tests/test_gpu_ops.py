@@ -310,6 +310,39 @@ def test_flash_attn64(dtype, B, H, Nq, Nk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Nq,Nk,growth", [(1, 5, 4096, 4096, 1.0),     # the hot shape: 64x64 latents, 5 heads (large-N kernel v3)
+                                             (2, 3, 2100, 512, 1.0),      # ragged Nq (store predicate), 2 unrolled trips
+                                             (1, 2, 2048, 1024, 5.0),     # later keys beat the first tile's row maximum by > 14 octaves
+                                             (1, 2, 2048, 320, 1.0),      # Nk % 256 != 0 -> v1 kernel on prescaled scores
+                                             (2, 2, 300, 256, 1.0)])      # below the large-N threshold -> v1 on prescaled scores
+def test_flash_attn64_prescaled(dtype, B, H, Nq, Nk, growth):
+    """q_prescaled: q.k already carries scale * log2(e) (folded into the projection GEMMs' epilogues by nets.py); the kernels
+    evaluate exp2(q.k - max).  Covers the generated-asm large-N kernel, its re-maximise slow path and the v1 fallbacks."""
+    ops = _ops()
+    d = dev()
+    Cc = H * 64
+    q = (rnd((B, Nq, Cc), 36) * 0.42).to(dtype)
+    k = rnd((B, Nk, Cc), 37) * 0.42
+    k[:, Nk // 2:] *= growth
+    k = k.to(dtype)
+    v = rnd((B, Nk, Cc), 38).to(dtype)
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty((B, Nq, Cc), dtype=dtype, device=d)
+    ops.launch(ops.make_flash_attn(dtype=dtype, q=q.to(d), k=k.to(d), vt=vt.to(d), out=out, B=B, H=H, Nq=Nq, Nk=Nk,
+                                   q_bs=Nq * Cc, q_ld=Cc, k_bs=Nk * Cc, k_ld=Cc, vt_bs=Cc * Nk, vt_ld=Nk, o_bs=Nq * Cc,
+                                   o_ld=Cc, scale=0.125, prescaled=True))
+    torch.cuda.synchronize()
+
+    def heads(t):
+        return t.double().reshape(B, -1, H, 64).transpose(1, 2)
+
+    p = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * math.log(2.0), dim=-1)
+    ref = (p @ heads(v)).transpose(1, 2).reshape(B, Nq, Cc)
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref) < TOL[dtype] * 1.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_flash_attn64_forced_rescale(dtype):
     """Online-softmax rescale branch: a late key dominates one query row (max jumps in the last tile)."""
     ops = _ops()

@@ -92,7 +92,7 @@ def main():
         print(f"{'PASS' if ok else 'FAIL'}  {name:44s} err {err:.2e} gnp {gerr:.1e}   tile {args.a}: {ta * 1e3:8.1f} us   tile {args.b}: {tb * 1e3:8.1f} us  ({ta / tb:4.2f}x)", flush=True)
         rows.append({"case": name, "ok": bool(ok), "err": err, "us_a": ta * 1e3, "us_b": tb * 1e3})
     os.makedirs(os.path.join(H.ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(H.ROOT, "gpurun_out", "hw_ab_tiles.json"), "w") as f:
+    with open(os.path.join(H.ROOT, "gpurun_out", f"hw_ab_tiles_{args.a}_vs_{args.b}_{args.dt}.json"), "w") as f:
         json.dump({"a": args.a, "b": args.b, "rows": rows}, f, indent=1)
     print("ALL PASS" if not bad else f"{bad} FAILED")
     return 1 if bad else 0

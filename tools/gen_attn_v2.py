@@ -53,11 +53,35 @@ def ar(base, n=1):
 
 
 class Gen:
-    def __init__(self):
+    def __init__(self, ahead=3, dma_spread=False, stamps=False, drop=""):
         self.lines = []
         self.label_id = 0
+        self.ahead, self.dma_spread, self.stamps = ahead, dma_spread, stamps
+        self.drop = set(drop.split(",")) if drop else set()      # timing experiments only (results become garbage)
+
+    def stamp(self, acc):
+        """Diagnostic build only: add the cycles since the previous stamp to SGPR accumulator `acc` (s78 sync, s79 DMA issue,
+        s80 phase 1, s81 phase 2).  s_memtime returns through the scalar cache: the lgkmcnt(0) it needs also drains LDS reads."""
+        if not self.stamps:
+            return
+        self.e("s_memtime s[74:75]")
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.e("s_sub_u32 s77, s74, s76")
+        self.e(f"s_add_u32 s{acc}, s{acc}, s77")
+        self.e("s_mov_b32 s76, s74")
 
     def e(self, s):
+        op = s.split()[0]
+        if ("exp" in self.drop and op == "v_exp_f32") or ("add" in self.drop and op == "v_add_f32") or \
+                ("cvt" in self.drop and op == "{CVT}") or ("dma" in self.drop and op.startswith("buffer_load")):
+            return
+        if "qkacc" in self.drop and op == "{MFMA}" and s.split()[1].startswith("v["):
+            # score MFMAs write (and chain from) the accumulator file instead of arch VGPRs: a[64:95]
+            parts = s.split(", ")
+            d = parts[0].split()[1]
+            base = int(d[2:d.index(":")])
+            acc = f"a[{64 + (base - 96) % 32}:{64 + (base - 96) % 32 + 15}]"
+            s = f"{{MFMA}} {acc}, {parts[1]}, {parts[2]}, {acc}"
         self.lines.append(s)
 
     def label(self, name):
@@ -200,17 +224,27 @@ class Gen:
     # ---- one tile ---------------------------------------------------------------------------------------------------
     def tile(self, stage, slowA, slowB):
         nxt, cur = (stage + 1) % 4, stage
-        skip = self.new_label("nodma")
         self.e("s_waitcnt vmcnt(0)")
         self.e("s_barrier")
+        self.stamp(78)
+        # tile t+2 goes into the stage tile t-2 left; s[S_X3] = 1 while such a tile exists
         self.e(f"s_add_u32 s{S_X2}, s{S_T}, 2")
         self.e(f"s_cmp_lt_u32 s{S_X2}, %[nt]")
-        self.e(f"s_cbranch_scc0 {skip}")
+        self.e(f"s_cselect_b32 s{S_X3}, 1, 0")
         self.dma_begin((stage + 2) % 4)
-        for w in range(4):
+
+        def dma(w, last):
+            skip = self.new_label("nodma")
+            self.e(f"s_cmp_eq_u32 s{S_X3}, 1")
+            self.e(f"s_cbranch_scc0 {skip}")
             self.dma_piece(w, self.DMA_LDS_OFF[w])
-        self.dma_advance()
-        self.label(skip)
+            if last:
+                self.dma_advance()
+            self.label(skip)
+        if not self.dma_spread:
+            for w in range(4):
+                dma(w, w == 3)
+        self.stamp(79)
         if stage == 0:
             nf = self.new_label("nofirstA")
             self.e(f"s_cmp_eq_u32 s{S_T}, 0")
@@ -230,8 +264,11 @@ class Gen:
             self.sm_exp("A", i)
             if i > 0:
                 self.sm_fin("A", i - 1)
+            if self.dma_spread and i in (1, 5, 9, 13):
+                dma((i - 1) // 4, i == 13)
         self.sm_fin("A", 15)
         self.check("A", slowA)
+        self.stamp(80)
         if stage == 0:
             nf = self.new_label("nofirstB")
             self.e(f"s_cmp_eq_u32 s{S_T}, 0")
@@ -239,12 +276,12 @@ class Gen:
             self.e("s_nop 15")
             self.remax_first("B")
             self.label(nf)
-        # ---- phase 2: softmax(B) beside S_A(t+1) (K(t+1) fragments) and O_A += V(t) P_A(t) (V(t) fragments), read 3 slots ahead
+        # ---- phase 2: softmax(B) beside S_A(t+1) (K(t+1) fragments) and O_A += V(t) P_A(t) (V(t) fragments), read AHEAD slots ahead
         reads = [("k", nxt, kb, ks) for kb in range(2) for ks in range(4)] + \
                 [("v", cur, db, kb, st) for db in range(2) for kb in range(2) for st in range(2)]
         mf = [("qk", "A", kb, ks) for kb in range(2) for ks in range(4)] + \
              [("pv", "A", db, kb, st) for db in range(2) for kb in range(2) for st in range(2)]
-        AHEAD = 3
+        AHEAD = self.ahead
 
         def issue(j):
             r = reads[j]
@@ -252,7 +289,7 @@ class Gen:
                 self.kread(*r[1:])
             else:
                 self.vread(*r[1:])
-        for j in range(AHEAD):
+        for j in range(min(AHEAD, 16)):
             issue(j)
         for i, m in enumerate(mf):
             if i + AHEAD < 16:
@@ -267,6 +304,7 @@ class Gen:
                 self.mfma_pv(*m[1:])
         self.sm_fin("B", 15)
         self.check("B", slowB)
+        self.stamp(81)
         self.e(f"s_add_u32 s{S_T}, s{S_T}, 1")
 
     # ---- whole stream ------------------------------------------------------------------------------------------------
@@ -312,6 +350,12 @@ class Gen:
         for kb in range(2):
             for ks in range(4):
                 self.mfma_qk("A", kb, ks)
+        if self.stamps:
+            for r in (78, 79, 80, 81):
+                e(f"s_mov_b32 s{r}, 0")
+            e("s_memtime s[74:75]")
+            e("s_waitcnt lgkmcnt(0)")
+            e("s_mov_b32 s76, s74")
         loop = ".Lattn3_loop_%="
         self.label(loop)
         for stage in range(4):
@@ -338,12 +382,23 @@ class Gen:
             e(f"v_accvgpr_read_b32 %[ob1{r:02d}], {ar(OB + 16 + r)}")
         e(f"v_mov_b32 %[la], {vr(LRUN['A'])}")
         e(f"v_mov_b32 %[lb], {vr(LRUN['B'])}")
+        if self.stamps:
+            for i, r in enumerate((78, 79, 80, 81)):
+                e(f"s_mov_b32 %[st{i}], s{r}")
         e(f"s_mov_b32 m0, s{S_M0}")
         e("s_nop 1")
 
 
 def main():
-    g = Gen()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ahead", type=int, default=int(os.environ.get("ATTN3_AHEAD", "3")))
+    ap.add_argument("--dma-spread", type=int, default=int(os.environ.get("ATTN3_DMA_SPREAD", "0")))
+    ap.add_argument("--stamps", type=int, default=0)
+    ap.add_argument("--out", default=OUT)
+    ap.add_argument("--drop", default="", help="timing experiments: comma list of exp,add,cvt,dma,qkacc (results become garbage)")
+    args = ap.parse_args()
+    g = Gen(ahead=args.ahead, dma_spread=bool(args.dma_spread), stamps=bool(args.stamps), drop=args.drop)
     g.build()
     out = ["// GENERATED by tools/gen_attn_v2.py — do not edit.  One inline-asm string: the main loop of flash_attn64_v3_kernel.",
            "// MFMA / CVT are string literals naming the dtype's instructions (v_mfma_f32_32x32x16_{bf16,f16}, v_cvt_pk_{bf16,f16}_f32).",
@@ -352,7 +407,8 @@ def main():
         parts = ln.replace("{MFMA}", '" MFMA "').replace("{CVT}", '" CVT "')
         out.append(f'    "{parts}\\n\\t" \\')
     out.append('    ""')
-    clob = [f'"v{i}"' for i in range(96, 256)] + [f'"a{i}"' for i in range(0, 256)] + [f'"s{i}"' for i in range(84, 94)] + ['"vcc"', '"scc"', '"memory"']
+    clob = [f'"v{i}"' for i in range(96, 256)] + [f'"a{i}"' for i in range(0, 256)] + \
+           [f'"s{i}"' for i in range(74 if args.stamps else 84, 94)] + ['"vcc"', '"scc"', '"memory"']
     out.append("#define EDTR_ATTN_V3_CLOBBERS " + ", ".join(clob))
     # operand lists over fixed C++ names: float oa0[16], oa1[16], ob0[16], ob1[16], la, lb; int kad[4], vad[4]; uint32_t doff[4];
     # U4 qA[4], qB[4]; u32x4 srd_k, srd_v; uint32_t ldsb, stepk; int nt
@@ -361,6 +417,8 @@ def main():
         for nm in ("oa0", "oa1", "ob0", "ob1"):
             outs.append(f'[{nm}{r:02d}] "=v"({nm}[{r}])')
     outs += ['[la] "=v"(la)', '[lb] "=v"(lb)']
+    if args.stamps:
+        outs += [f'[st{i}] "=s"(stamps[{i}])' for i in range(4)]
     out.append("#define EDTR_ATTN_V3_OUTS " + ", ".join(outs))
     ins = []
     for i in range(4):
@@ -370,9 +428,9 @@ def main():
             ins += [f'[qa{f}{w}] "v"(qA[{f}].{c})', f'[qb{f}{w}] "v"(qB[{f}].{c})']
     ins += ['[srdk] "s"(srd_k)', '[srdv] "s"(srd_v)', '[ldsb] "s"(ldsb)', '[stepk] "s"(stepk)', '[nt] "s"(nt)']
     out.append("#define EDTR_ATTN_V3_INS " + ", ".join(ins))
-    with open(OUT, "w") as f:
+    with open(args.out, "w") as f:
         f.write("\n".join(out) + "\n")
-    print(f"{OUT}: {len(g.lines)} asm lines")
+    print(f"{args.out}: {len(g.lines)} asm lines (ahead {args.ahead}, dma_spread {args.dma_spread}, stamps {args.stamps})")
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ DRY = os.environ.get("HIPFREE_DRY") == "1"
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
-edtr = C.CDLL(L.LIB_PATH)
+edtr = C.CDLL(os.environ.get("EDTR_LIB") or L.LIB_PATH)       # EDTR_LIB: a diagnostic / variant build (tools/exp/attn_variants.py)
 hip.hipMalloc.argtypes = [C.POINTER(vp), C.c_size_t]
 hip.hipFree.argtypes = [vp]
 hip.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
