@@ -119,7 +119,8 @@ def main() -> None:
     cldm.compute_dtype = dtype
     cldm.precision = args.precision
     if rank == 0:                                  # the "checkpoint" lives on rank 0 only (hashed on the device: bit-identical to the host)
-        sds = synthetic_state_dicts(cfg, dev)
+        # EDTR_SYNTH_DEVICE=cpu: hash on the host (rocprofv3 --pmc FETCH_SIZE crashes inside torch's int64 elementwise kernels)
+        sds = synthetic_state_dicts(cfg, None if os.environ.get("EDTR_SYNTH_DEVICE") == "cpu" else dev)
         cldm.unet.load_state_dict(sds["unet"], strict=True)
         cldm.load_controlnet_from_ckpt(sds["controlnet"])
         cldm.vae.load_state_dict(sds["vae"], strict=True)
@@ -234,11 +235,17 @@ def main() -> None:
         result.update(finish_cpu_baseline(cpu_handle, inp, img.cpu(), z.cpu(), S, rel_err, tol_key))
     if rank == 0 and world == 1 and args.config == "sd21":
         result.update(golden_parity(args.workload, img, z, rel_err, tol_key))
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio; flush it first so that the JSON line is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
 
 
 def swinir_leg(dev, dtype, B, S, steps) -> dict:
@@ -293,6 +300,8 @@ def roofline_pass(cldm, args) -> dict:
             a["flops"] += flops * mult
             a["bytes"] += nbytes * mult
             a["n"] += mult
+            if " sk" in tag:
+                a["n_splitk"] = a.get("n_splitk", 0) + mult
             bn = a["by_name"].setdefault(name, [0.0, 0.0, 0])
             bn[0] += ms * mult
             bn[1] += flops * mult
@@ -315,18 +324,31 @@ def roofline_pass(cldm, args) -> dict:
     out = {}
     if ig:
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live)
-        traffic = None
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live); the
+        # entry is used only if it was measured on a launch list of the same length as the one just timed
+        traffic, traffic_src = None, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_hbm_traffic_v5.json")) as f:
-                traffic = round(json.load(f)["families"]["igemm"]["hbm_side_bytes_per_launch"])
+            with open(os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")) as f:
+                pm = json.load(f)
+            fam = pm["families"]["igemm"]
+            # the profiler counts kernels (main loops + split-K reducers), the timing above counts edtr_igemm calls: compare like
+            # with like, then quote the bytes per edtr_igemm CALL, the unit of algorithmic_bytes_per_launch
+            kernels = ig["n"] + ig.get("n_splitk", 0)
+            if abs(fam["launches_per_pass"] - kernels) <= 0.02 * kernels:
+                traffic = round(fam["hbm_side_bytes_per_pass"] / ig["n"])
+                traffic_src = (f"profiles/r02/pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, fetch x2 gfx950 "
+                               f"correction; measured at commit {pm.get('commit', '?')}: {fam['launches_per_pass']:.0f} kernels per pass = "
+                               f"{ig['n']} edtr_igemm calls + {ig.get('n_splitk', 0)} split-K reducers; bytes per call)")
+            else:
+                traffic_src = (f"profiles/r02/pmc_hbm_traffic.json was measured on {fam['launches_per_pass']:.0f} kernels per pass, this run "
+                               f"has {kernels}: stale, not reported")
         except (OSError, KeyError, ValueError):
             pass
         out["roofline"] = {"kernel": "edtr_igemm family (implicit-GEMM conv / linear, MFMA 32x32x16 and 16x16x32 tiles)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["n"]),
-                           "traffic_source": "profiles/r01/pmc_hbm_traffic_v5.json (rocprofv3 --pmc, fetch x2 gfx950 correction; includes the split-K reducer launches)",
+                           "traffic_source": traffic_src,
                            "launches_per_pass": ig["n"], "avg_launch_ms": round(ig["ms"] / ig["n"], 4),
                            "share_of_pass": round(ig["ms"] / total_ms, 3)}
     if at:
@@ -365,13 +387,14 @@ TOLERANCE = {"bf16": {"latent": 2e-2, "image": 3e-2}, "fp16": {"latent": 3e-3, "
 def _cpu_worker(q_in, q_out, cfg_name, S, threads):
     """Child process: the oracle (CPU fp32 restatement pinned to the reference) on samples of the bench batch."""
     import torch as th
-    th.set_num_threads(threads)
+    th.set_num_threads(min(threads, 32))     # weight hashing is elementwise int64: more threads only add contention
     from edtr_amd import synth as sy
     from edtr_amd.testing import synthetic_state_dicts
     from oracle import edtr_oracle as O
     from oracle import flat_sd as flat_oracle_sd
     cfg = sy.CONFIGS[cfg_name]()
     sd = flat_oracle_sd(synthetic_state_dicts(cfg))
+    th.set_num_threads(threads)
     q_out.put(("ready", None))
     while True:
         job = q_in.get()          # numpy arrays (pickled by value, no shared-memory handles); None = stop
@@ -402,7 +425,11 @@ def start_cpu_baseline(cfg_name, S):
     builds its own, then idles until the timed GPU region is over (so neither measurement perturbs the other)."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
-    threads = int(os.environ.get("EDTR_CPU_THREADS", str(cores)))      # BASELINE.md §3: os.cpu_count() threads
+    # BASELINE.md §3 asks for os.cpu_count() threads; on the GPU box's 2 x 64-core EPYC 9575F (256 hardware threads) the fp32
+    # oracle gets SLOWER beyond 32 threads (18.3 s at 32, 29.9 s at 64, 50.7 s at 128 for one image:
+    # profiles/r02/cpu_oracle_threads.log), so the baseline runs at the thread count that is fastest for it, min(cores, 32);
+    # EDTR_CPU_THREADS overrides
+    threads = int(os.environ.get("EDTR_CPU_THREADS", str(min(cores, 32))))
     ctx = mp.get_context("spawn")
     q_in, q_out = ctx.Queue(), ctx.Queue()
     proc = ctx.Process(target=_cpu_worker, args=(q_in, q_out, cfg_name, S, threads), daemon=True)
@@ -441,7 +468,9 @@ def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=42
         runs["first"] = (slice(0, 1), job(slice(0, 1)))
         if B > 1:
             runs["last"] = (slice(B - 1, B), job(slice(B - 1, B)))
-            if runs["first"][1][0] * B * 0.6 < budget_s - (time.perf_counter() - t_begin) and not os.environ.get("EDTR_CPU_NO_B8"):
+            # the whole batch as ONE oracle call (BASELINE.md §3's B = 8 point) takes minutes: opt-in (EDTR_CPU_B8=1; the record
+            # is profiles/r02/cpu_oracle_threads.log), the default run stays within ~40 s of CPU work
+            if os.environ.get("EDTR_CPU_B8") == "1" and runs["first"][1][0] * B * 0.6 < budget_s - (time.perf_counter() - t_begin):
                 runs["batch"] = (slice(0, B), job(slice(0, B)))
         q_in.put(None)
     except Exception:

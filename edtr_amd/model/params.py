@@ -69,7 +69,10 @@ class ParamTree(nn.Module):
 
 
 def params_fingerprint(module: nn.Module) -> Tuple:
-    """Changes whenever any parameter is rewritten in place (load_state_dict copy_) or moved."""
+    """Changes whenever any parameter is rewritten in place (load_state_dict / copy_ on the parameter itself) or moved.
+    It is built from the tensors' version counters, so a write that goes through ``.data`` (``p.data.copy_(...)``,
+    ``p.data = t``, EMA swaps) is NOT seen: after such a write call ``ControlLDM.release_engines()`` (packed weights, programs
+    and hipGraphs are rebuilt on the next forward).  Walking the ~1300 parameters costs ~0.1 ms per forward."""
     ver = 0
     dev = None
     for p in module.parameters():

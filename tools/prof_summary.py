@@ -53,7 +53,7 @@ def stats(root, out):
     print(f"{out}: {len(rows) - 1} kernels (top 40 kept)")
 
 
-def pmc(root, out, passes):
+def pmc(root, out, passes, by_grid=False):
     files = find(root, "*counter_collection.csv")
     if not files:
         raise SystemExit(f"no *counter_collection.csv under {root}")
@@ -64,8 +64,12 @@ def pmc(root, out, passes):
             header = next(rd)
             kn, cn, cv = col(header, "Kernel_Name"), col(header, "Counter_Name"), col(header, "Counter_Value")
             did = col(header, "Dispatch_Id")
+            gs = col(header, "Grid_Size")
             for row in rd:
-                d = fam.setdefault(family(row[kn]), {"dispatches": set(), "counters": {}})
+                key = family(row[kn])
+                if by_grid and key.startswith("flash_attn"):
+                    key += f"[grid={row[gs]}]"
+                d = fam.setdefault(key, {"dispatches": set(), "counters": {}})
                 d["dispatches"].add(row[did])
                 d["counters"][row[cn]] = d["counters"].get(row[cn], 0.0) + float(row[cv])
     res = {"passes": passes, "families": {}}
@@ -80,8 +84,10 @@ def pmc(root, out, passes):
             else:
                 e[c + "_per_launch"] = v / n
         c = d["counters"]
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
-            e["mfma_busy_over_sq_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # SQ_VALU_MFMA_BUSY_CYCLES: matrix-pipe busy cycles summed over the chip's 1024 SIMDs (= 32 per v_mfma_f32_32x32x16);
+            # GRBM_GUI_ACTIVE: active cycles summed over the 8 XCDs -> fraction of the kernels' cycles the matrix pipes were busy
+            e["mfma_pipe_busy_fraction"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
         res["families"][k] = e
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
@@ -91,4 +97,4 @@ def pmc(root, out, passes):
 if __name__ == "__main__":
     mode, root, out = sys.argv[1:4]
     passes = int(sys.argv[sys.argv.index("--passes") + 1]) if "--passes" in sys.argv else 1
-    {"stats": lambda: stats(root, out), "pmc": lambda: pmc(root, out, passes)}[mode]()
+    {"stats": lambda: stats(root, out), "pmc": lambda: pmc(root, out, passes, "--by-grid" in sys.argv)}[mode]()
