@@ -46,10 +46,7 @@ __device__ __forceinline__ void dma16(uint32_t voff, const u32x4& srd, uint32_t 
                  : "memory");
 }
 
-// LSUM (staged experiment, EDTR_ATTN_LSUM_MFMA=1, not yet validated on hardware): the softmax row sums come from the matrix
-// core — a constant all-ones A fragment multiplies the same P^T fragments that feed O^T += V^T P^T — instead of 32 v_add_f32 per
-// lane and tile: the kernel is bound by vector ISSUE slots (v_exp 8 cycles, other VALU 4), an extra MFMA costs 8 of them.
-template <typename T, bool LSUM = false>
+template <typename T>
 __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_attn_params p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [2 buffers][K tile | V^T tile]
 
@@ -102,13 +99,6 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
     float m_run = -1e30f, l_run = 0.0f;
-    f32x16 ol;                     // LSUM: every row of this accumulator is the running row sum of the lane's query
-    U4 ones;
-    if constexpr (LSUM) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ol[r] = 0.0f;
-        ones.x = ones.y = ones.z = ones.w = T::kOnePair;
-    }
     const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;  // scores are kept raw; p = exp2(c*s - c*m)
     float mc = m_run * c;
 
@@ -174,10 +164,6 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
             m_run = m_new;
             mc = m_new * c;
             l_run *= alpha;
-            if constexpr (LSUM) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ol[r] *= alpha;
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
         }
@@ -189,20 +175,14 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c, -mc));
-                if constexpr (!LSUM) psum += pr[r];
+                psum += pr[r];
             }
             pf[kb][0].x = pack2<T>(pr[0], pr[1]);   pf[kb][0].y = pack2<T>(pr[2], pr[3]);
             pf[kb][0].z = pack2<T>(pr[4], pr[5]);   pf[kb][0].w = pack2<T>(pr[6], pr[7]);
             pf[kb][1].x = pack2<T>(pr[8], pr[9]);   pf[kb][1].y = pack2<T>(pr[10], pr[11]);
             pf[kb][1].z = pack2<T>(pr[12], pr[13]); pf[kb][1].w = pack2<T>(pr[14], pr[15]);
         }
-        if constexpr (!LSUM) l_run += psum;
-        if constexpr (LSUM) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) ol = T::mfma(ones, pf[kb][st], ol);
-        }
+        l_run += psum;
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -219,9 +199,7 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
     }
 
     // ---- normalise and store: lane (q, half) holds d = db*32 + 8g + 4*half + (0..3) in regs 4g..4g+3
-    float l_tot;
-    if constexpr (LSUM) l_tot = ol[0];      // the MFMA already summed over both lane halves' keys
-    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_ok) {
         uint16_t* op = static_cast<uint16_t*>(p.out) + b * p.o_bs + (int64_t)q_row * p.o_ld + h * 64;
@@ -412,18 +390,8 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
         return EDTR_OK;
     }
     dim3 grid((p.Nq + 127) / 128, p.H, p.B);
-    static int lsum = -1;           // staged experiment switch, read once
-    if (lsum < 0) {
-        const char* e = getenv("EDTR_ATTN_LSUM_MFMA");
-        lsum = (e && e[0] == '1') ? 1 : 0;
-    }
-    if (lsum) {
-        if (p.dtype == EDTR_BF16) hipLaunchKernelGGL((flash_attn64_kernel<BF16, true>), grid, dim3(kThreads), 0, s, p);
-        else hipLaunchKernelGGL((flash_attn64_kernel<F16, true>), grid, dim3(kThreads), 0, s, p);
-    } else if (p.dtype == EDTR_BF16)
-        hipLaunchKernelGGL((flash_attn64_kernel<BF16, false>), grid, dim3(kThreads), 0, s, p);
-    else
-        hipLaunchKernelGGL((flash_attn64_kernel<F16, false>), grid, dim3(kThreads), 0, s, p);
+    if (p.dtype == EDTR_BF16) hipLaunchKernelGGL((flash_attn64_kernel<BF16>), grid, dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((flash_attn64_kernel<F16>), grid, dim3(kThreads), 0, s, p);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

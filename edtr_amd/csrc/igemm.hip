@@ -119,29 +119,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // loaded once, and the ITER residual vectors are requested up front — before the barrier that publishes the staged
 // tile — so that their L2/HBM latency overlaps the staging instead of serialising ITER dependent round trips
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
-// SWZ (staged experiment, tile 13; BNO == 128 only): the staged tile is bank-swizzled — row ml keeps its 32-column halves
-// swapped when bit 2 of ml is set (the two lane halves of an accumulator store then hit disjoint banks), and the two float4
-// halves of a row vector are fetched in opposite order by the threads with n8 >= 8 (one ds_read_b128 of 16 lanes then covers
-// all 64 banks once instead of half of them twice).
-template <bool SWZ>
-__device__ __forceinline__ void read_staged8(const float* stage, int ml, int pitch, int n8, f32x4& s0, f32x4& s1) {
-    if constexpr (SWZ) {
-        const float* row = stage + ml * pitch + ((n8 ^ (((ml >> 2) & 1) << 2)) << 3);
-        const int h = (n8 >> 3) & 1;
-        const f32x4 first = *reinterpret_cast<const f32x4*>(row + 4 * h);
-        const f32x4 second = *reinterpret_cast<const f32x4*>(row + 4 * (1 - h));
-        s0 = h ? second : first;
-        s1 = h ? first : second;
-    } else {
-        s0 = *reinterpret_cast<const f32x4*>(stage + ml * pitch + n8 * 8);
-        s1 = *reinterpret_cast<const f32x4*>(stage + ml * pitch + n8 * 8 + 4);
-    }
-}
-
-template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool SWZ = false>
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8]) {
-    static_assert(!SWZ || (BNO == 128 && !GEGLU), "swizzled staging is defined for the 128-column tile only");
     // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
     constexpr int VPR = BNO / 8, RPI = THREADS / VPR, ITER = (BM + RPI - 1) / RPI;
     constexpr bool EXACT = (THREADS % VPR == 0) && (BM % RPI == 0);
@@ -157,12 +137,8 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             const int ml = r0 + RPI * it, m = m0 + ml;
             if (m < p.M && n_ok && (EXACT || ml < BM)) {
                 f32x4 s0, s1;
-                if constexpr (SWZ) {
-                    read_staged8<true>(stage, ml, BNO, n8, s0, s1);
-                } else {
-                    s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-                    s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
-                }
+                s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+                s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
                 float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
                 *reinterpret_cast<f32x4*>(o) = s0;
                 *reinterpret_cast<f32x4*>(o + 4) = s1;
@@ -206,12 +182,8 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         const int ml = r0 + RPI * it, m = m0 + ml;
         if (m < p.M && n_ok && (EXACT || ml < BM)) {
             f32x4 s0, s1;
-            if constexpr (SWZ) {
-                read_staged8<true>(stage, ml, BNO, n8, s0, s1);
-            } else {
-                s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-                s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
-            }
+            s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
+            s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
             float f[8];
             f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
 #pragma unroll
@@ -262,10 +234,9 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 }
 
 // Tile epilogue shared by both main-loop variants: accumulators -> LDS (fp32) -> row vectors of 8 columns.
-template <typename T, int MI, int NI, bool SWZ = false>
+template <typename T, int MI, int NI>
 __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16 (&acc)[MI][NI], char* smem, int m0, int n0,
                                               int64_t o_zoff) {
-    static_assert(!SWZ || (MI == 2 && NI == 2), "swizzled staging is defined for the 128 x 128 tile only");
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -296,8 +267,7 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if constexpr (SWZ) stage[ml * BNO + ((wn * 32 * NI + ni * 32 + l31) ^ (lh << 5))] = acc[mi][ni][r];   // bit 2 of ml == lh
-                    else stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
+                    stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
                 }
     }
     const int n_out = geglu ? p.N / 2 : p.N;
@@ -309,7 +279,7 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
     if (geglu) rows_phase<T, BM, BN / 2, true>(p, stage, m0, no0, n_out, o_zoff, false, gs, gq);
-    else rows_phase<T, BM, BN, false, 256, SWZ>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
+    else rows_phase<T, BM, BN, false>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
     if (gn_acc) {
         // lanes l, l+16, l+32, l+48 of a wave own the same columns: fold them, then fold the 4 waves through LDS
 #pragma unroll
@@ -541,10 +511,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
 // multiplied: counted s_waitcnt vmcnt(8) + raw s_barrier (a __syncthreads() would drain the prefetch).
 // Requires (C1 % 64 == 0, C2 == 0): every 64-wide K-tile lies inside one filter tap.
 // ------------------------------------------------------------------------------------------------------
-// NST = LDS stages.  2 (default): tile t+1 in flight while tile t is multiplied, two workgroups per CU hide each other's
-// waits.  4 (tile 11, experiment): three tiles in flight, 128 KiB of LDS, one workgroup per CU — for grids below one
-// resident round, where nobody else covers the HBM latency of the next weight tile.
-template <typename T, bool SPATIAL, bool FAST, int NST = 2, bool SWZ = false>
+template <typename T, bool SPATIAL, bool FAST>
 __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm_params p) {
     EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
     constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
@@ -772,23 +739,15 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     }
     EDTR_STAMP(1);
     if (nkt > 0) issue_tile(kt0, 0);
-    if constexpr (NST > 2) {
-#pragma unroll
-        for (int t = 1; t < NST - 1; ++t)
-            if (t < nkt) issue_tile(kt0 + t, t);
-    }
 
 #ifdef EDTR_STAMPS
     uint64_t stamp_acc[4] = {0, 0, 0, 0};
 #endif
-    int ring_cur = 0, ring_next = NST - 1;      // NST > 2: LDS slot of tile kt / of the tile issued in iteration kt
     for (int kt = 0; kt < nkt; ++kt) {
-        int cur;
-        if constexpr (NST == 2) cur = kt & 1; else cur = ring_cur;
+        const int cur = kt & 1;
 #ifdef EDTR_STAMPS
         const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (NST == 2) {
         if (kt + 1 < nkt) {
             issue_tile(kt0 + kt + 1, cur ^ 1);
 #ifdef EDTR_STAMPS
@@ -797,17 +756,6 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMAs of tile kt have landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        } else {
-            // slot ring_next held tile kt-1, whose readers passed the closing barrier of the previous iteration
-            if (kt + NST - 1 < nkt) issue_tile(kt0 + kt + NST - 1, ring_next);
-            const int ahead = min(NST - 1, nkt - 1 - kt);      // tiles issued after tile kt that may still be in flight
-            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ring_cur = ring_cur + 1 == NST ? 0 : ring_cur + 1;
-            ring_next = ring_next + 1 == NST ? 0 : ring_next + 1;
         }
 #ifdef EDTR_STAMPS
         const uint64_t ts1 = __builtin_amdgcn_s_memtime();
@@ -862,22 +810,22 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
 #undef STAMP_VALUE
 #define STAMP_VALUE 0
 #endif
-    tile_epilogue<T, MI, NI, SWZ>(p, acc, smem, m0, n0, o_zoff);
+    tile_epilogue<T, MI, NI>(p, acc, smem, m0, n0, o_zoff);
     EDTR_STAMP(4); EDTR_STAMP(7);
 }
 
-template <typename T, bool SPATIAL, bool FAST, int NST = 2, bool SWZ = false>
+template <typename T, bool SPATIAL, bool FAST>
 int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = NST * (128 + 128) * BK * 2;
+    constexpr int lds = 2 * (128 + 128) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST, NST, SWZ>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
-    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST, NST, SWZ>), grid, dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
     if (p.splitk > 1) {
         const int64_t nvec = (int64_t)p.M * (p.N >> 3);
@@ -2240,22 +2188,10 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
     if (tile >= 3 && tile <= 14) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
-        if (tile == 11) {  // tile 3 with a 4-deep LDS ring (experiment, not yet validated on hardware: opt-in only)
-            if (!fast) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_dma<T, true, true, 4>(p, s) : launch_dma<T, false, true, 4>(p, s);
-        }
         if (tile == 14) {  // 256 x 32 tile for skinny-N convolutions (N <= 32: the decoder's 3-channel output conv wastes 94 % of a
                            // 128-wide tile); an instantiation of the 16x16x32 template, experiment, same status
             if (!fast || p.act == EDTR_ACT_GEGLU || p.gn_partial) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_n160<T, true, 8, 1>(p, s) : launch_n160<T, false, 8, 1>(p, s);
-        }
-        if (tile == 13) {  // tile 3 with the bank-swizzled epilogue staging (experiment, same status; GEGLU keeps the plain staging)
-            if (!fast) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_dma<T, true, true, 2, true>(p, s) : launch_dma<T, false, true, 2, true>(p, s);
-        }
-        if (tile == 12) {  // the same with a 3-deep ring (96 KiB of LDS; same status)
-            if (!fast) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_dma<T, true, true, 3>(p, s) : launch_dma<T, false, true, 3>(p, s);
         }
         if (tile == 4) {
             if (!fast) return EDTR_E_UNSUPPORTED;
@@ -2402,30 +2338,16 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             tile = 8;
         else if (pp_ok && !(no_auto & (1 << 6)) && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4)
             tile = 6;
-        // Staged experiments, default off (A/B switches for a whole-path run on ONE device):
-        //   EDTR_IGEMM_DEEP=<max workgroups>  a tile-3 launch whose grid has at most that many workgroups (i.e. about one per
-        //                                     CU or fewer: nobody hides the DMA latency) runs the 4-deep-ring tile 11 instead
-        //   EDTR_IGEMM_SWZ=1                  every remaining tile-3 launch runs tile 13 (bank-swizzled epilogue staging)
-        static int deep_max = -1, swz = -1;
-        if (deep_max < 0) {
-            const char* e = getenv("EDTR_IGEMM_DEEP");
-            deep_max = e ? atoi(e) : 0;
-            const char* e2 = getenv("EDTR_IGEMM_SWZ");
-            swz = (e2 && e2[0] == '1') ? 1 : 0;
-        }
+        // 256x32 tile for skinny-N convolutions (the VAE decoder's 3-channel output conv: 94 % of a 128-wide tile is padding);
+        // validated against tile 3 on the MI355X (profiles/r02/ab_tiles_3_vs_14*.log).  EDTR_IGEMM_SKINNY=0 switches it off.
         static int skinny = -1;
         if (skinny < 0) {
-            const char* e3 = getenv("EDTR_IGEMM_SKINNY");      //   EDTR_IGEMM_SKINNY=1: automatic N <= 32 launches run tile 14
-            skinny = (e3 && e3[0] == '1') ? 1 : 0;
+            const char* e3 = getenv("EDTR_IGEMM_SKINNY");
+            skinny = (e3 && e3[0] == '0') ? 0 : 1;
         }
-        if (skinny && tile == 3 && p.N <= 32 && p.splitk <= 1 && !p.gn_partial && p.act != EDTR_ACT_GEGLU &&
+        if (skinny && tile == 3 && p.N <= 32 && p.M >= 65536 && p.splitk <= 1 && !p.gn_partial && p.act != EDTR_ACT_GEGLU &&
             (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
             tile = 14;
-        if (tile == 3 && (deep_max > 0 || swz) && (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial)) {
-            const int64_t wgs = big * (p.splitk > 1 ? p.splitk : 1);
-            if (deep_max > 0 && wgs <= deep_max && p.K / 64 / (p.splitk > 1 ? p.splitk : 1) >= 4) tile = 11;
-            else if (swz) tile = 13;
-        }
         // (tile 10 — the same 128x128 geometry with 16x16x32 MFMAs — is +9 % in isolation on the 512x512-level N = 128 VAE
         //  convolutions but -0.5..-1 % on the whole path in the same A/B; opt-in)
         // (the 64x128 tile 9 wins 10-30 % in isolation on the short-K GEMMs of the 16x16 / 8x8 latent levels but cost 1 % of
@@ -2435,7 +2357,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 14) return EDTR_E_DTYPE;
+    if (tile < 1 || tile > 14 || (tile >= 11 && tile <= 13)) return EDTR_E_DTYPE;     // 11-13: experiments of round 1, measured and removed
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

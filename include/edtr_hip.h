@@ -113,8 +113,9 @@ typedef struct edtr_igemm_params {
     int64_t o_zs_outer, o_zs_inner;
     int32_t tile;           /* 0 = auto; explicit main-loop choice (tests / A-B runs): 1 = 128x128 register-staged, 2 = 64x64,
                                3 = 128x128 LDS-DMA (2 stages), 4 = 3-stage BK32, 5 = 256x128, 6 = 256x256 ping-pong, 7 = 256x128 ring,
-                               8 = 128x160, 9 = 64x128, 10 = 128x128 with 16x16x32 MFMAs, 11 / 12 = tile 3 with a 4- / 3-deep LDS ring, 13 = tile 3 with bank-swizzled
-                               epilogue staging, 14 = 256x32 for N <= 32 (11-14: staged experiments, opt-in, never selected automatically) */
+                               8 = 128x160, 9 = 64x128, 10 = 128x128 with 16x16x32 MFMAs, 14 = 256x32 for N <= 32 (automatic for
+                               large-M skinny-N convolutions); 11-13 were round-1 experiments (deeper LDS rings, bank-swizzled
+                               epilogue staging), measured without gain on the MI355X and removed */
     /* split-K (small-M problems that cannot fill 256 CUs): K is cut into `splitk` runs of K-tiles, each
      * workgroup row writes an fp32 partial slab into `workspace` ([splitk][M][N] floats, caller-owned), and a
      * second launch sums the slabs and applies the epilogue.  splitk <= 1 disables it.  Needs Z == 1, no GEGLU. */

@@ -20,7 +20,7 @@ from hipfree import C, L  # noqa: E402
 
 GEMMS = [(256, 128, 64), (300, 72, 192), (4096, 320, 320), (130, 136, 128), (77, 640, 1024), (8, 1280, 320), (2048, 1280, 1280),
          (512, 1280, 1280), (8192, 640, 640), (2048, 1280, 2560)]
-CONVS = [(2, 64, 64, 128, 8, 0), (1, 32, 32, 64, 64, 0), (2, 16, 24, 64, 96, 0), (1, 32, 32, 128, 128, 0), (2, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 64, 1), (8, 16, 16, 1280, 1280, 0)]
+CONVS = [(8, 512, 512, 128, 8, 0), (2, 64, 64, 128, 8, 0), (1, 32, 32, 64, 64, 0), (2, 16, 24, 64, 96, 0), (1, 32, 32, 128, 128, 0), (2, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 64, 1), (8, 16, 16, 1280, 1280, 0)]
 
 
 def run(dt, tile, *, M, N, K, taps, spatial, C1, a, w, bias, res, splitk=1, gnp=False):
@@ -53,7 +53,7 @@ def run(dt, tile, *, M, N, K, taps, spatial, C1, a, w, bias, res, splitk=1, gnp=
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--a", type=int, default=3)
-    ap.add_argument("--b", type=int, default=11)
+    ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--tol", type=float, default=0.0, help="0 = bit-exact; else max |a-b| / max|a|")
     ap.add_argument("--dt", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
