@@ -185,3 +185,36 @@ def test_det512_full_size_meets_the_north_star(golden_dir):
     print(f"\n[high precision det512 full size] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     # the image golden is stored as fp16 samples (rounding 2^-11 relative per sample -> 2.8e-4 rms): budget it
     assert errs["z_pre"] < NORTH_STAR and errs["z"] < NORTH_STAR and errs["img"] < NORTH_STAR, errs
+
+
+def test_tiled_paths_meet_the_north_star(golden_dir):
+    """The tiled VAE (VAEHook: padded tiles, GroupNorm statistics pooled across tiles) and the latent-tiled sampler in the
+    high-precision mode against the reference's tiled outputs."""
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise
+    d = dev()
+    cldm = build_synthetic_cldm(synth.tiny_config(), d, precision="high")
+    g = np.load(os.path.join(golden_dir, "tiled_vae.npz"))
+    img = synth.synth_input("tvae:img", (1, 3, 192, 256), -1.0, 1.0).to(d)
+    zin = synth.synth_normal("tvae:z", (1, 4, 32, 40)).to(d)
+    z_t = cldm.vae_encode(img, sample=False, tiled=True, tile_size=64)
+    d_t = cldm.vae_decode(zin, tiled=True, tile_size=8)
+    torch.cuda.synchronize()
+    e_enc, e_dec = rel(z_t, g["z_tiled"]), rel(d_t, g["dec_tiled"])
+    g2 = np.load(os.path.join(golden_dir, "tiled.npz"))
+    sampler = SpacedSampler(Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).betas)
+    B, h, w = 1, 16, 24
+    x_T = synth.synth_normal("tiled:x_T", (B, 4, h, w)).to(d)
+    c_img = synth.synth_normal("tiled:c_img", (B, 4, h, w)).to(d)
+    c_txt = synth.synth_input("tiled:c_txt", (B, 77, 64), -1.0, 1.0).to(d)
+    noises = [synth.synth_normal(f"tiled:noise{i}", (B, 4, h, w)).to(d) for i in range(4)]
+    with injected_noise(noises):
+        z = sampler.manual_sample_with_timesteps(model=cldm, device=d, x_T=x_T, steps=4, used_timesteps=USED, batch_size=B,
+                                                 cond={"c_txt": c_txt, "c_img": c_img}, uncond=None, cfg_scale=1.0, tiled=True,
+                                                 tile_size=8, tile_stride=4, progress=False)
+    torch.cuda.synchronize()
+    e_z = rel(z, g2["z_tiled"])
+    print(f"\n[high precision tiled] tiled vae enc {e_enc:.2e} dec {e_dec:.2e}; latent-tiled sampler {e_z:.2e}")
+    assert e_enc < NORTH_STAR and e_dec < NORTH_STAR and e_z < NORTH_STAR
