@@ -246,6 +246,13 @@ class Program:
     def add(self, rec: Rec) -> Rec:
         self.recs.append(rec)
         self.lanes.append(self.lane)
+        # Measurement aid (EDTR_EXP_DUP=<substring of a launch name>): idempotent launches whose name matches are issued TWICE.
+        # The slowdown of a whole-path run is the MARGINAL wall-clock cost of that kernel class inside the overlapped hipGraph
+        # execution — what a per-launch event timing cannot show.  Never set in production.
+        dup = os.environ.get("EDTR_EXP_DUP")
+        if dup and dup in rec.name and not rec.name.endswith(".stats"):
+            self.recs.append(rec)
+            self.lanes.append(self.lane)
         return rec
 
     def fork(self) -> None:
