@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""How does the CPU oracle (bench.py's cpu_baseline) scale with torch threads on the GPU box's host?  B=1, 512x512, 4 steps."""
+"""How does the CPU oracle (bench.py's cpu_baseline) scale with torch threads on the GPU box's host?  B=1, 512x512, 4 steps.
+A script, not a pytest module (it lives under tests/ because only tests/, smoke() and bench.py's cpu_baseline leg may import
+oracle/): `python tests/cpu_oracle_threads.py` -> profiles/r02/cpu_oracle_threads.log."""
 import os
 import sys
 import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from edtr_amd import synth  # noqa: E402
 from edtr_amd.testing import synthetic_state_dicts  # noqa: E402
