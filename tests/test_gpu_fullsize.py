@@ -17,7 +17,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "high": None}      # "high" = the parity mode (precision="high")
 
 
 def _tol(name):
@@ -40,7 +40,7 @@ def _build(dev, dtype, cfg_name="sd21"):
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.sampler import SpacedSampler
     from edtr_amd.testing import build_synthetic_cldm
-    cldm = build_synthetic_cldm(synth.CONFIGS[cfg_name](), dev, dtype)
+    cldm = build_synthetic_cldm(synth.CONFIGS[cfg_name](), dev, dtype, precision="high" if dtype is None else "fast")
     diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
     return cldm, diffusion, SpacedSampler(diffusion.betas)
 
@@ -83,7 +83,7 @@ def test_det512_batch8_every_image(golden_dir, dname):
     print(f"[det512 B=8 {dname}] worst batch-8 vs batch-1 deviation over the 8 images: {worst:.2e}")
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "high"])
 def test_seg1024tiled_vs_reference_golden(golden_dir, dname):
     """BASELINE configs[3]: --vae-encoder-tiled --cldm-tiled at 1024x1024 (demo.py:96-124)."""
     from edtr_amd import workloads
@@ -104,7 +104,7 @@ def test_seg1024tiled_vs_reference_golden(golden_dir, dname):
     np.testing.assert_allclose(float(img.mean()), g["img_stats"][0], atol=5e-3)
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "high"])
 def test_det512s50_vs_reference_golden(golden_dir, dname):
     """BASELINE configs[4] per GPU (batch 4, 50 spaced steps from pure noise, every step the same program): image 0 vs the
     reference's `SpacedSampler.sample(steps=50)` with the same injected per-step noise.  50 sequential network evaluations
@@ -122,7 +122,8 @@ def test_det512s50_vs_reference_golden(golden_dir, dname):
     e_img = rel_err(_samples(img[:1]), g["img_samples"].astype(np.float32))
     print(f"\n[det512s50 {dname}] image 0 vs reference after 50 steps: latent {e_z:.2e} image {e_img:.2e}")
     assert torch.isfinite(img).all()
-    assert e_z < 2 * tol["latent"] and e_img < 2 * tol["image"]
+    k = 1 if dname == "high" else 2            # the parity mode holds the north-star 1e-3 even after 50 steps
+    assert e_z < k * tol["latent"] and e_img < k * tol["image"]
 
 
 @pytest.mark.parametrize("dname", ["bf16", "fp16"])
