@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // loaded once, and the ITER residual vectors are requested up front — before the barrier that publishes the staged
 // tile — so that their L2/HBM latency overlaps the staging instead of serialising ITER dependent round trips
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
-template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256>
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8]) {
     // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
@@ -134,7 +134,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int ml = r0 + RPI * it, m = m0 + ml;
+            const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
             if (m < p.M && n_ok && (EXACT || ml < BM)) {
                 f32x4 s0, s1;
                 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
@@ -151,7 +151,8 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     if (p.residual) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int m = m0 + r0 + RPI * it;
+            const int mlr = r0 + RPI * it;
+            const int m = PATCH16 ? m0 + (mlr >> 4) * p.OW + (mlr & 15) : m0 + mlr;
             res[it] = (m < p.M && n_ok && (EXACT || r0 + RPI * it < BM)) ? ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n) : zero16();
         }
     }
@@ -164,7 +165,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     }
     bool rv_rows = false;                     // time-embedding row differs between this tile's rows
     if (p.rowvec) {
-        const int m_last = min(m0 + BM, p.M) - 1;
+        const int m_last = PATCH16 ? m0 + 15 * p.OW + 15 : min(m0 + BM, p.M) - 1;
         const int img0 = m0 / p.rows_per_image;
         rv_rows = (m_last / p.rows_per_image) != img0;
         if (!rv_rows && n_ok) {
@@ -179,7 +180,8 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int ml = r0 + RPI * it, m = m0 + ml;
+        // PATCH16: the tile's rows are the pixels of a 16 x 16 output patch (row ml = 16 * y + x), m0 = its first pixel
+        const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
         if (m < p.M && n_ok && (EXACT || ml < BM)) {
             f32x4 s0, s1;
             s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
@@ -2176,6 +2178,249 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 }
 
 // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
+// ------------------------------------------------------------------------------------------------------
+// Halo tile (tile = 16): 3x3 / stride 1 / pad 1 convolutions whose 128x128 loop is bound by the L1 -> LDS path (64 B/clk/CU
+// at MFMA peak: every input element crosses it nine times, once per tap).  A workgroup owns a 16 x 16 patch of output
+// pixels x 128 output channels and keeps the 18 x 18 INPUT patch of the current 64-channel chunk in LDS: it is staged
+// once per chunk (40.5 KiB) and the nine taps read it at shifted addresses, so a chunk moves 40.5 + 9 x 16 KiB (weights)
+// instead of 9 x 48 KiB -> 20 B/clk/CU at MFMA peak.
+//   * LDS: two patch buffers (chunk c+1 lands while chunk c is multiplied) + a ring of three 16 KiB weight slices
+//     (tap t+2 lands while tap t is multiplied; 9 % 3 == 0 keeps the ring position a compile-time function of the tap).
+//     Patch image: pixel (py, px) at (py * 18 + px) * 128 B, 16-byte chunk c at slot c ^ ((px >> 1) & 7): the key depends on
+//     the COLUMN only and a patch row is 2304 B = 9 bank rows, so a tap's dy and the MFMA block's y are immediate offsets
+//     and only the three dx need their own address; 16 consecutive px read conflict-free like 16 consecutive tile rows.
+//   * 8 waves: wave (g, wr, wc) owns pixels y in [8 wr, 8 wr + 8) x all x (128 rows = 8 blocks of one pixel row), output
+//     channels [64 wc, +64) and the K HALF g of every 64-channel chunk (32 channels = one v_mfma_f32_16x16x32 step):
+//     128 x 64 per wave keeps the LDS reads at 12 fragments per 32 MFMAs; the two K halves are summed in the epilogue's
+//     fp32 staging.  Waves w and w+4 (g = 0 / 1) share a SIMD and run half a phase apart (ping-pong as in tile 6):
+//     a phase = 16 MFMAs (4 pixel rows x 4 column blocks); while one wave multiplies, its partner reads fragments and
+//     issues the DMA of a future slice.
+//   * per phase and wave: one weight piece (tap t+2), in phases 2..7 of a chunk also one piece of the next patch;
+//     odd phases wait vmcnt(issued in this and the previous phase) = "everything up to two phases ago has landed".
+// Output rows are patch pixels (rows_phase<PATCH16>); fused GroupNorm partials go to slot 2 * patch (slot 2 * patch + 1 = 0).
+// Requires taps == 9, stride 1, pad 1, no upsample / concat, C1 % 64 == 0, OH % 16 == OW % 16 == 0, buffer addressing.
+// ------------------------------------------------------------------------------------------------------
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <typename T>
+__global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_params p) {
+    EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
+    constexpr int PW = 18, PROW = PW * 128;
+    constexpr int PATCHB = 48 * 1024;          // 324 pixels x 128 B = 40.5 KiB, filled by 48 one-KiB pieces (the last 7.5 land in padding)
+    constexpr int BTAP = 128 * BK * 2;         // 16 KiB
+    constexpr int B_BASE = 2 * PATCHB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int tw = p.OW >> 4, tpi = tw * (p.OH >> 4);              // patches per row / per image
+    const int nbm = (p.M / (p.OH * p.OW)) * tpi, nbn = (p.N + 127) / 128;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int img = tm / tpi, tr = tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;
+    const int oy0 = ty * 16, ox0 = tx * 16, n0 = tn * 128;
+    const int m0 = (img * p.OH + oy0) * p.OW + ox0;                 // first pixel of the patch
+
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const u32x4 srd_a = make_srd(a1);
+    const u32x4 srd_w = make_srd(wp);
+    const int Cin = p.C1;
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    // split-K (blockIdx.y): this workgroup owns the 64-channel chunks [cbeg, cend) and writes an fp32 partial slab
+    const int nsplit = p.splitk > 1 ? p.splitk : 1, nchunk_all = Cin / BK;
+    const int cbeg = (int)blockIdx.y * nchunk_all / nsplit, cend = ((int)blockIdx.y + 1) * nchunk_all / nsplit;
+
+    // ---- staging geometry.  Patch piece q = wave + 8 j: LDS bytes [q KiB, +1 KiB) = pixels 8 q .. 8 q + 7, lane -> (pixel, slot)
+    uint32_t voff_p[6], voff_w[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + 8 * j) * 8 + (lane >> 3), slot = lane & 7, n = n0 + r;
+        const int c = slot ^ ((r >> 1) & 7);
+        voff_w[j] = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + c * 8) * 2) : kOobOffset;
+    }
+    // the weight slices of taps 0 and 1 start their flight before the patch addresses are worked out
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            dma16_buf(voff_w[j], srd_w, (uint32_t)((t * Cin + cbeg * BK) * 2), smem_base + B_BASE + t * BTAP + (wave + 8 * j) * 1024);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int u = (wave + 8 * j) * 64 + lane, pp = u >> 3, slot = u & 7;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = pp < PW * PW && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const int c = slot ^ ((px >> 1) & 7);
+        voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOobOffset;
+    }
+    auto stage_w = [&](int chunk, int tap, int j, int buf) {
+        const uint32_t vo = chunk < cend ? voff_w[j] : kOobOffset;
+        dma16_buf(vo, srd_w, (uint32_t)((tap * Cin + chunk * BK) * 2), smem_base + B_BASE + buf * BTAP + (wave + 8 * j) * 1024);
+    };
+    auto stage_p = [&](int chunk, int j, int par) {
+        const uint32_t vo = chunk < cend ? voff_p[j] : kOobOffset;
+        dma16_buf(vo, srd_a, (uint32_t)(chunk * BK * 2), smem_base + par * PATCHB + (wave + 8 * j) * 1024);
+    };
+
+    // ---- fragment read geometry: A block mb of tap (ky, kx) = patch row 8 wr + mb + ky, pixels l15 + kx, K chunk 4 g + lq
+    int a_rd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = l15 + kx;
+        a_rd[kx] = (wr * 8 * PW + px) * 128 + (((g * 4 + lq) ^ ((px >> 1) & 7)) << 4);
+    }
+    const int b_rd = tile_off(wc * 64 + l15, g * 4 + lq);            // + nb * 2048
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    U4 afr[4], bfr[4];
+
+    // ---- prologue: patch of chunk 0, weight slices of taps 0 and 1
+    EDTR_STAMP(1);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) stage_p(cbeg, j, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run half a phase behind their SIMD partners
+    asm volatile("" ::: "memory");
+    EDTR_STAMP(2);
+
+    for (int c = cbeg; c < cend; ++c) {
+        const int par = (c - cbeg) & 1;
+        const char* pa = smem + par * PATCHB;
+        auto phase = [&](auto TAPc, auto SUBc) {
+            constexpr int TAP = decltype(TAPc)::value, SUB = decltype(SUBc)::value, KY = TAP / 3, KX = TAP % 3, BUF = TAP % 3;
+            constexpr int TAP2 = (TAP + 2) % 9, BUF2 = TAP2 % 3, PH = 2 * TAP + SUB;      // PH: phase inside the chunk, 0..17
+            const int c2 = TAP + 2 >= 9 ? c + 1 : c;
+            if constexpr (SUB == 0) {
+                const char* pb = smem + B_BASE + BUF * BTAP + b_rd;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(pb + nb * 2048);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (SUB * 4 + mb + KY) * PROW);
+            stage_w(c2, TAP2, SUB, BUF2);
+            if constexpr (PH >= 2 && PH < 8) stage_p(c + 1, PH - 2, par ^ 1);
+            if constexpr (SUB == 1) {
+                // issued in this and the previous phase: 1 weight piece each, + 1 patch piece each in phases 2..7
+                if constexpr (PH == 3 || PH == 5 || PH == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[SUB * 4 + mb][nb] = T::mfma16(afr[mb], bfr[nb], acc[SUB * 4 + mb][nb]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto tap_body = [&](auto TAPc) { phase(TAPc, IC<0>{}); phase(TAPc, IC<1>{}); };
+        tap_body(IC<0>{}); tap_body(IC<1>{}); tap_body(IC<2>{}); tap_body(IC<3>{}); tap_body(IC<4>{});
+        tap_body(IC<5>{}); tap_body(IC<6>{}); tap_body(IC<7>{}); tap_body(IC<8>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave groups
+    __syncthreads();
+    EDTR_STAMP(3);
+
+    // ---- epilogue: the two K halves meet in the fp32 staging tile [256 pixels][128 channels] (128 KiB)
+    float* stage = reinterpret_cast<float*>(smem);
+    auto sidx = [&](int mb, int nb, int r) { return (wr * 128 + mb * 16 + 4 * lq + r) * 128 + wc * 64 + nb * 16 + l15; };
+    if (g == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[sidx(mb, nb, r)] = acc[mb][nb][r];
+    }
+    __syncthreads();
+    if (g == 1) {
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[sidx(mb, nb, r)] += acc[mb][nb][r];   // (ds_add_f32 here: 10x slower, measured)
+    }
+    const bool gn_acc = p.gn_partial != nullptr;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
+    rows_phase<T, 256, 128, false, 512, true>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq);
+    if (gn_acc) {
+        // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gs[j] += __shfl_xor(gs[j], 16, 64); gs[j] += __shfl_xor(gs[j], 32, 64);
+            gq[j] += __shfl_xor(gq[j], 16, 64); gq[j] += __shfl_xor(gq[j], 32, 64);
+        }
+        __syncthreads();                       // every thread is done reading the staged tile
+        if (lane < 16) {
+            float* dst = stage + (wave * 128 + lane * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float a = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { a += stage[(w * 128 + tid) * 2]; q += stage[(w * 128 + tid) * 2 + 1]; }
+            float* dst = p.gn_partial + ((int64_t)(2 * tm) * p.N + n0 + tid) * 2;     // two 128-row slots per 256-pixel patch
+            dst[0] = a;
+            dst[1] = q;
+            dst[2 * p.N] = 0.0f;
+            dst[2 * p.N + 1] = 0.0f;
+        }
+    }
+    EDTR_STAMP(4); EDTR_STAMP(7);
+}
+
+template <typename T>
+int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int lds = 2 * 48 * 1024 + 3 * 128 * BK * 2;     // 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nbm = (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4), nbn = (p.N + 127) / 128;
+    hipLaunchKernelGGL((igemm_halo_kernel<T>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
+        int64_t blocks = (nvec + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        EDTR_LAUNCH_CHECK();
+    }
+    return EDTR_OK;
+}
+
+// the halo tile's shape requirements (the caller checks buffer addressability)
+static bool igemm_halo_ok(const edtr_igemm_params& p, bool spatial) {
+    return spatial && p.taps == 9 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && !p.upsample2x && p.C2 == 0 && (p.C1 & 63) == 0 &&
+           p.OH == p.IH && p.OW == p.IW && (p.OH & 15) == 0 && (p.OW & 15) == 0 && p.Z == 1 && p.splitk <= p.C1 / 64 &&
+           p.act != EDTR_ACT_GEGLU && p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW;
+}
+
 static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
     const int64_t a_rows = spatial ? (int64_t)(p.M / (p.OH * p.OW)) * p.IH * p.IW : p.M;
     const int64_t a_bytes = (a_rows + (spatial ? 3 * (int64_t)p.IW + 3 : 0)) * p.ld1 * 2 + (int64_t)p.K * 2;
@@ -2185,6 +2430,10 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
+    if (tile == 16) {      // halo tile for 3x3 / stride 1 convolutions
+        if (!igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
+        return launch_halo<T>(p, s);
+    }
     if (tile >= 3 && tile <= 14) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
         const bool fast = (!p.upsample2x || (p.stride == 1 && (tile == 3 || tile >= 6))) && igemm_fast_addressable(p, spatial);
@@ -2338,6 +2587,19 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             tile = 8;
         else if (pp_ok && !(no_auto & (1 << 6)) && p.K >= 1024 && nb256 >= 120 && p.N * 5 >= nbn256 * 256 * 4)
             tile = 6;
+        // Halo tile: 3x3 / stride 1 convolutions on 16-pixel-aligned images.  Measured on the MI355X against the tile chosen above
+        // (profiles/r02/halo_tile_experiments.log): 1.16-1.27x over the 128x128 loop on the N = 128 convolutions of the VAE's 512x512
+        // level, 1.03-1.13x over the 256x256 ping-pong on its 256 / 128 / 64-pixel levels, 1.39x over the 128x160 tile at 640
+        // channels; NOT where 128-column tiles pad N (N = 320: the 160-column tile wins) or with fewer than 96 units
+        // (16x16-pixel patches x 128-column tiles: too few workgroups; the callers use split-K there).  EDTR_IGEMM_HALO=0 switches it off.
+        static int halo = -1;
+        if (halo < 0) {
+            const char* e4 = getenv("EDTR_IGEMM_HALO");
+            halo = (e4 && e4[0] == '0') ? 0 : 1;
+        }
+        if (halo && dma_ok && (p.N & 127) == 0 && igemm_halo_ok(p, spatial) && igemm_fast_addressable(p, spatial) &&
+            (int64_t)(p.M >> 8) * (p.N >> 7) * p.splitk >= 96)
+            tile = 16;
         // 256x32 tile for skinny-N convolutions (the VAE decoder's 3-channel output conv: 94 % of a 128-wide tile is padding);
         // validated against tile 3 on the MI355X (profiles/r02/ab_tiles_3_vs_14*.log).  EDTR_IGEMM_SKINNY=0 switches it off.
         static int skinny = -1;
@@ -2357,7 +2619,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 14 || (tile >= 11 && tile <= 13)) return EDTR_E_DTYPE;     // 11-13: experiments of round 1, measured and removed
+    if (tile < 1 || tile > 16 || (tile >= 11 && tile <= 13) || tile == 15) return EDTR_E_DTYPE;     // 11-13, 15: experiments, measured and removed
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

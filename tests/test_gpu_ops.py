@@ -766,3 +766,112 @@ def test_skinny_n_conv_tile14_matches_tile3(dtype):
     with pytest.raises(RuntimeError):                       # the removed experiments are rejected, not silently remapped
         ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=outs[0], taps=9, M=B * H * W, N=cout, C1=cin, ld1=cin, ldw=9 * cin,
                                   ldc=cout, spatial=(H, W, H, W, 1, 1, 1, 0), out_f32=True, tile=11))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Halo tile (tile 16): 3x3 / stride 1 convolutions keep the 18 x 18 input patch of a 16 x 16 output patch in LDS and read the
+# nine taps from it.  Same products as tile 3 in another summation order (chunk-major K, two K halves per chunk): fp32
+# reference for the absolute bound, tile 3 for the tight one; every epilogue path the UNet / VAE convolutions use.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # B, H, W, cin, cout, bias, rowvec, SiLU, residual, gn_partial, out_f32
+    (2, 32, 48, 128, 128, True, False, 0, False, True, False),     # VAE ResBlock conv1: bias + fused GroupNorm partials
+    (3, 16, 16, 64, 256, True, True, 0, False, True, False),       # UNet ResBlock conv1: + time-embedding row per image
+    (1, 48, 32, 192, 320, True, False, 0, True, True, False),      # conv2 + skip; N = 320: a 64-wide last column tile
+    (2, 16, 32, 128, 128, True, False, 1, False, False, False),    # SiLU epilogue
+    (1, 32, 32, 384, 128, False, False, 0, False, False, True),    # fp32 output (the parity mode's convs: K = 9 * 3C)
+])
+def test_halo_conv_tile16(dtype, case):
+    import torch.nn.functional as F
+    from edtr_amd import lib as L
+    ops = _ops()
+    d = dev()
+    B, H, W, cin, cout, use_bias, use_rv, act, use_res, use_gn, out_f32 = case
+    M = B * H * W
+    x = rnd((M, cin), 301).to(dtype)
+    w = rnd((cout, 9 * cin), 302, 1 / math.sqrt(9 * cin)).to(dtype)
+    bias = rnd((cout,), 303).to(d) if use_bias else None
+    rv = rnd((B, cout), 304).to(d) if use_rv else None
+    res = rnd((M, cout), 305).to(dtype).to(d) if use_res else None
+    xd, wd = x.to(d), w.to(d)
+    outs, gns = {}, {}
+    for t in (3, 16):
+        out = torch.full((M, cout), float("nan"), dtype=torch.float32 if out_f32 else dtype, device=d)
+        gn = torch.full((M // 128, cout, 2), float("nan"), dtype=torch.float32, device=d) if use_gn else None
+        ops.launch(ops.make_igemm(dtype=dtype, a1=xd, w=wd, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, rowvec=rv, rowvec_ld=cout if use_rv else 0,
+                                  rows_per_image=H * W, act=L.ACT_SILU if act else L.ACT_NONE, residual=res, ldr=cout, out_f32=out_f32, gn_partial=gn, tile=t))
+        outs[t], gns[t] = out, gn
+    torch.cuda.synchronize()
+    # fp32 reference on the rounded operands (weights are packed [cout][ky][kx][cin])
+    xr = x.float().reshape(B, H, W, cin).permute(0, 3, 1, 2)
+    wr = w.float().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xr, wr, bias.cpu() if use_bias else None, padding=1)
+    if use_rv:
+        ref = ref + rv.cpu()[:, :, None, None]
+    if act == 1:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1).reshape(M, cout)
+    if use_res:
+        ref = ref + res.float().cpu()
+    assert torch.isfinite(outs[16].float()).all()
+    assert rel(outs[16], ref) < (2e-5 if out_f32 else TOL[dtype])
+    assert rel(outs[16], outs[3]) < (2e-6 if out_f32 else TOL[dtype])           # same products, other summation order
+    if use_gn:
+        # the per-tile partials sit in other slots (one 256-pixel patch = two 128-row slots): compare the per-image sums
+        s16, s3 = (g.double().reshape(B, -1, cout, 2).sum(1) for g in (gns[16], gns[3]))
+        assert torch.isfinite(s16).all()
+        assert float((s16 - s3).abs().max() / s3.abs().max()) < 1e-5
+        want = torch.stack([ref.double().reshape(B, H * W, cout).sum(1), (ref.double() ** 2).reshape(B, H * W, cout).sum(1)], -1)
+        assert float((s16.cpu() - want).abs().max() / want.abs().max()) < (1e-5 if out_f32 else 5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_halo_conv_splitk(dtype):
+    """Split-K over the 64-channel chunks (the 16x16-latent convolutions: 8 patches x 10 column tiles fill a third of the chip):
+    fp32 partial slabs + the shared reducer, with bias / residual applied there."""
+    ops = _ops()
+    d = dev()
+    B, H, W, cin, cout, S = 2, 16, 16, 640, 256, 3
+    M = B * H * W
+    x = rnd((M, cin), 321).to(dtype).to(d)
+    w = rnd((cout, 9 * cin), 322, 1 / math.sqrt(9 * cin)).to(dtype).to(d)
+    bias = rnd((cout,), 323).to(d)
+    res = rnd((M, cout), 324).to(dtype).to(d)
+    outs = []
+    for t, sk in ((3, 1), (16, S), (3, S)):
+        out = torch.full((M, cout), float("nan"), dtype=dtype, device=d)
+        ws = torch.empty(sk * M * cout, dtype=torch.float32, device=d) if sk > 1 else None
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, residual=res, ldr=cout, tile=t, splitk=sk, workspace=ws))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[1].float()).all()
+    assert rel(outs[1], outs[0]) < TOL[dtype] and rel(outs[1], outs[2]) < TOL[dtype]
+
+
+def test_halo_conv_is_the_automatic_choice_and_rejects_other_shapes():
+    """tile 0 picks the halo tile for >= 96 units of 16x16 pixels x 128 channels (N a multiple of 128); an explicit tile 16
+    on a shape it cannot run (stride 2, image not 16-pixel aligned) is an error, not a silent fallback."""
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    B, H, W, cin, cout = 6, 64, 64, 64, 128                      # 6 * 16 patches = 96 units
+    M = B * H * W
+    x = rnd((M, cin), 311).to(dtype).to(d)
+    w = rnd((cout, 9 * cin), 312, 1 / math.sqrt(9 * cin)).to(dtype).to(d)
+    outs = []
+    for t in (16, 0, 3):
+        out = torch.empty((M, cout), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), tile=t))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])                         # tile 0 (auto) ran the halo tile
+    assert rel(outs[0], outs[2]) < TOL[dtype]
+    for spatial, m in (((64, 64, 32, 32, 2, 1, 1, 0), B * 32 * 32), ((24, 24, 24, 24, 1, 1, 1, 0), B * 24 * 24)):
+        xs = rnd((B * spatial[0] * spatial[1], cin), 313).to(dtype).to(d)
+        with pytest.raises(RuntimeError):
+            ops.launch(ops.make_igemm(dtype=dtype, a1=xs, w=w, out=torch.empty((m, cout), dtype=dtype, device=d), taps=9, M=m, N=cout,
+                                      C1=cin, ld1=cin, ldw=9 * cin, ldc=cout, spatial=spatial, tile=16))

@@ -37,7 +37,7 @@ def run():
     lib.edtr_igemm.argtypes = [C.POINTER(L.IgemmParams), C.c_void_p]
     DT = torch.bfloat16
 
-    def case(label, M, N, Cin, taps=1, H=0, residual=False, act=0):
+    def case(label, M, N, Cin, taps=1, H=0, residual=False, act=0, tile=3):
         K = taps * Cin
         a = (torch.randn(M, Cin, device=dev)).to(DT)
         w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(DT)
@@ -45,7 +45,7 @@ def run():
         out = torch.empty(M, n_out, dtype=DT, device=dev)
         res = torch.randn(M, n_out, device=dev).to(DT) if residual else None
         bias = torch.zeros(N, device=dev)
-        nb = ((M + 127) // 128) * ((N + 127) // 128)
+        nb = ((M + 127) // 128) * ((N + 127) // 128) if tile < 16 else min(256 if tile == 17 else 1 << 30, (M // 256) * ((N + 127) // 128))
         stamps = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
         p = L.IgemmParams()
         p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = 0 if DT == torch.bfloat16 else 1, taps, M, N, K, 1, 1
@@ -55,10 +55,11 @@ def run():
             p.stride, p.pad_t, p.pad_l = 1, (1 if taps == 9 else 0), (1 if taps == 9 else 0)
         p.w, p.ldw, p.alpha = w.data_ptr(), K, 1.0
         p.bias_n, p.act = bias.data_ptr(), act
+        p.act_slope = float(os.environ.get('EDTR_SLOPE', '0'))
         if res is not None:
             p.residual, p.ldr = res.data_ptr(), n_out
         p.out, p.ldc = out.data_ptr(), n_out
-        p.tile, p.splitk = 3, 1
+        p.tile, p.splitk = tile, 1
         p.workspace, p.workspace_bytes = stamps.data_ptr(), stamps.numel() * 8
         s = torch.cuda.current_stream().cuda_stream
         for _ in range(3):
@@ -89,10 +90,19 @@ def run():
         flops = 2.0 * M * N * K
         print(f"{label:34s} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF | WGs {nb:5d} first-us {first_wave:4d} CUs {slots:3d} | span {span_us:6.1f} us "
               f"WG life {life_us:5.1f} us | cycles med: prologue {int(np.median(pro)):5d} first-tile {int(np.median(first)):5d} "
+              + (f"[t17: epi-setup {int(np.median(st[:, 8] - st[:, 3]))} mbloop {int(np.median(st[:, 9] - st[:, 8]))} gn+rest {int(np.median(st[:, 4] - st[:, 9]))} | unit2 loop {int(np.median(st[:, 10] - st[:, 4]))} epi {int(np.median(st[:, 11] - st[:, 10]))}] " if tile == 17 else "") +
               f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d} | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}",
               flush=True)
 
     B = 8
+    if len(sys.argv) > 2 and sys.argv[2] == "halo":
+        for t in (16,):
+            case(f"t{t} conv 512^2 128->128", B * 512 * 512, 128, 128, taps=9, H=512, tile=t)
+            case(f"t{t} conv 512^2 256->128", B * 512 * 512, 128, 256, taps=9, H=512, tile=t)
+            case(f"t{t} conv 256^2 256->256", B * 256 * 256, 256, 256, taps=9, H=256, tile=t)
+            case(f"t{t} conv 128^2 512->512", B * 128 * 128, 512, 512, taps=9, H=128, tile=t)
+            case(f"t{t} conv 32^2 640->640", B * 1024, 640, 640, taps=9, H=32, tile=t)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "spatial1":
         case("1x1 spatial 64^2 K320 N320", B * 4096, 320, 320, taps=1, H=64)
         case("1x1 spatial 64^2 K1280 N320", B * 4096, 320, 1280, taps=1, H=64)
