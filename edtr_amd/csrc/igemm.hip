@@ -2186,9 +2186,10 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 // instead of 9 x 48 KiB -> 20 B/clk/CU at MFMA peak.
 //   * LDS: two patch buffers (chunk c+1 lands while chunk c is multiplied) + a ring of three 16 KiB weight slices
 //     (tap t+2 lands while tap t is multiplied; 9 % 3 == 0 keeps the ring position a compile-time function of the tap).
-//     Patch image: pixel (py, px) at (py * 18 + px) * 128 B, 16-byte chunk c at slot c ^ ((px >> 1) & 7): the key depends on
+//     Patch image: pixel (py, px) at (py * 18 + px) * 128 B, 16-byte chunk c at slot c ^ (px & 7): the key depends on
 //     the COLUMN only and a patch row is 2304 B = 9 bank rows, so a tap's dy and the MFMA block's y are immediate offsets
-//     and only the three dx need their own address; 16 consecutive px read conflict-free like 16 consecutive tile rows.
+//     and only the three dx need their own address.  px & 7 keeps the ds_read_b128 of 16 consecutive px conflict-free for
+//     every dx (the tile rows' (r >> 1) & 7 is 2-way conflicted when the run starts at an odd / offset column).
 //   * 8 waves: wave (g, wr, wc) owns pixels y in [8 wr, 8 wr + 8) x all x (128 rows = 8 blocks of one pixel row), output
 //     channels [64 wc, +64) and the K HALF g of every 64-channel chunk (32 channels = one v_mfma_f32_16x16x32 step):
 //     128 x 64 per wave keeps the LDS reads at 12 fragments per 32 MFMAs; the two K halves are summed in the epilogue's
@@ -2258,7 +2259,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
         const int py = pp / PW, px = pp - py * PW;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         const bool ok = pp < PW * PW && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const int c = slot ^ ((px >> 1) & 7);
+        const int c = slot ^ (px & 7);
         voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOobOffset;
     }
     auto stage_w = [&](int chunk, int tap, int j, int buf) {
@@ -2275,7 +2276,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int px = l15 + kx;
-        a_rd[kx] = (wr * 8 * PW + px) * 128 + (((g * 4 + lq) ^ ((px >> 1) & 7)) << 4);
+        a_rd[kx] = (wr * 8 * PW + px) * 128 + (((g * 4 + lq) ^ (px & 7)) << 4);
     }
     const int b_rd = tile_off(wc * 64 + l15, g * 4 + lq);            // + nb * 2048
 
