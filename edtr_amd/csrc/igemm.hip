@@ -2353,6 +2353,11 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
                 for (int r = 0; r < 4; ++r) stage[sidx(mb, nb, r)] = acc[mb][nb][r];
     }
     __syncthreads();
+#ifdef EDTR_STAMPS
+#undef STAMP_VALUE
+#define STAMP_VALUE __builtin_amdgcn_s_memtime()
+    EDTR_STAMP(8);
+#endif
     if (g == 1) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
@@ -2361,6 +2366,10 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stage[sidx(mb, nb, r)] += acc[mb][nb][r];   // (ds_add_f32 here: 10x slower, measured)
     }
+#ifdef EDTR_STAMPS
+    __syncthreads();
+    EDTR_STAMP(9);
+#endif
     const bool gn_acc = p.gn_partial != nullptr;
     float gs[8], gq[8];
 #pragma unroll

@@ -114,17 +114,22 @@ typedef struct edtr_igemm_params {
     int32_t tile;           /* 0 = auto; explicit main-loop choice (tests / A-B runs): 1 = 128x128 register-staged, 2 = 64x64,
                                3 = 128x128 LDS-DMA (2 stages), 4 = 3-stage BK32, 5 = 256x128, 6 = 256x256 ping-pong, 7 = 256x128 ring,
                                8 = 128x160, 9 = 64x128, 10 = 128x128 with 16x16x32 MFMAs, 14 = 256x32 for N <= 32 (automatic for
-                               large-M skinny-N convolutions); 11-13 were round-1 experiments (deeper LDS rings, bank-swizzled
-                               epilogue staging), measured without gain on the MI355X and removed */
+                               large-M skinny-N convolutions), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions on images whose
+                               height and width are multiples of 16: the 18x18 input patch of a 16x16 output patch stays in LDS for
+                               the nine taps; automatic for N % 128 == 0 and >= 96 units incl. split-K; EDTR_E_UNSUPPORTED for any
+                               other shape); 11-13, 15 and 17 were experiments (deeper LDS rings, bank-swizzled epilogue staging,
+                               in-workgroup split-K, persistent / two-workgroup halo variants), measured without gain and removed */
     /* split-K (small-M problems that cannot fill 256 CUs): K is cut into `splitk` runs of K-tiles, each
      * workgroup row writes an fp32 partial slab into `workspace` ([splitk][M][N] floats, caller-owned), and a
      * second launch sums the slabs and applies the epilogue.  splitk <= 1 disables it.  Needs Z == 1, no GEGLU. */
     int32_t splitk;
     void* workspace; int64_t workspace_bytes;
     /* fused GroupNorm statistics of the OUTPUT (optional): the epilogue also writes, per 128-row tile, the per-column
-     * sum and sum of squares of the values it stores: gn_partial[(M/128)][N][2] fp32.  edtr_gn_finalize folds them into
+     * sum and sum of squares of the values it stores: gn_partial[(M/128)][N][2] fp32 (which rows a slot covers is the
+     * kernel's business — the halo tile fills slot 2k with a 256-pixel patch and zeroes slot 2k+1 — only the per-image
+     * totals over an image's H*W/128 consecutive slots are defined).  edtr_gn_finalize folds them into
      * the fp64 sums edtr_gn_apply consumes, so the separate statistics pass over the tensor (edtr_gn_stats) disappears.
-     * Needs M % 128 == 0, 16-bit output, no GEGLU / split-K / z-batching, tile 0/1/3. */
+     * Needs M % 128 == 0, 16-bit output, no GEGLU / split-K / z-batching, tile 0/1/3/6/7/8/10/16. */
     float* gn_partial;
     float act_slope;        /* negative-side slope of EDTR_ACT_LRELU (0 <= slope <= 1) */
 } edtr_igemm_params;

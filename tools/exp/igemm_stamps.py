@@ -90,6 +90,7 @@ def run():
         flops = 2.0 * M * N * K
         print(f"{label:34s} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF | WGs {nb:5d} first-us {first_wave:4d} CUs {slots:3d} | span {span_us:6.1f} us "
               f"WG life {life_us:5.1f} us | cycles med: prologue {int(np.median(pro)):5d} first-tile {int(np.median(first)):5d} "
+              + (f"[t16 epilogue: K-half-0 write {int(np.median(st[:, 8] - st[:, 3]))} K-half-1 add {int(np.median(st[:, 9] - st[:, 8]))} rows {int(np.median(st[:, 4] - st[:, 9]))}] " if tile == 16 else "")
               + (f"[t17: epi-setup {int(np.median(st[:, 8] - st[:, 3]))} mbloop {int(np.median(st[:, 9] - st[:, 8]))} gn+rest {int(np.median(st[:, 4] - st[:, 9]))} | unit2 loop {int(np.median(st[:, 10] - st[:, 4]))} epi {int(np.median(st[:, 11] - st[:, 10]))}] " if tile == 17 else "") +
               f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d} | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}",
               flush=True)
