@@ -119,9 +119,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // loaded once, and the ITER residual vectors are requested up front — before the barrier that publishes the staged
 // tile — so that their L2/HBM latency overlaps the staging instead of serialising ITER dependent round trips
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
-template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false, int PITCH = BNO, typename Hook = NoHook>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
-                                           int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8]) {
+                                           int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8], Hook before_publish = Hook()) {
     // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
     constexpr int VPR = BNO / 8, RPI = THREADS / VPR, ITER = (BM + RPI - 1) / RPI;
     constexpr bool EXACT = (THREADS % VPR == 0) && (BM % RPI == 0);
@@ -131,14 +133,15 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     const bool n_ok = n < n_out && (EXACT || r0 < RPI);
 
     if (p.splitk > 1) {                       // fp32 partial slab, finished by splitk_reduce_kernel
+        before_publish();
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
             if (m < p.M && n_ok && (EXACT || ml < BM)) {
                 f32x4 s0, s1;
-                s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-                s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+                s0 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8);
+                s1 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8 + 4);
                 float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
                 *reinterpret_cast<f32x4*>(o) = s0;
                 *reinterpret_cast<f32x4*>(o + 4) = s1;
@@ -176,6 +179,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     }
     const float alpha = GEGLU ? 1.0f : p.alpha;
     const bool silu = p.act == EDTR_ACT_SILU, gelu = p.act == EDTR_ACT_GELU, lrelu = p.act == EDTR_ACT_LRELU;
+    before_publish();                         // the caller's last staging step runs under the flight of the loads above
     __syncthreads();                          // staged tile visible
 
 #pragma unroll
@@ -184,8 +188,8 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
         if (m < p.M && n_ok && (EXACT || ml < BM)) {
             f32x4 s0, s1;
-            s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-            s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
+            s0 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8);
+            s1 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8 + 4);
             float f[8];
             f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
 #pragma unroll
@@ -2326,7 +2330,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[SUB * 4 + mb][nb] = T::mfma16(afr[mb], bfr[nb], acc[SUB * 4 + mb][nb]);
+                for (int nb = 0; nb < 4; ++nb) acc[SUB * 4 + mb][nb] = T::mfma16(bfr[nb], afr[mb], acc[SUB * 4 + mb][nb]);    // transposed: D[channel][pixel]
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -2341,16 +2345,17 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     __syncthreads();
     EDTR_STAMP(3);
 
-    // ---- epilogue: the two K halves meet in the fp32 staging tile [256 pixels][128 channels] (128 KiB)
+    // ---- epilogue: the two K halves meet in the fp32 staging tile [256 pixels][128 channels], 528-byte rows (129 KiB).  The product
+    // is transposed (weights are the MFMA's row operand), so a lane holds 4 CONSECUTIVE channels of pixel l15 per block: 16-byte
+    // LDS accesses (32 per lane and K half instead of 128 dword ones; the 528-byte pitch keeps the 8-lane write groups conflict-free)
+    constexpr int SPITCH = 132;                          // floats per staged row
     float* stage = reinterpret_cast<float*>(smem);
-    auto sidx = [&](int mb, int nb, int r) { return (wr * 128 + mb * 16 + 4 * lq + r) * 128 + wc * 64 + nb * 16 + l15; };
+    auto sptr = [&](int mb, int nb) { return stage + (wr * 128 + mb * 16 + l15) * SPITCH + wc * 64 + nb * 16 + 4 * lq; };
     if (g == 0) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) stage[sidx(mb, nb, r)] = acc[mb][nb][r];
+            for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4*>(sptr(mb, nb)) = acc[mb][nb];
     }
     __syncthreads();
 #ifdef EDTR_STAMPS
@@ -2358,23 +2363,24 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 #define STAMP_VALUE __builtin_amdgcn_s_memtime()
     EDTR_STAMP(8);
 #endif
-    if (g == 1) {
+    // the second K half is added inside rows_phase, between its operand prefetch (bias, time-embedding row, residual vectors)
+    // and the barrier that publishes the tile: the loads fly under the 2.6k cycles of this pass
+    auto add_second_half = [&]() {
+        if (g == 1) {
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb)
+            for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) stage[sidx(mb, nb, r)] += acc[mb][nb][r];   // (ds_add_f32 here: 10x slower, measured)
-    }
-#ifdef EDTR_STAMPS
-    __syncthreads();
-    EDTR_STAMP(9);
-#endif
+                for (int nb = 0; nb < 4; ++nb) {         // (ds_add_f32 here: 10x slower, measured)
+                    f32x4* q = reinterpret_cast<f32x4*>(sptr(mb, nb));
+                    *q = *q + acc[mb][nb];
+                }
+        }
+    };
     const bool gn_acc = p.gn_partial != nullptr;
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    rows_phase<T, 256, 128, false, 512, true>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq);
+    rows_phase<T, 256, 128, false, 512, true, SPITCH>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);
     if (gn_acc) {
         // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
 #pragma unroll
