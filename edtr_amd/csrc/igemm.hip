@@ -39,6 +39,22 @@ constexpr int kThreads = 256;
 constexpr int BK = 64;
 
 
+// Tile order inside an XCD's contiguous range of workgroups (every kernel first maps blockIdx -> bid so that an XCD owns a
+// contiguous range).  Normally the column tile runs fastest: an XCD walks whole rows of tiles and its L2 keeps the A rows.
+// When the weights are the larger operand by far (the 3x3 convolutions at the 16x16 / 8x8 latent levels: M = 512..2048 rows
+// against 1280 x 11520 weights) the row tile runs fastest instead, so that the workgroups sharing a weight slice sit on ONE XCD:
+// with the other order every XCD streamed every weight from memory (PMC: 226 MB fetched per launch for 30 MB of weights).
+__device__ __forceinline__ void tile_coords(const edtr_igemm_params& p, int bid, int nbm, int nbn, int& tm, int& tn) {
+    const bool weight_heavy = (int64_t)p.N * p.K > 4 * (int64_t)p.M * (p.C1 + p.C2);
+    if (weight_heavy) {
+        tn = bid / nbm;
+        tm = bid - tn * nbm;
+    } else {
+        tm = bid / nbn;
+        tn = bid - tm * nbn;
+    }
+}
+
 // Row-vector epilogue shared by the main kernel and the split-K reducer: 8 consecutive output columns of row m.
 template <typename T>
 __device__ __forceinline__ void finish_vector(const edtr_igemm_params& p, float (&f)[8], int m, int n, bool scale_bias,
@@ -329,7 +345,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- batch (grid.z) offsets
@@ -534,7 +551,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
@@ -869,7 +887,8 @@ __global__ void __launch_bounds__(kThreads, 3) igemm_p3_kernel(const edtr_igemm_
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
@@ -1096,7 +1115,8 @@ __global__ void __launch_bounds__(512, 2) igemm_big_kernel(const edtr_igemm_para
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
@@ -1336,7 +1356,8 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
 
     const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
@@ -1642,7 +1663,8 @@ __global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * 256, n0 = tn * 128;
 
     const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
@@ -1909,7 +1931,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
@@ -2227,7 +2250,8 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tm = bid / nbn, tn = bid - tm * nbn;
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
     const int img = tm / tpi, tr = tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;
     const int oy0 = ty * 16, ox0 = tx * 16, n0 = tn * 128;
     const int m0 = (img * p.OH + oy0) * p.OW + ox0;                 // first pixel of the patch

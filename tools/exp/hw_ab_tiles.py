@@ -59,13 +59,15 @@ def main():
     ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--tol", type=float, default=0.0, help="0 = bit-exact; else max |a-b| / max|a|")
     ap.add_argument("--dt", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--cases", default="all", choices=["all", "halo"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
+    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
     args = ap.parse_args()
     dt = 0 if args.dt == "bf16" else 1
     rng = np.random.default_rng(0)
     rows, bad = [], 0
     cases = [("gemm", g, 1) for g in GEMMS] + [("gemm", (2048, 1280, 5120), 3), ("gemm", (512, 1280, 1280), 2)]
     cases += [("conv", c, 1) for c in CONVS] + [("conv", (8, 8, 8, 1280, 1280, 0), 6)]
+    if args.cases == "smallm":      # the 8x8-latent convolutions: which split-K count?
+        cases = [("conv", (8, 8, 8, 1280, 1280, 0), k) for k in (4, 6, 8, 9, 10, 12, 15)] + [("conv", (8, 8, 8, 2560, 1280, 0), k) for k in (6, 8, 12, 16)]
     if args.cases == "halo":
         cases = [("conv", c, 1) for c in HALO] + [("conv", (8, 16, 16, 1280, 1280, 0), 3), ("conv", (8, 16, 16, 2560, 1280, 0), 3),
                                                   ("conv", (8, 16, 16, 1920, 1280, 0), 3), ("conv", (8, 16, 16, 1280, 1280, 0), 2),
