@@ -45,7 +45,25 @@ constexpr int BK = 64;
 // against 1280 x 11520 weights) the row tile runs fastest instead, so that the workgroups sharing a weight slice sit on ONE XCD:
 // with the other order every XCD streamed every weight from memory (PMC: 226 MB fetched per launch for 30 MB of weights).
 __device__ __forceinline__ void tile_coords(const edtr_igemm_params& p, int bid, int nbm, int nbn, int& tm, int& tn) {
-    const bool weight_heavy = (int64_t)p.N * p.K > 4 * (int64_t)p.M * (p.C1 + p.C2);
+    const int64_t a_bytes = (int64_t)p.M * (p.C1 + p.C2) * 2, w_bytes = (int64_t)p.N * p.K * 2;
+    // Neither operand fits an XCD's 4 MiB L2 and both tile counts are multiples of 8 (the 32x32-latent GEGLU projection,
+    // M = 8192 x N = 5120 x K = 640: PMC 393 MB fetched per launch for 17 MB of operands, 5 TB/s — the launch ran at the HBM
+    // rate): walk 8 x 8 super-blocks of tiles (one resident round of an XCD) so that 8 A row-panels + 8 W column-panels
+    // (<= 3 MiB) serve 64 tiles.  Only when the model says it halves the traffic of both linear orders.
+    if (((nbm | nbn) & 7) == 0) {
+        const int64_t a_row = a_bytes / nbm, w_col = w_bytes / nbn, cap = 3 << 20;
+        const int64_t cost_rows = a_bytes + w_bytes * (w_bytes <= cap ? 8 : nbm);      // column tile fastest
+        const int64_t cost_cols = w_bytes + a_bytes * (a_bytes <= cap ? 8 : nbn);      // row tile fastest
+        const int64_t cost_2d = (int64_t)nbm * nbn * (a_row + w_col) / 8;
+        if (8 * (a_row + w_col) <= cap && 2 * cost_2d <= (cost_rows < cost_cols ? cost_rows : cost_cols)) {
+            const int blk = bid >> 6, r = bid & 63, nbn8 = nbn >> 3;
+            const int bm = blk / nbn8, bn = blk - bm * nbn8;
+            tm = bm * 8 + (r >> 3);
+            tn = bn * 8 + (r & 7);
+            return;
+        }
+    }
+    const bool weight_heavy = w_bytes > 4 * a_bytes;
     if (weight_heavy) {
         tn = bid / nbm;
         tm = bid - tn * nbm;

@@ -1,3 +1,6 @@
+"""Per-kernel / per-grid attribution of one rocprofv3 --pmc FETCH_SIZE (or WRITE_SIZE) pass over bench.py (igemm family only):
+    python3 tools/exp/pmc_by_kernel.py <rocprof dir> FETCH_SIZE
+3 passes of the path are assumed (program build, warm-up, timed)."""
 import csv,glob,sys,collections,json
 root=sys.argv[1]
 files=sorted(glob.glob(root+"/**/*counter_collection.csv",recursive=True))
@@ -8,7 +11,7 @@ for f in files:
     for r in rd:
         n=r[kn]
         if "igemm" not in n and "splitk" not in n: continue
-        short=n.split("(")[0].replace("void (anonymous namespace)::","")[:60]
+        short=n.replace("void (anonymous namespace)::","").replace("(edtr_igemm_params)","").replace("(anonymous namespace)::","")[:60]
         key=(short,r[gs])
         agg[key][0]+=1; agg[key][1]+=float(r[cv])
 rows=sorted(agg.items(),key=lambda kv:-kv[1][1])
