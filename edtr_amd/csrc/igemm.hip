@@ -51,7 +51,8 @@ __device__ __forceinline__ void tile_coords(const edtr_igemm_params& p, int bid,
     // rate): walk 8 x 8 super-blocks of tiles (one resident round of an XCD) so that 8 A row-panels + 8 W column-panels
     // (<= 3 MiB) serve 64 tiles.  Only when the model says it halves the traffic of both linear orders.
     if (((nbm | nbn) & 7) == 0) {
-        const int64_t a_row = a_bytes / nbm, w_col = w_bytes / nbn, cap = 3 << 20;
+        // (32-bit divisions: a 64-bit one costs a couple of hundred instructions in every workgroup's prologue)
+        const int64_t a_row = (int64_t)((p.M + nbm - 1) / nbm) * (p.C1 + p.C2) * 2, w_col = (int64_t)((p.N + nbn - 1) / nbn) * p.K * 2, cap = 3 << 20;
         const int64_t cost_rows = a_bytes + w_bytes * (w_bytes <= cap ? 8 : nbm);      // column tile fastest
         const int64_t cost_cols = w_bytes + a_bytes * (a_bytes <= cap ? 8 : nbn);      // row tile fastest
         const int64_t cost_2d = (int64_t)nbm * nbn * (a_row + w_col) / 8;
