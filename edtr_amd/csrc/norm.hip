@@ -1,6 +1,7 @@
 // HBM-bound normalisation kernels for gfx950: GroupNorm statistics / apply(+SiLU), LayerNorm,
 // row softmax.  All 16-bit traffic is moved as 16-byte vectors (8 elements per lane), all
 // arithmetic is fp32 (GroupNorm sums are combined across workgroups in fp64).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -112,6 +113,9 @@ __global__ void gn_stats_kernel(const edtr_gn_params p, int CV, int R, int ppb) 
 // the [pixels x channels] slab is streamed as 16-byte vectors, 4 independent loads in flight per thread.
 // ------------------------------------------------------------------------------------------
 constexpr int GN_CC = 256;  // channels per workgroup in the apply kernel
+// A/B switch for measurements: EDTR_GN_APPLY_GENERIC=1 keeps every chunk on the generic (divide per vector) loop
+__device__ int g_gn_apply_generic = 0;
+__device__ __forceinline__ bool gn_apply_generic_only() { return g_gn_apply_generic != 0; }
 
 template <typename IO>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, int ppb) {
@@ -141,6 +145,39 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
     const in_t* xb = static_cast<const in_t*>(p.x) + ((int64_t)b * p.HW + pix0) * p.ldx + c0;
     out_t* yb = static_cast<out_t*>(p.y) + ((int64_t)b * p.HW + pix0) * p.ldy + c0;
     const int total = npix * ncv;
+    if ((ncv & (ncv - 1)) == 0 && ncv <= 256 && !gn_apply_generic_only()) {
+        // The chunk's vector count is a power of two (every SD / VAE width: 128 / 256 / 512, and 320 = 256 + 64, 640 = 2 x 256 +
+        // 128, ...): a thread keeps ONE 8-channel vector for all of its pixels, so scale / shift live in registers and the
+        // (pixel, vector) split is a shift — the generic loop below spends as many instructions on its integer division and
+        // four LDS reads per vector as on the normalisation itself.
+        const int sh_ = __builtin_ctz(ncv), cvf = tid & (ncv - 1), prow = tid >> sh_, pstep = 256 >> sh_;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + cvf * 8), a1 = *reinterpret_cast<const f32x4*>(sc + cvf * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh + cvf * 8), b1 = *reinterpret_cast<const f32x4*>(sh + cvf * 8 + 4);
+        const in_t* xt = xb + cvf * 8;
+        out_t* yt = yb + cvf * 8;
+        for (int px0 = prow; px0 < npix; px0 += 4 * pstep) {
+            float fv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (px0 + u * pstep < npix) IO::load8(xt + (int64_t)(px0 + u * pstep) * p.ldx, fv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (px0 + u * pstep >= npix) continue;
+                float (&f)[8] = fv[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] = f[j] * a0[j] + b0[j];
+                    f[j + 4] = f[j + 4] * a1[j] + b1[j];
+                }
+                if (p.silu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+                }
+                IO::store8(yt + (int64_t)(px0 + u * pstep) * p.ldy, p.C, f);
+            }
+        }
+        return;
+    }
     for (int i0 = tid; i0 < total; i0 += 4 * 256) {
         float fv[4][8];
         int pi[4], cv[4];
@@ -322,6 +359,12 @@ extern "C" int edtr_gn_apply(const edtr_gn_params* pp, edtr_stream_t stream) {
     const edtr_gn_params& p = *pp;
     if (int e = check_gn(p, true)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static int generic = -1;
+    if (generic < 0) {
+        const char* e = getenv("EDTR_GN_APPLY_GENERIC");
+        generic = (e && e[0] == '1') ? 1 : 0;
+        if (generic) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gn_apply_generic), &generic, sizeof(int));
+    }
     const int nchunk_c = (p.C + GN_CC - 1) / GN_CC;
     // ~2048 workgroups when the tensor allows it, at least 8 pixels (>= 1 vector per thread at 256 channels) each
     int64_t want = (2048 + (int64_t)p.B * nchunk_c - 1) / ((int64_t)p.B * nchunk_c);
