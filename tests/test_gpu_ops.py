@@ -875,3 +875,28 @@ def test_halo_conv_is_the_automatic_choice_and_rejects_other_shapes():
         with pytest.raises(RuntimeError):
             ops.launch(ops.make_igemm(dtype=dtype, a1=xs, w=w, out=torch.empty((m, cout), dtype=dtype, device=d), taps=9, M=m, N=cout,
                                       C1=cin, ld1=cin, ldw=9 * cin, ldc=cout, spatial=spatial, tile=16))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tile order (`tile_coords` in igemm.hip): the blockIdx -> (row tile, column tile) map switches with the operand sizes — column tile
+# fastest, row tile fastest (weights > 4x the activations) or 8x8 super-blocks (neither operand fits an L2, both tile counts
+# multiples of 8).  Every order must cover every tile exactly once: full-output comparison on one shape per rule and per kernel.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [3, 6, 8, 1])
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 128),      # 8 x 8 tiles of 128: the super-block order (model: traffic halves)
+                                   (2048, 2048, 128),      # 16 x 16 tiles: four super-blocks
+                                   (128, 1024, 2048),      # weights 16x the activations: row tile fastest
+                                   (384, 1280, 1024),      # row tile fastest with ragged counts (3 x 10 tiles)
+                                   (1536, 320, 256)])      # default order
+def test_gemm_tile_orders_cover_every_tile(M, N, K, tile):
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    a = rnd((M, K), 331).to(dtype)
+    w = rnd((N, K), 332, 1 / math.sqrt(K)).to(dtype)
+    ref = a.float() @ w.float().t()
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=a.to(d), w=w.to(d), out=out, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N, tile=tile))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()                # an uncovered tile stays NaN
+    assert rel(out.float(), ref) < TOL[dtype]
