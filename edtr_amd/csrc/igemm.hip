@@ -2649,15 +2649,15 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         // Halo tile: 3x3 / stride 1 convolutions on 16-pixel-aligned images.  Measured on the MI355X against the tile chosen above
         // (profiles/r02/halo_tile_experiments.log): 1.16-1.27x over the 128x128 loop on the N = 128 convolutions of the VAE's 512x512
         // level, 1.03-1.13x over the 256x256 ping-pong on its 256 / 128 / 64-pixel levels, 1.39x over the 128x160 tile at 640
-        // channels; NOT where 128-column tiles pad N (N = 320: the 160-column tile wins) or with fewer than 96 units
-        // (16x16-pixel patches x 128-column tiles: too few workgroups; the callers use split-K there).  EDTR_IGEMM_HALO=0 switches it off.
+        // channels; NOT where 128-column tiles pad N (N = 320: the 160-column tile wins) or with fewer than 48 units
+        // (16x16-pixel patches x 128-column tiles; measured: 1.3-1.4x over the 128x160 tile at 80 units, 1.04-1.29x at 64, equal at 32).  EDTR_IGEMM_HALO=0 switches it off.
         static int halo = -1;
         if (halo < 0) {
             const char* e4 = getenv("EDTR_IGEMM_HALO");
             halo = (e4 && e4[0] == '0') ? 0 : 1;
         }
         if (halo && dma_ok && (p.N & 127) == 0 && igemm_halo_ok(p, spatial) && igemm_fast_addressable(p, spatial) &&
-            (int64_t)(p.M >> 8) * (p.N >> 7) * p.splitk >= 96)
+            (int64_t)(p.M >> 8) * (p.N >> 7) * p.splitk >= 48)
             tile = 16;
         // 256x32 tile for skinny-N convolutions (the VAE decoder's 3-channel output conv: 94 % of a 128-wide tile is padding);
         // validated against tile 3 on the MI355X (profiles/r02/ab_tiles_3_vs_14*.log).  EDTR_IGEMM_SKINNY=0 switches it off.

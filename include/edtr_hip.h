@@ -116,7 +116,7 @@ typedef struct edtr_igemm_params {
                                8 = 128x160, 9 = 64x128, 10 = 128x128 with 16x16x32 MFMAs, 14 = 256x32 for N <= 32 (automatic for
                                large-M skinny-N convolutions), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions on images whose
                                height and width are multiples of 16: the 18x18 input patch of a 16x16 output patch stays in LDS for
-                               the nine taps; automatic for N % 128 == 0 and >= 96 units incl. split-K; EDTR_E_UNSUPPORTED for any
+                               the nine taps; automatic for N % 128 == 0 and >= 48 units incl. split-K; EDTR_E_UNSUPPORTED for any
                                other shape); 11-13, 15 and 17 were experiments (deeper LDS rings, bank-swizzled epilogue staging,
                                in-workgroup split-K, persistent / two-workgroup halo variants), measured without gain and removed */
     /* split-K (small-M problems that cannot fill 256 CUs): K is cut into `splitk` runs of K-tiles, each

@@ -852,12 +852,12 @@ def test_halo_conv_splitk(dtype):
 
 
 def test_halo_conv_is_the_automatic_choice_and_rejects_other_shapes():
-    """tile 0 picks the halo tile for >= 96 units of 16x16 pixels x 128 channels (N a multiple of 128); an explicit tile 16
+    """tile 0 picks the halo tile for >= 48 units of 16x16 pixels x 128 channels (N a multiple of 128); an explicit tile 16
     on a shape it cannot run (stride 2, image not 16-pixel aligned) is an error, not a silent fallback."""
     ops = _ops()
     d = dev()
     dtype = torch.bfloat16
-    B, H, W, cin, cout = 6, 64, 64, 64, 128                      # 6 * 16 patches = 96 units
+    B, H, W, cin, cout = 3, 64, 64, 64, 128                      # 3 * 16 patches = 48 units
     M = B * H * W
     x = rnd((M, cin), 311).to(dtype).to(d)
     w = rnd((cout, 9 * cin), 312, 1 / math.sqrt(9 * cin)).to(dtype).to(d)
