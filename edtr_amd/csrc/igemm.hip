@@ -2249,11 +2249,15 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------------
 template <int V> using IC = std::integral_constant<int, V>;
 
-template <typename T>
+template <typename T, bool UP2>
 __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_params p) {
     EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
-    constexpr int PW = 18, PROW = PW * 128;
-    constexpr int PATCHB = 48 * 1024;          // 324 pixels x 128 B = 40.5 KiB, filled by 48 one-KiB pieces (the last 7.5 land in padding)
+    // UP2 (nearest-2x upsample fused into the gather, `Upsample` of the UNet / VAE decoder): output pixel (y, x), tap (ky, kx) reads
+    // SOURCE pixel ((oy0 + y + ky - 1) >> 1, (ox0 + x + kx - 1) >> 1): the patch is 10 x 10 source pixels (12.5 KiB per chunk),
+    // patch row of block row y and tap ky = (y + ky + 1) >> 1, patch column of lane x and tap kx = (x + kx + 1) >> 1.
+    constexpr int PW = UP2 ? 10 : 18, PROW = PW * 128;
+    constexpr int NPP = UP2 ? 2 : 6;           // patch pieces (1 KiB = 8 pixels) per wave and chunk
+    constexpr int PATCHB = UP2 ? 16 * 1024 : 48 * 1024;    // 324 (100) pixels x 128 B, filled by 48 (16) one-KiB pieces, the tail lands in padding
     constexpr int BTAP = 128 * BK * 2;         // 16 KiB
     constexpr int B_BASE = 2 * PATCHB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2273,6 +2277,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     tile_coords(p, bid, nbm, nbn, tm, tn);
     const int img = tm / tpi, tr = tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;
     const int oy0 = ty * 16, ox0 = tx * 16, n0 = tn * 128;
+    const int sy0 = UP2 ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UP2 ? (ox0 >> 1) - 1 : ox0 - 1;     // source pixel of patch position (0, 0)
     const int m0 = (img * p.OH + oy0) * p.OW + ox0;                 // first pixel of the patch
 
     const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
@@ -2287,7 +2292,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     const int cbeg = (int)blockIdx.y * nchunk_all / nsplit, cend = ((int)blockIdx.y + 1) * nchunk_all / nsplit;
 
     // ---- staging geometry.  Patch piece q = wave + 8 j: LDS bytes [q KiB, +1 KiB) = pixels 8 q .. 8 q + 7, lane -> (pixel, slot)
-    uint32_t voff_p[6], voff_w[2];
+    uint32_t voff_p[NPP], voff_w[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = (wave + 8 * j) * 8 + (lane >> 3), slot = lane & 7, n = n0 + r;
@@ -2301,10 +2306,10 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
         for (int j = 0; j < 2; ++j)
             dma16_buf(voff_w[j], srd_w, (uint32_t)((t * Cin + cbeg * BK) * 2), smem_base + B_BASE + t * BTAP + (wave + 8 * j) * 1024);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < NPP; ++j) {
         const int u = (wave + 8 * j) * 64 + lane, pp = u >> 3, slot = u & 7;
         const int py = pp / PW, px = pp - py * PW;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const int iy = sy0 + py, ix = sx0 + px;
         const bool ok = pp < PW * PW && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         const int c = slot ^ (px & 7);
         voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOobOffset;
@@ -2322,8 +2327,8 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     int a_rd[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int px = l15 + kx;
-        a_rd[kx] = (wr * 8 * PW + px) * 128 + (((g * 4 + lq) ^ (px & 7)) << 4);
+        const int px = UP2 ? (l15 + kx + 1) >> 1 : l15 + kx;
+        a_rd[kx] = (wr * (UP2 ? 4 : 8) * PW + px) * 128 + (((g * 4 + lq) ^ (px & 7)) << 4);
     }
     const int b_rd = tile_off(wc * 64 + l15, g * 4 + lq);            // + nb * 2048
 
@@ -2337,7 +2342,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     // ---- prologue: patch of chunk 0, weight slices of taps 0 and 1
     EDTR_STAMP(1);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) stage_p(cbeg, j, 0);
+    for (int j = 0; j < NPP; ++j) stage_p(cbeg, j, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run half a phase behind their SIMD partners
@@ -2358,12 +2363,12 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
             }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
-                afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (SUB * 4 + mb + KY) * PROW);
+                afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (UP2 ? (SUB * 4 + mb + KY + 1) >> 1 : SUB * 4 + mb + KY) * PROW);
             stage_w(c2, TAP2, SUB, BUF2);
-            if constexpr (PH >= 2 && PH < 8) stage_p(c + 1, PH - 2, par ^ 1);
+            if constexpr (PH >= 2 && PH < 2 + NPP) stage_p(c + 1, PH - 2, par ^ 1);
             if constexpr (SUB == 1) {
-                // issued in this and the previous phase: 1 weight piece each, + 1 patch piece each in phases 2..7
-                if constexpr (PH == 3 || PH == 5 || PH == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                // issued in this and the previous phase: 1 weight piece each, + 1 patch piece each in phases 2 .. 2 + NPP - 1
+                if constexpr (PH == 3 || (!UP2 && (PH == 5 || PH == 7))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
@@ -2452,16 +2457,16 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     EDTR_STAMP(4); EDTR_STAMP(7);
 }
 
-template <typename T>
+template <typename T, bool UP2>
 int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 2 * 48 * 1024 + 3 * 128 * BK * 2;     // 144 KiB
+    constexpr int lds = UP2 ? 256 * 132 * 4 : 2 * 48 * 1024 + 3 * 128 * BK * 2;     // 144 KiB; UP2: main loop 80 KiB, the epilogue's staging tile 132 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T, UP2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int nbm = (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4), nbn = (p.N + 127) / 128;
-    hipLaunchKernelGGL((igemm_halo_kernel<T>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((igemm_halo_kernel<T, UP2>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
     EDTR_LAUNCH_CHECK();
     if (p.splitk > 1) {
         const int64_t nvec = (int64_t)p.M * (p.N >> 3);
@@ -2475,8 +2480,9 @@ int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
 
 // the halo tile's shape requirements (the caller checks buffer addressability)
 static bool igemm_halo_ok(const edtr_igemm_params& p, bool spatial) {
-    return spatial && p.taps == 9 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && !p.upsample2x && p.C2 == 0 && (p.C1 & 63) == 0 &&
-           p.OH == p.IH && p.OW == p.IW && (p.OH & 15) == 0 && (p.OW & 15) == 0 && p.Z == 1 && p.splitk <= p.C1 / 64 &&
+    const int up = p.upsample2x ? 2 : 1;
+    return spatial && p.taps == 9 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.C2 == 0 && (p.C1 & 63) == 0 &&
+           p.OH == p.IH * up && p.OW == p.IW * up && (p.OH & 15) == 0 && (p.OW & 15) == 0 && p.Z == 1 && p.splitk <= p.C1 / 64 &&
            p.act != EDTR_ACT_GEGLU && p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW;
 }
 
@@ -2491,7 +2497,7 @@ template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
     if (tile == 16) {      // halo tile for 3x3 / stride 1 convolutions
         if (!igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
-        return launch_halo<T>(p, s);
+        return p.upsample2x ? launch_halo<T, true>(p, s) : launch_halo<T, false>(p, s);
     }
     if (tile >= 3 && tile <= 14) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)

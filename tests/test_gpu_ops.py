@@ -783,13 +783,28 @@ def test_skinny_n_conv_tile14_matches_tile3(dtype):
     (1, 32, 32, 384, 128, False, False, 0, False, False, True),    # fp32 output (the parity mode's convs: K = 9 * 3C)
 ])
 def test_halo_conv_tile16(dtype, case):
+    _halo_case(dtype, case, ups=False)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    (2, 16, 24, 128, 128, True, False, 0, False, True, False),     # Upsample: nearest-2x fused into the gather (source 16 x 24 -> 32 x 48)
+    (1, 8, 8, 192, 256, True, False, 0, False, False, False),      # one 16 x 16 output patch per image: every border
+    (3, 24, 16, 64, 320, True, False, 0, True, False, False),      # + residual, ragged last column tile
+])
+def test_halo_conv_tile16_upsample2x(dtype, case):
+    _halo_case(dtype, case, ups=True)
+
+
+def _halo_case(dtype, case, ups):
     import torch.nn.functional as F
     from edtr_amd import lib as L
     ops = _ops()
     d = dev()
-    B, H, W, cin, cout, use_bias, use_rv, act, use_res, use_gn, out_f32 = case
+    B, IH, IW, cin, cout, use_bias, use_rv, act, use_res, use_gn, out_f32 = case
+    H, W = (2 * IH, 2 * IW) if ups else (IH, IW)              # output size
     M = B * H * W
-    x = rnd((M, cin), 301).to(dtype)
+    x = rnd((B * IH * IW, cin), 301).to(dtype)
     w = rnd((cout, 9 * cin), 302, 1 / math.sqrt(9 * cin)).to(dtype)
     bias = rnd((cout,), 303).to(d) if use_bias else None
     rv = rnd((B, cout), 304).to(d) if use_rv else None
@@ -800,12 +815,14 @@ def test_halo_conv_tile16(dtype, case):
         out = torch.full((M, cout), float("nan"), dtype=torch.float32 if out_f32 else dtype, device=d)
         gn = torch.full((M // 128, cout, 2), float("nan"), dtype=torch.float32, device=d) if use_gn else None
         ops.launch(ops.make_igemm(dtype=dtype, a1=xd, w=wd, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
-                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, rowvec=rv, rowvec_ld=cout if use_rv else 0,
+                                  spatial=(IH, IW, H, W, 1, 1, 1, int(ups)), bias_n=bias, rowvec=rv, rowvec_ld=cout if use_rv else 0,
                                   rows_per_image=H * W, act=L.ACT_SILU if act else L.ACT_NONE, residual=res, ldr=cout, out_f32=out_f32, gn_partial=gn, tile=t))
         outs[t], gns[t] = out, gn
     torch.cuda.synchronize()
     # fp32 reference on the rounded operands (weights are packed [cout][ky][kx][cin])
-    xr = x.float().reshape(B, H, W, cin).permute(0, 3, 1, 2)
+    xr = x.float().reshape(B, IH, IW, cin).permute(0, 3, 1, 2)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
     wr = w.float().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
     ref = F.conv2d(xr, wr, bias.cpu() if use_bias else None, padding=1)
     if use_rv:

@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--tol", type=float, default=0.0, help="0 = bit-exact; else max |a-b| / max|a|")
     ap.add_argument("--dt", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
+    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4", "up2"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
     args = ap.parse_args()
     dt = 0 if args.dt == "bf16" else 1
     rng = np.random.default_rng(0)
@@ -68,6 +68,9 @@ def main():
     cases += [("conv", c, 1) for c in CONVS] + [("conv", (8, 8, 8, 1280, 1280, 0), 6)]
     if args.cases == "smallm":      # the 8x8-latent convolutions: which split-K count?
         cases = [("conv", (8, 8, 8, 1280, 1280, 0), k) for k in (4, 6, 8, 9, 10, 12, 15)] + [("conv", (8, 8, 8, 2560, 1280, 0), k) for k in (6, 8, 12, 16)]
+    if args.cases == "up2":         # nearest-2x upsample convolutions (VAE decoder / UNet Upsample)
+        cases = [("conv", c, 1) for c in [(2, 16, 16, 64, 128, 1), (1, 24, 8, 128, 256, 1), (8, 256, 256, 256, 256, 1), (8, 128, 128, 512, 512, 1),
+                                           (8, 64, 64, 512, 512, 1), (8, 32, 32, 640, 640, 1), (8, 16, 16, 1280, 1280, 1), (8, 8, 8, 1280, 1280, 1)]]
     if args.cases == "b4":          # batch-4 UNet shapes (det512s50): is the halo tile's 96-unit threshold right?
         cases = [("conv", c, 1) for c in [(4, 32, 32, 640, 640, 0), (4, 32, 32, 1280, 640, 0), (4, 32, 32, 960, 640, 0), (4, 64, 64, 128, 128, 0), (4, 64, 64, 512, 512, 0),
                                            (1, 64, 64, 512, 512, 0), (1, 128, 128, 512, 512, 0), (2, 64, 64, 512, 512, 0)]]
