@@ -114,7 +114,7 @@ typedef struct edtr_igemm_params {
     int32_t tile;           /* 0 = auto; explicit main-loop choice (tests / A-B runs): 1 = 128x128 register-staged, 2 = 64x64,
                                3 = 128x128 LDS-DMA (2 stages), 4 = 3-stage BK32, 5 = 256x128, 6 = 256x256 ping-pong, 7 = 256x128 ring,
                                8 = 128x160, 9 = 64x128, 10 = 128x128 with 16x16x32 MFMAs, 14 = 256x32 for N <= 32 (automatic for
-                               large-M skinny-N convolutions), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions on images whose
+                               large-M skinny-N convolutions), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions, plain or nearest-2x upsampled, on outputs whose
                                height and width are multiples of 16: the 18x18 input patch of a 16x16 output patch stays in LDS for
                                the nine taps; automatic for N % 128 == 0 and >= 48 units incl. split-K; EDTR_E_UNSUPPORTED for any
                                other shape); 11-13, 15 and 17 were experiments (deeper LDS rings, bank-swizzled epilogue staging,
