@@ -2245,7 +2245,9 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 //   * per phase and wave: one weight piece (tap t+2), in phases 2..7 of a chunk also one piece of the next patch;
 //     odd phases wait vmcnt(issued in this and the previous phase) = "everything up to two phases ago has landed".
 // Output rows are patch pixels (rows_phase<PATCH16>); fused GroupNorm partials go to slot 2 * patch (slot 2 * patch + 1 = 0).
-// Requires taps == 9, stride 1, pad 1, no upsample / concat, C1 % 64 == 0, OH % 16 == OW % 16 == 0, buffer addressing.
+// Split-K (blockIdx.y) cuts the chunk range; the partial slabs go through the shared reducer.  UP2 = the nearest-2x upsample fused
+// into the gather (10 x 10 source patch, see the constants below).
+// Requires taps == 9, stride 1, pad 1, no concat, C1 % 64 == 0, OH % 16 == OW % 16 == 0, buffer addressing.
 // ------------------------------------------------------------------------------------------------------
 template <int V> using IC = std::integral_constant<int, V>;
 
