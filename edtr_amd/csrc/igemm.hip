@@ -45,7 +45,7 @@ constexpr int BK = 64;
 // against 1280 x 11520 weights) the row tile runs fastest instead, so that the workgroups sharing a weight slice sit on ONE XCD:
 // with the other order every XCD streamed every weight from memory (PMC: 226 MB fetched per launch for 30 MB of weights).
 __device__ __forceinline__ void tile_coords(const edtr_igemm_params& p, int bid, int nbm, int nbn, int& tm, int& tn) {
-    const int64_t a_bytes = (int64_t)p.M * (p.C1 + p.C2) * 2, w_bytes = (int64_t)p.N * p.K * 2;
+    const int64_t a_bytes = (int64_t)(p.upsample2x ? p.M >> 2 : p.M) * (p.C1 + p.C2) * 2, w_bytes = (int64_t)p.N * p.K * 2;   // (upsample: a quarter of the rows exist)
     // Neither operand fits an XCD's 4 MiB L2 and both tile counts are multiples of 8 (the 32x32-latent GEGLU projection,
     // M = 8192 x N = 5120 x K = 640: PMC 393 MB fetched per launch for 17 MB of operands, 5 TB/s — the launch ran at the HBM
     // rate): walk 8 x 8 super-blocks of tiles (one resident round of an XCD) so that 8 A row-panels + 8 W column-panels
