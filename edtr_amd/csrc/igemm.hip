@@ -2480,6 +2480,172 @@ int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 128x128 tile for SMALL grids (tile = 15): plain GEMMs whose 128x128 tile grid leaves at most one workgroup per CU — the
+// short linears of the 16x16 / 8x8 latent levels (M = 512 .. 2048).  There the two-workgroups-per-CU loop of tile 3 has nobody
+// to overlap with: each wave issues its 8 DMAs, waits, multiplies (stamps: 1.4k cycles per K-tile for 512 of MFMA).  Here one
+// workgroup of EIGHT waves ping-pongs with itself, as tiles 6 / 16 do: wave (g, wr, wc) owns 64 rows x 64 columns x the K HALF g
+// of every 64-deep K-tile (16 v_mfma_f32_16x16x32 per K-tile); waves w and w+4 share a SIMD and run half a phase apart, so one
+// multiplies while its partner reads fragments and issues its 4 of the K-tile's 32 DMA pieces two K-tiles ahead.  Ring of four
+// 32 KiB K-tile slots (a slot is restaged two phases after its last read).  The two K halves meet in the epilogue's staging
+// tile, as in tile 16.  Non-spatial, C2 == 0, C1 % 64 == 0, Z == 1, no GEGLU; split-K over K-tiles (blockIdx.y).
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(512, 1) igemm_pp128_kernel(const edtr_igemm_params p) {
+    constexpr int HALF = 128 * BK * 2, SLOT = 2 * HALF, RING = 4;     // A rows then W rows of one K-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    int tm, tn;
+    tile_coords(p, bid, nbm, nbn, tm, tn);
+    const int m0 = tm * 128, n0 = tn * 128;
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const u32x4 srd_a = make_srd(p.a1);
+    const u32x4 srd_w = make_srd(p.w);
+    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
+    const int nsplit = p.splitk > 1 ? p.splitk : 1, nkt_all = p.K / BK;
+    const int kbeg = (int)blockIdx.y * nkt_all / nsplit, kend = ((int)blockIdx.y + 1) * nkt_all / nsplit;
+
+    // ---- staging: a K-tile is 32 one-KiB pieces (8 rows each): this wave's A rows (wave + 8 j) * 8 + (lane >> 3), j = 0, 1, and the same W rows
+    uint32_t voff_a[2], voff_w[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + 8 * j) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        voff_a[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.ld1 + c * 8) * 2) : kOobOffset;
+        voff_w[j] = n0 + r < nvalid ? (uint32_t)(((int64_t)(n0 + r) * p.ldw + c * 8) * 2) : kOobOffset;
+    }
+    auto stage = [&](int kt, int slot) {
+        const bool live = kt < kend;
+        const uint32_t so = (uint32_t)kt * (BK * 2), dst = smem_base + slot * SLOT + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            dma16_buf(live ? voff_a[j] : kOobOffset, srd_a, so, dst + j * 8192);
+            dma16_buf(live ? voff_w[j] : kOobOffset, srd_w, so, dst + HALF + j * 8192);
+        }
+    };
+    const int a_rd = tile_off(wr * 64 + l15, g * 4 + lq);           // + mb * 2048
+    const int b_rd = HALF + tile_off(wc * 64 + l15, g * 4 + lq);    // + nb * 2048
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    U4 afr[4], bfr[4];
+
+    stage(kbeg, 0);
+    stage(kbeg + 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // the first K-tile has landed (the second may still fly)
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();                      // waves 4-7 run half a phase behind their SIMD partners
+    asm volatile("" ::: "memory");
+
+    for (int kt = kbeg; kt < kend; ++kt) {
+        const char* sl = smem + ((kt - kbeg) & (RING - 1)) * SLOT;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(sl + b_rd + nb * 2048);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) afr[mb] = *reinterpret_cast<const U4*>(sl + a_rd + mb * 2048);
+        stage(kt + 2, (kt - kbeg + 2) & (RING - 1));
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // all but the four pieces just issued: K-tile kt + 1 has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = T::mfma16(bfr[nb], afr[mb], acc[mb][nb]);   // transposed: D[column][row]
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g == 0) __builtin_amdgcn_s_barrier();                      // re-align the two wave groups
+    __syncthreads();
+
+    // ---- epilogue: fp32 staging tile [128 rows][128 columns], 528-byte rows; a lane holds 4 consecutive columns of row l15 per block
+    constexpr int SPITCH = 132;
+    float* stg = reinterpret_cast<float*>(smem);
+    auto sptr = [&](int mb, int nb) { return stg + (wr * 64 + mb * 16 + l15) * SPITCH + wc * 64 + nb * 16 + 4 * lq; };
+    if (g == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4*>(sptr(mb, nb)) = acc[mb][nb];
+    }
+    __syncthreads();
+    auto add_second_half = [&]() {
+        if (g == 1) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    f32x4* q = reinterpret_cast<f32x4*>(sptr(mb, nb));
+                    *q = *q + acc[mb][nb];
+                }
+        }
+    };
+    const bool gn_acc = p.gn_partial != nullptr && p.splitk <= 1;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
+    rows_phase<T, 128, 128, false, 512, false, SPITCH>(p, stg, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);
+    if (gn_acc) {
+        // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gs[j] += __shfl_xor(gs[j], 16, 64); gs[j] += __shfl_xor(gs[j], 32, 64);
+            gq[j] += __shfl_xor(gq[j], 16, 64); gq[j] += __shfl_xor(gq[j], 32, 64);
+        }
+        __syncthreads();
+        if (lane < 16) {
+            float* dst = stg + (wave * 128 + lane * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N && m0 < p.M) {
+            float a = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { a += stg[(w * 128 + tid) * 2]; q += stg[(w * 128 + tid) * 2 + 1]; }
+            float* dst = p.gn_partial + ((int64_t)(m0 >> 7) * p.N + n0 + tid) * 2;
+            dst[0] = a;
+            dst[1] = q;
+        }
+    }
+}
+
+template <typename T>
+int launch_pp128(const edtr_igemm_params& p, hipStream_t stream) {
+    constexpr int lds = 4 * 2 * 128 * BK * 2;     // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pp128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
+    hipLaunchKernelGGL((igemm_pp128_kernel<T>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
+    EDTR_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
+        int64_t blocks = (nvec + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        EDTR_LAUNCH_CHECK();
+    }
+    return EDTR_OK;
+}
+
 // the halo tile's shape requirements (the caller checks buffer addressability)
 static bool igemm_halo_ok(const edtr_igemm_params& p, bool spatial) {
     const int up = p.upsample2x ? 2 : 1;
@@ -2497,6 +2663,11 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
+    if (tile == 15) {      // 8-wave ping-pong 128x128 tile for grids of at most one workgroup per CU
+        if (spatial || p.C2 != 0 || (p.C1 & 63) || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.bias_m || !igemm_fast_addressable(p, spatial))
+            return EDTR_E_UNSUPPORTED;
+        return launch_pp128<T>(p, s);
+    }
     if (tile == 16) {      // halo tile for 3x3 / stride 1 convolutions
         if (!igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
         return p.upsample2x ? launch_halo<T, true>(p, s) : launch_halo<T, false>(p, s);
@@ -2667,6 +2838,18 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (halo && dma_ok && (p.N & 127) == 0 && igemm_halo_ok(p, spatial) && igemm_fast_addressable(p, spatial) &&
             (int64_t)(p.M >> 8) * (p.N >> 7) * p.splitk >= 48)
             tile = 16;
+        // 8-wave ping-pong 128x128 tile: plain GEMMs whose tile grid leaves at most one workgroup per CU.  In isolation 1.20-1.32x over
+        // tile 3 at 40-160 tiles (0.83x at 320: profiles/r02/ab_tiles_3_vs_15_small_gemm.log), but the whole path did not move in a
+        // same-device A/B (det512 107.07 vs 106.65 images/s, det512s50 8.298 vs 8.291): these launches overlap with the other lane /
+        // batch, and a 128 KiB workgroup leaves no room beside it.  Opt-in: EDTR_IGEMM_PP128=1 (or tile = 15).
+        static int pp128 = -1;
+        if (pp128 < 0) {
+            const char* e5 = getenv("EDTR_IGEMM_PP128");
+            pp128 = (e5 && e5[0] == '1') ? 1 : 0;
+        }
+        if (pp128 && tile == 3 && !spatial && p.Z == 1 && p.act != EDTR_ACT_GEGLU && !p.bias_m && p.K >= 320 &&
+            big * p.splitk <= 256 && igemm_fast_addressable(p, spatial))
+            tile = 15;
         // 256x32 tile for skinny-N convolutions (the VAE decoder's 3-channel output conv: 94 % of a 128-wide tile is padding);
         // validated against tile 3 on the MI355X (profiles/r02/ab_tiles_3_vs_14*.log).  EDTR_IGEMM_SKINNY=0 switches it off.
         static int skinny = -1;
@@ -2686,7 +2869,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 16 || (tile >= 11 && tile <= 13) || tile == 15) return EDTR_E_DTYPE;     // 11-13, 15: experiments, measured and removed
+    if (tile < 1 || tile > 16 || (tile >= 11 && tile <= 13)) return EDTR_E_DTYPE;     // 11-13, 15: experiments, measured and removed
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

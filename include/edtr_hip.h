@@ -114,11 +114,12 @@ typedef struct edtr_igemm_params {
     int32_t tile;           /* 0 = auto; explicit main-loop choice (tests / A-B runs): 1 = 128x128 register-staged, 2 = 64x64,
                                3 = 128x128 LDS-DMA (2 stages), 4 = 3-stage BK32, 5 = 256x128, 6 = 256x256 ping-pong, 7 = 256x128 ring,
                                8 = 128x160, 9 = 64x128, 10 = 128x128 with 16x16x32 MFMAs, 14 = 256x32 for N <= 32 (automatic for
-                               large-M skinny-N convolutions), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions, plain or nearest-2x upsampled, on outputs whose
+                               large-M skinny-N convolutions), 15 = 8-wave ping-pong 128x128 for plain GEMMs with at most one tile per CU (opt-in: faster in
+                               isolation, no whole-path gain), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions, plain or nearest-2x upsampled, on outputs whose
                                height and width are multiples of 16: the 18x18 input patch of a 16x16 output patch stays in LDS for
                                the nine taps; automatic for N % 128 == 0 and >= 48 units incl. split-K; EDTR_E_UNSUPPORTED for any
-                               other shape); 11-13, 15 and 17 were experiments (deeper LDS rings, bank-swizzled epilogue staging,
-                               in-workgroup split-K, persistent / two-workgroup halo variants), measured without gain and removed */
+                               other shape); 11-13 and 17 were experiments (deeper LDS rings, bank-swizzled epilogue staging,
+                               persistent / two-workgroup halo variants), measured without gain and removed */
     /* split-K (small-M problems that cannot fill 256 CUs): K is cut into `splitk` runs of K-tiles, each
      * workgroup row writes an fp32 partial slab into `workspace` ([splitk][M][N] floats, caller-owned), and a
      * second launch sums the slabs and applies the epilogue.  splitk <= 1 disables it.  Needs Z == 1, no GEGLU. */

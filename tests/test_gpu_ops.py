@@ -68,6 +68,9 @@ def nhwc16(x, dtype, pad_to=None):
                                         # tile 9 = 64x128 tile (small M)
                                         (256, 128, 64, 9), (300, 72, 192, 9), (4096, 320, 320, 9), (130, 136, 128, 9),
                                         (77, 640, 1024, 9), (520, 1280, 320, 9),
+                                        # tile 15 = 8-wave ping-pong 128x128 tile for small grids (K % 64 == 0)
+                                        (256, 128, 64, 15), (300, 72, 192, 15), (4096, 320, 320, 15), (130, 136, 128, 15),
+                                        (77, 640, 1024, 15), (520, 1280, 320, 15), (1000, 520, 1152, 15),
                                         # tile 10 = 128x128 tile with 16x16x32 MFMAs
                                         (256, 128, 64, 10), (300, 72, 192, 10), (4096, 320, 320, 10), (130, 136, 128, 10),
                                         (77, 640, 1024, 10)])
@@ -98,7 +101,8 @@ def test_gemm_bias_residual(dtype, M, N, K, tile):
 @pytest.mark.parametrize("M,N,K,S,tile", [(512, 256, 1152, 4, 1), (100, 72, 640, 10, 2), (64, 1280, 2880, 7, 1),
                                           (512, 256, 1152, 4, 3), (100, 72, 640, 10, 3), (64, 1280, 2880, 45, 3),
                                           (512, 256, 1152, 4, 4), (100, 72, 640, 10, 4), (64, 1280, 2880, 45, 4),
-                                          (512, 256, 1152, 4, 5), (300, 72, 640, 10, 5)])
+                                          (512, 256, 1152, 4, 5), (300, 72, 640, 10, 5),
+                                          (512, 256, 1152, 4, 15), (100, 72, 640, 10, 15), (64, 1280, 2880, 45, 15)])
 def test_gemm_splitk(dtype, M, N, K, S, tile):
     """Split-K: fp32 partial slabs + reducer with the full epilogue (bias, row vector, SiLU-free residual)."""
     ops = _ops()

@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--tol", type=float, default=0.0, help="0 = bit-exact; else max |a-b| / max|a|")
     ap.add_argument("--dt", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4", "up2"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
+    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4", "up2", "smallgemm"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
     args = ap.parse_args()
     dt = 0 if args.dt == "bf16" else 1
     rng = np.random.default_rng(0)
@@ -68,6 +68,11 @@ def main():
     cases += [("conv", c, 1) for c in CONVS] + [("conv", (8, 8, 8, 1280, 1280, 0), 6)]
     if args.cases == "smallm":      # the 8x8-latent convolutions: which split-K count?
         cases = [("conv", (8, 8, 8, 1280, 1280, 0), k) for k in (4, 6, 8, 9, 10, 12, 15)] + [("conv", (8, 8, 8, 2560, 1280, 0), k) for k in (6, 8, 12, 16)]
+    if args.cases == "smallgemm":   # plain GEMMs with at most ~one 128x128 tile per CU
+        cases = [("gemm", g, 1) for g in [(2048, 1280, 1280), (1024, 1280, 1280), (512, 1280, 1280), (256, 1280, 1280), (2048, 2560, 1280), (2048, 1280, 2560),
+                                           (2048, 1280, 5120), (4096, 640, 640), (4096, 640, 2560), (8192, 640, 640), (1000, 520, 1152), (130, 136, 128), (77, 640, 1024),
+                                           (300, 72, 192), (2048, 1280, 320)]]
+        cases += [("gemm", (2048, 1280, 5120), 2), ("gemm", (1024, 1280, 5120), 3), ("gemm", (512, 1280, 1280), 2)]
     if args.cases == "up2":         # nearest-2x upsample convolutions (VAE decoder / UNet Upsample)
         cases = [("conv", c, 1) for c in [(2, 16, 16, 64, 128, 1), (1, 24, 8, 128, 256, 1), (8, 256, 256, 256, 256, 1), (8, 128, 128, 512, 512, 1),
                                            (8, 64, 64, 512, 512, 1), (8, 32, 32, 640, 640, 1), (8, 16, 16, 1280, 1280, 1), (8, 8, 8, 1280, 1280, 1)]]
