@@ -48,9 +48,17 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
-    ap.add_argument("--precision", default="fast", choices=["fast", "high"],
-                    help="fast = 16-bit activation storage in --dtype (headline); high = the parity mode (fp32 stream, bf16 split-3 "
-                         "products, fp16 attention) that meets the 1e-3 north-star tolerance")
+    ap.add_argument("--precision", default="fast", choices=["fast", "mixed", "high"],
+                    help="fast = 16-bit activation storage in --dtype (headline); mixed = the fast parity mode (fp32 stream, fp16 "
+                         "operands, 1-3 products per layer class: edtr_amd/precision.py); high = the robust parity mode (fp32 stream, "
+                         "bf16 split-3 products everywhere).  Both parity modes meet the 1e-3 north-star tolerance")
+    ap.add_argument("--parity-steps", type=int, default=3,
+                    help="after the headline (fast) measurement, time this many passes of the parity mode (mixed) in the same run and "
+                         "report them as \"parity_mode\" (0 = skip; skipped for N > 1 and for the non-default workloads)")
+    ap.add_argument("--breakdown-json", default=None, help="write the per-launch-name time table of the roofline pass to this file")
+    ap.add_argument("--dup", default=None, help="measurement aid: issue every idempotent launch whose name contains this string twice "
+                                                "(marginal wall-clock cost of a kernel class inside the overlapped graphs)")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # launcher self-test: rendezvous only, no model
     ap.add_argument("--workload", default="det512", choices=["det512", "seg1024tiled", "det512s50"],
                     help="det512 = BASELINE configs[1] (default); seg1024tiled = configs[3]: one 1024x1024 image, tiled VAE encoder "
                          "(256-px tiles), latent-tiled denoiser (64/32 latent tiles), untiled decoder (demo.py:99-124); det512s50 = configs[4] per GPU: batch 4 of 512x512, 50-step sampler from pure noise")
@@ -66,6 +74,11 @@ def main() -> None:
                     help="also time the SwinIR pre-restoration in front of the path (excluded from the metric, SURVEY.md §8d) and "
                          "report it separately as \"pre_restoration\"")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without torch.distributed.run: start the N ranks ourselves.  This process has made no GPU
+        # call (importing torch does not initialise HIP) and makes none: it only waits and forwards rank 0's JSON line.
+        raise SystemExit(launch_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,6 +98,8 @@ def main() -> None:
         cpu_handle = start_cpu_baseline(args.config, args.size)
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if args.dry_run:
+        raise SystemExit(dry_run_rank(rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the EDTR MI355X path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -95,13 +110,15 @@ def main() -> None:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
-
+    rccl_ranks = count_ranks(dist, dev) if dist is not None else 1
+    if rccl_ranks != world:
+        raise SystemExit(f"bench.py: RCCL sees {rccl_ranks} ranks, expected {world}")
 
     from edtr_amd import synth, workloads
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.model import ControlLDM
     from edtr_amd.model.params import skip_init
-    from edtr_amd.parallel import broadcast_packed
+    from edtr_amd.parallel import broadcast_packed, verify_packed_store
     from edtr_amd.sampler import SpacedSampler
     from edtr_amd.testing import rel_err, synthetic_state_dicts
 
@@ -168,24 +185,45 @@ def main() -> None:
         calls, nbytes = broadcast_packed(cldm, src=0)
         torch.cuda.synchronize()
         bcast = {"collectives": calls, "GiB": round(nbytes / 2**30, 3), "seconds": round(time.time() - t0, 2)}
+        # every rank must now hold rank 0's packed store bit for bit: a receiver that re-packed from its placeholder parameters
+        # would still "restore" images at full speed, so the throughput is refused unless the checksums agree on all ranks
+        bcast["verified_on_all_ranks"] = verify_packed_store(cldm, src=0)
         log(f"[rank {rank}] packed weights broadcast over RCCL: {bcast}")
+        if not bcast["verified_on_all_ranks"]:
+            raise SystemExit("bench.py: a rank's packed weight store differs from rank 0's after the broadcast")
         for sl_ in slots:                          # results of the warm-up pass on the receiving ranks were computed from zeros
             cldm.engine_slot = sl_
             img, z = one_pass()
         torch.cuda.synchronize()
-    if not args.no_graph:
+    if args.dup:
+        n_dup = sum(e.step_prog.duplicate_launches(args.dup) for e in cldm._cldm_engines.values())
+        n_dup += sum(e.prog.duplicate_launches(args.dup) for e in cldm._vae_engines.values())
+        log(f"[rank {rank}] --dup {args.dup}: {n_dup} launches doubled (measurement aid: the throughput below is NOT a result)")
+
+    def capture_all():
+        if args.no_graph:
+            return
         for e in cldm._cldm_engines.values():
             e.step_prog.capture(parallel_lanes=not args.serial_lanes)
         for e in cldm._vae_engines.values():
             e.prog.capture()
 
-    def run_steps(n):
+    capture_all()
+    step_events = []
+
+    def run_steps(n, record=False):
         out = None
         for i in range(n):
             k = i % args.inflight
             cldm.engine_slot = k
             with torch.cuda.stream(streams[k]):
+                if record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 out = one_pass()
+                if record:
+                    e1.record()
+                    step_events.append((e0, e1))
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
         return out
@@ -195,9 +233,12 @@ def main() -> None:
     img, z = run_steps(max(1, args.warmup) * args.inflight)
     barrier()
     t0 = time.perf_counter()
-    img, z = run_steps(args.steps)
+    img, z = run_steps(args.steps, record=True)
     barrier()
     elapsed = time.perf_counter() - t0
+    # HIP events around every pass on its own stream: the latency of ONE pass while `inflight` passes overlap (not a throughput)
+    lat = sorted(a.elapsed_time(b) for a, b in step_events)
+    pass_latency_ms = lat[len(lat) // 2] if lat else None
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -205,12 +246,14 @@ def main() -> None:
     ms_per_step = elapsed / args.steps * 1e3
     value = GB * args.steps / elapsed
 
-    tol_key = "high" if args.precision == "high" else args.dtype
+    tol_key = args.precision if args.precision != "fast" else args.dtype
+    std_shape = (B, S) == workloads.WORKLOADS[args.workload][:2]        # the FLOP count per image below is for this shape only
     result = {
         "metric": f"restored {S}x{S} images/sec @ {50 if s50 else 4} denoise steps",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 split-3 products over an fp32 stream (precision=high)" if args.precision == "high" else args.dtype,
+        "dtype": {"high": "bf16 split-3 products over an fp32 stream (precision=high)",
+                  "mixed": "fp16 1-3-part products over an fp32 stream (precision=mixed)"}.get(args.precision, args.dtype),
         "data": "synthetic",
         "config": {"workload": (f"EDTR-seg s4 ({args.config}), configs[3]: tiled vae_encode (256-px tiles) + q_sample(t=200) + 4 x latent-tiled "
                                 f"(64/32) ControlNet+UNet + untiled vae_decode, batch {B}/GPU of {S}x{S}") if tiled else
@@ -219,10 +262,16 @@ def main() -> None:
                                f"EDTR-det s4 ({args.config}): vae_encode + q_sample(t=200) + 4 x (ControlNet+UNet) + "
                                f"vae_decode, batch {B}/GPU of {S}x{S}", "global_batch": GB, "image_size": S,
                    "denoise_steps": 50 if s50 else 4, "parallelism": f"batch-sharded x{world}", "graphs": not args.no_graph,
-                   "batches_in_flight": args.inflight},
-        "weight_broadcast": bcast,
-        "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE_BY_WORKLOAD[args.workload] / (world * PEAK_TFLOPS * 1e12), 4) if args.config == "sd21" else None,
+                   "batches_in_flight": args.inflight, "precision": args.precision},
+        "weight_broadcast": bcast, "rccl_ranks": rccl_ranks,
+        "pass_latency_ms_median_hip_events": round(pass_latency_ms, 3) if pass_latency_ms is not None else None,
+        "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE_BY_WORKLOAD[args.workload] / (world * PEAK_TFLOPS * 1e12), 4)
+        if (args.config == "sd21" and std_shape) else None,
     }
+    if args.precision == "mixed":
+        result["config"]["precision_policy"] = cldm._policy().describe()
+    if args.dup:
+        result["INVALID_measurement_aid"] = f"--dup {args.dup}"
 
     if rank == 0 and args.swinir:
         try:
@@ -230,11 +279,18 @@ def main() -> None:
         except Exception as e:       # reported separately: must never take the headline line down with it
             result["pre_restoration"] = {"error": repr(e)}
     if rank == 0 and not args.no_roofline:
-        result.update(roofline_pass(cldm, args))
+        result.update(roofline_pass(cldm, args, ms_per_step))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(finish_cpu_baseline(cpu_handle, inp, img.cpu(), z.cpu(), S, rel_err, tol_key))
     if rank == 0 and args.config == "sd21":     # rank 0's shard starts at image 0 of the global batch: same images as the golden's
         result.update(golden_parity(args.workload, img, z, rel_err, tol_key))
+    if (rank == 0 and world == 1 and args.parity_steps > 0 and args.precision == "fast" and args.workload == "det512"
+            and args.config == "sd21" and std_shape and not args.dup):
+        # ---- the mode that meets the north-star tolerance, timed in the SAME run (the headline above is the fast bf16 mode)
+        try:
+            result["parity_mode"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err)
+        except Exception as e:       # never take the headline down
+            result["parity_mode"] = {"error": repr(e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -246,6 +302,104 @@ def main() -> None:
         except Exception:
             pass
         print(json.dumps(result), flush=True)
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """Start `n` fresh child processes of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+    127.0.0.1), wait for all of them and forward rank 0's JSON line.  The parent never touches the GPU (a process that has
+    initialised HIP must not be replaced or forked on this pool), never re-execs, and exits non-zero if any rank failed or if
+    the line does not report `n` ranks."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        log(f"bench.py launcher: rank exit codes {codes}; rank 0 printed (NOT forwarded as a result):\n{out0 or ''}")
+        return next(c for c in codes if c) or 1
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    try:
+        line = json.loads(lines[-1])
+    except (IndexError, ValueError):
+        log("bench.py launcher: rank 0 printed no JSON line")
+        return 1
+    if line.get("rccl_ranks") != n or line.get("n_gpus") != n:
+        log(f"bench.py launcher: asked for {n} ranks, the result line reports rccl_ranks={line.get('rccl_ranks')} n_gpus={line.get('n_gpus')}")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def count_ranks(dist, dev) -> int:
+    """Ranks that actually take part in a collective (all-reduce of ones over the process group)."""
+    one = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(one)
+    return int(one.item())
+
+
+def dry_run_rank(rank: int, world: int) -> int:
+    """Launcher self-test (tests/test_dist_cpu.py): rendezvous + one all-reduce, no model, no GPU needed with
+    EDTR_BENCH_BACKEND=gloo.  Rank 0 prints a JSON line shaped like the real one."""
+    import torch.distributed as dist
+    backend = os.environ.get("EDTR_BENCH_BACKEND", "nccl")
+    if world > 1 or os.environ.get("EDTR_BENCH_DIST"):
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if backend == "nccl" else torch.device("cpu")
+        ranks = count_ranks(dist, dev)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if os.environ.get("EDTR_BENCH_DRY_FAIL_RANK") == str(rank):      # the self-test's failure injection
+        return 3
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "backend": backend}), flush=True)
+    return 0
+
+
+def parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err) -> dict:
+    """Switch the SAME model to the mixed-precision parity mode (fp32 stream, fp16 operands, 1-3 products per layer class),
+    rebuild its programs, time `--parity-steps` passes the way the headline was timed, and check the result against the
+    reference golden.  The fast-mode engines are dropped (the roofline pass over them has already run)."""
+    t0 = time.time()
+    cldm.precision = cldm.unet.precision = cldm.controlnet.precision = "mixed"
+    for sl_ in range(args.inflight):
+        cldm.engine_slot = sl_
+        one_pass()
+    torch.cuda.synchronize()
+    capture_all()
+    run_steps(args.inflight)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    t0 = time.perf_counter()
+    img, z = run_steps(args.parity_steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.parity_steps * 1e3
+    out = {"precision": "mixed", "policy": cldm._policy().describe(), "images_per_s": round(B / ms * 1e3, 3), "ms_per_step": round(ms, 3),
+           "steps": args.parity_steps, "build_seconds": round(build_s, 1),
+           "mfma_frac_whole_path": round(B / ms * 1e3 * FLOP_PER_IMAGE / (PEAK_TFLOPS * 1e12), 4),
+           "note": "same model, same inputs, same run as the headline; fp32 activation stream + multi-part fp16 products "
+                   "(algorithmic FLOP unchanged: the extra products are precision overhead, not counted)"}
+    gp = golden_parity(args.workload, img, z, rel_err, "mixed").get("parity_vs_reference_golden")
+    if gp:
+        out.update(rel_err_latent=gp["rel_err_latent"], rel_err_image=gp["rel_err_image_samples"], fixture=gp["fixture"],
+                   images=gp["images"], meets_north_star=bool(gp["rel_err_latent"] < NORTH_STAR and gp["rel_err_image_samples"] < NORTH_STAR), north_star=NORTH_STAR)
+    return out
 
 
 def swinir_leg(dev, dtype, B, S, steps) -> dict:
@@ -272,7 +426,7 @@ def swinir_leg(dev, dtype, B, S, steps) -> dict:
             "images_per_s": round(B / ms * 1e3, 2), "tflops": round(eng.prog.total_flops() / ms / 1e9, 1), "launches": len(eng.prog.recs)}
 
 
-def roofline_pass(cldm, args) -> dict:
+def roofline_pass(cldm, args, ms_per_step=None) -> dict:
     """Per-launch HIP-event timing of every program once (eager replay on the launch stream), aggregated by kernel."""
     agg = {}
     shapes = {}
@@ -328,35 +482,62 @@ def roofline_pass(cldm, args) -> dict:
         # entry is used only if it was measured on a launch list of the same length as the one just timed
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")) as f:
+            from edtr_amd.build import source_hash
+            with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
                 pm = json.load(f)
+            if pm.get("kernel_source_hash") != source_hash():
+                raise ValueError(f"{PMC_TRAFFIC_FILE} was measured on kernel sources {pm.get('kernel_source_hash')}, this build is "
+                                 f"{source_hash()}: stale, not reported")
             fam = pm["families"]["igemm"]
             # the profiler counts kernels (main loops + split-K reducers), the timing above counts edtr_igemm calls: compare like
             # with like, then quote the bytes per edtr_igemm CALL, the unit of algorithmic_bytes_per_launch
             kernels = ig["n"] + ig.get("n_splitk", 0)
             if abs(fam["launches_per_pass"] - kernels) <= 0.02 * kernels:
                 traffic = round(fam["hbm_side_bytes_per_pass"] / ig["n"])
-                traffic_src = (f"profiles/r02/pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, fetch x2 gfx950 "
-                               f"correction; measured at commit {pm.get('commit', '?')}: {fam['launches_per_pass']:.0f} kernels per pass = "
+                traffic_src = (f"{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, fetch x2 gfx950 "
+                               f"correction; kernel sources {pm.get('kernel_source_hash')}: {fam['launches_per_pass']:.0f} kernels per pass = "
                                f"{ig['n']} edtr_igemm calls + {ig.get('n_splitk', 0)} split-K reducers; bytes per call)")
             else:
-                traffic_src = (f"profiles/r02/pmc_hbm_traffic.json was measured on {fam['launches_per_pass']:.0f} kernels per pass, this run "
+                traffic_src = (f"{PMC_TRAFFIC_FILE} was measured on {fam['launches_per_pass']:.0f} kernels per pass, this run "
                                f"has {kernels}: stale, not reported")
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError) :
             pass
+        except ValueError as e:
+            traffic_src = str(e)
         out["roofline"] = {"kernel": "edtr_igemm family (implicit-GEMM conv / linear, MFMA 32x32x16 and 16x16x32 tiles)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["n"]),
                            "traffic_source": traffic_src,
                            "launches_per_pass": ig["n"], "avg_launch_ms": round(ig["ms"] / ig["n"], 4),
-                           "share_of_pass": round(ig["ms"] / total_ms, 3)}
+                           "share_of_pass": round(ig["ms"] / total_ms, 3),
+                           "how": "achieved = sum of algorithmic FLOP / sum of per-launch durations, every launch alone on the launch "
+                                  "stream between two HIP events in an eager replay AFTER the timed region (isolated-launch figure); "
+                                  "inside the timed region two lanes and two batches overlap, so the family's share of the wall is "
+                                  "smaller than ms_per_pass_isolated",
+                           "ms_per_pass_isolated": round(ig["ms"], 3)}
+        if ms_per_step:
+            # self-consistent in-situ bound: the family's FLOP of one pass over the WALL time of one pass of the timed region
+            # (as if nothing else ran): what the timed region certainly sustained, <= the isolated figure by construction
+            lo = ig["flops"] / (ms_per_step * 1e-3) / 1e12
+            out["roofline"]["in_timed_region"] = {"achieved_lower_bound": round(lo, 2), "frac_lower_bound": round(lo / PEAK_TFLOPS, 4),
+                                                  "wall_ms_per_pass": round(ms_per_step, 3)}
     if at:
         ach = at["flops"] / (at["ms"] * 1e-3) / 1e12
         out["roofline_attention"] = {"kernel": "flash_attn64_kernel", "bound": "mfma", "achieved": round(ach, 2),
                                      "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
                                      "launches_per_pass": at["n"], "share_of_pass": round(at["ms"] / total_ms, 3)}
     out["kernel_time_ms_per_pass"] = {k: round(a["ms"], 3) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    out["launches_per_pass"] = int(sum(a["n"] for a in agg.values()))
+    if args.breakdown_json:
+        table = {}
+        for kind, a in agg.items():
+            for name, (ms, fl, n) in a["by_name"].items():
+                table[name] = {"kernel": kind, "ms": round(ms, 4), "flops": fl, "n": n}
+        os.makedirs(os.path.dirname(os.path.abspath(args.breakdown_json)), exist_ok=True)
+        with open(args.breakdown_json, "w") as f:
+            json.dump({"by_name": table, "by_shape": {t: {"ms": round(v[0], 4), "flops": v[1], "n": v[2]} for t, v in shapes.items()},
+                       "total_ms": total_ms, "precision": args.precision, "workload": args.workload}, f, indent=1)
     return out
 
 
@@ -378,10 +559,13 @@ def kernel_of(name: str) -> str:
     return "igemm_kernel"
 
 
-# relative-L2 tolerances of the 16-bit storage modes against the fp32 reference at full size (measured values and the error
-# budget are in DESIGN.md §5; the north-star 1e-3 is asserted for the parity mode, EDTR_AMD_PRECISION=high)
-TOLERANCE = {"bf16": {"latent": 2e-2, "image": 3e-2}, "fp16": {"latent": 3e-3, "image": 5e-3},
-             "high": {"latent": 1e-3, "image": 1e-3}}
+# relative-L2 tolerances against the fp32 reference at full size, each <= 1.5 x its measured value (bf16 6.2e-3 /
+# 1.2e-2, fp16 8.6e-4 / 1.5e-3, high 7.2e-5 / 7.4e-5) so that a 2x regression of a mode's numerics fails the run; the north-star
+# 1e-3 is what the parity modes (mixed, high) must additionally meet
+TOLERANCE = {"bf16": {"latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"latent": 1.3e-3, "image": 2.3e-3},
+             "mixed": {"latent": 1e-3, "image": 1e-3}, "high": {"latent": 1.2e-4, "image": 1.5e-4}}
+NORTH_STAR = 1e-3
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r03", "pmc_hbm_traffic.json")
 
 
 def _cpu_worker(q_in, q_out, cfg_name, S, threads):
@@ -502,7 +686,7 @@ def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=42
         log(f"!!! PARITY FAILURE: GPU vs CPU oracle {parity} (tolerance {tol}) — the throughput above is NOT a valid result")
     dt1 = runs["first"][1][0]
     b1 = 1.0 / dt1
-    out = {"value": round(b1, 5), "unit": "images/s", "cores": threads, "kind": "port", "cpu_model": cpu,
+    out = {"value": round(b1, 5), "unit": "images/s", "cores": threads, "threads_all": cores, "kind": "port", "cpu_model": cpu,
            "sample": f"B=1: image 0 of the batch, {S}x{S}, 4 steps, fp32 oracle on torch CPU kernels, {threads} threads of "
                      f"{cores} host cores ({dt1:.1f} s)", "b1_images_per_s": round(b1, 5)}
     if "batch" in runs:
@@ -510,6 +694,11 @@ def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=42
         out["b8_images_per_s"] = round(B / dt8, 5)
         out["value"] = round(max(b1, B / dt8), 5)
         out["sample"] += f"; B={B}: the whole batch in one oracle call ({dt8:.1f} s); value = the faster of the two"
+    else:
+        out["b8_images_per_s"] = None
+        out["b8_note"] = (f"BASELINE.md §3's B={B} point is opt-in (EDTR_CPU_B8=1): one oracle call on the whole batch did not finish in "
+                          f"the {budget_s:.0f} s budget on this host class (profiles/r02/cpu_oracle_threads.log), the default run "
+                          "stays within ~40 s of CPU work; threads: the oracle is fastest at min(cores, 32) on 256 hardware threads")
     return {"cpu_baseline": out, "parity": dict(parity, ok=ok, tolerance=tol, against="CPU oracle (fp32, pinned to the reference)")}
 
 

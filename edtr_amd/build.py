@@ -11,6 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
 SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "swin.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "edtr_hip.h")]
+# files #include'd by one source only (generated code): a regenerated .inc must rebuild its object
+EXTRA_DEPS = {"attention.hip": [os.path.join(CSRC, "attn_v3_loop.inc")]}
 ARCH = "gfx950"
 
 
@@ -28,6 +30,18 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash() -> str:
+    """sha1 over the kernel sources (csrc/*.hip, *.inc, *.h and the ABI header): stamps measurements that are read back later
+    (bench.py refuses a committed PMC traffic figure measured on different kernel code; .git does not travel to the GPU box)."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".inc", ".h")))
+    for path in [os.path.join(CSRC, f) for f in files] + [HEADERS[1]]:
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
@@ -36,7 +50,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, [s] + HEADERS + EXTRA_DEPS.get(src, [])):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
@@ -51,4 +65,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--hash" in sys.argv:
+        print(source_hash())
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True))

@@ -112,8 +112,39 @@ __global__ void __launch_bounds__(256) split3_kernel(const void* src, int64_t ro
         const U4 lov = pack8<BF16>(lo);
         uint16_t* dp = dst + r * ld_dst + cv * 8;
         stg16(dp, hi);
-        stg16(dp + C, pattern ? hi : lov);
-        stg16(dp + 2 * C, pattern ? lov : hi);
+        if (pattern) { stg16(dp + C, hi); stg16(dp + 2 * C, lov); }      // (a select between two structs goes through scratch)
+        else { stg16(dp + C, lov); stg16(dp + 2 * C, hi); }
+    }
+}
+
+// [rows][C] (fp32 or 16-bit) -> PARTS-part operand of 16-bit type OT: [hi] / [hi | lo] / [hi | lo | hi]
+template <typename SRC, typename OT, int PARTS>
+__global__ void __launch_bounds__(256) split_operand_kernel(const void* src, int64_t rows, int CV, int C, int64_t ld_src,
+                                                           uint16_t* dst, int64_t ld_dst) {
+    const int64_t total = rows * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / CV;
+        const int cv = (int)(i - r * CV);
+        float f[8];
+        if constexpr (sizeof(typename SRC::elem) == 4) {
+            const float* sp = static_cast<const float*>(src) + r * ld_src + cv * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[j + 4] = b[j]; }
+        } else {
+            unpack8<SRC>(ldg16(static_cast<const uint16_t*>(src) + r * ld_src + cv * 8), f);
+        }
+        const U4 hi = pack8<OT>(f);
+        uint16_t* dp = dst + r * ld_dst + cv * 8;
+        stg16(dp, hi);
+        if constexpr (PARTS >= 2) {
+            float back[8], lo[8];
+            unpack8<OT>(hi, back);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = f[j] - back[j];
+            stg16(dp + C, pack8<OT>(lo));
+        }
+        if constexpr (PARTS == 3) stg16(dp + 2 * C, hi);
     }
 }
 
@@ -147,15 +178,23 @@ __global__ void temb_kernel(const int64_t* t, int dim, typename T::elem* out, in
     }
 }
 
+// one element of the spaced-sampler update, with the rounding points fixed (explicit fma) so that the scalar-coefficient and
+// the device-indexed kernels agree bit for bit
+__device__ __forceinline__ void sampler_update_elem(float xv, float e, float nz, float c_recip, float c_recipm1, float coef1,
+                                                    float coef2, float sigma, float& p0, float& xp) {
+    p0 = __builtin_fmaf(c_recip, xv, -(c_recipm1 * e));
+    const float mean = __builtin_fmaf(coef1, p0, coef2 * xv);
+    xp = __builtin_fmaf(sigma, nz, mean);
+}
+
 __global__ void __launch_bounds__(256) sampler_update_kernel(const float* x, const float* eps, const float* noise,
                                                             float c_recip, float c_recipm1, float coef1, float coef2,
                                                             float sigma, float* x_prev, float* pred_x0, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float xv = x[i];
-        const float p0 = c_recip * xv - c_recipm1 * eps[i];
-        const float mean = coef1 * p0 + coef2 * xv;
+        float p0, xp;
+        sampler_update_elem(x[i], eps[i], noise[i], c_recip, c_recipm1, coef1, coef2, sigma, p0, xp);
         if (pred_x0) pred_x0[i] = p0;
-        x_prev[i] = mean + sigma * noise[i];
+        x_prev[i] = xp;
     }
 }
 
@@ -172,6 +211,38 @@ __global__ void __launch_bounds__(256) q_sample_kernel(const float* x, const flo
         int64_t ti = t[i / per_image];
         ti = ti < 0 ? 0 : (ti >= n_tab ? n_tab - 1 : ti);
         out[i] = tab_a[ti] * x[i] + tab_b[ti] * noise[i];
+    }
+}
+
+// sampler update with the step index read on the device: coefs[n_steps][5] = (c_recip, c_recipm1, coef1, coef2, sigma)
+__global__ void __launch_bounds__(256) sampler_update_indexed_kernel(const float* x, const float* eps, const float* noise,
+                                                                    const int64_t* index, const float* coefs, int n_steps,
+                                                                    float* x_prev, float* pred_x0, int64_t per_image, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int64_t k = index[i / per_image];
+        k = k < 0 ? 0 : (k >= n_steps ? n_steps - 1 : k);
+        const float* c = coefs + k * 5;
+        float p0, xp;
+        sampler_update_elem(x[i], eps[i], noise[i], c[0], c[1], c[2], c[3], c[4], p0, xp);
+        if (pred_x0) pred_x0[i] = p0;
+        x_prev[i] = xp;
+    }
+}
+
+// VAE posterior: out (NCHW) = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale from NHWC fp32 moments rows
+__global__ void __launch_bounds__(256) gaussian_sample_kernel(const float* moments, int ld, const float* noise, float* out, int C,
+                                                             int64_t HW, float scale, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t px = i % HW, bc = i / HW;
+        const int c = (int)(bc % C);
+        const int64_t b = bc / C;
+        const float* row = moments + (b * HW + px) * ld;
+        float v = row[c];
+        if (noise) {
+            const float lv = fminf(fmaxf(row[C + c], -30.0f), 20.0f);
+            v += expf(0.5f * lv) * noise[i];
+        }
+        out[i] = v * scale;
     }
 }
 
@@ -252,13 +323,13 @@ extern "C" int edtr_device_info(int* compute_units, int64_t* hbm_bytes, char* ar
 extern "C" int edtr_nchw_to_nhwc(int dtype, const float* src, int B, int C, int64_t HW, void* dst, int ld, int coff,
                                  int zero_pad_to, float scale, float shift, edtr_stream_t stream) {
     if (!src || !dst) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
+    if (dtype < EDTR_BF16 || dtype > EDTR_F32_H3) return EDTR_E_DTYPE;
     if (B <= 0 || C <= 0 || HW <= 0 || ld <= 0 || coff < 0) return EDTR_E_SHAPE;
     const int cpad = zero_pad_to > C ? zero_pad_to : C;
     if (coff + cpad > ld) return EDTR_E_SHAPE;
     dim3 grid((unsigned)((HW + 63) / 64), B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == EDTR_F32_SPLIT)       // high-precision mode: the NHWC activation stays fp32
+    if (dtype >= EDTR_F32_SPLIT)       // high / mixed precision modes: the NHWC activation stays fp32
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32E>, grid, dim3(256), 0, s, src, C, HW, static_cast<float*>(dst), ld, coff,
                            cpad, scale, shift);
     else if (dtype == EDTR_BF16)
@@ -289,9 +360,9 @@ extern "C" int edtr_nhwc_to_nchw(int dtype, const void* src, int src_f32, int B,
 extern "C" int edtr_add(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,
                         int C, edtr_stream_t stream) {
     if (!a || !out) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
+    if (dtype < EDTR_BF16 || dtype > EDTR_F32_H3) return EDTR_E_DTYPE;
     if (rows <= 0 || C <= 0) return EDTR_E_SHAPE;
-    if (dtype == EDTR_F32_SPLIT) {     // fp32 in / out
+    if (dtype >= EDTR_F32_SPLIT) {     // fp32 in / out (every fp32-stream code)
         if ((C & 3) || (lda & 3) || (ldo & 3) || (b && (ldb & 3)) || !aligned16(a) || (b && !aligned16(b)) || !aligned16(out))
             return EDTR_E_ALIGN;
         hipLaunchKernelGGL(add_f32_kernel, dim3(blocks_for(rows * (C >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -356,10 +427,10 @@ extern "C" int edtr_embed_tokens(int dtype, const int64_t* tokens, const float* 
 extern "C" int edtr_timestep_embedding(int dtype, const int64_t* t, int B, int dim, void* out, int ld,
                                        edtr_stream_t stream) {
     if (!t || !out) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
+    if (dtype < EDTR_BF16 || dtype > EDTR_F32_H3) return EDTR_E_DTYPE;
     if (B <= 0 || dim <= 0 || (dim & 1) || ld < dim) return EDTR_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == EDTR_F32_SPLIT)
+    if (dtype >= EDTR_F32_SPLIT)
         hipLaunchKernelGGL(temb_kernel<F32E>, dim3(B), dim3(256), 0, s, t, dim, static_cast<float*>(out), ld);
     else if (dtype == EDTR_BF16)
         hipLaunchKernelGGL(temb_kernel<BF16>, dim3(B), dim3(256), 0, s, t, dim, static_cast<uint16_t*>(out), ld);
@@ -392,16 +463,68 @@ extern "C" int edtr_axpby(const float* x, const float* y, float a, float b, floa
 extern "C" int edtr_split3(int src_dtype, const void* src, int64_t rows, int C, int64_t ld_src, int pattern, void* dst,
                            int64_t ld_dst, edtr_stream_t stream) {
     if (!src || !dst) return EDTR_E_NULL;
-    if (src_dtype != EDTR_BF16 && src_dtype != EDTR_F16 && src_dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
+    if (src_dtype < EDTR_BF16 || src_dtype > EDTR_F32_H3) return EDTR_E_DTYPE;
     if (rows <= 0 || C <= 0 || ld_dst < 3 * (int64_t)C || ld_src < C || (pattern != 0 && pattern != 1)) return EDTR_E_SHAPE;
     if ((C & 7) || (ld_src & 7) || (ld_dst & 7) || !aligned16(src) || !aligned16(dst)) return EDTR_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int CV = C >> 3;
     const unsigned blocks = blocks_for(rows * CV);
     uint16_t* d = static_cast<uint16_t*>(dst);
-    if (src_dtype == EDTR_F32_SPLIT) hipLaunchKernelGGL(split3_kernel<F32E>, dim3(blocks), dim3(256), 0, s, src, rows, CV, C, ld_src, pattern, d, ld_dst);
+    if (src_dtype >= EDTR_F32_SPLIT) hipLaunchKernelGGL(split3_kernel<F32E>, dim3(blocks), dim3(256), 0, s, src, rows, CV, C, ld_src, pattern, d, ld_dst);
     else if (src_dtype == EDTR_BF16) hipLaunchKernelGGL(split3_kernel<BF16>, dim3(blocks), dim3(256), 0, s, src, rows, CV, C, ld_src, pattern, d, ld_dst);
     else hipLaunchKernelGGL(split3_kernel<F16>, dim3(blocks), dim3(256), 0, s, src, rows, CV, C, ld_src, pattern, d, ld_dst);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_split_operand(int src_dtype, const void* src, int64_t rows, int C, int64_t ld_src, int op_fmt, void* dst,
+                                  int64_t ld_dst, edtr_stream_t stream) {
+    if (!src || !dst) return EDTR_E_NULL;
+    if (src_dtype < EDTR_BF16 || src_dtype > EDTR_F32_H3 || op_fmt < EDTR_F32_SPLIT || op_fmt > EDTR_F32_H3) return EDTR_E_DTYPE;
+    const int parts = op_fmt == EDTR_F32_H1 ? 1 : (op_fmt == EDTR_F32_H2 ? 2 : 3);
+    if (rows <= 0 || C <= 0 || ld_dst < parts * (int64_t)C || ld_src < C) return EDTR_E_SHAPE;
+    const bool src32 = src_dtype >= EDTR_F32_SPLIT;
+    if ((C & 7) || (ld_src & (src32 ? 3 : 7)) || (ld_dst & 7) || !aligned16(src) || !aligned16(dst)) return EDTR_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int CV = C >> 3;
+    const dim3 grid(blocks_for(rows * CV)), block(256);
+    uint16_t* d = static_cast<uint16_t*>(dst);
+#define EDTR_SPLIT_LAUNCH(SRC, OT, PARTS) hipLaunchKernelGGL((split_operand_kernel<SRC, OT, PARTS>), grid, block, 0, s, src, rows, CV, C, ld_src, d, ld_dst)
+#define EDTR_SPLIT_SRC(OT, PARTS)                                              \
+    do {                                                                        \
+        if (src32) EDTR_SPLIT_LAUNCH(F32E, OT, PARTS);                          \
+        else if (src_dtype == EDTR_BF16) EDTR_SPLIT_LAUNCH(BF16, OT, PARTS);    \
+        else EDTR_SPLIT_LAUNCH(F16, OT, PARTS);                                 \
+    } while (0)
+    if (op_fmt == EDTR_F32_SPLIT) EDTR_SPLIT_SRC(BF16, 3);
+    else if (op_fmt == EDTR_F32_H1) EDTR_SPLIT_SRC(F16, 1);
+    else if (op_fmt == EDTR_F32_H2) EDTR_SPLIT_SRC(F16, 2);
+    else EDTR_SPLIT_SRC(F16, 3);
+#undef EDTR_SPLIT_SRC
+#undef EDTR_SPLIT_LAUNCH
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_sampler_update_indexed(const float* x, const float* eps, const float* noise, const int64_t* index,
+                                           const float* coefs, int n_steps, float* x_prev, float* pred_x0, int B,
+                                           int64_t per_image, edtr_stream_t stream) {
+    if (!x || !eps || !noise || !index || !coefs || !x_prev) return EDTR_E_NULL;
+    if (B <= 0 || per_image <= 0 || n_steps <= 0) return EDTR_E_SHAPE;
+    const int64_t n = (int64_t)B * per_image;
+    hipLaunchKernelGGL(sampler_update_indexed_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, eps,
+                       noise, index, coefs, n_steps, x_prev, pred_x0, per_image, n);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_gaussian_sample(const float* moments, int ld, const float* noise, float* out, int B, int C, int64_t HW,
+                                    float scale, edtr_stream_t stream) {
+    if (!moments || !out) return EDTR_E_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0 || ld < 2 * C) return EDTR_E_SHAPE;
+    const int64_t n = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), moments, ld,
+                       noise, out, C, HW, scale, n);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

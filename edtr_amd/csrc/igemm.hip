@@ -106,7 +106,12 @@ __device__ __forceinline__ void finish_vector(const edtr_igemm_params& p, float 
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], f[j] * p.act_slope);   // slope in [0, 1]
     }
-    if (p.residual) {
+    if (p.residual && p.residual_f32) {
+        const float* rp = static_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] += r0[j]; f[j + 4] += r1[j]; }
+    } else if (p.residual) {
         const U4 rv = ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n);
         float rf[8];
         unpack8<T>(rv, rf);
@@ -186,7 +191,8 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     }
 
     U4 res[ITER];
-    if (p.residual) {
+    const bool res16 = p.residual && !p.residual_f32;     // an fp32 residual (fp32 activation stream) is read inside the row loop
+    if (res16) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int mlr = r0 + RPI * it;
@@ -249,11 +255,16 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], f[j] * p.act_slope);
             }
-            if (p.residual) {
+            if (res16) {
                 float rf[8];
                 unpack8<T>(res[it], rf);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] += rf[j];
+            } else if (p.residual) {
+                const float* rp = static_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] += r0[j]; f[j + 4] += r1[j]; }
             }
             const int64_t oidx = o_zoff + (int64_t)m * p.ldc + n;
             if (p.out_f32) {
@@ -2777,7 +2788,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         return EDTR_E_ALIGN;
     const int n_out = p.act == EDTR_ACT_GEGLU ? p.N / 2 : p.N;
     if (p.act == EDTR_ACT_GEGLU && (p.N & 63)) return EDTR_E_ALIGN;
-    if ((n_out & 7) || (p.ldc & (p.out_f32 ? 3 : 7)) || (p.residual && (p.ldr & 7))) return EDTR_E_ALIGN;
+    if ((n_out & 7) || (p.ldc & (p.out_f32 ? 3 : 7)) || (p.residual && (p.ldr & (p.residual_f32 ? 3 : 7)))) return EDTR_E_ALIGN;
     if (!aligned16(p.a1) || !aligned16(p.w) || !aligned16(p.out) || (p.a2 && !aligned16(p.a2)) ||
         (p.residual && !aligned16(p.residual)))
         return EDTR_E_ALIGN;
@@ -2836,7 +2847,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             halo = (e4 && e4[0] == '0') ? 0 : 1;
         }
         if (halo && dma_ok && (p.N & 127) == 0 && igemm_halo_ok(p, spatial) && igemm_fast_addressable(p, spatial) &&
-            (int64_t)(p.M >> 8) * (p.N >> 7) * p.splitk >= 48)
+            (int64_t)(p.M >> 8) * (p.N >> 7) * p.splitk >= 48)      // (p.splitk was normalised to >= 1 above)
             tile = 16;
         // 8-wave ping-pong 128x128 tile: plain GEMMs whose tile grid leaves at most one workgroup per CU.  In isolation 1.20-1.32x over
         // tile 3 at 40-160 tiles (0.83x at 320: profiles/r02/ab_tiles_3_vs_15_small_gemm.log), but the whole path did not move in a
@@ -2867,9 +2878,9 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     }
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
-    if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.out_f32 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
+    if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 16 || (tile >= 11 && tile <= 13)) return EDTR_E_DTYPE;     // 11-13, 15: experiments, measured and removed
+    if (tile < 1 || tile > 16 || (tile >= 11 && tile <= 13)) return EDTR_E_DTYPE;     // 11-13: experiments, measured and removed (15 is opt-in)
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

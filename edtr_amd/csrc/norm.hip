@@ -17,7 +17,10 @@ struct IO16 {
     static __device__ __forceinline__ void load8(const in_t* p, float (&f)[8]) { unpack8<T>(ldg16(p), f); }
     static __device__ __forceinline__ void store8(out_t* p, int, const float (&f)[8]) { stg16(p, pack8<T>(f)); }
 };
-struct IOF32S {
+// IOF32<OT, PARTS>: fp32 rows in, PARTS-part GEMM operand of 16-bit type OT out.  PARTS = 3: [hi | lo | hi] (bf16: the
+// high-precision mode EDTR_F32_SPLIT; fp16: EDTR_F32_H3), 2: [hi | lo] (EDTR_F32_H2), 1: [x] (EDTR_F32_H1).
+template <typename OT, int PARTS>
+struct IOF32 {
     using in_t = float;
     using out_t = uint16_t;
     static __device__ __forceinline__ void load8(const in_t* p, float (&f)[8]) {
@@ -26,17 +29,33 @@ struct IOF32S {
         for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[j + 4] = b[j]; }
     }
     static __device__ __forceinline__ void store8(out_t* p, int C, const float (&f)[8]) {
-        float lo[8];
-        const U4 hi = pack8<BF16>(f);
-        float back[8];
-        unpack8<BF16>(hi, back);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lo[j] = f[j] - back[j];
+        const U4 hi = pack8<OT>(f);
         stg16(p, hi);
-        stg16(p + C, pack8<BF16>(lo));
-        stg16(p + 2 * C, hi);
+        if constexpr (PARTS >= 2) {
+            float lo[8], back[8];
+            unpack8<OT>(hi, back);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = f[j] - back[j];
+            stg16(p + C, pack8<OT>(lo));
+        }
+        if constexpr (PARTS == 3) stg16(p + 2 * C, hi);
     }
 };
+using IOF32S = IOF32<BF16, 3>;
+
+// run `body(IO{})` for the storage traits of a dtype code (false: unknown code)
+template <typename F>
+bool with_io(int dtype, F&& body) {
+    switch (dtype) {
+        case EDTR_BF16: body(IO16<BF16>{}); return true;
+        case EDTR_F16: body(IO16<F16>{}); return true;
+        case EDTR_F32_SPLIT: body(IOF32<BF16, 3>{}); return true;
+        case EDTR_F32_H1: body(IOF32<F16, 1>{}); return true;
+        case EDTR_F32_H2: body(IOF32<F16, 2>{}); return true;
+        case EDTR_F32_H3: body(IOF32<F16, 3>{}); return true;
+        default: return false;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // GroupNorm statistics.  grid (pixel chunks <= 64 per image, B); block = CV * R threads (CV = C/8 channel
@@ -306,7 +325,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* s, int c
 int check_gn(const edtr_gn_params& p, bool apply) {
     if (!p.x || !p.sums) return EDTR_E_NULL;
     if (apply && (!p.y || !p.gamma || !p.beta)) return EDTR_E_NULL;
-    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16 && p.dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
+    if (p.dtype < EDTR_BF16 || p.dtype > EDTR_F32_H3) return EDTR_E_DTYPE;
     if (p.B <= 0 || p.HW <= 0 || p.C <= 0 || p.groups <= 0 || p.groups > 64) return EDTR_E_SHAPE;
     if (p.C % p.groups) return EDTR_E_SHAPE;
     if ((p.C & 7) || (p.ldx & 7) || (apply && (p.ldy & 7))) return EDTR_E_ALIGN;
@@ -348,7 +367,7 @@ extern "C" int edtr_gn_stats(const edtr_gn_params* pp, edtr_stream_t stream) {
         hipLaunchKernelGGL(gn_stats_kernel<IO16<BF16>>, grid, dim3(threads), lds, s, p, CV, R, ppb);
     else if (p.dtype == EDTR_F16)
         hipLaunchKernelGGL(gn_stats_kernel<IO16<F16>>, grid, dim3(threads), lds, s, p, CV, R, ppb);
-    else
+    else      // every fp32-stream code reads the same fp32 rows
         hipLaunchKernelGGL(gn_stats_kernel<IOF32S>, grid, dim3(threads), lds, s, p, CV, R, ppb);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
@@ -373,12 +392,9 @@ extern "C" int edtr_gn_apply(const edtr_gn_params* pp, edtr_stream_t stream) {
     if (ppb < 8) ppb = 8;
     if (ppb > 256) ppb = 256;
     dim3 grid((unsigned)((p.HW + ppb - 1) / ppb), nchunk_c, p.B);
-    if (p.dtype == EDTR_BF16)
-        hipLaunchKernelGGL(gn_apply_kernel<IO16<BF16>>, grid, dim3(256), 0, s, p, (int)ppb);
-    else if (p.dtype == EDTR_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<IO16<F16>>, grid, dim3(256), 0, s, p, (int)ppb);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<IOF32S>, grid, dim3(256), 0, s, p, (int)ppb);
+    with_io(p.dtype, [&](auto io) {
+        hipLaunchKernelGGL(gn_apply_kernel<decltype(io)>, grid, dim3(256), 0, s, p, (int)ppb);
+    });
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }
@@ -421,7 +437,7 @@ extern "C" int edtr_gn_pool(double* sums, const float* weights, const float* cou
 extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int c_valid, int ldx, const float* gamma,
                               const float* beta, float eps, void* y, int ldy, edtr_stream_t stream) {
     if (!x || !y || !gamma || !beta) return EDTR_E_NULL;
-    if (dtype != EDTR_BF16 && dtype != EDTR_F16 && dtype != EDTR_F32_SPLIT) return EDTR_E_DTYPE;
+    if (dtype < EDTR_BF16 || dtype > EDTR_F32_H3) return EDTR_E_DTYPE;
     if (rows <= 0 || C <= 0 || c_valid < 0 || c_valid > C) return EDTR_E_SHAPE;
     if (C > 2048) return EDTR_E_UNSUPPORTED;
     if ((C & 7) || (ldx & 7) || (ldy & 7) || !aligned16(x) || !aligned16(y)) return EDTR_E_ALIGN;
@@ -430,9 +446,13 @@ extern "C" int edtr_layernorm(int dtype, const void* x, int64_t rows, int C, int
     dim3 grid((unsigned)((rows + 3) / 4));
     const uint16_t* xp = static_cast<const uint16_t*>(x);
     uint16_t* yp = static_cast<uint16_t*>(y);
-    if (dtype == EDTR_F32_SPLIT) {       // fp32 rows in, bf16 [hi | lo | hi] GEMM operand out (3*C columns)
+    if (dtype >= EDTR_F32_SPLIT) {       // fp32 rows in, 1..3-part GEMM operand out
         if (c_valid != C) return EDTR_E_UNSUPPORTED;
-        hipLaunchKernelGGL((layernorm_kernel<IOF32S, false>), grid, dim3(256), 0, s, static_cast<const float*>(x), rows, C, C, ldx, gamma, beta, eps, yp, ldy);
+        with_io(dtype, [&](auto io) {
+            using IO = decltype(io);
+            if constexpr (sizeof(typename IO::in_t) == 4)
+                hipLaunchKernelGGL((layernorm_kernel<IO, false>), grid, dim3(256), 0, s, static_cast<const float*>(x), rows, C, C, ldx, gamma, beta, eps, yp, ldy);
+        });
     } else if (dtype == EDTR_BF16) {
         if (c_valid == C) hipLaunchKernelGGL((layernorm_kernel<IO16<BF16>, false>), grid, dim3(256), 0, s, xp, rows, C, C, ldx, gamma, beta, eps, yp, ldy);
         else hipLaunchKernelGGL((layernorm_kernel<IO16<BF16>, true>), grid, dim3(256), 0, s, xp, rows, C, c_valid, ldx, gamma, beta, eps, yp, ldy);

@@ -126,62 +126,110 @@ class EngineCache(collections.OrderedDict):
 # ----------------------------------------------------------------------------------------------
 # packed weights
 # ----------------------------------------------------------------------------------------------
+class WRef:
+    """A packed matrix of the store, resolved per part count: ``get(parts)`` packs on first use (fast mode: parts is 1,
+    high mode: always the bf16 split-3 form, mixed mode: fp16 with 1 / 2 / 3 parts as the precision policy asks).
+    ``shape`` is the logical (one-part) [N, K]."""
+
+    def __init__(self, store: "WeightStore", key: tuple, build, shape):
+        self.store, self.key, self.build, self.shape = store, key, build, tuple(shape)
+
+    def get(self, parts: int = 1) -> torch.Tensor:
+        if self.store.dtype != ops.MIXED:
+            parts = 3 if self.store.dtype == ops.F32S else 1
+        key = self.key + (parts,)
+        if key not in self.store.cache:
+            self.store.cache[key] = self.build(parts)
+        return self.store.cache[key]
+
+
 class WeightStore:
     """fp32 parameters (reference names/shapes) -> device-resident packed 16-bit matrices + fp32 vectors.
-    Packs lazily, caches per (kind, names); ``invalidate()`` after the parameters change."""
+    Packs lazily, caches per (kind, names, parts); ``invalidate()`` after the parameters change."""
 
     def __init__(self, params: Dict[str, torch.Tensor], dtype, device: torch.device):
-        """``dtype``: torch.bfloat16 / torch.float16, or ops.F32S for the high-precision mode (bf16 matrices whose K axis is
-        the split [hi | hi | lo], three times as wide; see include/edtr_hip.h EDTR_F32_SPLIT)."""
+        """``dtype``: torch.bfloat16 / torch.float16; ops.F32S for the high-precision mode (bf16 matrices whose K axis is
+        the split [hi | hi | lo], three times as wide; see include/edtr_hip.h EDTR_F32_SPLIT); ops.MIXED for the mixed mode
+        (fp16 matrices with 1..3 parts per WRef.get)."""
         self.params, self.dtype, self.device = params, dtype, device
         self.cache: Dict[tuple, object] = {}
+        self.frozen: Optional[str] = None     # set on ranks whose fp32 parameters are placeholders (parallel.broadcast_packed)
 
     def invalidate(self):
         self.cache.clear()
 
     def _p(self, name: str) -> torch.Tensor:
+        if self.frozen:
+            raise RuntimeError(f"weight store is frozen ({self.frozen}): packing {name!r} now would read placeholder parameters; "
+                               "build every program before the packed broadcast, or broadcast the fp32 parameters")
         return self.params[name].detach().to(self.device, torch.float32)
 
-    def vec(self, name: str, n_pad: Optional[int] = None) -> torch.Tensor:
-        key = ("vec", name, n_pad)
+    def shape_of(self, name: str):
+        return tuple(self.params[name].shape)
+
+    def vec(self, name: str, n_pad: Optional[int] = None, scale: float = 1.0) -> torch.Tensor:
+        """fp32 vector (bias / norm affine), optionally pre-multiplied (a conv's alpha-scaled bias): cached, so that it is part
+        of the packed store a multi-GPU start-up broadcasts."""
+        key = ("vec", name, n_pad, float(scale))
         if key not in self.cache:
             v = self._p(name).reshape(-1)
-            self.cache[key] = ops.pad_bias(v, n_pad or v.numel()).contiguous()
+            v = ops.pad_bias(v, n_pad or v.numel())
+            self.cache[key] = (v * scale if scale != 1.0 else v).contiguous()
         return self.cache[key]
 
-    def conv(self, prefix: str, cin_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(w16 [Np, taps*Cinp], bias f32 [Np]) for ``prefix + 'weight'/'bias'`` (3x3 or 1x1 conv)."""
-        key = ("conv", prefix, cin_pad)
-        if key not in self.cache:
-            w = self._p(prefix + "weight")
-            wp = ops.pack_conv_weight(w, self.dtype, cin_pad=cin_pad)
-            self.cache[key] = (wp, self.vec(prefix + "bias", wp.shape[0]))
-        return self.cache[key]
+    def conv(self, prefix: str, cin_pad: Optional[int] = None, bias_scale: float = 1.0) -> Tuple[WRef, torch.Tensor]:
+        """(WRef of [Np, taps*Cinp], bias f32 [Np]) for ``prefix + 'weight'/'bias'`` (3x3 or 1x1 conv)."""
+        co, ci, kh, kw = self.shape_of(prefix + "weight")
+        cip, cop = cin_pad or round_up(ci, 8), round_up(co, 8)
+        ref = WRef(self, ("conv", prefix, cin_pad),
+                   lambda parts: ops.pack_conv_weight(self._p(prefix + "weight"), self.dtype, cin_pad=cin_pad, parts=parts),
+                   (cop, kh * kw * cip))
+        return ref, self.vec(prefix + "bias", cop, bias_scale)
 
     def linear(self, names: Sequence[str], biases: Optional[Sequence[Optional[str]]] = None):
         """Row-concatenation of several [out, in] matrices (fused projections) + matching fp32 bias (or None)."""
-        key = ("linear", tuple(names), tuple(biases) if biases else None)
-        if key not in self.cache:
+        names = tuple(names)
+        n_rows = [self.shape_of(n)[0] for n in names]
+        k = 1
+        for d in self.shape_of(names[0])[1:]:
+            k *= d
+        npad = round_up(sum(n_rows), 8)
+
+        def build(parts):
             ws = [self._p(n).reshape(self.params[n].shape[0], -1) for n in names]
-            w = torch.cat(ws, dim=0)
-            wp = ops.pack_linear_weight(w, self.dtype)
-            b = None
-            if biases:
-                parts = [self._p(bn).reshape(-1) if bn else torch.zeros(ws[i].shape[0], device=self.device)
-                         for i, bn in enumerate(biases)]
-                b = ops.pad_bias(torch.cat(parts), wp.shape[0])
-            self.cache[key] = (wp, b)
-        return self.cache[key]
+            return ops.pack_linear_weight(torch.cat(ws, dim=0), self.dtype, parts=parts)
+
+        ref = WRef(self, ("linear", names), build, (npad, round_up(k, 8)))
+        b = None
+        if biases:
+            key = ("linear.bias", names, tuple(biases))
+            if key not in self.cache:
+                parts_ = [self._p(bn).reshape(-1) if bn else torch.zeros(n_rows[i], device=self.device)
+                          for i, bn in enumerate(biases)]
+                self.cache[key] = ops.pad_bias(torch.cat(parts_), npad)
+            b = self.cache[key]
+        return ref, b
 
     def rows(self, name: str, r0: int, r1: int, bias: Optional[str] = None):
         """Rows r0..r1 of one [out, in] matrix (e.g. the q/k or the v part of a fused in_proj) + the matching bias slice."""
-        key = ("rows", name, r0, r1, bias)
-        if key not in self.cache:
+        shp = self.shape_of(name)
+        k = 1
+        for d in shp[1:]:
+            k *= d
+        npad = round_up(r1 - r0, 8)
+
+        def build(parts):
             w = self._p(name)
-            wp = ops.pack_linear_weight(w.reshape(w.shape[0], -1)[r0:r1].contiguous(), self.dtype)
-            b = ops.pad_bias(self._p(bias).reshape(-1)[r0:r1].contiguous(), wp.shape[0]) if bias else None
-            self.cache[key] = (wp, b)
-        return self.cache[key]
+            return ops.pack_linear_weight(w.reshape(w.shape[0], -1)[r0:r1].contiguous(), self.dtype, parts=parts)
+
+        ref = WRef(self, ("rows", name, r0, r1), build, (npad, round_up(k, 8)))
+        b = None
+        if bias:
+            key = ("rows.bias", name, r0, r1, bias)
+            if key not in self.cache:
+                self.cache[key] = ops.pad_bias(self._p(bias).reshape(-1)[r0:r1].contiguous(), npad)
+            b = self.cache[key]
+        return ref, b
 
     def raw(self, name: str) -> torch.Tensor:
         """The fp32 parameter itself on the device (embedding tables)."""
@@ -191,12 +239,31 @@ class WeightStore:
         return self.cache[key]
 
     def geglu(self, wname: str, bname: str):
-        key = ("geglu", wname)
-        if key not in self.cache:
-            w, b = self._p(wname), self._p(bname)
+        n, k = self.shape_of(wname)[0], self.shape_of(wname)[1]
+
+        def build(parts):
+            w = self._p(wname)
             perm = ops.geglu_perm(w.shape[0] // 2).to(self.device)
-            self.cache[key] = (ops.pack_linear_weight(w[perm], self.dtype), b[perm].contiguous())
-        return self.cache[key]
+            return ops.pack_linear_weight(w[perm], self.dtype, parts=parts)
+
+        ref = WRef(self, ("geglu", wname), build, (round_up(n, 8), round_up(k, 8)))
+        key = ("geglu.bias", bname)
+        if key not in self.cache:
+            b = self._p(bname)
+            self.cache[key] = b[ops.geglu_perm(b.shape[0] // 2).to(self.device)].contiguous()
+        return ref, self.cache[key]
+
+    def tensors(self) -> List[torch.Tensor]:
+        """Every device tensor of the store in a deterministic order (same programs -> same keys on every rank)."""
+        out: List[torch.Tensor] = []
+        seen = set()
+        for key in sorted(self.cache, key=repr):
+            val = self.cache[key]
+            for t in (val if isinstance(val, (tuple, list)) else (val,)):
+                if isinstance(t, torch.Tensor) and t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    out.append(t)
+        return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -246,14 +313,30 @@ class Program:
     def add(self, rec: Rec) -> Rec:
         self.recs.append(rec)
         self.lanes.append(self.lane)
-        # Measurement aid (EDTR_EXP_DUP=<substring of a launch name>): idempotent launches whose name matches are issued TWICE.
-        # The slowdown of a whole-path run is the MARGINAL wall-clock cost of that kernel class inside the overlapped hipGraph
-        # execution — what a per-launch event timing cannot show.  Never set in production.
-        dup = os.environ.get("EDTR_EXP_DUP")
-        if dup and dup in rec.name and not rec.name.endswith(".stats"):
-            self.recs.append(rec)
-            self.lanes.append(self.lane)
         return rec
+
+    def duplicate_launches(self, substr: str, idempotent=("conv", "qk", "vT", "attn2.q", "geglu", "flash", "layernorm", ".apply",
+                                                          "proj_in", "time_embed", "emb_layers", "ctx_", "zero_conv")) -> int:
+        """Measurement aid for tools / bench.py --dup (never used by the product path): every launch whose name contains
+        ``substr`` AND is known to be idempotent (writes only its own output, no in-place residual, no atomics) is issued twice.
+        The slowdown of a whole-path run is the MARGINAL wall-clock cost of that kernel class inside the overlapped hipGraph
+        execution — what a per-launch event timing cannot show.  Call before capture(); returns the count."""
+        if self.graph is not None:
+            raise RuntimeError("duplicate_launches() must run before capture()")
+        recs, lanes, marks, n = [], [], {}, 0
+        for i, (r, ln) in enumerate(zip(self.recs, self.lanes)):
+            if i in self.marks:
+                marks[len(recs)] = self.marks[i]
+            recs.append(r)
+            lanes.append(ln)
+            if substr in r.name and any(k in r.name for k in idempotent) and not r.name.endswith(".stats"):
+                recs.append(r)
+                lanes.append(ln)
+                n += 1
+        if len(self.recs) in self.marks:
+            marks[len(recs)] = self.marks[len(self.recs)]
+        self.recs, self.lanes, self.marks = recs, lanes, marks
+        return n
 
     def fork(self) -> None:
         self.marks[len(self.recs)] = "fork"
@@ -331,20 +414,22 @@ class Program:
 # ----------------------------------------------------------------------------------------------
 # activations + primitive emitters
 # ----------------------------------------------------------------------------------------------
-class Op3:
-    """High-precision GEMM operand: bf16 ``t3`` [rows, 3*C] = [hi | lo | hi] of an fp32 [rows, C] activation."""
+class OpN:
+    """Multi-part GEMM operand of the high / mixed precision modes: 16-bit ``t`` [rows, parts*C] = [hi | lo | hi][:parts]
+    of an fp32 [rows, C] activation (the output of a normalisation, or of an explicit edtr_split_operand launch).
+    A consumer that wants fewer parts reads a prefix of the columns."""
 
-    def __init__(self, t3: torch.Tensor, C: int):
-        self.t3, self.C = t3, C
+    def __init__(self, t: torch.Tensor, C: int, parts: int):
+        self.t, self.C, self.parts = t, C, parts
 
     def stride(self, dim: int) -> int:
-        return self.t3.stride(dim)
+        return self.t.stride(dim)
 
 
 @dataclass
 class Act:
-    """NHWC activation: ``t`` is a 2-D view [B*H*W, C] (row stride ``ld`` >= C) of 16-bit storage — fp32 storage, or an Op3
-    (the output of a normalisation, which only ever feeds a GEMM) in the high-precision mode."""
+    """NHWC activation: ``t`` is a 2-D view [B*H*W, C] (row stride ``ld`` >= C) of 16-bit storage — fp32 storage, or an OpN
+    (the output of a normalisation, which only ever feeds a GEMM) in the high / mixed precision modes."""
     t: object
     B: int
     H: int
@@ -362,19 +447,52 @@ class Act:
 
 
 class Emitter:
-    """Primitive emitters.  ``precision="high"`` selects the parity mode: fp32 activation stream, every GEMM / convolution
-    as a bf16 split-3 product (3x the K, fp32 out), residual adds as fp32 launches, attention operands in fp16."""
+    """Primitive emitters.  Precision modes:
+      "fast"  : 16-bit activation storage in ``dtype``, one product per GEMM.
+      "high"  : the robust parity mode — fp32 activation stream, every GEMM / convolution as a bf16 split-3 product
+                (3x the K, fp32 out), attention operands in fp16.
+      "mixed" : the fast parity mode — the same fp32 stream, fp16 operands, and a per-layer part count (1 / 2 / 3 products)
+                from ``policy`` (edtr_amd/precision.py)."""
 
-    def __init__(self, prog: Program, arena: Arena, store: WeightStore, dtype: torch.dtype, precision: str = "fast"):
+    def __init__(self, prog: Program, arena: Arena, store: WeightStore, dtype: torch.dtype, precision: str = "fast",
+                 policy=None):
+        from .precision import ConstPolicy, mixed_policy
         self.prog, self.arena, self.store = prog, arena, store
-        self.hp = precision == "high"
-        if self.hp != (store.dtype == ops.F32S):
+        if precision not in ("fast", "high", "mixed"):
+            raise ValueError(f"unknown precision mode {precision!r}")
+        self.precision = precision
+        self.hp = precision != "fast"                              # fp32 activation stream
+        want = {"fast": dtype, "high": ops.F32S, "mixed": ops.MIXED}[precision]
+        if store.dtype != want:
             raise ValueError("the weight store and the emitter must agree on the precision mode")
-        self.dtype = torch.bfloat16 if self.hp else dtype          # MFMA operand type of edtr_igemm
+        if precision == "high":
+            self.dtype, self.policy = torch.bfloat16, ConstPolicy(3)    # MFMA operand type of edtr_igemm
+        elif precision == "mixed":
+            self.dtype, self.policy = torch.float16, (policy or mixed_policy())
+        else:
+            self.dtype, self.policy = dtype, ConstPolicy(1)
         self.attn_dtype = torch.float16 if self.hp else dtype      # q / k / v^T / P of the attention kernels
         self.act_dtype = torch.float32 if self.hp else dtype       # storage of the activation stream
-        self.io = ops.F32S if self.hp else dtype                    # dtype code of the norm / layout / elementwise launches
+        # dtype code of the layout / elementwise / statistics launches (every fp32-stream code means the same to them)
+        self.io = ops.F32S if self.hp else dtype
+        self.direct16 = precision == "mixed"      # a 16-bit GEMM output IS an attention / one-part operand (same fp16 type)
         self.last_gnp = None
+
+    # -- precision plumbing ---------------------------------------------------------------------
+    def parts_for(self, name: str, M: int = 0, N: int = 0, K: int = 0) -> int:
+        return self.policy.parts(name, M, N, K) if self.hp else 1
+
+    def feeds_parts(self, feeds, M: int = 0) -> int:
+        """Part count a normalisation must write for the GEMM classes it feeds (the widest of them)."""
+        if not self.hp:
+            return 1
+        if not feeds:
+            return 3
+        return max(self.parts_for(f, M) for f in feeds)
+
+    def op_fmt(self, parts: int):
+        """dtype code under which a norm / split launch writes a ``parts``-part operand."""
+        return ops.F32S if self.precision == "high" else ops.F32H[parts]
 
     # -- memory
     def new(self, rows: int, cols: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -385,66 +503,82 @@ class Emitter:
             if isinstance(t, Act):
                 self.arena.free(t.gnp)
                 t = t.t
-            if isinstance(t, Op3):
-                t = t.t3
+            if isinstance(t, OpN):
+                t = t.t
             self.arena.free(t)
 
-    # -- high-precision operands ------------------------------------------------------------------
-    def _operand(self, a, rows: int, C: int, pattern: int = 0):
-        """(bf16 [rows, 3C] operand, temporary to free or None) of an fp32 / fp16 activation or of a ready Op3."""
-        if isinstance(a, Op3):
-            if a.C != C or pattern != 0:
-                raise ValueError("Op3 operand does not match the GEMM")
-            return a.t3, None
-        t3 = self.arena.alloc((rows, 3 * C), torch.bfloat16)
-        self.prog.add(ops.make_split3(src=a, rows=rows, C=C, dst=t3, pattern=pattern))
-        return t3, t3
+    # -- multi-part operands --------------------------------------------------------------------
+    def _operand(self, a, rows: int, C: int, parts: int):
+        """(16-bit operand tensor, temporary to free or None, parts actually used) of an fp32 / 16-bit activation or of a
+        ready OpN."""
+        if isinstance(a, OpN):
+            if a.C != C or a.parts < parts:
+                raise ValueError(f"operand has {a.parts} part(s) of {a.C} columns, the GEMM wants {parts} of {C}")
+            return a.t, None, parts
+        if a.dtype == self.dtype:
+            # already the MFMA operand type (mixed mode: an fp16 attention / GEGLU output): its low part is exactly zero, so
+            # more activation parts buy nothing — the one-part product
+            return a, None, 1
+        t = self.arena.alloc((rows, parts * C), self.dtype)
+        self.prog.add(ops.make_split_operand(src=a, rows=rows, C=C, dst=t, fmt=self.op_fmt(parts)))
+        return t, t, parts
 
     def to16(self, x: torch.Tensor, rows: int, C: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """High-precision mode: a 16-bit copy (attention operand) of an fp32 [rows, C] view."""
+        """fp32 stream: a 16-bit copy (attention operand) of an fp32 [rows, C] view."""
         y = self.arena.alloc((rows, C), dtype or self.attn_dtype)
         self.prog.add(ops.make_cast16(dtype=dtype or self.attn_dtype, src=x, rows=rows, C=C, dst=y))
         return y
 
+    @staticmethod
+    def _w(w, parts: int) -> torch.Tensor:
+        return w.get(parts) if isinstance(w, WRef) else w
+
     # -- GEMM family ------------------------------------------------------------------------
-    def gemm(self, a, w: torch.Tensor, M: int, N: int, K: int, *, bias=None, out=None, act=0,
+    def gemm(self, a, w, M: int, N: int, K: int, *, bias=None, out=None, act=0,
              residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,
-             **kw) -> torch.Tensor:
-        """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld)."""
+             out16=False, feeds=None, **kw) -> torch.Tensor:
+        """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld); ``w`` is a
+        WRef of the store (or a ready packed tensor).  fp32-stream modes: the output is fp32 unless ``out16`` (an attention
+        operand, mixed mode only) or ``feeds`` names a GEMM class that takes it as a one-part operand."""
         n_out = N // 2 if act == L.ACT_GEGLU else N
         self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
+        parts = self.parts_for(name, M, N, K)
+        tmp = None
         if self.hp:
-            if out is None:
-                out = self.new(M, n_out, torch.float32)
-            a3, tmp = self._operand(a, M, K)
-            self.prog.add(ops.make_igemm(
-                dtype=self.dtype, a1=a3, w=w, out=out, M=M, N=N, C1=3 * K, ld1=a3.stride(0), ldw=w.stride(0),
-                ldc=out.stride(0), bias_n=bias, act=act, rowvec=rowvec, rowvec_ld=rowvec.stride(0) if rowvec is not None else 0,
-                rows_per_image=rows_per_image, out_f32=True, alpha=alpha, name=name, **kw))
-            self.arena.free(tmp)
-            if residual is not None:
-                self.add(out, residual, M, n_out, out=out)
-            return out
+            a, tmp, parts = self._operand(a, M, K, parts)
+            if out is not None:
+                out_f32 = out.dtype == torch.float32
+            else:
+                want16 = self.direct16 and (out16 or (feeds is not None and self.parts_for(feeds, M) == 1))
+                out_f32 = not want16
         if out is None:
-            out = self.new(M, n_out, torch.float32 if out_f32 else None)
-        tile, splitk = ops.choose_splitk(M, N, K, kw.get("Z", 1), act) if "tile" not in kw else (kw.pop("tile"), 1)
+            out = self.new(M, n_out, torch.float32 if out_f32 else (self.dtype if self.hp else None))
+        wt = self._w(w, parts)
+        Ke = parts * K
+        if "tile" in kw:
+            tile, splitk = kw.pop("tile"), 1
+        else:
+            tile, splitk = ops.choose_splitk(M, N, Ke, kw.get("Z", 1), act)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
-        if (stats_hw and act == 0 and not out_f32 and out.stride(0) == N and "Z" not in kw
-                and ops.gn_fusable(M, N, K, stats_hw, splitk=splitk)):
+        if (stats_hw and act == 0 and (self.hp or not out_f32) and out.stride(0) == N and "Z" not in kw
+                and ops.gn_fusable(M, N, Ke, stats_hw, splitk=splitk)):
             self.last_gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
             kw["gn_partial"] = self.last_gnp
+        res32 = residual is not None and residual.dtype == torch.float32
         self.prog.add(ops.make_igemm(
-            dtype=self.dtype, a1=a, w=w, out=out, M=M, N=N, C1=K, ld1=a.stride(0), ldw=w.stride(0), ldc=out.stride(0),
-            bias_n=bias, act=act, residual=residual, ldr=residual.stride(0) if residual is not None else 0,
+            dtype=self.dtype, a1=a, w=wt, out=out, M=M, N=N, C1=Ke, ld1=a.stride(0), ldw=wt.stride(0), ldc=out.stride(0),
+            bias_n=bias, act=act, residual=residual, ldr=residual.stride(0) if residual is not None else 0, residual_f32=res32,
             rowvec=rowvec, rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=rows_per_image,
             out_f32=out_f32, alpha=alpha, name=name, tile=tile, splitk=splitk, workspace=ws, **kw))
         self.arena.free(ws)
+        self.arena.free(tmp)
         return out
 
     def conv(self, x: Act, prefix: str, *, taps=9, stride=1, pad_tl=1, ups=False, rowvec=None, residual=None,
              out=None, out_f32=False, alpha=1.0, name=None, stats=False) -> Act:
         """3x3 (or 1x1) convolution of an NHWC activation with the packed weight ``prefix``."""
-        w, bias = self.store.conv(prefix, cin_pad=x.C)
+        name = name or ("conv3x3" if taps == 9 else "conv1x1")
+        w, bias = self.store.conv(prefix, cin_pad=x.C, bias_scale=alpha)      # the epilogue applies alpha before the bias
         N = w.shape[0]
         if taps == 9:
             LH, LW = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
@@ -455,78 +589,77 @@ class Emitter:
         else:
             OH, OW, spatial = x.H, x.W, None
         M = x.B * OH * OW
-        if alpha != 1.0:
-            bias = bias * alpha  # epilogue applies alpha before the bias
+        parts = self.parts_for(name, M, N, taps * x.C)
+        a, tmp = x.t, None
         if self.hp:
-            if out is None:
-                out = self.new(M, N, torch.float32)
-            a3, tmp = self._operand(x.t, x.rows, x.C)
-            self.prog.add(ops.make_igemm(
-                dtype=self.dtype, a1=a3, w=w, out=out, taps=taps, M=M, N=N, C1=3 * x.C, ld1=a3.stride(0), ldw=w.stride(0),
-                ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
-                rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, out_f32=True, alpha=alpha,
-                name=name or ("conv3x3" if taps == 9 else "conv1x1")))
-            self.arena.free(tmp)
-            if residual is not None:
-                self.add(out, residual, M, N, out=out)
-            return Act(out, x.B, OH, OW, N, None)
+            a, tmp, parts = self._operand(x.t, x.rows, x.C, parts)
+            out_f32 = True if out is None else out.dtype == torch.float32
+        Ce = parts * x.C
+        wt = self._w(w, parts)
         if out is None:
             out = self.new(M, N, torch.float32 if out_f32 else None)
-        tile, splitk = ops.choose_splitk(M, N, taps * x.C)
+        tile, splitk = ops.choose_splitk(M, N, taps * Ce)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
-        if stats and not out_f32 and out.stride(0) == N and ops.gn_fusable(M, N, x.C, OH * OW, splitk=splitk):
+        if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk):
             gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
+        res32 = residual is not None and residual.dtype == torch.float32
         self.prog.add(ops.make_igemm(
-            dtype=self.dtype, a1=x.t, w=w, out=out, taps=taps, M=M, N=N, C1=x.C, ld1=x.ld, ldw=w.stride(0),
+            dtype=self.dtype, a1=a, w=wt, out=out, taps=taps, M=M, N=N, C1=Ce, ld1=a.stride(0), ldw=wt.stride(0),
             ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
-            ldr=residual.stride(0) if residual is not None else 0, out_f32=out_f32, alpha=alpha, tile=tile, splitk=splitk,
-            workspace=ws, gn_partial=gnp, name=name or ("conv3x3" if taps == 9 else "conv1x1")))
+            ldr=residual.stride(0) if residual is not None else 0, residual_f32=res32, out_f32=out_f32, alpha=alpha, tile=tile,
+            splitk=splitk, workspace=ws, gn_partial=gnp, name=name))
         self.arena.free(ws)
+        self.arena.free(tmp)
         return Act(out, x.B, OH, OW, N, gnp)
 
     # -- norms --------------------------------------------------------------------------------
     def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, y: torch.Tensor,
-                 sums_zeroed: bool = False):
+                 sums_zeroed: bool = False, parts: int = 1):
         gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
         c_real = self.store.params[prefix + "weight"].numel()
         if c_real != x.C:
             raise ValueError(f"GroupNorm {prefix}: activation has {x.C} channels, parameter has {c_real}")
-        return ops.make_gn(dtype=self.io, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C, sums=sums, gamma=gamma,
-                           beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed)
+        return ops.make_gn(dtype=self.op_fmt(parts) if self.hp else self.io, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C,
+                           sums=sums, gamma=gamma, beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed)
 
-    def _gn_out(self, x: Act):
-        """(buffer the apply launch writes, what the Act carries): high-precision mode = the split-3 operand itself."""
+    def _norm_out(self, rows: int, C: int, parts: int):
+        """(buffer the apply launch writes, what the caller carries): fp32-stream modes = the multi-part operand itself."""
         if self.hp:
-            y3 = self.arena.alloc((x.rows, 3 * x.C), torch.bfloat16)
-            return y3, Op3(y3, x.C)
-        y = self.new(x.rows, x.C)
+            t = self.arena.alloc((rows, parts * C), self.dtype)
+            return t, OpN(t, C, parts)
+        y = self.new(rows, C)
         return y, y
 
-    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None) -> Act:
+    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None, feeds=None) -> Act:
+        """``feeds``: the GEMM classes that consume the result (their precision policy decides how many operand parts the
+        apply launch writes in the fp32-stream modes)."""
+        parts = self.feeds_parts(feeds, x.rows)
         if out is not None:
             y, carried = out, out
         else:
-            y, carried = self._gn_out(x)
+            y, carried = self._norm_out(x.rows, x.C, parts)
         if x.gnp is not None:    # the producer's epilogue already reduced this tensor per 128-row tile
             sums = self.arena.alloc((x.B, 32, 2), torch.float64)
-            _, ap = self._gn_recs(x, prefix, eps, silu, sums, y)
+            _, ap = self._gn_recs(x, prefix, eps, silu, sums, y, parts=parts)
             st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
         else:                    # atomically accumulated statistics: a pre-zeroed pool slot, never reused in this program
             sums = self.prog.sums_slot(self.arena, x.B)
-            st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=True)
+            st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=True, parts=parts)
         self.prog.add(st)
         self.prog.add(ap)
         if x.gnp is not None:
             self.arena.free(sums)
         return Act(carried, x.B, x.H, x.W, x.C)
 
-    def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, sums_zeroed: bool = False):
+    def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, sums_zeroed: bool = False,
+                      feeds=None):
         """Statistics half only (tiled VAE: the caller pools `sums` across tiles before the apply half).
         Returns a closure that emits the apply half and yields the normalised activation."""
-        y, carried = self._gn_out(x)
-        st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=sums_zeroed)
+        parts = self.feeds_parts(feeds, x.rows)
+        y, carried = self._norm_out(x.rows, x.C, parts)
+        st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=sums_zeroed, parts=parts)
         if x.gnp is not None:
             st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
         self.prog.add(st)
@@ -536,13 +669,10 @@ class Emitter:
             return Act(carried, x.B, x.H, x.W, x.C)
         return apply
 
-    def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str):
-        if self.hp:
-            y3 = self.arena.alloc((rows, 3 * C), torch.bfloat16)
-            y, carried = y3, Op3(y3, C)
-        else:
-            y = carried = self.new(rows, C)
-        self.prog.add(ops.make_layernorm(dtype=self.io, x=x, rows=rows, C=C, ldx=x.stride(0),
+    def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str, feeds=None):
+        parts = self.feeds_parts(feeds, rows)
+        y, carried = self._norm_out(rows, C, parts)
+        self.prog.add(ops.make_layernorm(dtype=self.op_fmt(parts) if self.hp else self.io, x=x, rows=rows, C=C, ldx=x.stride(0),
                                          gamma=self.store.vec(prefix + "weight"), beta=self.store.vec(prefix + "bias"),
                                          eps=1e-5, y=y, ldy=y.stride(0)))
         return carried
@@ -577,7 +707,7 @@ class Emitter:
               out=None, causal: bool = False, prescaled: bool = False) -> torch.Tensor:
         C = H * 64
         tmp = []
-        if self.hp:      # fp32 projections -> fp16 operands (k / v^T of the context arrive already cast)
+        if self.hp:      # fp32 projections -> fp16 operands (mixed mode: the projections wrote fp16 already; k / v^T of the context arrive cast)
             if q.dtype == torch.float32:
                 q = self.to16(q, B * Nq, C)
                 tmp.append(q)
@@ -598,21 +728,23 @@ class Emitter:
         self.free(*tmp)
         return out
 
-    def vt_gemm(self, wv: torch.Tensor, x, *, B, Ntok, Cin, bias_m=None, name="v_transposed", alpha=1.0) -> Tuple[torch.Tensor, int]:
-        """V^T[b] = Wv @ x[b]^T  ->  [B, Cout, roundup8(Ntok)] (padding keys exactly zero when bias_m is None)."""
+    def vt_gemm(self, wv, x, *, B, Ntok, Cin, bias_m=None, name="v_transposed", alpha=1.0, out16=True) -> Tuple[torch.Tensor, int]:
+        """V^T[b] = Wv @ x[b]^T  ->  [B, Cout, roundup8(Ntok)] (padding keys exactly zero when bias_m is None).
+        fp32-stream modes: A = the packed weight [Wh | Wh | Wl][:parts], B operand = x as [hi | lo | hi][:parts]
+        (wh*xh + wh*xl + wl*xh); the mixed mode writes the fp16 attention operand directly (``out16``), the high mode
+        writes fp32 (its MFMA type is bf16) and the attention emitter casts."""
         Cout = wv.shape[0]
         ldv = round_up(Ntok, 8)
-        if self.hp:      # A = [Wh | Wh | Wl] (the packed weight), B operand = x as [hi | lo | hi]: wh*xh + wh*xl + wl*xh
-            vt = self.arena.alloc((B * Cout, ldv), torch.float32)
-            x3, tmp = self._operand(x, B * Ntok, Cin)
-            self.prog.add(ops.make_igemm(dtype=self.dtype, a1=wv, w=x3, out=vt, M=Cout, N=ldv, n_valid=Ntok, C1=3 * Cin,
-                                         ld1=wv.stride(0), ldw=x3.stride(0), ldc=ldv, Z=B, a_zs=(0, 0),
-                                         w_zs=(Ntok * x3.stride(0), 0), o_zs=(Cout * ldv, 0), bias_m=bias_m, out_f32=True,
-                                         alpha=alpha, name=name))
-            self.arena.free(tmp)
-            return vt, ldv
-        vt = self.arena.alloc((B * Cout, ldv), self.dtype)
-        self.prog.add(ops.make_igemm(dtype=self.dtype, a1=wv, w=x, out=vt, M=Cout, N=ldv, n_valid=Ntok, C1=Cin,
-                                     ld1=wv.stride(0), ldw=x.stride(0), ldc=ldv, Z=B, a_zs=(0, 0),
-                                     w_zs=(Ntok * x.stride(0), 0), o_zs=(Cout * ldv, 0), bias_m=bias_m, alpha=alpha, name=name))
+        parts = self.parts_for(name, Cout, ldv, Cin)
+        tmp = None
+        if self.hp:
+            x, tmp, parts = self._operand(x, B * Ntok, Cin, parts)
+        f32 = self.hp and not (self.direct16 and out16)
+        wt = self._w(wv, parts)
+        vt = self.arena.alloc((B * Cout, ldv), torch.float32 if f32 else self.dtype)
+        self.prog.add(ops.make_igemm(dtype=self.dtype, a1=wt, w=x, out=vt, M=Cout, N=ldv, n_valid=Ntok, C1=parts * Cin,
+                                     ld1=wt.stride(0), ldw=x.stride(0), ldc=ldv, Z=B, a_zs=(0, 0),
+                                     w_zs=(Ntok * x.stride(0), 0), o_zs=(Cout * ldv, 0), bias_m=bias_m, out_f32=f32,
+                                     alpha=alpha, name=name))
+        self.arena.free(tmp)
         return vt, ldv

@@ -9,7 +9,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
 
-BF16, F16, F32_SPLIT = 0, 1, 2
+BF16, F16, F32_SPLIT, F32_H1, F32_H2, F32_H3 = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3, 4
 
 DECLARED_SYMBOLS = [
@@ -18,6 +18,7 @@ DECLARED_SYMBOLS = [
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample", "edtr_split3", "edtr_cast16",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle",
+    "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample",
 ]
 
 
@@ -43,6 +44,7 @@ class IgemmParams(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("gn_partial", C.c_void_p),
         ("act_slope", C.c_float),
+        ("residual_f32", C.c_int32),
     ]
 
 
@@ -119,6 +121,9 @@ def load() -> C.CDLL:
     lib.edtr_q_sample.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
     lib.edtr_split3.argtypes = [i32, vp, i64, i32, i64, i32, vp, i64, vp]
     lib.edtr_cast16.argtypes = [i32, vp, i64, i32, i64, vp, i64, vp]
+    lib.edtr_split_operand.argtypes = [i32, vp, i64, i32, i64, i32, vp, i64, vp]
+    lib.edtr_sampler_update_indexed.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, i64, vp]
+    lib.edtr_gaussian_sample.argtypes = [vp, i32, vp, vp, i32, i32, i64, f32, vp]
     lib.edtr_tile_accumulate.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.edtr_divide.argtypes = [vp, vp, vp, i64, vp]
     lib.edtr_wavelet_level.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
@@ -136,7 +141,7 @@ def load() -> C.CDLL:
     lib.edtr_embed_tokens.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.edtr_window_attn.argtypes = [C.POINTER(WindowAttnParams), vp]
     lib.edtr_pixel_unshuffle.argtypes = [i32, vp, i32, i32, i32, i32, i32, vp, f32, vp, i32, i32, vp]
-    if lib.edtr_abi_version() != 5:
+    if lib.edtr_abi_version() != 6:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -25,18 +25,25 @@ def default_compute_dtype() -> torch.dtype:
     return _DTYPES[os.environ.get("EDTR_AMD_DTYPE", "bf16").lower()]
 
 
+PRECISIONS = ("fast", "mixed", "high")
+
+
 def default_precision() -> str:
-    """"fast": 16-bit activation storage in `compute_dtype` (the throughput modes).  "high": the parity mode — fp32
+    """"fast": 16-bit activation storage in `compute_dtype` (the throughput modes).  "high": the robust parity mode — fp32
     activation stream, every convolution / linear as a bf16 split-3 product with fp32 accumulation (~16 mantissa bits per
-    operand), fp16 attention operands; `compute_dtype` is ignored.  EDTR_AMD_PRECISION selects the default."""
+    operand), fp16 attention operands.  "mixed": the fast parity mode — the same fp32 stream, fp16 operands and a per-layer
+    number of products (edtr_amd/precision.py).  `compute_dtype` is ignored by the two parity modes.  EDTR_AMD_PRECISION
+    selects the default."""
     p = os.environ.get("EDTR_AMD_PRECISION", "fast").lower()
-    if p not in ("fast", "high"):
-        raise ValueError(f"EDTR_AMD_PRECISION must be 'fast' or 'high', got {p!r}")
+    if p not in PRECISIONS:
+        raise ValueError(f"EDTR_AMD_PRECISION must be one of {PRECISIONS}, got {p!r}")
     return p
 
 
 def _store_dtype(precision: str, compute_dtype):
-    return ops_mod.F32S if precision == "high" else compute_dtype
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+    return {"high": ops_mod.F32S, "mixed": ops_mod.MIXED}.get(precision, compute_dtype)
 
 
 def _require_gpu(t: torch.Tensor, what: str) -> None:
@@ -70,12 +77,18 @@ class _NetPart(ParamTree):
         self._part_store = None
         self._part_fp = None
         self._part_engines = EngineCache(lambda e: e.prog.release_graph())
+        self.precision_policy = None      # mixed mode: a precision.PrecisionPolicy (None = the shipped allocation)
 
     def _device(self) -> torch.device:
         return next(self.parameters()).device
 
+    def _policy(self):
+        from ..precision import mixed_policy
+        return (self.precision_policy or mixed_policy()) if self.precision == "mixed" else None
+
     def _store(self) -> WeightStore:
-        fp = (params_fingerprint(self), self.compute_dtype, self.precision)
+        pol = self._policy()
+        fp = (params_fingerprint(self), self.compute_dtype, self.precision, pol.key() if pol else None)
         if fp != self._part_fp:
             self._part_engines.drop_all()
             self._part_store, self._part_fp = None, fp
@@ -177,14 +190,14 @@ class CldmEngine:
 
         # ---- context program
         self.ctx_prog = Program("cldm.context")
-        em = Emitter(self.ctx_prog, self.arena, store, dt, owner.precision)
+        em = Emitter(self.ctx_prog, self.arena, store, dt, owner.precision, owner._policy())
         ctx16 = em.cast_flat(self.ctx_in, B * nctx * ua.context_dim).view(B * nctx, ua.context_dim)
         self.kv_c = nets.emit_context_kv(em, "controlnet.", ca, ctx16, B, nctx)
         self.kv_u = nets.emit_context_kv(em, "unet.", ua, ctx16, B, nctx)
 
         # ---- step program
         self.step_prog = Program("cldm.step")
-        em = Emitter(self.step_prog, self.arena, store, dt, owner.precision)
+        em = Emitter(self.step_prog, self.arena, store, dt, owner.precision, owner._policy())
         hw = h * w
         cin_c = ca.in_channels + ca.hint_channels
         x8c = em.new(B * hw, arch_round8(cin_c))
@@ -197,7 +210,7 @@ class CldmEngine:
         tab_u, offs_u = nets.emit_time_rows(em, "unet.", ua, self.t_in, B)
         # ControlNet (lane 1, own arena) is independent of the UNet encoder + middle block (lane 0): two graph branches
         self.arena_cn = Arena(dev)
-        em_cn = Emitter(self.step_prog, self.arena_cn, store, dt, owner.precision)
+        em_cn = Emitter(self.step_prog, self.arena_cn, store, dt, owner.precision, owner._policy())
         self.step_prog.fork()
         self.step_prog.set_lane(1)
         ctrl = nets.emit_controlnet(em_cn, "controlnet.", ca, Act(x8c, B, h, w, x8c.shape[1]), tab_c, offs_c, self.kv_c,
@@ -234,7 +247,7 @@ class _PartEngineBase:
         a = part.arch
         self.arena = Arena(dev)
         self.prog = Program(name)
-        em = Emitter(self.prog, self.arena, store, part.compute_dtype, part.precision)
+        em = Emitter(self.prog, self.arena, store, part.compute_dtype, part.precision, part._policy())
         f32 = torch.float32
         self.x_in = torch.zeros((B, a.in_channels, h, w), dtype=f32, device=dev)
         self.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
@@ -325,7 +338,7 @@ class VaeEngine:
     ``tile_size`` > 0 builds the tiled form (reference utils/tilevae VAEHook, non-fast mode): padded tiles cut from the
     full NHWC tensor, GroupNorm statistics pooled across tiles, valid regions written back."""
 
-    def __init__(self, owner: "ControlLDM", kind: str, B: int, H: int, W: int, tile_size: int = 0):
+    def __init__(self, owner: "ControlLDM", kind: str, B: int, H: int, W: int, tile_size: int = 0, sample: bool = False):
         dev = owner._device()
         dt = owner.compute_dtype
         self.arena = Arena(dev)
@@ -333,8 +346,9 @@ class VaeEngine:
         dd = owner.vae.cfg["ddconfig"]
         f32 = torch.float32
         self.prog = Program(f"vae.{kind}" + (".tiled" if tile_size else ""))
-        self.nan_probe = None      # tiled form: (row, col) of the first output pixel of every tile
-        em = Emitter(self.prog, self.arena, store, dt, owner.precision)
+        self.nan_probe = None      # tiled form: (rows, cols) index tensors of the first output pixel of every tile
+        self.noise_in = None       # encoder with sample=True: the N(0, 1) draw of DiagonalGaussianDistribution.sample()
+        em = Emitter(self.prog, self.arena, store, dt, owner.precision, owner._policy())
         sf = owner.scale_factor
         nlev = len(dd["ch_mult"])
         is_dec = kind == "decode"
@@ -352,11 +366,17 @@ class VaeEngine:
                 y = nets.emit_vae_net(em, "vae.encoder.", layers, Act(x, B, H, W, cp), final_f32=False)
             else:
                 y = self._tiled(em, "vae.encoder.", layers, x, B, H, W, cp, tile_size, False, h, w)
-                self.nan_probe = [(ob[2], ob[0]) for ob in nets.split_tiles(H, W, tile_size, False)[1]]
+                self.nan_probe = self._probe_index(nets.split_tiles(H, W, tile_size, False)[1], dev)
             # quant_conv 1x1 (model/vae.py:727) then DiagonalGaussianDistribution.mode() = first half (distributions.py:30,64)
+            # or .sample() = mean + exp(0.5 * clamp(logvar)) * N(0, 1) (distributions.py:29-41), times scale_factor (cldm.py:131-134)
             m = em.conv(y, "vae.quant_conv.", taps=1, out_f32=True, name="vae.quant_conv")
             em.free(y)
-            em.to_nchw(m.t, B, owner.vae.embed_dim, h * w, self.out, scale=sf)
+            if sample:
+                self.noise_in = torch.zeros_like(self.out)
+                em.prog.add(ops_mod.make_gaussian_sample(moments=m.t, ld=m.t.stride(0), noise=self.noise_in, out=self.out, B=B,
+                                                         C=owner.vae.embed_dim, HW=h * w, scale=sf))
+            else:
+                em.to_nchw(m.t, B, owner.vae.embed_dim, h * w, self.out, scale=sf)
         else:
             zc = dd["z_channels"]
             self.inp = torch.zeros((B, zc, H, W), dtype=f32, device=dev)
@@ -371,7 +391,7 @@ class VaeEngine:
                 y = nets.emit_vae_net(em, "vae.decoder.", layers, z2, final_f32=True)
             else:
                 y = self._tiled(em, "vae.decoder.", layers, z2.t, B, H, W, z2.C, tile_size, True, H * up, W * up)
-                self.nan_probe = [(ob[2], ob[0]) for ob in nets.split_tiles(H, W, tile_size, True)[1]]
+                self.nan_probe = self._probe_index(nets.split_tiles(H, W, tile_size, True)[1], dev)
             em.to_nchw(y.t, B, dd["out_ch"], y.H * y.W, self.out)
 
     @staticmethod
@@ -406,17 +426,26 @@ class VaeEngine:
             em.free(r)
         return Act(out, B, OH, OW, Co)
 
-    def run(self, x: torch.Tensor) -> torch.Tensor:
+    @staticmethod
+    def _probe_index(out_boxes, dev):
+        """Index tensors (built once) of the first output pixel of every tile, for the NaN probe of run()."""
+        return (torch.tensor([ob[2] for ob in out_boxes], device=dev), torch.tensor([ob[0] for ob in out_boxes], device=dev))
+
+    def run(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         self.inp.copy_(x)
+        if self.noise_in is not None:
+            self.noise_in.copy_(noise)
         self.prog.run()
-        if self.nan_probe and not torch.cuda.is_current_stream_capturing():
+        if (self.nan_probe is not None and VaeEngine.NAN_PROBE and not torch.cuda.is_current_stream_capturing()):
             # test_for_nans(tile, "vae") of the reference (utils/tilevae/tilevae.py:66-69,435,548): one element per tile is
-            # looked at; like there, this costs a device round trip per call (tiled VAE only)
-            rows = torch.tensor([r for r, _ in self.nan_probe], device=self.out.device)
-            cols = torch.tensor([c for _, c in self.nan_probe], device=self.out.device)
+            # looked at (batch 0, channel 0); like there, this costs a device round trip per call (tiled VAE only).  Skipped
+            # under hipGraph capture (a sync is illegal there) and when EDTR_VAE_NAN_PROBE=0 (benchmarks).
+            rows, cols = self.nan_probe
             if bool(torch.isnan(self.out[0, 0, rows, cols]).any()):
                 raise NansException("vae")
         return self.out
+
+    NAN_PROBE = os.environ.get("EDTR_VAE_NAN_PROBE", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------------
@@ -436,7 +465,8 @@ class ControlLDM(nn.Module):
         self.scale_factor = latent_scale_factor
         self.control_scales = [1.0] * 13
         self.compute_dtype = default_compute_dtype()
-        self.precision = default_precision()      # "fast" | "high" (parity mode), see default_precision()
+        self.precision = default_precision()      # "fast" | "mixed" | "high" (parity modes), see default_precision()
+        self.precision_policy = None              # mixed mode: a precision.PrecisionPolicy (None = the shipped allocation)
         # engines (static buffers + programs) are cached per shape AND per slot: a caller that keeps two batches in
         # flight on two HIP streams flips the slot so the batches never share a buffer (bench.py --inflight 2)
         self.engine_slot = 0
@@ -449,14 +479,33 @@ class ControlLDM(nn.Module):
     def _device(self) -> torch.device:
         return next(self.unet.parameters()).device
 
+    def _policy(self):
+        from ..precision import mixed_policy
+        return (self.precision_policy or mixed_policy()) if self.precision == "mixed" else None
+
     def _check_fresh(self) -> None:
-        fp = (params_fingerprint(self.unet), params_fingerprint(self.controlnet), params_fingerprint(self.vae),
-              self.compute_dtype, self.precision, tuple(self.control_scales))
+        pol = self._policy()
+        wfp = (params_fingerprint(self.unet), params_fingerprint(self.controlnet), params_fingerprint(self.vae),
+               self.compute_dtype, self.precision)
+        fp = (wfp, tuple(self.control_scales), pol.key() if pol else None)
         if fp != self._fingerprint:
-            self.release_engines()
+            # programs depend on everything; the packed store only on the parameters and the storage format, so a change of
+            # control_scales / precision policy rebuilds the programs over the SAME store (its entries are keyed by part count
+            # and bias scale)
+            keep = self._weights if (self._fingerprint is not None and self._fingerprint[0] == wfp) else None
+            if keep is None:
+                self.release_engines()      # (raises on a rank whose parameters are placeholders: see WeightStore.frozen)
+            else:
+                self._cldm_engines.drop_all()
+                self._vae_engines.drop_all()
             self._fingerprint = fp
 
     def release_engines(self) -> None:
+        """Drop every program / hipGraph AND the packed weights (call after writes through ``.data``)."""
+        if self._weights is not None and self._weights.frozen:
+            raise RuntimeError(f"cannot rebuild the engines: {self._weights.frozen} (the fp32 parameters of this rank are placeholders; "
+                               "changing control_scales / precision / compute_dtype after the packed broadcast needs a "
+                               "parallel.broadcast_parameters first)")
         self._cldm_engines.drop_all()
         self._vae_engines.drop_all()
         self._weights = None
@@ -481,10 +530,10 @@ class ControlLDM(nn.Module):
         key = (B, h, w, nctx, self.engine_slot)
         return self._cldm_engines.fetch(key, lambda: CldmEngine(self, B, h, w, nctx))
 
-    def vae_engine(self, kind: str, B: int, H: int, W: int, tile_size: int = 0) -> VaeEngine:
+    def vae_engine(self, kind: str, B: int, H: int, W: int, tile_size: int = 0, sample: bool = False) -> VaeEngine:
         self._check_fresh()
-        key = (kind, B, H, W, tile_size, self.engine_slot)
-        return self._vae_engines.fetch(key, lambda: VaeEngine(self, kind, B, H, W, tile_size))
+        key = (kind + (".sample" if sample else ""), B, H, W, tile_size, self.engine_slot)
+        return self._vae_engines.fetch(key, lambda: VaeEngine(self, kind, B, H, W, tile_size, sample))
 
     # -- checkpoint ingestion (reference model/cldm.py:46-105) -----------------------------------
     @torch.no_grad()
@@ -538,13 +587,16 @@ class ControlLDM(nn.Module):
     @torch.no_grad()
     def vae_encode(self, image: torch.Tensor, sample: bool = True, tiled: bool = False, tile_size: int = -1) -> torch.Tensor:
         _require_gpu(image, "vae_encode")
-        if sample:
-            raise NotImplementedError("vae_encode(sample=True) is a training-time path; the restoration path uses "
-                                      "sample=False (posterior mode)")
         B, _, H, W = image.shape
         if tiled and tile_size <= 0:
             raise ValueError("vae_encode(tiled=True) needs a positive tile_size (image pixels)")
-        return self.vae_engine("encode", B, H, W, tile_size if tiled else 0).run(image).clone()
+        eng = self.vae_engine("encode", B, H, W, tile_size if tiled else 0, sample=bool(sample))
+        if not sample:
+            return eng.run(image).clone()
+        # DiagonalGaussianDistribution.sample(): the reference draws torch.randn(mean.shape) on the HOST generator and moves it
+        # to the device (model/distributions.py:38-41); the same call here, so a seeded run sees the same draw
+        noise = torch.randn(tuple(eng.out.shape)).to(device=image.device)
+        return eng.run(image, noise).clone()
 
     @torch.no_grad()
     def vae_decode(self, z: torch.Tensor, tiled: bool = False, tile_size: int = -1) -> torch.Tensor:

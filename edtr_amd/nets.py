@@ -74,9 +74,9 @@ def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: in
     wk, _ = em.store.linear([P + l.prefix + t + "to_k.weight" for l in layers])
     wv, _ = em.store.linear([P + l.prefix + t + "to_v.weight" for l in layers])
     kv.sumC, kv.Nctx = wk.shape[0], Nctx
-    kv.k_all = em.gemm(ctx16, wk, B * Nctx, kv.sumC, a.context_dim, name="ctx_k(all)")
+    kv.k_all = em.gemm(ctx16, wk, B * Nctx, kv.sumC, a.context_dim, name="ctx_k(all)", out16=True)
     kv.vt_all, kv.ldv = em.vt_gemm(wv, ctx16, B=B, Ntok=Nctx, Cin=a.context_dim, name="ctx_vT(all)")
-    if em.hp:      # the attention kernel's operands are fp16 in the high-precision mode: cast once per prompt
+    if kv.k_all.dtype == torch.float32:      # high mode (bf16 MFMA type): the attention operands are fp16, cast once per prompt
         k32, v32 = kv.k_all, kv.vt_all
         kv.k_all = em.to16(k32, B * Nctx, kv.sumC)
         kv.vt_all = em.to16(v32, B * kv.sumC, kv.ldv)
@@ -94,10 +94,10 @@ def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: in
 def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, offs: Dict[str, int], out=None) -> Act:
     """model/unet.py:203-223: GN-SiLU-conv (+bias +emb row) ; GN-SiLU-conv (+bias) + skip(x)."""
     p = P + l.prefix
-    n1 = em.group_norm(x, p + "in_layers.0.", 1e-5, True)
+    n1 = em.group_norm(x, p + "in_layers.0.", 1e-5, True, feeds=("res.conv1",))
     h = em.conv(n1, p + "in_layers.2.", rowvec=table[:, offs[l.prefix]:], name="res.conv1", stats=True)
     em.free(n1)
-    n2 = em.group_norm(h, p + "out_layers.0.", 1e-5, True)
+    n2 = em.group_norm(h, p + "out_layers.0.", 1e-5, True, feeds=("res.conv2",))
     em.free(h)
     if l.cin != l.cout:
         skip = em.conv(x, p + "skip_connection.", taps=1, name="res.skip1x1").t
@@ -121,7 +121,7 @@ def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C:
     c = ATTN_PRESCALE
     if ctx is None:   # self attention: fused [Wq;Wk] projection, V^T via the operand-swapped GEMM
         wqk, _ = em.store.linear([p + "to_q.weight", p + "to_k.weight"])
-        qk = em.gemm(x, wqk, B * N, 2 * C, C, alpha=math.sqrt(c), name="attn1.qk")
+        qk = em.gemm(x, wqk, B * N, 2 * C, C, alpha=math.sqrt(c), name="attn1.qk", out16=True)
         wv, _ = em.store.linear([p + "to_v.weight"])
         vt, ldv = em.vt_gemm(wv, x, B=B, Ntok=N, Cin=C, name="attn1.vT")
         o = em.flash(qk[:, :C], qk[:, C:], vt, B=B, H=heads, Nq=N, Nk=N, k_bs=N * qk.stride(0), vt_bs=C * ldv, vt_ld=ldv,
@@ -130,7 +130,7 @@ def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C:
     else:
         k, vt, k_bs, vt_bs, ldv, nctx = ctx
         wq, _ = em.store.linear([p + "to_q.weight"])
-        q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q")
+        q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=True)
         o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv, prescaled=True)
         em.free(q)
     wo, bo = em.store.linear([p + "to_out.0.weight"], [p + "to_out.0.bias"])
@@ -144,24 +144,24 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     p = P + l.prefix
     B, N, C = x.B, x.H * x.W, x.C
     rows = B * N
-    n = em.group_norm(x, p + "norm.", 1e-6, False)
+    n = em.group_norm(x, p + "norm.", 1e-6, False, feeds=("st.proj_in",))
     wi, bi = em.store.linear([p + "proj_in.weight"], [p + "proj_in.bias"])
     t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in")
     em.free(n)
     tb = p + "transformer_blocks.0."
-    l1 = em.layer_norm(t, rows, C, tb + "norm1.")
+    l1 = em.layer_norm(t, rows, C, tb + "norm1.", feeds=("attn1.qk", "attn1.vT"))
     t1 = emit_attention_core(em, tb + "attn1.", l1, B, N, C, l.heads, None, t)
     em.free(l1, t)
-    l2 = em.layer_norm(t1, rows, C, tb + "norm2.")
+    l2 = em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",))
     off = kv.offs[l.prefix]
     k_view = kv.k_all[:, off:off + C]
     vt_view = kv.vt_all.view(B, kv.sumC, kv.ldv)[:, off:off + C, :]
     ctx = (k_view, vt_view, kv.Nctx * kv.sumC, kv.sumC * kv.ldv, kv.ldv, kv.Nctx)
     t2 = emit_attention_core(em, tb + "attn2.", l2, B, N, C, l.heads, ctx, t1)
     em.free(l2, t1)
-    l3 = em.layer_norm(t2, rows, C, tb + "norm3.")
+    l3 = em.layer_norm(t2, rows, C, tb + "norm3.", feeds=("ff.geglu",))
     wg, bg = em.store.geglu(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias")
-    g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu")
+    g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out")
     em.free(l3)
     wf, bf = em.store.linear([tb + "ff.net.2.weight"], [tb + "ff.net.2.bias"])
     t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out")
@@ -259,7 +259,7 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
         else:
             y = emit_block(em, P, layers, xin, table, offs, kv, keep_input=True)
             em.free(cat)
-    n = em.group_norm(y, P + "out.0.", 1e-5, True)
+    n = em.group_norm(y, P + "out.0.", 1e-5, True, feeds=("unet.out_conv",))
     em.free(y)
     eps = em.conv(n, P + "out.2.", out_f32=True, name="unet.out_conv")
     em.free(n)
@@ -269,22 +269,22 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
 # ----------------------------------------------------------------------------------------------
 # VAE
 # ----------------------------------------------------------------------------------------------
-def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool):
+def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool, feeds=None):
     """GroupNorm as a suspension point of a VAE emission generator: yields the activation (the driver answers with the
     fp64 sums slice to fill), emits the statistics launch, yields again (the driver may pool the sums across tiles),
     then emits the apply launch.  Plain and tiled VAE share every other line of emission code."""
     sums = yield x
-    apply = em.gn_stats_into(x, prefix, 1e-6, silu, sums, sums_zeroed=True)     # slots of the program's pre-zeroed pool
+    apply = em.gn_stats_into(x, prefix, 1e-6, silu, sums, sums_zeroed=True, feeds=feeds)     # slots of the program's pre-zeroed pool
     yield None
     return apply()
 
 
 def _g_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act):
     """model/vae.py:103-124 (tiled form: resblock2task, utils/tilevae/tilevae.py:86-106)."""
-    n1 = yield from _g_norm(em, x, p + "norm1.", True)
+    n1 = yield from _g_norm(em, x, p + "norm1.", True, ("vae.conv1",))
     h = em.conv(n1, p + "conv1.", name="vae.conv1", stats=True)
     em.free(n1)
-    n2 = yield from _g_norm(em, h, p + "norm2.", True)
+    n2 = yield from _g_norm(em, h, p + "norm2.", True, ("vae.conv2",))
     em.free(h)
     if l.cin != l.cout:
         skip = em.conv(x, p + "nin_shortcut.", taps=1, name="vae.nin_shortcut").t
@@ -305,14 +305,14 @@ def _g_vae_attn(em: Emitter, p: str, x: Act):
     rows = B * N
     if N % 4:
         raise ValueError("VAE attention needs h*w to be a multiple of 4")
-    n = yield from _g_norm(em, x, p + "norm.", False)
+    n = yield from _g_norm(em, x, p + "norm.", False, ("vae.attn.qk", "vae.attn.vT"))
     wqk, bqk = em.store.linear([p + "q.weight", p + "k.weight"], [p + "q.bias", p + "k.bias"])
-    qk = em.gemm(n.t, wqk, rows, 2 * C, C, bias=bqk, name="vae.attn.qk")
+    qk = em.gemm(n.t, wqk, rows, 2 * C, C, bias=bqk, name="vae.attn.qk", out16=True)
     wv, _ = em.store.linear([p + "v.weight"])
     vt, ldv = em.vt_gemm(wv, n.t, B=B, Ntok=N, Cin=C, bias_m=em.store.vec(p + "v.bias"), name="vae.attn.vT")
     em.free(n)
     adt = em.attn_dtype
-    if em.hp:      # the two batched products of this one layer run on fp16 operands cut from the fp32 projections
+    if qk.dtype == torch.float32:      # high mode: the two batched products of this one layer run on fp16 operands cut from the fp32 projections
         qk32, vt32 = qk, vt
         qk = em.to16(qk32, rows, 2 * C)
         vt = em.to16(vt32, B * C, ldv)
@@ -357,7 +357,7 @@ def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: 
         elif l.kind == "up":
             y = em.conv(h, p, ups=True, name="vae.upsample.conv", stats=True)           # nearest x2 + conv: vae.py:35-39
         elif l.kind == "norm_out":
-            y = yield from _g_norm(em, h, p, True)
+            y = yield from _g_norm(em, h, p, True, ("vae.conv_out",))
         else:
             raise ValueError(l.kind)
         if not first:

@@ -15,7 +15,10 @@ import torch
 from . import lib as L
 
 F32S = "f32_split"     # high-precision mode: fp32 activation stream, bf16 split-3 GEMM operands (edtr_hip.h EDTR_F32_SPLIT)
-_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, F32S: L.F32_SPLIT}
+# mixed-precision mode: fp32 activation stream, fp16 GEMM operands of 1 / 2 / 3 parts (edtr_hip.h EDTR_F32_H1 / H2 / H3)
+F32H = {1: "f32_h1", 2: "f32_h2", 3: "f32_h3"}
+MIXED = "f32_mixed"    # WeightStore dtype of the mixed mode: fp16 matrices packed per requested part count
+_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, F32S: L.F32_SPLIT, F32H[1]: L.F32_H1, F32H[2]: L.F32_H2, F32H[3]: L.F32_H3}
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -62,7 +65,8 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                rowvec: Optional[torch.Tensor] = None, rowvec_ld: int = 0, rows_per_image: int = 0, act: int = 0,
                residual: Optional[torch.Tensor] = None, ldr: int = 0, out_f32: bool = False, n_valid: int = 0,
                tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None,
-               gn_partial: Optional[torch.Tensor] = None, act_slope: float = 0.0, name: str = "igemm") -> Rec:
+               gn_partial: Optional[torch.Tensor] = None, act_slope: float = 0.0, residual_f32: bool = False,
+               name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -84,12 +88,13 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
         p.workspace, p.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     p.gn_partial = ptr(gn_partial)
     p.act_slope = act_slope
+    p.residual_f32 = int(residual_f32)
     flops = 2.0 * M * N * p.K * Z
     # algorithmic HBM bytes: every operand once (a conv reads its input image once, not once per tap)
     a_rows = (M // (p.OH * p.OW)) * p.IH * p.IW if spatial else M
     n_out = N // 2 if act == L.ACT_GEGLU else N
     nbytes = Z * (2.0 * a_rows * (C1 + C2) + 2.0 * N * p.K + (4.0 if out_f32 else 2.0) * M * n_out
-                  + (2.0 * M * n_out if residual is not None else 0.0))
+                  + ((4.0 if residual_f32 else 2.0) * M * n_out if residual is not None else 0.0))
     rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
                                                     gn_partial), name, flops, nbytes)
     rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
@@ -252,6 +257,26 @@ def make_split3(*, src: torch.Tensor, rows: int, C: int, dst: torch.Tensor, patt
     return Rec(L.load().edtr_split3, args, (src, dst), name, 0.0, (src.element_size() + 6.0) * rows * C)
 
 
+def make_split_operand(*, src: torch.Tensor, rows: int, C: int, dst: torch.Tensor, fmt, name="split_operand") -> Rec:
+    """[rows, C] fp32 / 16-bit -> GEMM operand in format ``fmt`` (F32S: bf16 [hi|lo|hi]; F32H[p]: fp16, p parts)."""
+    code = L.F32_SPLIT if src.dtype == torch.float32 else dt_code(src.dtype)
+    parts = 3 if fmt == F32S else {v: k for k, v in F32H.items()}[fmt]
+    args = (code, ptr(src), rows, C, src.stride(0), dt_code(fmt), ptr(dst), dst.stride(0))
+    return Rec(L.load().edtr_split_operand, args, (src, dst), name, 0.0, (src.element_size() + 2.0 * parts) * rows * C)
+
+
+def make_sampler_update_indexed(*, x, eps, noise, index, coefs, x_prev, pred_x0, name="sampler_update") -> Rec:
+    B = x.shape[0]
+    per = x.numel() // B
+    args = (ptr(x), ptr(eps), ptr(noise), ptr(index), ptr(coefs), coefs.shape[0], ptr(x_prev), ptr(pred_x0), B, per)
+    return Rec(L.load().edtr_sampler_update_indexed, args, (x, eps, noise, index, coefs, x_prev, pred_x0), name, 0.0, 20.0 * x.numel())
+
+
+def make_gaussian_sample(*, moments, ld, noise, out, B, C, HW, scale, name="gaussian_sample") -> Rec:
+    args = (ptr(moments), ld, ptr(noise), ptr(out), B, C, HW, float(scale))
+    return Rec(L.load().edtr_gaussian_sample, args, (moments, noise, out), name, 0.0, 16.0 * B * C * HW)
+
+
 def make_cast16(*, dtype, src: torch.Tensor, rows: int, C: int, dst: torch.Tensor, name="cast16") -> Rec:
     args = (dt_code(dtype), ptr(src), rows, C, src.stride(0), ptr(dst), dst.stride(0))
     return Rec(L.load().edtr_cast16, args, (src, dst), name, 0.0, 6.0 * rows * C)
@@ -287,36 +312,50 @@ def round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-def split3_weight(w: torch.Tensor) -> torch.Tensor:
-    """fp32 [..., C] -> bf16 [..., 3C] = [hi | hi | lo] along the last axis: the weight side of the high-precision product
-    (activation operand [hi | lo | hi]): xh*wh + xl*wh + xh*wl."""
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+def split3_weight(w: torch.Tensor, dtype: torch.dtype = torch.bfloat16, parts: int = 3) -> torch.Tensor:
+    """fp32 [..., C] -> 16-bit [..., parts*C] along the last axis, the weight side of a multi-part product:
+    parts 3 = [hi | hi | lo] against the activation operand [hi | lo | hi] (xh*wh + xl*wh + xh*wl), parts 2 = [hi | hi] against
+    [hi | lo] (the activation exact, the weight rounded once), parts 1 = [hi]."""
+    hi = w.to(dtype)
+    if parts == 1:
+        return hi.contiguous()
+    if parts == 2:
+        return torch.cat([hi, hi], dim=-1).contiguous()
+    lo = (w - hi.float()).to(dtype)
     return torch.cat([hi, hi, lo], dim=-1).contiguous()
 
 
+def _weight_format(dtype, parts: int):
+    """(16-bit storage dtype, part count) of a packed matrix for a WeightStore dtype."""
+    if dtype == F32S:
+        return torch.bfloat16, 3
+    if dtype == MIXED:
+        if parts not in (1, 2, 3):
+            raise ValueError(f"mixed-precision weights have 1..3 parts, got {parts}")
+        return torch.float16, parts
+    return dtype, 1
+
+
 def pack_conv_weight(w: torch.Tensor, dtype, cin_pad: Optional[int] = None,
-                     cout_pad: Optional[int] = None) -> torch.Tensor:
+                     cout_pad: Optional[int] = None, parts: int = 1) -> torch.Tensor:
     """[Cout, Cin, kh, kw] fp32 -> [Cout_pad][kh][kw][Cin_pad] 16-bit, flattened to [N][K] (K contiguous).
-    dtype == F32S: bf16 [Cout_pad][kh][kw][3*Cin_pad] with the channel axis split [hi | hi | lo]."""
+    dtype == F32S / MIXED: [Cout_pad][kh][kw][parts*Cin_pad] with the channel axis split (split3_weight)."""
     co, ci, kh, kw = w.shape
     cip = cin_pad or round_up(ci, 8)
     cop = cout_pad or round_up(co, 8)
     out = torch.zeros((cop, kh, kw, cip), dtype=torch.float32, device=w.device)
     out[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
-    if dtype == F32S:
-        return split3_weight(out).reshape(cop, kh * kw * 3 * cip)
-    return out.reshape(cop, kh * kw * cip).to(dtype).contiguous()
+    dt16, parts = _weight_format(dtype, parts)
+    return split3_weight(out, dt16, parts).reshape(cop, kh * kw * parts * cip)
 
 
-def pack_linear_weight(w: torch.Tensor, dtype, n_pad: Optional[int] = None) -> torch.Tensor:
+def pack_linear_weight(w: torch.Tensor, dtype, n_pad: Optional[int] = None, parts: int = 1) -> torch.Tensor:
     n, k = w.shape
     npad = n_pad or round_up(n, 8)
     out = torch.zeros((npad, round_up(k, 8)), dtype=torch.float32, device=w.device)
     out[:n, :k] = w
-    if dtype == F32S:
-        return split3_weight(out)
-    return out.to(dtype).contiguous()
+    dt16, parts = _weight_format(dtype, parts)
+    return split3_weight(out, dt16, parts)
 
 
 def geglu_perm(inner: int) -> torch.Tensor:

@@ -58,30 +58,26 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, bucket_bytes: in
                     off += n
                 calls += 1
                 nbytes += flat.numel() * flat.element_size()
+    w = getattr(module, "_weights", None)
+    if w is not None and getattr(w, "frozen", None):
+        w.frozen = None                                 # real parameters now: packing from them is legitimate again
     return calls, nbytes
 
 
 def broadcast_packed(model, src: int = 0, bucket_bytes: int = 1 << 29) -> Tuple[int, int]:
     """Start-up weight distribution as SURVEY.md §8(e) specifies it: ONE bucketed broadcast of the PACKED 16-bit weight store
-    (plus its small fp32 bias / norm vectors) from rank `src`, in place.  Every rank has already built the same kernel
-    programs (a warm-up pass packs whatever its parameters hold — zeros on the receiving ranks), so the packed tensors exist
-    at fixed addresses inside the launch records and hipGraphs; overwriting them in place needs no re-packing and no
-    re-capture.  About half the bytes of the fp32 parameters and no per-rank packing work.  Returns (collectives, bytes)."""
+    (plus its small fp32 bias / norm vectors, alpha-scaled biases included) from rank `src`, in place.  Every rank has already
+    built the same kernel programs (a warm-up pass packs whatever its parameters hold — placeholders on the receiving ranks),
+    so the packed tensors exist at fixed addresses inside the launch records and hipGraphs; overwriting them in place needs
+    no re-packing and no re-capture.  About half the bytes of the fp32 parameters and no per-rank packing work.
+
+    The receiving ranks' fp32 parameters are still placeholders afterwards, so their store is FROZEN: a later cache miss (a new
+    shape that needs an unpacked weight, `release_engines()` after changing control_scales / precision / compute_dtype) raises
+    instead of silently re-packing from placeholders; `broadcast_parameters` lifts the freeze.  Returns (collectives, bytes)."""
     import torch.distributed as dist
     store = model._store()
-    tensors: List[torch.Tensor] = []
-    for key in sorted(store.cache, key=repr):          # identical order on every rank (same programs -> same keys)
-        val = store.cache[key]
-        for t in (val if isinstance(val, (tuple, list)) else (val,)):
-            if isinstance(t, torch.Tensor):
-                tensors.append(t)
-    seen, uniq = set(), []
-    for t in tensors:                                   # a bias vector can be shared by two cache entries
-        if t.data_ptr() not in seen:
-            seen.add(t.data_ptr())
-            uniq.append(t)
     by_dtype = {}
-    for t in uniq:
+    for t in store.tensors():                           # identical order on every rank (same programs -> same keys)
         by_dtype.setdefault(t.dtype, []).append(t)
     calls = nbytes = 0
     with torch.no_grad():
@@ -96,5 +92,30 @@ def broadcast_packed(model, src: int = 0, bucket_bytes: int = 1 << 29) -> Tuple[
                     off += n
                 calls += 1
                 nbytes += flat.numel() * flat.element_size()
+    if dist.get_rank() != src:
+        store.frozen = f"packed weights were received from rank {src}"
     model.weights_updated_in_place()
     return calls, nbytes
+
+
+def store_checksum(model) -> torch.Tensor:
+    """fp64 [2] = (sum, sum of squares) over every tensor of the packed store, computed on the device in store order."""
+    store = model._store()
+    acc = None
+    for t in store.tensors():
+        v = t.detach().reshape(-1).to(torch.float64)
+        part = torch.stack([v.sum(), (v * v).sum()])
+        acc = part if acc is None else acc + part
+    return acc
+
+
+def verify_packed_store(model, src: int = 0) -> bool:
+    """Every rank compares the checksum of its packed store with rank `src`'s and the verdicts are all-reduced (MIN): True on
+    every rank only if every rank holds rank `src`'s weights.  bench.py refuses to report a multi-GPU throughput otherwise."""
+    import torch.distributed as dist
+    mine = store_checksum(model)
+    ref = mine.clone()
+    dist.broadcast(ref, src=src)
+    ok = torch.tensor([1 if bool(torch.equal(mine, ref)) else 0], dtype=torch.int32, device=mine.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(ok.item())

@@ -1,0 +1,70 @@
+"""Per-layer operand precision of the mixed mode (`ControlLDM.precision = "mixed"`, EDTR_AMD_PRECISION=mixed).
+
+The reference computes in fp32 (its GPU path: fp16 autocast with fp32 GroupNorm / LayerNorm / softmax and an fp32 VAE and
+sampler, main/det/test_edtr.py:95-136, model/util.py:161-163).  16-bit MFMA operands cannot reproduce it to the north-star
+1e-3: every fp16 rounding of a weight or of an activation that enters a GEMM costs ~2^-12 relative, and the ~250 GEMMs /
+convolutions in series add up to 1.5e-3 on the decoded image.  The matrix cores have no wider operand, so
+precision is bought with MORE PRODUCTS over the same fp16 MFMA kernel (edtr_igemm, fp32 accumulation, K = parts * C):
+
+    parts 1   x16 . W16                      one fp16 rounding of the activation and one of the weight
+    parts 2   [xh | xl] . [Wh | Wh]          activation exact (~22 bits), weight rounded once          2 x the MFMA work
+    parts 3   [xh | xl | xh] . [Wh | Wh | Wl]  both exact (~22 bits)                                    3 x the MFMA work
+
+over an fp32 activation stream (no rounding of layer outputs).  Errors of independent roundings add in quadrature while the
+cost of a layer is its FLOP count, so the cheap, numerous layers (the UNet / ControlNet linears and small-latent
+convolutions: launch-bound, tripling K costs little) take 3 parts and the few FLOP-heavy ones (the VAE's 512 / 256-pixel
+levels) take as few as the error budget allows.  The table below is that allocation; `tools/exp/precision_budget_gpu.py`
+measures the per-class sensitivities it was chosen from (profiles/r03/precision_sensitivity.json).
+
+A policy maps the emitter's launch-class name (the `name=` of Emitter.gemm / conv: "res.conv1", "attn1.qk", "vae.conv2", ...)
+and the GEMM shape to a part count.  EDTR_AMD_POLICY (JSON: {"default": 2, "vae.conv1": 1, "vae.conv1@2097152": 1, ...};
+"<name>@<M>" addresses one resolution level) overrides it for experiments.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional
+
+
+class PrecisionPolicy:
+    def __init__(self, default: int = 2, table: Optional[Dict[str, int]] = None, label: str = "custom"):
+        self.default = int(default)
+        self.table = dict(table or {})
+        self.label = label
+        for k, v in list(self.table.items()) + [("default", self.default)]:
+            if v not in (1, 2, 3):
+                raise ValueError(f"precision policy: {k} -> {v!r} (parts must be 1, 2 or 3)")
+
+    def parts(self, name: str, M: int = 0, N: int = 0, K: int = 0) -> int:
+        hit = self.table.get(f"{name}@{M}")
+        if hit is None:
+            hit = self.table.get(name)
+        return self.default if hit is None else hit
+
+    def key(self):
+        return (self.default, tuple(sorted(self.table.items())))
+
+    def describe(self) -> dict:
+        return {"label": self.label, "default": self.default, "table": dict(sorted(self.table.items()))}
+
+
+class ConstPolicy(PrecisionPolicy):
+    """Every GEMM the same part count (fast mode: 1; high mode: 3)."""
+
+    def __init__(self, parts: int):
+        super().__init__(parts, {}, f"const{parts}")
+
+
+# The shipped allocation (see the module docstring; measured numbers in DESIGN.md §5).
+MIXED_TABLE: Dict[str, int] = {}
+MIXED_DEFAULT = 2
+
+
+def mixed_policy() -> PrecisionPolicy:
+    env = os.environ.get("EDTR_AMD_POLICY")
+    if env:
+        spec = json.loads(env)
+        default = int(spec.pop("default", MIXED_DEFAULT))
+        return PrecisionPolicy(default, {k: int(v) for k, v in spec.items()}, "env")
+    return PrecisionPolicy(MIXED_DEFAULT, MIXED_TABLE, "mixed-r03")

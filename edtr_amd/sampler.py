@@ -50,6 +50,7 @@ class SpacedSampler(nn.Module):
         self.original_alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
         self.context = {}
         self._host_tables: Dict[str, np.ndarray] = {}
+        self._coef_cache = None      # device copy of the per-step coefficient rows (edtr_sampler_update_indexed), per schedule
 
     def register(self, name: str, value: np.ndarray) -> None:
         self.register_buffer(name, torch.tensor(value, dtype=torch.float32))
@@ -81,6 +82,7 @@ class SpacedSampler(nn.Module):
         self.register("posterior_log_variance_clipped", post_logvar)
         self.register("posterior_mean_coef1", betas * np.sqrt(ac_prev) / (1.0 - ac))
         self.register("posterior_mean_coef2", (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac))
+        self._coef_cache = None
 
     # -- algebra kept for API parity (reference :135-164); GPU tensors, torch indexing only -----------------
     def q_posterior_mean_variance(self, x_start, x_t, t):
@@ -114,14 +116,31 @@ class SpacedSampler(nn.Module):
     def p_sample(self, model, x, t, index, cond, uncond, cfg_scale):
         """eps -> x0 -> posterior mean -> x_{t-1} (reference :184-204).  `index` must be uniform over the batch (it
         always is: the loop builds it with torch.full_like)."""
-        idx = index if isinstance(index, int) else int(index.reshape(-1)[0].item())
         eps = self.predict_noise(model, x, t, cond, uncond, cfg_scale).contiguous().float()
         noise = torch.randn_like(x)     # drawn every step, masked on the last one (reference :199-203)
         x = x.contiguous().float()
         x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+        if torch.is_tensor(index) and index.device.type == "cuda":
+            # a caller following the reference signature literally (index = torch.full_like(ts, ...), utils/sampler.py:311-312):
+            # the coefficients are gathered on the device, per image, with no host round trip
+            idx = index.reshape(-1).to(torch.int64)
+            if idx.numel() == 1 and x.shape[0] > 1:
+                idx = idx.expand(x.shape[0])
+            ops.launch(ops.make_sampler_update_indexed(x=x, eps=eps, noise=noise.contiguous().float(), index=idx.contiguous(),
+                                                       coefs=self._coef_table(x.device), x_prev=x_prev, pred_x0=pred_x0))
+            return x_prev, pred_x0
+        idx = int(index) if not torch.is_tensor(index) else int(index.reshape(-1)[0])      # host tensor / int: no device sync
         ops.launch(ops.make_sampler_update(x=x, eps=eps, noise=noise.contiguous().float(), coefs=self._coefs(idx),
                                            x_prev=x_prev, pred_x0=pred_x0, n=x.numel()))
         return x_prev, pred_x0
+
+    def _coef_table(self, device) -> torch.Tensor:
+        """[n_steps, 5] fp32 on the device: the rows _coefs() returns, for edtr_sampler_update_indexed (built per schedule)."""
+        hit = self._coef_cache
+        if hit is None or hit[0] != str(device):
+            n = len(self._host_tables["posterior_variance"])
+            hit = self._coef_cache = (str(device), torch.tensor([self._coefs(i) for i in range(n)], dtype=torch.float32).to(device))
+        return hit[1]
 
     def _install_tiling(self, model, tile_size: int, tile_stride: int) -> None:
         # NB: like the reference (:288-303) the patched forward is never restored.

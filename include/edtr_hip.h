@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 5
+#define EDTR_ABI_VERSION 6
 
 enum edtr_dtype {
     EDTR_BF16 = 0, EDTR_F16 = 1,
@@ -40,7 +40,14 @@ enum edtr_dtype {
      * "split-3" operand [hi | lo | hi] (3*C columns; hi = bf16(x), lo = bf16(x - hi)).  edtr_igemm (dtype EDTR_BF16, K = 3*C
      * per tap) multiplies it with weights packed [Wh | Wh | Wl]: hi*Wh + lo*Wh + hi*Wl = x*w to ~16 mantissa bits, fp32
      * accumulation, fp32 output.  This is what lets the path meet the 1e-3 parity target that 16-bit operands cannot. */
-    EDTR_F32_SPLIT = 2
+    EDTR_F32_SPLIT = 2,
+    /* Mixed-precision mode: the same fp32 activation stream, but GEMM operands are FP16 and the number of operand parts is
+     * chosen per layer (edtr_amd/precision.py): H1 = [x] (one fp16 rounding of the activation: a plain fp16 GEMM over an fp32
+     * stream), H2 = [hi | lo] (2*C columns, hi = fp16(x), lo = fp16(x - hi): the activation is exact to ~22 bits, weights
+     * packed [Wh | Wh] keep their single fp16 rounding), H3 = [hi | lo | hi] against [Wh | Wh | Wl] (~22 bits on both
+     * sides).  A consumer may read a PREFIX of the parts ([hi], [hi | lo]) of a wider operand through ld1.  Every entry
+     * point that accepts EDTR_F32_SPLIT accepts these; those that write no GEMM operand treat all four alike. */
+    EDTR_F32_H1 = 3, EDTR_F32_H2 = 4, EDTR_F32_H3 = 5
 };
 
 enum edtr_error {
@@ -130,9 +137,11 @@ typedef struct edtr_igemm_params {
      * kernel's business — the halo tile fills slot 2k with a 256-pixel patch and zeroes slot 2k+1 — only the per-image
      * totals over an image's H*W/128 consecutive slots are defined).  edtr_gn_finalize folds them into
      * the fp64 sums edtr_gn_apply consumes, so the separate statistics pass over the tensor (edtr_gn_stats) disappears.
-     * Needs M % 128 == 0, 16-bit output, no GEGLU / split-K / z-batching, tile 0/1/3/6/7/8/10/16. */
+     * Needs M % 128 == 0, no GEGLU / split-K / z-batching, tile 0/1/3/6/7/8/10/16 (16-bit or fp32 output). */
     float* gn_partial;
     float act_slope;        /* negative-side slope of EDTR_ACT_LRELU (0 <= slope <= 1) */
+    int32_t residual_f32;   /* nonzero: `residual` is fp32 (ldr in floats, multiple of 4): the fp32 activation stream of the
+                               high / mixed precision modes adds its skip inside the epilogue instead of in a separate launch */
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -280,6 +289,19 @@ int edtr_timestep_embedding(int dtype, const int64_t* t, int B, int dim, void* o
 int edtr_sampler_update(const float* x, const float* eps, const float* noise, float c_recip,
                         float c_recipm1, float coef1, float coef2, float sigma, float* x_prev,
                         float* pred_x0, int64_t n, edtr_stream_t stream);
+/* The same update with the step index read on the DEVICE (no host round trip for a caller that follows the reference
+ * signature literally and hands p_sample a GPU `index` tensor, utils/sampler.py:189-204,311-312):
+ *   coefs[n_steps][5] fp32 rows = (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1,
+ *   posterior_mean_coef2, sqrt(posterior_variance) * [i != 0]);  image b of B uses row index[b] (clamped into the table). */
+int edtr_sampler_update_indexed(const float* x, const float* eps, const float* noise, const int64_t* index,
+                                const float* coefs, int n_steps, float* x_prev, float* pred_x0, int B,
+                                int64_t per_image, edtr_stream_t stream);
+/* DiagonalGaussianDistribution.sample() of the VAE posterior on the quant_conv output (model/distributions.py:24-41,
+ * model/cldm.py:131-132):  out[b][c][p] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[b][c][p]) * scale  with
+ * mean = moments[(b*HW+p)*ld + c], logvar = moments[(b*HW+p)*ld + C + c] (fp32 NHWC rows of 2*C valid columns);
+ * noise == NULL gives mode() * scale.  out / noise: NCHW fp32 [B][C][HW]. */
+int edtr_gaussian_sample(const float* moments, int ld, const float* noise, float* out, int B, int C, int64_t HW,
+                         float scale, edtr_stream_t stream);
 /* out = a*x + b*y (fp32).  replaces: Diffusion.q_sample, model/gaussian_diffusion.py:80-84. */
 int edtr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n,
                edtr_stream_t stream);
@@ -294,6 +316,10 @@ int edtr_q_sample(const float* x, const float* noise, const int64_t* t, const fl
  * product).  src_dtype: EDTR_F32_SPLIT = fp32 source, EDTR_BF16 / EDTR_F16 = 16-bit source.  C, ld_src, ld_dst multiples of 8. */
 int edtr_split3(int src_dtype, const void* src, int64_t rows, int C, int64_t ld_src, int pattern, void* dst, int64_t ld_dst,
                 edtr_stream_t stream);
+/* The general operand writer: dst[rows][parts*C] in the format `op_fmt` (EDTR_F32_SPLIT = bf16 [hi|lo|hi]; EDTR_F32_H1/H2/H3 =
+ * fp16 [x] / [hi|lo] / [hi|lo|hi]) from an fp32 (src_dtype = any fp32-stream code) or 16-bit source. */
+int edtr_split_operand(int src_dtype, const void* src, int64_t rows, int C, int64_t ld_src, int op_fmt, void* dst,
+                       int64_t ld_dst, edtr_stream_t stream);
 /* fp32 [rows][C] -> 16-bit [rows][C] with independent row strides (high-precision mode: the fp16 q / k / v^T operands of
  * edtr_flash_attn64 are cut from fp32 projection outputs).  C, ld_dst multiples of 8; ld_src multiple of 4. */
 int edtr_cast16(int dst_dtype, const float* src, int64_t rows, int C, int64_t ld_src, void* dst, int64_t ld_dst,

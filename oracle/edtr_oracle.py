@@ -383,6 +383,17 @@ def vae_encode(sd: SD, cfg: dict, image: torch.Tensor, p: str = "vae.") -> torch
     return mean * cfg["latent_scale_factor"]
 
 
+def vae_encode_sample(sd: SD, cfg: dict, image: torch.Tensor, noise: torch.Tensor, p: str = "vae.") -> torch.Tensor:
+    """ControlLDM.vae_encode(sample=True), the signature's default: DiagonalGaussianDistribution.sample() =
+    mean + exp(0.5 * clamp(logvar, -30, 20)) * noise, times the latent scale (model/cldm.py:131-132,
+    model/distributions.py:24-41).  ``noise`` is the torch.randn(mean.shape) draw the reference makes on the host."""
+    dd = cfg["vae_cfg"]["ddconfig"]
+    moments = conv(sd, p + "quant_conv.", vae_encoder(sd, dd, image, p + "encoder."), padding=0)
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return (mean + std * noise) * cfg["latent_scale_factor"]
+
+
 def vae_decode(sd: SD, cfg: dict, z: torch.Tensor, p: str = "vae.") -> torch.Tensor:
     """ControlLDM.vae_decode: z / scale, post_quant_conv, decoder.  model/cldm.py:136-156, model/vae.py:731-734."""
     dd = cfg["vae_cfg"]["ddconfig"]

@@ -87,16 +87,32 @@ def _worker_packed(rank: int, world: int, port: int, q):
         m.load_controlnet_from_ckpt(sds["controlnet"])
         m.vae.load_state_dict(sds["vae"])
     store = m._store()
+    from edtr_amd.parallel import verify_packed_store
     w, b = store.conv("unet.input_blocks.1.0.in_layers.2.", cin_pad=64)
+    w = w.get()
     wl, _ = store.linear(["unet.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight",
                           "unet.input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight"])
+    wl = wl.get()
     g = store.vec("vae.encoder.norm_out.weight")
     wg, bg = store.geglu("unet.input_blocks.1.1.transformer_blocks.0.ff.net.0.proj.weight",
                          "unet.input_blocks.1.1.transformer_blocks.0.ff.net.0.proj.bias")
-    ptrs = [t.data_ptr() for t in (w, b, wl, g, wg, bg)]
+    wg = wg.get()
+    _, bz = store.conv("controlnet.zero_convs.0.0.", cin_pad=64, bias_scale=0.5)    # an alpha-scaled bias is a store tensor too
+    ptrs = [t.data_ptr() for t in (w, b, wl, g, wg, bg, bz)]
+    assert not verify_packed_store(m, src=0)            # before the broadcast rank 1 holds zeros: the check must see it
     calls, nbytes = broadcast_packed(m, src=0, bucket_bytes=1 << 20)
-    assert ptrs == [t.data_ptr() for t in (w, b, wl, g, wg, bg)]
-    q.put((rank, calls, nbytes, [float(t.double().abs().sum()) for t in (w, b, wl, g, wg, bg)]))
+    assert ptrs == [t.data_ptr() for t in (w, b, wl, g, wg, bg, bz)]
+    assert verify_packed_store(m, src=0)
+    # the receiver's fp32 parameters are still placeholders: a cache miss must raise, never re-pack silently from them
+    if rank == 1:
+        import pytest
+        with pytest.raises(RuntimeError, match="frozen"):
+            store.vec("vae.decoder.norm_out.weight")
+        with pytest.raises(RuntimeError, match="placeholders"):
+            m.release_engines()
+    else:
+        store.vec("vae.decoder.norm_out.weight")
+    q.put((rank, calls, nbytes, [float(t.double().abs().sum()) for t in (w, b, wl, g, wg, bg, bz)]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -178,3 +194,32 @@ def test_two_rank_restore_dataset_sharding_and_metric():
     gts = [(im + 0.03 * synth.synth_normal(f"ds:n{i}", tuple(im.shape))).clamp(0, 1) for i, im in enumerate(imgs)]
     want = sum(float(evalutil.calculate_psnr_pt(a[None], b[None], 0)[0]) for a, b in zip(imgs, gts)) / len(imgs)
     assert abs(ps0 - want) < 1e-6 and abs(ps1 - want) < 1e-6
+
+
+def _run_bench_launcher(extra_env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(EDTR_BENCH_BACKEND="gloo", **extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_self_launcher_starts_one_rank_per_gpu_and_forwards_rank0():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run must start two ranks itself (before any GPU call in the
+    parent), rendezvous on 127.0.0.1, and print exactly rank 0's JSON line with rccl_ranks == 2.
+    Dry-run mode: gloo, rendezvous + one all-reduce, no model."""
+    import json
+    r = _run_bench_launcher({})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dry_run"] is True
+
+
+def test_bench_self_launcher_fails_when_a_rank_fails():
+    r = _run_bench_launcher({"EDTR_BENCH_DRY_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not r.stdout.strip(), "no result line may be forwarded when a rank failed"

@@ -1,0 +1,308 @@
+"""The mixed-precision parity mode and the ABI-v6 entry points on the MI355X (pytest -m gpu).
+
+Mixed mode (edtr_amd/precision.py): fp32 activation stream, fp16 MFMA operands, 1 / 2 / 3 products per GEMM chosen per layer
+class.  Kernel-level checks of the operand writers and of the multi-part products, then the tiny pipeline under the three
+constant policies (errors must fall with the part count) and under the shipped allocation (north-star 1e-3), against the
+REFERENCE's outputs (tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR = 1e-3
+USED = [50, 100, 150, 200]
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _parts_ref(x, dtype, parts):
+    hi = x.to(dtype)
+    lo = (x - hi.float()).to(dtype)
+    return torch.cat([hi, lo, hi][:parts], dim=1)
+
+
+@pytest.mark.parametrize("src", ["f32", "f16", "bf16"])
+def test_split_operand_formats_bit_exact(src):
+    """edtr_split_operand: every operand format from an fp32 / 16-bit source, bit for bit."""
+    from edtr_amd import ops
+    d = dev()
+    M, K = 301, 200
+    x = rnd((M, K), 1, 3.0)
+    if src != "f32":
+        x = x.to(torch.float16 if src == "f16" else torch.bfloat16)
+    xd = x.to(d)
+    xf = x.float()
+    for fmt, dt, parts in [(ops.F32S, torch.bfloat16, 3), (ops.F32H[1], torch.float16, 1), (ops.F32H[2], torch.float16, 2),
+                           (ops.F32H[3], torch.float16, 3)]:
+        y = torch.full((M, parts * K + 8), 7.0, dtype=dt, device=d)          # padded row stride: columns beyond stay untouched
+        ops.launch(ops.make_split_operand(src=xd, rows=M, C=K, dst=y, fmt=fmt))
+        torch.cuda.synchronize()
+        assert torch.equal(y[:, :parts * K].cpu(), _parts_ref(xf, dt, parts)), (src, fmt)
+        assert bool((y[:, parts * K:] == 7.0).all())
+
+
+def test_fp16_multi_part_products():
+    """x @ w^T through edtr_igemm with 1 / 2 / 3 fp16 parts: one rounding of each operand, the activation exact, both exact."""
+    from edtr_amd import ops
+    d = dev()
+    M, N, K = 300, 72, 256
+    x, w = rnd((M, K), 1), rnd((N, K), 2, 0.1)
+    want = x.double() @ w.double().t()
+    errs = {}
+    for parts in (1, 2, 3):
+        xp = torch.empty((M, parts * K), dtype=torch.float16, device=d)
+        ops.launch(ops.make_split_operand(src=x.to(d), rows=M, C=K, dst=xp, fmt=ops.F32H[parts]))
+        wp = ops.pack_linear_weight(w, ops.MIXED, parts=parts).to(d)
+        assert tuple(wp.shape) == (N, parts * K) and wp.dtype == torch.float16
+        out = torch.empty((M, N), dtype=torch.float32, device=d)
+        ops.launch(ops.make_igemm(dtype=torch.float16, a1=xp, w=wp, out=out, M=M, N=N, C1=parts * K, ld1=parts * K,
+                                  ldw=parts * K, ldc=N, out_f32=True))
+        torch.cuda.synchronize()
+        errs[parts] = rel(out, want)
+    # references of what each part count should achieve
+    xh, wh = x.half().double(), w.half().double()
+    e1 = rel(xh @ wh.t(), want)
+    e2 = rel(x.double() @ wh.t(), want)
+    print(f"\n[fp16 parts] measured {errs}; ideal one-rounding-each {e1:.2e}, weight-only {e2:.2e}")
+    assert abs(errs[1] - e1) < 0.2 * e1 and abs(errs[2] - e2) < 0.2 * e2
+    assert errs[3] < 2e-6 and errs[2] < 0.85 * errs[1]
+    # a wider operand read through its prefix (what a norm feeding several GEMM classes produces)
+    x3 = torch.empty((M, 3 * K), dtype=torch.float16, device=d)
+    ops.launch(ops.make_split_operand(src=x.to(d), rows=M, C=K, dst=x3, fmt=ops.F32H[3]))
+    w2 = ops.pack_linear_weight(w, ops.MIXED, parts=2).to(d)
+    out = torch.empty((M, N), dtype=torch.float32, device=d)
+    ops.launch(ops.make_igemm(dtype=torch.float16, a1=x3, w=w2, out=out, M=M, N=N, C1=2 * K, ld1=3 * K, ldw=2 * K, ldc=N, out_f32=True))
+    torch.cuda.synchronize()
+    assert abs(rel(out, want) - errs[2]) < 1e-7
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3])
+def test_norms_write_fp16_parts(parts):
+    """GroupNorm(+SiLU) and LayerNorm over the fp32 stream writing the fp16 operand of 1 / 2 / 3 parts."""
+    import torch.nn.functional as F
+    from edtr_amd import ops
+    d = dev()
+    B, C, H, W = 2, 64, 12, 10
+    x = rnd((B, C, H, W), 3, 2.0) + 0.5
+    gamma, beta = 1 + 0.1 * rnd((C,), 4), 0.1 * rnd((C,), 5)
+    xn = x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(d)
+    sums = torch.zeros((B, 32, 2), dtype=torch.float64, device=d)
+    y = torch.empty((B * H * W, parts * C), dtype=torch.float16, device=d)
+    st, ap = ops.make_gn(dtype=ops.F32H[parts], x=xn, ldx=C, B=B, HW=H * W, C=C, sums=sums, gamma=gamma.to(d), beta=beta.to(d),
+                         eps=1e-6, silu=True, y=y, ldy=parts * C)
+    ops.launch(st)
+    ops.launch(ap)
+    torch.cuda.synchronize()
+    want = F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-6)).permute(0, 2, 3, 1).reshape(B * H * W, C)
+    yf = y.float().cpu()
+    got = yf[:, :C] + (yf[:, C:2 * C] if parts >= 2 else 0)
+    e = rel(got, want)
+    print(f"\n[gn fp16 x{parts}] rel err {e:.2e}")
+    assert e < (3e-4 if parts == 1 else 3e-6)
+    if parts == 3:
+        assert torch.equal(yf[:, :C], yf[:, 2 * C:])
+    rows, Cl = 70, 320
+    t = rnd((rows, Cl), 6, 3.0)
+    g2, b2 = 1 + 0.1 * rnd((Cl,), 7), 0.1 * rnd((Cl,), 8)
+    o = torch.empty((rows, parts * Cl), dtype=torch.float16, device=d)
+    ops.launch(ops.make_layernorm(dtype=ops.F32H[parts], x=t.to(d), rows=rows, C=Cl, ldx=Cl, gamma=g2.to(d), beta=b2.to(d),
+                                  eps=1e-5, y=o, ldy=parts * Cl))
+    torch.cuda.synchronize()
+    of = o.float().cpu()
+    e = rel(of[:, :Cl] + (of[:, Cl:2 * Cl] if parts >= 2 else 0), F.layer_norm(t.double(), (Cl,), g2.double(), b2.double(), 1e-5))
+    print(f"[ln fp16 x{parts}] rel err {e:.2e}")
+    assert e < (3e-4 if parts == 1 else 3e-6)
+
+
+@pytest.mark.parametrize("tile,splitk", [(0, 1), (3, 1), (6, 1), (8, 1), (16, 1), (3, 2)])
+def test_igemm_fp32_residual_and_fused_stats_with_fp32_output(tile, splitk):
+    """The fp32 stream's epilogue: fp32 residual read inside the row loop (and by the split-K reducer), GroupNorm partials of
+    an fp32 output."""
+    from edtr_amd import ops
+    d = dev()
+    B, H, W, Cin, Cout = 2, 32, 32, 128, 320 if tile == 8 else 256
+    conv = tile in (0, 16)
+    x = rnd((B * H * W, Cin), 1).half()
+    wt = rnd((Cout, Cin, 3, 3) if conv else (Cout, Cin), 2, 0.05)
+    res = rnd((B * H * W, Cout), 3)
+    bias = rnd((Cout,), 4)
+    M, N = B * H * W, Cout
+    K = 9 * Cin if conv else Cin
+    w16 = (ops.pack_conv_weight(wt, torch.float16, cin_pad=Cin) if conv else ops.pack_linear_weight(wt, torch.float16)).to(d)
+    out = torch.empty((M, N), dtype=torch.float32, device=d)
+    gnp = torch.zeros((M // 128, N, 2), dtype=torch.float32, device=d) if splitk == 1 else None
+    ws = torch.empty((splitk * M * N,), dtype=torch.float32, device=d) if splitk > 1 else None
+    rec = ops.make_igemm(dtype=torch.float16, a1=x.to(d), w=w16, out=out, taps=9 if conv else 1, M=M, N=N, C1=Cin, ld1=Cin, ldw=K,
+                         ldc=N, spatial=(H, W, H, W, 1, 1, 1, 0) if conv else None, bias_n=bias.to(d), residual=res.to(d), ldr=N,
+                         residual_f32=True, out_f32=True, tile=tile, splitk=splitk, workspace=ws, gn_partial=gnp, rows_per_image=H * W)
+    ops.launch(rec)
+    torch.cuda.synchronize()
+    xf = x.double()
+    if conv:
+        xi = xf.reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+        want = torch.nn.functional.conv2d(xi, wt.half().double(), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        want = xf @ wt.half().double().t()
+    want = want + bias.double() + res.double()
+    e = rel(out, want)
+    print(f"\n[fp32 residual tile {tile} sk {splitk}] rel err {e:.2e}")
+    assert e < 2e-6
+    if gnp is not None:
+        per_image = gnp.double().cpu().reshape(B, (H * W) // 128, N, 2).sum(1)
+        o = out.double().cpu().reshape(B, H * W, N)
+        assert rel(per_image[..., 0], o.sum(1)) < 1e-5 and rel(per_image[..., 1], (o * o).sum(1)) < 1e-5
+
+
+def test_sampler_update_indexed_and_gaussian_sample():
+    from edtr_amd import ops
+    d = dev()
+    B = 4
+    x, eps, noise = (rnd((B, 4, 16, 24), s).to(d) for s in (1, 2, 3))
+    coefs = torch.tensor([[1.02, 0.22, 1.0, 0.0, 0.0], [1.05, 0.34, 0.55, 0.44, 0.16], [1.1, 0.45, 0.4, 0.59, 0.21],
+                          [1.15, 0.57, 0.33, 0.66, 0.25]], dtype=torch.float32)
+    index = torch.tensor([3, 0, 2, 1], dtype=torch.int64)
+    xp, p0 = torch.empty_like(x), torch.empty_like(x)
+    ops.launch(ops.make_sampler_update_indexed(x=x, eps=eps, noise=noise, index=index.to(d), coefs=coefs.to(d), x_prev=xp, pred_x0=p0))
+    torch.cuda.synchronize()
+    for b in range(B):
+        xr, pr = torch.empty_like(x[b]), torch.empty_like(x[b])
+        ops.launch(ops.make_sampler_update(x=x[b].contiguous(), eps=eps[b].contiguous(), noise=noise[b].contiguous(),
+                                           coefs=[float(v) for v in coefs[index[b]]], x_prev=xr, pred_x0=pr, n=xr.numel()))
+        torch.cuda.synchronize()
+        assert torch.equal(xr, xp[b]) and torch.equal(pr, p0[b])
+    # posterior sample of the VAE from NHWC moments rows
+    C, HW, ld = 4, 16 * 24, 8
+    mom = rnd((B * HW, ld), 5, 2.0)
+    mom[:, 4:] *= 12.0                                       # exercise the clamp(-30, 20)
+    out = torch.empty((B, C, 16, 24), dtype=torch.float32, device=d)
+    ops.launch(ops.make_gaussian_sample(moments=mom.to(d), ld=ld, noise=noise, out=out, B=B, C=C, HW=HW, scale=0.18215))
+    torch.cuda.synchronize()
+    m = mom.reshape(B, HW, ld).permute(0, 2, 1).reshape(B, ld, 16, 24).double()
+    want = (m[:, :4] + torch.exp(0.5 * m[:, 4:].clamp(-30.0, 20.0)) * noise.double().cpu()) * 0.18215
+    assert rel(out, want) < 1e-6
+    ops.launch(ops.make_gaussian_sample(moments=mom.to(d), ld=ld, noise=None, out=out, B=B, C=C, HW=HW, scale=2.0))
+    torch.cuda.synchronize()
+    assert rel(out, m[:, :4] * 2.0) < 1e-7
+
+
+@pytest.mark.parametrize("precision", ["fast", "mixed", "high"])
+def test_vae_encode_sample_default_vs_reference_golden(golden_dir, precision):
+    """vae_encode(image) with the signature's default sample=True against the reference's seeded call."""
+    from edtr_amd import synth
+    from edtr_amd.testing import build_synthetic_cldm
+    d = dev()
+    g = np.load(os.path.join(golden_dir, "vae_sample.npz"))
+    cldm = build_synthetic_cldm(synth.tiny_config(), d, dtype=torch.float16, precision=precision)
+    img = synth.synth_input("vsample:img", (2, 3, 64, 96), -1.0, 1.0).to(d)
+    torch.manual_seed(int(g["seed"][0]))
+    z = cldm.vae_encode(img)
+    zm = cldm.vae_encode(img, sample=False)
+    torch.cuda.synchronize()
+    e, em = rel(z, g["z_sample"]), rel(zm, g["z_mode"])
+    print(f"\n[vae_encode sample=True, {precision}] sample {e:.2e} mode {em:.2e}")
+    tol = {"fast": 4e-3, "mixed": NORTH_STAR, "high": NORTH_STAR}[precision]
+    assert e < tol and em < tol
+
+
+def test_p_sample_with_a_device_index_makes_no_host_sync():
+    """A caller that follows the reference signature literally (index = torch.full_like(ts, ...) on the GPU,
+    utils/sampler.py:311-312) gets the same update as the int path, through edtr_sampler_update_indexed."""
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import injected_noise
+    d = dev()
+    sampler = SpacedSampler(Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).betas)
+    sampler.make_schedule(4, USED)
+    sampler.to(d)
+    x, eps, noise = (rnd((2, 4, 8, 8), s).to(d) for s in (1, 2, 3))
+    model = lambda x_, t_, c_: eps
+    ts = torch.full((2,), 150, device=d, dtype=torch.long)
+    with injected_noise([noise, noise]):
+        a = sampler.p_sample(model, x, ts, 2, None, None, 1.0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            pass
+        b = sampler.p_sample(model, x, ts, torch.full_like(ts, 2), None, None, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def _tiny_pipeline(golden_dir, policy, name="tiny_pipeline.npz", tag="tiny", B=2, H=128, W=128):
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise
+    d = dev()
+    g = np.load(os.path.join(golden_dir, name))
+    cldm = build_synthetic_cldm(synth.tiny_config(), d, precision="mixed")
+    cldm.precision_policy = policy
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(d)
+    sampler = SpacedSampler(diffusion.betas)
+    pre_res = synth.synth_input(f"{tag}:pre_res", (B, 3, H, W), 0.0, 1.0).to(d)
+    c_txt = synth.synth_input(f"{tag}:c_txt", (B, 77, 64), -1.0, 1.0).to(d)
+    noises = [synth.synth_normal(f"{tag}:noise{i}", (B, 4, H // 8, W // 8)).to(d) for i in range(5)]
+    z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
+    x_T = diffusion.q_sample(z_pre, torch.full((B,), 200, dtype=torch.int64, device=d), noises[0])
+    with injected_noise(noises[1:]):
+        z = sampler.manual_sample_with_timesteps(model=cldm, device=d, x_T=x_T, steps=4, used_timesteps=USED, batch_size=B,
+                                                 cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+    img = cldm.vae_decode(z)
+    torch.cuda.synchronize()
+    return {"z_pre": rel(z_pre, g["z_pre"]), "z": rel(z, g["z"]), "img": rel(img, g["img"])}
+
+
+def test_tiny_pipeline_error_falls_with_the_part_count(golden_dir):
+    from edtr_amd.precision import ConstPolicy
+    errs = {p: _tiny_pipeline(golden_dir, ConstPolicy(p)) for p in (1, 2, 3)}
+    for p, e in errs.items():
+        print(f"\n[mixed tiny, {p} part(s) everywhere] " + " ".join(f"{k}={v:.2e}" for k, v in e.items()))
+    assert errs[3]["img"] < 1e-4 and errs[3]["z"] < 1e-4          # ~22-bit operands: the fp32 reference to 1e-5 .. 1e-4
+    assert errs[2]["img"] < errs[1]["img"] and errs[3]["img"] < 0.5 * errs[2]["img"]
+    assert errs[1]["img"] < 3e-3                                    # fp16 operands over an fp32 stream
+
+
+@pytest.mark.parametrize("name,tag,B,H,W", [("tiny_pipeline.npz", "tiny", 2, 128, 128), ("tiny_pipeline_rect.npz", "tinyrect", 1, 192, 128)])
+def test_tiny_pipeline_shipped_policy_meets_the_north_star(golden_dir, name, tag, B, H, W):
+    from edtr_amd.precision import mixed_policy
+    errs = _tiny_pipeline(golden_dir, mixed_policy(), name, tag, B, H, W)
+    print(f"\n[mixed tiny, shipped policy] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert all(v < NORTH_STAR for v in errs.values()), errs
+
+
+def test_det512_full_size_mixed_meets_the_north_star(golden_dir):
+    """BASELINE configs[1] at full size in the mixed mode (shipped allocation): images 3 and 7 of the bench batch."""
+    from edtr_amd import synth, workloads
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm
+    d = dev()
+    g = np.load(os.path.join(golden_dir, "full_det512.npz"))
+    cldm = build_synthetic_cldm(synth.sd21_config(), d, precision="mixed")
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(d)
+    sampler = SpacedSampler(diffusion.betas)
+    full = workloads.make_inputs("det512", 1024, d, 8, 512)
+    sel = [int(k) for k in g["images"]]
+    inp = workloads.Inputs(full.pre_res[sel].contiguous(), full.c_txt[sel].contiguous(), [n[sel].contiguous() for n in full.noises], [],
+                           full.t_start[:len(sel)])
+    img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "det512")
+    torch.cuda.synchronize()
+    errs = {"z_pre": rel(tr["z_pre"], g["z_pre"]), "z": rel(z, g["z"]),
+            "img": rel(img[:, :, 1::4, 2::4], g["img_samples"].astype(np.float32))}
+    print(f"\n[mixed det512 full size] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert errs["z_pre"] < NORTH_STAR and errs["z"] < NORTH_STAR and errs["img"] < NORTH_STAR, errs

@@ -191,6 +191,20 @@ def test_tiled_vae(golden_dir):
         assert rel_err(O.vae_encode_tiled(sd, cfg, small, 64), O.vae_encode(sd, cfg, small)) == 0.0
 
 
+def test_vae_encode_sample_default(golden_dir):
+    """vae_encode's DEFAULT path (sample=True): the oracle's restatement of DiagonalGaussianDistribution.sample() against the
+    reference's own seeded call (tools/make_goldens.py gen_vaesample; the reference draws on the host generator)."""
+    g = np.load(os.path.join(golden_dir, "vae_sample.npz"))
+    cfg = synth.tiny_config()
+    sd = synth_sd(os.path.join(golden_dir, "manifest_tiny.json"), parts=("vae",))
+    img = synth.synth_input("vsample:img", (2, 3, 64, 96), -1.0, 1.0)
+    torch.manual_seed(int(g["seed"][0]))
+    noise = torch.randn(tuple(g["z_sample"].shape))
+    with torch.no_grad():
+        assert rel_err(O.vae_encode_sample(sd, cfg, img, noise), g["z_sample"]) < 2e-5
+        assert rel_err(O.vae_encode(sd, cfg, img), g["z_mode"]) < 2e-5
+
+
 def _clip_sd(tag, cfg):
     from edtr_amd.model.clip import clip_text_param_spec
     return {"clip." + k: synth.synth_param(f"clip{tag}." + k, shp) for k, shp in clip_text_param_spec(cfg["embed_dim"], cfg["text_cfg"])}

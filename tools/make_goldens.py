@@ -4,7 +4,7 @@
 
 Run in the build container only (the reference does not exist on the GPU box):
 
-    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,wavelet,clip,psnr,swinir,full]
+    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,tiledvae,vaesample,wavelet,clip,psnr,swinir,full,tokens]
 
 Fixtures are data (inputs are regenerated from edtr_amd.synth formulas, expected outputs
 are stored); nothing from the reference's source travels.
@@ -266,6 +266,23 @@ def gen_tiledvae():
           float(np.linalg.norm(out["dec_tiled"] - out["dec_plain"]) / np.linalg.norm(out["dec_plain"])))
 
 
+def gen_vaesample():
+    """ControlLDM.vae_encode with its DEFAULT sample=True (model/cldm.py:107-134, model/distributions.py:38-41) on the tiny
+    config: the reference draws torch.randn(mean.shape) on the host generator, so a seeded call is reproducible anywhere."""
+    cldm, cfg = build_reference_cldm("tiny")
+    img = synth.synth_input("vsample:img", (2, 3, 64, 96), -1.0, 1.0)
+    out = {"seed": np.array([1234])}
+    with torch.no_grad():
+        torch.manual_seed(1234)
+        out["z_sample"] = cldm.vae_encode(img).numpy()                       # sample=True is the signature's default
+        out["z_mode"] = cldm.vae_encode(img, sample=False).numpy()
+        moments = cldm.vae.quant_conv(cldm.vae.encoder(img))
+        out["logvar_minmax"] = np.array([float(moments[:, 4:].min()), float(moments[:, 4:].max())])
+    np.savez_compressed(os.path.join(GOLD, "vae_sample.npz"), **out)
+    print("vae_sample.npz written; |sample - mode| / |mode| =",
+          float(np.linalg.norm(out["z_sample"] - out["z_mode"]) / np.linalg.norm(out["z_mode"])), "logvar range", out["logvar_minmax"])
+
+
 def gen_wavelet():
     _, _, _, ref_common = ref_import.import_reference()
     a = synth.synth_input("wav:content", (2, 3, 96, 80), 0.0, 1.0)
@@ -492,14 +509,14 @@ def gen_full():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,wavelet,clip,psnr,swinir,full,tokens")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,vaesample,wavelet,clip,psnr,swinir,full,tokens")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens}[name]()
+         "vaesample": gen_vaesample, "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens}[name]()
 
 
 if __name__ == "__main__":
