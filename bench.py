@@ -562,8 +562,8 @@ def kernel_of(name: str) -> str:
 # relative-L2 tolerances against the fp32 reference at full size, each <= 1.5 x its measured value (bf16 6.2e-3 /
 # 1.2e-2, fp16 8.6e-4 / 1.5e-3, high 7.2e-5 / 7.4e-5) so that a 2x regression of a mode's numerics fails the run; the north-star
 # 1e-3 is what the parity modes (mixed, high) must additionally meet
-TOLERANCE = {"bf16": {"latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"latent": 1.3e-3, "image": 2.3e-3},
-             "mixed": {"latent": 1e-3, "image": 1e-3}, "high": {"latent": 1.2e-4, "image": 1.5e-4}}
+TOLERANCE = {"bf16": {"z_pre": 1.75e-2, "latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"z_pre": 2.2e-3, "latent": 1.3e-3, "image": 2.3e-3},
+             "mixed": {"z_pre": 1e-3, "latent": 8.5e-4, "image": 9e-4}, "high": {"z_pre": 1.2e-4, "latent": 1.2e-4, "image": 1.5e-4}}
 NORTH_STAR = 1e-3
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r03", "pmc_hbm_traffic.json")
 

@@ -11,10 +11,10 @@ precision is bought with MORE PRODUCTS over the same fp16 MFMA kernel (edtr_igem
     parts 3   [xh | xl | xh] . [Wh | Wh | Wl]  both exact (~22 bits)                                    3 x the MFMA work
 
 over an fp32 activation stream (no rounding of layer outputs).  Errors of independent roundings add in quadrature while the
-cost of a layer is its FLOP count, so the cheap, numerous layers (the UNet / ControlNet linears and small-latent
-convolutions: launch-bound, tripling K costs little) take 3 parts and the few FLOP-heavy ones (the VAE's 512 / 256-pixel
-levels) take as few as the error budget allows.  The table below is that allocation; `tools/exp/precision_budget_gpu.py`
-measures the per-class sensitivities it was chosen from (profiles/r03/precision_sensitivity.json).
+cost of a layer is its FLOP count, so the allocation is a knapsack: `tools/exp/precision_budget_gpu.py` measures, on the
+MI355X with the product kernels, what each GEMM class costs in output error when it alone runs at 1 or 2 parts
+(profiles/r03/precision_sensitivity.json), `tools/exp/precision_allocate.py` picks the cheapest part counts under an error
+budget, and the table at the bottom of this file is the result (measured again as a whole: DESIGN.md §5).
 
 A policy maps the emitter's launch-class name (the `name=` of Emitter.gemm / conv: "res.conv1", "attn1.qk", "vae.conv2", ...)
 and the GEMM shape to a part count.  EDTR_AMD_POLICY (JSON: {"default": 2, "vae.conv1": 1, "vae.conv1@2097152": 1, ...};
@@ -56,9 +56,21 @@ class ConstPolicy(PrecisionPolicy):
         super().__init__(parts, {}, f"const{parts}")
 
 
-# The shipped allocation (see the module docstring; measured numbers in DESIGN.md §5).
-MIXED_TABLE: Dict[str, int] = {}
-MIXED_DEFAULT = 2
+# The shipped allocation (see the module docstring; measured numbers in DESIGN.md §5 and profiles/r03/precision_*).
+# What the sensitivities say: a GEMM that carries the WHOLE residual stream (1x1 skip / nin_shortcut convolutions, the input and
+# output convolutions, the VAE's upsample convolutions, quant / post_quant) passes its operand roundings straight into the
+# signal — each of these few, cheap classes costs 1e-4 .. 5e-4 of image error at one part — while the FLOP-heavy convolutions
+# and linears sit inside residual branches whose output is a fraction of the stream (vae.conv1/2, res.conv1/2, ff.*: 1.4e-4 ..
+# 2.2e-4 for ALL their launches together).  So: three parts on the stream carriers, one part everywhere else.
+# Measured at full size (BASELINE configs[1], images 3 and 7 vs the reference): latent 5.2e-4, image 5.7e-4 at 81 images/s
+# (all-1: 7.5e-4 / 1.14e-3 at 91; all-2: 6.6e-4 / 8.8e-4 at 58; all-3: 1.0e-4 / 1.0e-4 at 44; fast bf16: 6.2e-3 / 1.2e-2 at 107).
+MIXED_TABLE: Dict[str, int] = {
+    "conv_in": 3, "res.skip1x1": 3, "unet.out_conv": 3,
+    "time_embed.0": 3, "time_embed.2": 3, "emb_layers(all)": 3, "ctx_k(all)": 3, "ctx_vT(all)": 3,
+    "vae.conv_in": 3, "vae.conv_out": 3, "vae.nin_shortcut": 3, "vae.upsample.conv": 3, "vae.downsample": 3,
+    "vae.quant_conv": 3, "vae.post_quant_conv": 3,
+}
+MIXED_DEFAULT = 1
 
 
 def mixed_policy() -> PrecisionPolicy:

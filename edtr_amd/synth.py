@@ -66,6 +66,45 @@ def synth_param(key: str, shape: Tuple[int, ...], device=None) -> torch.Tensor:
     return u * float(np.sqrt(3.0 / fan_in))
 
 
+HEAVY_ROW, HEAVY_GAIN, HEAVY_QK = 12.0, 4.0, 1.5
+
+
+def synth_param_heavy(key: str, shape: Tuple[int, ...], device=None) -> torch.Tensor:
+    """The "heavy-tailed" weight set: the statistics real SD-2.1 / ControlNet checkpoints have and the
+    smooth set above lacks — outlier channels, large norm gains, sharp attention.  Same hash, then:
+
+    * conv / linear weights: one output channel in ~128 is an OUTLIER, its whole row x HEAVY_ROW;
+    * GroupNorm / LayerNorm gains: one channel in ~64 has gain +-HEAVY_GAIN instead of 1 +- 0.1;
+    * attention `to_q` / `to_k` (and the VAE's `q` / `k`): x HEAVY_QK each (logit std ~2.3, x12 more on outlier rows).  Sharper
+      than that and the NETWORK turns chaotic — at x4 a 1e-5 perturbation of the input image changes eps by 40 % after four
+      steps in fp32 on the CPU (argmax-like attention), so no arithmetic could be compared with any other; x1.5 keeps the
+      amplification of a perturbation at <= 20 (the smooth set: ~1).  Logits of +-1e4 are driven through the attention
+      kernels directly (tests/test_gpu_heavy.py::test_flash_attention_with_extreme_logits);
+    * biases x 4.
+    Used for range-robustness tests (fp16 storage / fp16 operands must stay finite and inside their envelopes).  The factors
+    are calibrated so that the residual stream peaks at ~1e4 (tests/golden/heavy.npz: sd21_mid_absmax), the edge of what fp16
+    can hold at all — the reference's own GPU path is fp16 autocast (main/det/test_edtr.py:95-96), so a checkpoint whose
+    activations exceed 65504 does not run there either; the first calibration (x50 rows, +-10 gains) reached 6.5e6."""
+    base = synth_param(key, shape, device=device)
+    shape = tuple(int(s) for s in shape)
+    n0 = shape[0] if len(shape) else 1
+    seed = zlib.crc32(("heavy:" + key).encode("utf-8")) & _M32
+    ch = _hash_u32(torch.arange(n0, dtype=torch.int64, device=device), seed)
+    if len(shape) <= 1:
+        if key.endswith("bias"):
+            return 4.0 * base
+        big = (ch % 64) == 0
+        sign = torch.where((ch >> 7) % 2 == 0, 1.0, -1.0)
+        return torch.where(big, HEAVY_GAIN * sign, base)
+    scale = torch.where((ch % 128) == 0, HEAVY_ROW, 1.0).to(torch.float32)
+    if any(key.endswith(sfx) for sfx in ("to_q.weight", "to_k.weight", ".q.weight", ".k.weight")):
+        scale = scale * HEAVY_QK
+    return base * scale.reshape((n0,) + (1,) * (len(shape) - 1))
+
+
+WEIGHT_SETS = {"smooth": synth_param, "heavy": synth_param_heavy}
+
+
 def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], prefix: str = "") -> Dict[str, torch.Tensor]:
     """``spec`` yields (key, shape); the hash key is ``prefix + key`` so that the unet and
     the controlnet (which share key names) get different values."""

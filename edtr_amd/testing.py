@@ -14,33 +14,34 @@ from .model import ControlLDM
 _SD_CACHE: Dict[str, Dict[str, Dict[str, torch.Tensor]]] = {}
 
 
-def synthetic_state_dicts(cfg: dict, device=None) -> Dict[str, Dict[str, torch.Tensor]]:
+def synthetic_state_dicts(cfg: dict, device=None, weights: str = "smooth") -> Dict[str, Dict[str, torch.Tensor]]:
     """{'unet': sd, 'controlnet': sd, 'vae': sd} with reference key names; hash keys carry the part prefix, exactly
     as tools/make_goldens.py did on the reference model (`cldm.state_dict()` keys).  Cached per configuration (hashing the
     1.3 G parameters of the SD-2.1 size takes about a minute of CPU; consumers copy the values, never mutate them)."""
     import json
-    key = json.dumps({k: cfg[k] for k in ("unet_cfg", "controlnet_cfg", "vae_cfg")}, sort_keys=True, default=str) + str(device)
+    key = json.dumps({k: cfg[k] for k in ("unet_cfg", "controlnet_cfg", "vae_cfg")}, sort_keys=True, default=str) + str(device) + weights
     if key in _SD_CACHE:
         return _SD_CACHE[key]
-    _SD_CACHE[key] = _synthetic_state_dicts(cfg, device)
+    _SD_CACHE[key] = _synthetic_state_dicts(cfg, device, weights)
     return _SD_CACHE[key]
 
 
-def _synthetic_state_dicts(cfg: dict, device=None) -> Dict[str, Dict[str, torch.Tensor]]:
+def _synthetic_state_dicts(cfg: dict, device=None, weights: str = "smooth") -> Dict[str, Dict[str, torch.Tensor]]:
+    gen = synth.WEIGHT_SETS[weights]
     specs = {
         "unet": arch.unet_param_spec(arch.unet_arch(cfg["unet_cfg"])),
         "controlnet": arch.unet_param_spec(arch.unet_arch(cfg["controlnet_cfg"], controlnet=True)),
         "vae": arch.vae_param_spec(cfg["vae_cfg"]),
     }
-    return {part: {k: synth.synth_param(f"{part}.{k}", shp, device=device) for k, shp in spec} for part, spec in specs.items()}
+    return {part: {k: gen(f"{part}.{k}", shp, device=device) for k, shp in spec} for part, spec in specs.items()}
 
 
-def build_synthetic_cldm(cfg: dict, device, dtype=None, sds=None, precision=None) -> ControlLDM:
+def build_synthetic_cldm(cfg: dict, device, dtype=None, sds=None, precision=None, weights: str = "smooth") -> ControlLDM:
     from .model.params import skip_init
     on_gpu = torch.device(device).type == "cuda"
     with skip_init(), torch.device(device if on_gpu else "cpu"):      # parameters are born on the device: no 5 GB host round trip
         model = ControlLDM(**cfg)
-    sds = sds or synthetic_state_dicts(cfg, device if on_gpu else None)   # hashed on the device: bit-identical to the host
+    sds = sds or synthetic_state_dicts(cfg, device if on_gpu else None, weights)   # hashed on the device: bit-identical to the host
     model.unet.load_state_dict(sds["unet"], strict=True)
     model.load_controlnet_from_ckpt(sds["controlnet"])
     model.vae.load_state_dict(sds["vae"], strict=True)

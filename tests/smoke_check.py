@@ -34,9 +34,10 @@ def smoke(verbose: bool = True) -> dict:
         ref_img, tr = O.restore(flat_oracle_sd(sds), cfg, O.make_betas(), pre_res, c_txt, noises, used, 200,
                                 return_trace=True)
     out = {}
-    # the parity mode ("high": fp32 stream, bf16 split-3 products, fp16 attention) must meet the north-star 1e-3; the two
-    # 16-bit storage modes are held to their measured envelopes
-    for mode, dtype, tol in (("high", None, 1e-3), ("fast", torch.float16, 8e-3), ("fast", torch.bfloat16, 5e-2)):
+    # the parity modes ("mixed": fp32 stream, fp16 1-3-part products; "high": bf16 split-3 everywhere) must meet the north-star
+    # 1e-3 — and are held, like the two 16-bit storage modes, to 1.5 x their measured errors
+    # (measured: mixed 4.7e-4 / 5.2e-4, high 7.5e-5 / 7.6e-5, fp16 7.6e-4 / 1.45e-3, bf16 5.8e-3 / 1.12e-2; each bound <= 1.5 x)
+    for mode, dtype, tol in (("mixed", None, 7.8e-4), ("high", None, 1.15e-4), ("fast", torch.float16, 2.2e-3), ("fast", torch.bfloat16, 1.7e-2)):
         cldm = build_synthetic_cldm(cfg, dev, dtype, sds, precision=mode)
         diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
         sampler = SpacedSampler(diffusion.betas)
@@ -49,7 +50,7 @@ def smoke(verbose: bool = True) -> dict:
         img = cldm.vae_decode(z)
         torch.cuda.synchronize()
         e_z, e_img = rel_err(z, tr["z"]), rel_err(img, ref_img)
-        tag = "precision=high" if mode == "high" else str(dtype)
+        tag = f"precision={mode}" if mode != "fast" else str(dtype)
         out[tag] = (e_z, e_img)
         if verbose:
             print(f"smoke[{tag}]: rel err latent {e_z:.2e}, image {e_img:.2e} (tolerance {tol:.0e})")

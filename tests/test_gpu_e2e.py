@@ -15,8 +15,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 USED = [50, 100, 150, 200]
-TOL = {torch.float16: dict(z_pre=2e-3, eps=4e-3, z=4e-3, img=6e-3),
-       torch.bfloat16: dict(z_pre=1.5e-2, eps=3e-2, z=3e-2, img=4e-2)}
+# <= 1.5 x the measured values (fp16: z_pre 1.47e-3, eps 2.43e-3, z 8.5e-4, img 1.49e-3; bf16: 1.18e-2, 1.96e-2, 6.7e-3, 1.18e-2)
+TOL = {torch.float16: dict(z_pre=2.2e-3, eps=3.6e-3, z=1.3e-3, img=2.2e-3),
+       torch.bfloat16: dict(z_pre=1.75e-2, eps=2.9e-2, z=1.0e-2, img=1.77e-2)}
 
 
 def _run(golden_dir, name, tag, B, H, W, dtype):
@@ -324,7 +325,7 @@ def test_full_size_batch_invariance_and_determinism():
     z1, img1 = run([1])
     ez, ei = rel_err(z3[1:2], z1), rel_err(img3[1:2], img1)
     print(f"\n[full size] batch-3 vs batch-1: latent {ez:.2e}, image {ei:.2e}")
-    assert ez < 2e-2 and ei < 3e-2
+    assert ez < 8e-3 and ei < 1.85e-2          # measured 5.2e-3 / 1.23e-2 (bf16 rounding: tile choice / split-K depend on M)
     assert torch.isfinite(img3).all() and float(img3.abs().max()) < 50.0
 
 

@@ -17,7 +17,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "high": None}      # "high" = the parity mode (precision="high")
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "high": None, "mixed": None}      # "high" / "mixed" = the parity modes
 
 
 def _tol(name):
@@ -35,12 +35,12 @@ def _samples(img):
     return img[:, :, 1::4, 2::4]
 
 
-def _build(dev, dtype, cfg_name="sd21"):
+def _build(dev, dtype, cfg_name="sd21", precision=None):
     from edtr_amd import synth
     from edtr_amd.diffusion import Diffusion
     from edtr_amd.sampler import SpacedSampler
     from edtr_amd.testing import build_synthetic_cldm
-    cldm = build_synthetic_cldm(synth.CONFIGS[cfg_name](), dev, dtype, precision="high" if dtype is None else "fast")
+    cldm = build_synthetic_cldm(synth.CONFIGS[cfg_name](), dev, dtype, precision=precision or ("high" if dtype is None else "fast"))
     diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
     return cldm, diffusion, SpacedSampler(diffusion.betas)
 
@@ -71,7 +71,7 @@ def test_det512_batch8_every_image(golden_dir, dname):
     per_image = [(rel_err(z[k:k + 1], g["z"][i:i + 1]), rel_err(_samples(img[k:k + 1]), g["img_samples"][i:i + 1].astype(np.float32)))
                  for i, k in enumerate(sel)]
     print(f"\n[det512 B=8 {dname}] images {sel} vs reference: z_pre {e_pre:.2e} latent {e_z:.2e} image {e_img:.2e}; per image {per_image}")
-    assert e_pre < tol["latent"] and e_z < tol["latent"] and e_img < tol["image"]
+    assert e_pre < tol["z_pre"] and e_z < tol["latent"] and e_img < tol["image"]
     np.testing.assert_allclose(float(img[sel].mean()), g["img_stats"][0], atol=5e-3)
     # every image of the batch vs the same image travelling alone (batch 1: other tile choices, same arithmetic)
     worst = 0.0
@@ -83,14 +83,14 @@ def test_det512_batch8_every_image(golden_dir, dname):
     print(f"[det512 B=8 {dname}] worst batch-8 vs batch-1 deviation over the 8 images: {worst:.2e}")
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16", "high"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "high", "mixed"])
 def test_seg1024tiled_vs_reference_golden(golden_dir, dname):
     """BASELINE configs[3]: --vae-encoder-tiled --cldm-tiled at 1024x1024 (demo.py:96-124)."""
     from edtr_amd import workloads
     from edtr_amd.testing import rel_err
     dev = _need_gpu()
     g = np.load(os.path.join(golden_dir, "full_seg1024.npz"))
-    cldm, diffusion, sampler = _build(dev, DTYPES[dname])
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision=dname if dname in ("high", "mixed") else None)
     inp = workloads.make_inputs("seg1024tiled", 1024, dev, 1, 1024)
     fwd = cldm.forward
     img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "seg1024tiled", fwd)
@@ -100,20 +100,21 @@ def test_seg1024tiled_vs_reference_golden(golden_dir, dname):
     e_img = rel_err(_samples(img), g["img_samples"].astype(np.float32))
     print(f"\n[seg1024tiled {dname}] vs reference: tiled z_pre {e_pre:.2e} latent {e_z:.2e} image {e_img:.2e}")
     assert tuple(img.shape) == (1, 3, 1024, 1024) and torch.isfinite(img).all()
-    assert e_pre < tol["latent"] and e_z < tol["latent"] and e_img < tol["image"]
+    assert e_pre < tol["z_pre"] and e_z < tol["latent"] and e_img < tol["image"]
     np.testing.assert_allclose(float(img.mean()), g["img_stats"][0], atol=5e-3)
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16", "high"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "high", "mixed"])
 def test_det512s50_vs_reference_golden(golden_dir, dname):
     """BASELINE configs[4] per GPU (batch 4, 50 spaced steps from pure noise, every step the same program): image 0 vs the
     reference's `SpacedSampler.sample(steps=50)` with the same injected per-step noise.  50 sequential network evaluations
-    compound the 16-bit rounding: the tolerance is 2x the per-4-step one."""
+    compound the rounding differently from the 4-step path (measured: smaller for the 16-bit modes, larger for the parity
+    modes): the parity modes are held to the north-star 1e-3, the 16-bit modes to their 4-step envelopes."""
     from edtr_amd import workloads
     from edtr_amd.testing import rel_err
     dev = _need_gpu()
     g = np.load(os.path.join(golden_dir, "full_s50.npz"))
-    cldm, diffusion, sampler = _build(dev, DTYPES[dname])
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision=dname if dname in ("high", "mixed") else None)
     inp = workloads.make_inputs("det512s50", 1024, dev, 4, 512, with_step_noises=True)
     img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "det512s50")
     torch.cuda.synchronize()
@@ -122,8 +123,9 @@ def test_det512s50_vs_reference_golden(golden_dir, dname):
     e_img = rel_err(_samples(img[:1]), g["img_samples"].astype(np.float32))
     print(f"\n[det512s50 {dname}] image 0 vs reference after 50 steps: latent {e_z:.2e} image {e_img:.2e}")
     assert torch.isfinite(img).all()
-    k = 1 if dname == "high" else 2            # the parity mode holds the north-star 1e-3 even after 50 steps
-    assert e_z < k * tol["latent"] and e_img < k * tol["image"]
+    if dname in ("high", "mixed"):
+        tol = {"latent": 1e-3, "image": 1e-3}   # the parity modes hold the north-star 1e-3 even after 50 steps
+    assert e_z < tol["latent"] and e_img < tol["image"]
 
 
 @pytest.mark.parametrize("dname", ["bf16", "fp16"])
@@ -134,7 +136,7 @@ def test_controlnet_controls_vs_reference_golden(golden_dir, dname):
     from edtr_amd.testing import rel_err
     dev = _need_gpu()
     dtype = DTYPES[dname]
-    tol = 4e-3 if dname == "fp16" else 3e-2
+    tol = 2.8e-3 if dname == "fp16" else 2.4e-2      # measured worst (ctrl12, tiny): 1.89e-3 / 1.61e-2
     # tiny config: controls of the first step (t = 200) of the tiny pipeline golden
     g = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))
     cldm, _, _ = _build(dev, dtype, "tiny")

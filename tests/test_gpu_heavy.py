@@ -1,0 +1,124 @@
+"""Range robustness on the MI355X (pytest -m gpu): the HEAVY-TAILED synthetic weight set (edtr_amd.synth.synth_param_heavy:
+outlier channels, large norm gains, sharp attention; residual stream peaking at ~2e4, the edge of fp16) against the
+reference's outputs on the same weights (tests/golden/heavy.npz, tools/make_goldens.py gen_heavy).  Every precision mode must
+stay finite and inside its envelope; the attention kernel is also driven to logits of +-1e4 on its own.
+
+The smooth weight set of the other fixtures has benign statistics (no outlier channels); released checkpoints do not exist
+offline, so this is the closest stand-in for their operand range (VERDICT r02 missing 5 / next 9)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+USED = [50, 100, 150, 200]
+# mode -> (compute dtype, precision, tolerances).  This network amplifies a perturbation ~10-30x more than the smooth set
+# (sharper attention: the fp32 oracle itself is 6.6e-5 from the reference here, 2e-5 there), and the attention operands are
+# fp16 in EVERY mode (as in the reference's own fp16-autocast GPU path), which is what bounds the parity modes on it.
+# Tolerances: <= 1.5 x the measured values (profiles/r03/heavy_weights_tests.log):
+#   tiny pipeline (z_pre, z, img):  bf16 9.0e-3 5.9e-2 9.4e-2 | fp16 1.1e-3 6.9e-3 1.08e-2 | mixed 4.4e-4 1.03e-2 1.53e-2 | high 4.8e-5 2.2e-3 3.3e-3
+#   SD-2.1 widths (eps, vae_z, vae_dec): bf16 6.0e-2 1.1e-2 1.1e-2 | fp16 5.7e-3 1.4e-3 1.4e-3 | mixed 3.9e-3 4.7e-4 4.1e-4 | high 2.6e-3 1.2e-4 1.9e-4
+MODES = {"bf16": (torch.bfloat16, "fast", dict(z_pre=1.35e-2, z=8.8e-2, img=1.4e-1, eps=9e-2, vae=1.65e-2)),
+         "fp16": (torch.float16, "fast", dict(z_pre=1.65e-3, z=1.03e-2, img=1.6e-2, eps=8.5e-3, vae=2.1e-3)),
+         "mixed": (None, "mixed", dict(z_pre=6.6e-4, z=1.55e-2, img=2.3e-2, eps=5.8e-3, vae=7e-4)),
+         "high": (None, "high", dict(z_pre=7.2e-5, z=3.3e-3, img=5e-3, eps=3.9e-3, vae=2.9e-4))}
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def finite(*ts):
+    return all(bool(torch.isfinite(t).all()) for t in ts)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_tiny_pipeline_heavy_weights(golden_dir, mode):
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise
+    d = dev()
+    dtype, precision, tol = MODES[mode]
+    g = np.load(os.path.join(golden_dir, "heavy.npz"))
+    cldm = build_synthetic_cldm(synth.tiny_config(), d, dtype, precision=precision, weights="heavy")
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(d)
+    sampler = SpacedSampler(diffusion.betas)
+    B, H, W = 2, 128, 128
+    pre_res = synth.synth_input("heavy:pre_res", (B, 3, H, W), 0.0, 1.0).to(d)
+    c_txt = synth.synth_input("heavy:c_txt", (B, 77, 64), -1.0, 1.0).to(d)
+    noises = [synth.synth_normal(f"heavy:noise{i}", (B, 4, H // 8, W // 8)).to(d) for i in range(5)]
+    z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
+    x_T = diffusion.q_sample(z_pre, torch.full((B,), 200, dtype=torch.int64, device=d), noises[0])
+    with injected_noise(noises[1:]):
+        z = sampler.manual_sample_with_timesteps(model=cldm, device=d, x_T=x_T, steps=4, used_timesteps=USED, batch_size=B,
+                                                 cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+    img = cldm.vae_decode(z)
+    torch.cuda.synchronize()
+    assert finite(z_pre, z, img), "non-finite values with the heavy-tailed weights"
+    errs = {"z_pre": rel(z_pre, g["z_pre"]), "z": rel(z, g["z"]), "img": rel(img, g["img"])}
+    print(f"\n[heavy tiny, {mode}] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert all(v < tol[k] for k, v in errs.items()), errs
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_sd21_width_step_and_vae_heavy_weights(golden_dir, mode):
+    """SD-2.1 widths: one ControlNet + UNet evaluation (residual stream up to ~2e4) and the VAE, heavy weights."""
+    from edtr_amd import synth
+    from edtr_amd.testing import build_synthetic_cldm
+    d = dev()
+    dtype, precision, tol = MODES[mode]
+    g = np.load(os.path.join(golden_dir, "heavy.npz"))
+    cldm = build_synthetic_cldm(synth.sd21_config(), d, dtype, precision=precision, weights="heavy")
+    x = synth.synth_normal("heavy:x", (1, 4, 32, 32)).to(d)
+    c_img = synth.synth_normal("heavy:c_img", (1, 4, 32, 32)).to(d)
+    c_txt = synth.synth_input("heavy:c_txt", (1, 77, 1024), -1.0, 1.0).to(d)
+    eps = cldm.forward(x, torch.tensor([200], device=d), {"c_txt": c_txt, "c_img": c_img})
+    z = cldm.vae_encode(synth.synth_input("heavy:img", (1, 3, 128, 128), -1.0, 1.0).to(d), sample=False)
+    dec = cldm.vae_decode(synth.synth_normal("heavy:zdec", (1, 4, 16, 16)).to(d))
+    torch.cuda.synchronize()
+    assert finite(eps, z, dec), "non-finite values with the heavy-tailed weights"
+    errs = {"eps": rel(eps, g["sd21_eps"]), "vae_z": rel(z, g["sd21_vae_z"]), "vae_dec": rel(dec, g["sd21_vae_dec"])}
+    print(f"\n[heavy sd21 widths, {mode}; reference stream peak {float(g['sd21_mid_absmax'][0]):.0f} at the middle block] "
+          + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert errs["eps"] < tol["eps"] and errs["vae_z"] < tol["vae"] and errs["vae_dec"] < tol["vae"], errs
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,peak", [(256, 1.0e4), (4096, 1.0e4), (1024, 300.0)])
+def test_flash_attention_with_extreme_logits(dtype, N, peak):
+    """Logits up to +-peak (softmax essentially one-hot, exp of the raw logit overflows fp32 at 88): both attention kernels
+    (the general one and, at N = 4096, the generated-asm large-N one incl. its re-maximise path) against torch softmax in
+    fp64 on the same 16-bit inputs."""
+    from edtr_amd import ops
+    d = dev()
+    B, H = 1, 2
+    g = torch.Generator().manual_seed(7)
+    s = (peak * 8.0 / 64.0) ** 0.5           # q.k / 8 over 64 dims of magnitude s*s: |logit| up to ~peak for aligned vectors
+    q = (torch.randn((B, N, H * 64), generator=g) * s).to(dtype)
+    k = (torch.randn((B, N, H * 64), generator=g) * s).to(dtype)
+    k[:, ::7] = q[:, ::7]                    # aligned pairs: the largest logits sit on these keys
+    v = torch.randn((B, N, H * 64), generator=g).to(dtype)
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty((B * N, H * 64), dtype=dtype, device=d)
+    qd, kd, vtd = q.to(d).reshape(B * N, -1), k.to(d).reshape(B * N, -1), vt.to(d).reshape(B * H * 64, N)
+    ops.launch(ops.make_flash_attn(dtype=dtype, q=qd, k=kd, vt=vtd, out=out, B=B, H=H, Nq=N, Nk=N, q_bs=N * H * 64, q_ld=H * 64,
+                                   k_bs=N * H * 64, k_ld=H * 64, vt_bs=H * 64 * N, vt_ld=N, o_bs=N * H * 64, o_ld=H * 64,
+                                   scale=1.0 / 8.0))
+    torch.cuda.synchronize()
+    assert finite(out)
+    qf, kf, vf = (t.double().reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+    logits = qf @ kf.transpose(-1, -2) / 8.0
+    want = (torch.softmax(logits, dim=-1) @ vf).permute(0, 2, 1, 3).reshape(B * N, H * 64)
+    e = rel(out.float(), want)
+    print(f"\n[attention, {dtype}, N={N}] max |logit| {float(logits.abs().max()):.0f}; rel err {e:.2e}")
+    assert e < (1.6e-3 if dtype == torch.bfloat16 else 2.2e-4)          # measured <= 1.03e-3 / 1.4e-4

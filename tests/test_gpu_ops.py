@@ -1,7 +1,9 @@
 """Per-kernel parity tests (run on the MI355X box: pytest -m gpu).  Every HIP kernel is called through the
 C ABI (edtr_amd.ops -> libedtr_hip.so) and compared with a plain torch fp32 CPU computation of the same op
 on the same 16-bit-rounded inputs.  Stated tolerances (relative L2 error of the output tensor):
-  bf16 storage: 6e-3 (one output rounding is 2^-9 = 2e-3 max)     fp16 storage: 1e-3."""
+  bf16 storage: 3.5e-3     fp16 storage: 4.4e-4
+(<= 1.5 x the largest error any kernel measures, 2.34e-3 / 2.95e-4 — the attention kernels; test_zz_measured_error_envelope
+prints the current envelope; a 2x regression of any kernel's numerics fails)."""
 import math
 
 import pytest
@@ -11,7 +13,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.bfloat16, torch.float16]
-TOL = {torch.bfloat16: 6e-3, torch.float16: 1e-3}
+TOL = {torch.bfloat16: 3.5e-3, torch.float16: 4.4e-4}
 
 
 def _ops():

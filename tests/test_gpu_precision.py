@@ -11,6 +11,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 NORTH_STAR = 1e-3
+# what the mode is held to: 1.5 x its largest measured error (per-step eps 2.1e-4; latents / images 2e-5 .. 7.5e-5)
+HIGH_TOL = 3.2e-4
 USED = [50, 100, 150, 200]
 
 
@@ -138,7 +140,7 @@ def _pipeline(golden_dir, name, tag, B, H, W):
 @pytest.mark.parametrize("name,tag,B,H,W", [("tiny_pipeline.npz", "tiny", 2, 128, 128), ("tiny_pipeline_rect.npz", "tinyrect", 1, 192, 128)])
 def test_tiny_pipeline_meets_the_north_star(golden_dir, name, tag, B, H, W):
     errs = _pipeline(golden_dir, name, tag, B, H, W)
-    assert all(v < NORTH_STAR for v in errs.values()), errs
+    assert all(v < HIGH_TOL for v in errs.values()), errs
 
 
 def test_sd21_width_networks_meet_the_north_star(golden_dir):
@@ -159,7 +161,7 @@ def test_sd21_width_networks_meet_the_north_star(golden_dir):
     torch.cuda.synchronize()
     errs = {"eps": rel(eps, g["eps"]), "vae_z": rel(z, g["vae_z"]), "vae_dec": rel(dec, g["vae_dec"]), "ctrl12": rel(ctrl[12], g["ctrl12"])}
     print(f"\n[high precision sd21 widths] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
-    assert all(v < NORTH_STAR for v in errs.values()), errs
+    assert all(v < HIGH_TOL for v in errs.values()), errs
 
 
 def test_det512_full_size_meets_the_north_star(golden_dir):
@@ -184,7 +186,7 @@ def test_det512_full_size_meets_the_north_star(golden_dir):
             "img": rel(img[:, :, 1::4, 2::4], g["img_samples"].astype(np.float32))}
     print(f"\n[high precision det512 full size] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     # the image golden is stored as fp16 samples (rounding 2^-11 relative per sample -> 2.8e-4 rms): budget it
-    assert errs["z_pre"] < NORTH_STAR and errs["z"] < NORTH_STAR and errs["img"] < NORTH_STAR, errs
+    assert errs["z_pre"] < 4e-5 and errs["z"] < 1.1e-4 and errs["img"] < 1.1e-4, errs      # measured 1.8e-5 / 7.2e-5 / 7.3e-5
 
 
 def test_tiled_paths_meet_the_north_star(golden_dir):
@@ -217,4 +219,4 @@ def test_tiled_paths_meet_the_north_star(golden_dir):
     torch.cuda.synchronize()
     e_z = rel(z, g2["z_tiled"])
     print(f"\n[high precision tiled] tiled vae enc {e_enc:.2e} dec {e_dec:.2e}; latent-tiled sampler {e_z:.2e}")
-    assert e_enc < NORTH_STAR and e_dec < NORTH_STAR and e_z < NORTH_STAR
+    assert e_enc < 5e-5 and e_dec < 5e-5 and e_z < 5.5e-5      # measured 3.0e-5 / 1.7e-5 / 3.4e-5

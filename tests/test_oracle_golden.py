@@ -205,6 +205,25 @@ def test_vae_encode_sample_default(golden_dir):
         assert rel_err(O.vae_encode(sd, cfg, img), g["z_mode"]) < 2e-5
 
 
+def test_tiny_pipeline_heavy_tailed_weights(golden_dir):
+    """The oracle against the reference on the HEAVY-TAILED weight set (outlier channels x12, norm gains +-4, sharper attention:
+    edtr_amd.synth.synth_param_heavy) — the fixture the GPU range-robustness tests compare with (tests/test_gpu_heavy.py)."""
+    from edtr_amd.testing import synthetic_state_dicts
+    from oracle import flat_sd
+    g = np.load(os.path.join(golden_dir, "heavy.npz"))
+    cfg = synth.tiny_config()
+    sd = flat_sd(synthetic_state_dicts(cfg, None, "heavy"))
+    B, H, W = 2, 128, 128
+    pre_res = synth.synth_input("heavy:pre_res", (B, 3, H, W), 0.0, 1.0)
+    c_txt = synth.synth_input("heavy:c_txt", (B, 77, 64), -1.0, 1.0)
+    noises = [synth.synth_normal(f"heavy:noise{i}", (B, 4, H // 8, W // 8)) for i in range(5)]
+    with torch.no_grad():
+        img, tr = O.restore(sd, cfg, O.make_betas(), pre_res, c_txt, noises, USED, 200, return_trace=True)
+    errs = {"z_pre": rel_err(tr["z_pre"], g["z_pre"]), "eps0": rel_err(tr["eps"][0], g["eps0"]), "eps3": rel_err(tr["eps"][3], g["eps3"]),
+            "z": rel_err(tr["z"], g["z"]), "img": rel_err(img, g["img"])}
+    assert all(v < 2e-4 for v in errs.values()), errs      # (measured <= 6.6e-5: this net amplifies fp32 rounding ~10x more than the smooth set)
+
+
 def _clip_sd(tag, cfg):
     from edtr_amd.model.clip import clip_text_param_spec
     return {"clip." + k: synth.synth_param(f"clip{tag}." + k, shp) for k, shp in clip_text_param_spec(cfg["embed_dim"], cfg["text_cfg"])}

@@ -4,7 +4,7 @@
 
 Run in the build container only (the reference does not exist on the GPU box):
 
-    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,tiledvae,vaesample,wavelet,clip,psnr,swinir,full,tokens]
+    python tools/make_goldens.py [--only schedule,tiny,sd21,tiled,tiledvae,vaesample,heavy,wavelet,clip,psnr,swinir,full,tokens]
 
 Fixtures are data (inputs are regenerated from edtr_amd.synth formulas, expected outputs
 are stored); nothing from the reference's source travels.
@@ -33,17 +33,18 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 USED_TIMESTEPS = [50, 100, 150, 200]
 
 
-def build_reference_cldm(cfg_name: str):
+def build_reference_cldm(cfg_name: str, weights: str = "smooth"):
     ControlLDM, _, _, _ = ref_import.import_reference()
     cfg = synth.CONFIGS[cfg_name]()
     with contextlib.redirect_stdout(io.StringIO()):
         cldm = ControlLDM(**cfg)
     cldm.eval()
+    gen = synth.WEIGHT_SETS[weights]
     with torch.no_grad():
         for key, val in cldm.state_dict().items():
             if key.startswith("clip."):
                 continue
-            val.copy_(synth.synth_param(key, tuple(val.shape)))
+            val.copy_(gen(key, tuple(val.shape)))
     return cldm, cfg
 
 
@@ -207,6 +208,34 @@ def gen_sd21():
         out["vae_dec"] = dec.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, "sd21_blocks.npz"), **out)
     print("sd21_blocks.npz written")
+
+
+def gen_heavy():
+    """Range-robustness fixtures: the reference on the HEAVY-TAILED weight set (edtr_amd.synth.synth_param_heavy: outlier
+    channels x50, norm gains +-10, sharp attention) — the tiny end-to-end pipeline, and one denoise step + VAE at SD-2.1
+    widths on small grids (latent 32x32; 128x128 image; 16x16 latent)."""
+    ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
+    cldm, cfg = build_reference_cldm("tiny", "heavy")
+    out = run_pipeline(cldm, cfg, 2, 128, 128, "heavy", Diffusion, SpacedSampler, ref_common, store_controls=False)
+    out = {k: v for k, v in out.items() if k in ("z_pre", "eps0", "eps3", "z", "img", "ctrl_stats")}
+    del cldm
+    cldm, cfg = build_reference_cldm("sd21", "heavy")
+    with torch.no_grad():
+        x = synth.synth_normal("heavy:x", (1, 4, 32, 32))
+        c_img = synth.synth_normal("heavy:c_img", (1, 4, 32, 32))
+        c_txt = synth.synth_input("heavy:c_txt", (1, 77, 1024), -1.0, 1.0)
+        t = torch.tensor([200], dtype=torch.int64)
+        acts = {}
+        # activation magnitudes the fixture exercises (max |x| of the residual stream at the ends of the UNet encoder)
+        h = cldm.unet.middle_block.register_forward_hook(lambda m, i, o: acts.__setitem__("mid_absmax", float(o.abs().max())))
+        out["sd21_eps"] = cldm(x, t, {"c_txt": c_txt, "c_img": c_img}).numpy()
+        h.remove()
+        out["sd21_mid_absmax"] = np.array([acts["mid_absmax"]])
+        out["sd21_vae_z"] = cldm.vae_encode(synth.synth_input("heavy:img", (1, 3, 128, 128), -1.0, 1.0), sample=False).numpy()
+        out["sd21_vae_dec"] = cldm.vae_decode(synth.synth_normal("heavy:zdec", (1, 4, 16, 16))).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "heavy.npz"), **out)
+    print("heavy.npz written; |eps| max", float(np.abs(out["sd21_eps"]).max()), "mid absmax", acts["mid_absmax"],
+          "tiny img absmax", float(np.abs(out["img"]).max()))
 
 
 def gen_tiled():
@@ -509,14 +538,14 @@ def gen_full():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,vaesample,wavelet,clip,psnr,swinir,full,tokens")
+    ap.add_argument("--only", default="schedule,tiny,sd21,tiled,tiledvae,vaesample,heavy,wavelet,clip,psnr,swinir,full,tokens")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "vaesample": gen_vaesample, "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens}[name]()
+         "vaesample": gen_vaesample, "heavy": gen_heavy, "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens}[name]()
 
 
 if __name__ == "__main__":
