@@ -161,6 +161,30 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
+// Transposed store of a staged tile whose columns are the V part of a fused [Q; K; V] projection: V^T[image][c][token], 8
+// consecutive tokens (rows of the tile) of one column per 16-byte store.  Lane (slot, cl): 16 adjacent columns per slot — the
+// LDS reads of a slot walk 16 adjacent banks (slots collide 4-way: 8 reads per lane, negligible), the 16-byte stores of the
+// lanes that share a column are adjacent in memory.
+template <typename T, int BM, int BNO, int THREADS, int PITCH>
+__device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float* stage, int m0, int no0) {
+    static_assert(BM % 8 == 0 && BNO % 16 == 0 && THREADS % 16 == 0, "vt_store tiling");
+    constexpr int TG = BM / 8, NCB = BNO / 16, SLOTS = THREADS / 16, PAIRS = TG * NCB;
+    const int tid = threadIdx.x, cl = tid & 15, slot = tid >> 4;
+    const int vt_rows = p.N - p.vt_col0;
+    uint16_t* vt = static_cast<uint16_t*>(p.vt_out);
+    for (int u = slot; u < PAIRS; u += SLOTS) {
+        const int tg = u % TG, cb = u / TG;
+        const int cloc = cb * 16 + cl, n = no0 + cloc, m = m0 + tg * 8;
+        if (m >= p.M || n >= p.N) continue;
+        const float b = p.bias_n ? p.bias_n[n] : 0.0f;
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = __builtin_fmaf(stage[(tg * 8 + i) * PITCH + cloc], p.vt_alpha, b);
+        const int img = m / p.rows_per_image, tok = m - img * p.rows_per_image;
+        stg16(vt + ((int64_t)img * vt_rows + (n - p.vt_col0)) * p.vt_ld + tok, pack8<T>(f));
+    }
+}
+
 template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false, int PITCH = BNO, typename Hook = NoHook>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8], Hook before_publish = Hook()) {
@@ -188,6 +212,15 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             }
         }
         return;
+    }
+
+    if constexpr (!GEGLU && !PATCH16) {
+        if (p.vt_out != nullptr && no0 >= p.vt_col0) {    // a V tile of the fused [Q; K; V] projection: transposed store
+            before_publish();
+            __syncthreads();
+            vt_store<T, BM, BNO, THREADS, PITCH>(p, stage, m0, no0);
+            return;
+        }
     }
 
     U4 res[ITER];
@@ -2809,6 +2842,13 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (p.splitk > (p.K + 63) / 64) return EDTR_E_SHAPE;
     }
 
+    if (p.vt_out) {
+        if (p.Z != 1 || p.splitk > 1 || p.act == EDTR_ACT_GEGLU || p.residual || p.rowvec || p.gn_partial || p.out_f32 || spatial)
+            return EDTR_E_UNSUPPORTED;
+        if (p.rows_per_image <= 0 || (p.rows_per_image & 7) || (p.M & 7) || p.vt_col0 <= 0 || p.vt_col0 >= p.N) return EDTR_E_SHAPE;
+        if ((p.vt_ld & 7) || p.vt_ld < p.rows_per_image || !aligned16(p.vt_out)) return EDTR_E_ALIGN;
+    }
+
     // the LDS-DMA main loops need every 64-wide K-tile inside one tap of one source
     const bool dma_ok = p.C2 == 0 && (p.C1 & 63) == 0;
     int tile = p.tile;
@@ -2875,6 +2915,13 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         //  convolutions but -0.5..-1 % on the whole path in the same A/B; opt-in)
         // (the 64x128 tile 9 wins 10-30 % in isolation on the short-K GEMMs of the 16x16 / 8x8 latent levels but cost 1 % of
         //  whole-path throughput in an A/B on one device — its 3 workgroups per CU crowd the concurrent stream — so it stays opt-in)
+    }
+    if (p.vt_out) {     // the transposed V store needs whole column tiles of V: tiles 1 / 3 (128 columns) or 8 (160)
+        if (p.tile == 0 && !((tile == 8 && p.vt_col0 % 160 == 0) || ((tile == 1 || tile == 3) && p.vt_col0 % 128 == 0)))
+            tile = (dma_ok && p.N % 160 == 0 && p.vt_col0 % 160 == 0 && igemm_fast_addressable(p, spatial)) ? 8
+                   : (p.vt_col0 % 128 == 0 ? (dma_ok ? 3 : 1) : -1);
+        const int bn = tile == 8 ? 160 : 128;
+        if (!(tile == 1 || tile == 3 || tile == 8) || p.vt_col0 % bn != 0) return EDTR_E_UNSUPPORTED;
     }
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;

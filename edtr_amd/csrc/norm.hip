@@ -142,13 +142,46 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
     using out_t = typename IO::out_t;
     __shared__ __attribute__((aligned(16))) float sc[GN_CC];
     __shared__ __attribute__((aligned(16))) float sh[GN_CC];
+    // fused finalize: per-channel totals of the producer's tile partials, for the chunk's channels extended to whole groups
+    // (the SD widths' 10 / 20 / 40 channels per group do not divide the 256-channel chunk: <= 2 x 63 extra channels)
+    __shared__ double chan_s[GN_CC + 128], chan_q[GN_CC + 128];
     const int tid = threadIdx.x, b = blockIdx.z;
     const int c0 = blockIdx.y * GN_CC;
     const int cc = min(GN_CC, p.C - c0);
     const int cpg = p.C / p.groups;
     const double cnt = (double)p.HW * cpg;
+    const int glo = (c0 / cpg) * cpg;                                   // first channel of the first group touching the chunk
+    if (p.partial) {
+        // every workgroup folds the <= 64 tiles x (its channels, extended to whole groups) itself — a few KB from L2 — instead
+        // of a separate finalize launch
+        const int ghi = min(p.C, ((c0 + cc + cpg - 1) / cpg) * cpg);
+        for (int ch = glo + tid; ch < ghi; ch += 256) {
+            const float* src = p.partial + ((int64_t)b * p.tiles_per_image * p.C + ch) * 2;
+            double s = 0.0, q = 0.0;
+            for (int t = 0; t < p.tiles_per_image; ++t) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(src + (int64_t)t * p.C * 2);
+                s += (double)v[0];
+                q += (double)v[1];
+            }
+            chan_s[ch - glo] = s;
+            chan_q[ch - glo] = q;
+        }
+        __syncthreads();
+    }
     for (int c = tid; c < cc; c += 256) {
-        const double* src = p.sums + ((int64_t)b * p.groups + (c0 + c) / cpg) * 2;
+        double gsum[2];
+        if (p.partial) {
+            const int g0 = ((c0 + c) / cpg) * cpg - glo;      // first channel of this channel's group, relative to glo
+            double s = 0.0, q = 0.0;
+            for (int j = 0; j < cpg; ++j) { s += chan_s[g0 + j]; q += chan_q[g0 + j]; }
+            gsum[0] = s;
+            gsum[1] = q;
+        } else {
+            const double* srcd = p.sums + ((int64_t)b * p.groups + (c0 + c) / cpg) * 2;
+            gsum[0] = srcd[0];
+            gsum[1] = srcd[1];
+        }
+        const double* src = gsum;
         const double mean = src[0] / cnt;
         double var = src[1] / cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
@@ -323,7 +356,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* s, int c
 }
 
 int check_gn(const edtr_gn_params& p, bool apply) {
-    if (!p.x || !p.sums) return EDTR_E_NULL;
+    if (!p.x || (!p.sums && !(apply && p.partial))) return EDTR_E_NULL;
     if (apply && (!p.y || !p.gamma || !p.beta)) return EDTR_E_NULL;
     if (p.dtype < EDTR_BF16 || p.dtype > EDTR_F32_H3) return EDTR_E_DTYPE;
     if (p.B <= 0 || p.HW <= 0 || p.C <= 0 || p.groups <= 0 || p.groups > 64) return EDTR_E_SHAPE;
@@ -377,6 +410,11 @@ extern "C" int edtr_gn_apply(const edtr_gn_params* pp, edtr_stream_t stream) {
     if (!pp) return EDTR_E_NULL;
     const edtr_gn_params& p = *pp;
     if (int e = check_gn(p, true)) return e;
+    if (p.partial) {      // fused finalize: few tiles; a chunk extended to whole groups must fit the LDS arrays
+        const int cpg = p.C / p.groups;
+        if (p.tiles_per_image <= 0 || p.tiles_per_image > 64 || (int64_t)p.tiles_per_image * 128 != p.HW) return EDTR_E_SHAPE;
+        if (cpg > 64) return EDTR_E_UNSUPPORTED;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     static int generic = -1;
     if (generic < 0) {

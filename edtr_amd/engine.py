@@ -574,6 +574,31 @@ class Emitter:
         self.arena.free(tmp)
         return out
 
+    def fused_qkv_ok(self, N: int, C: int) -> bool:
+        """Can a self-attention's q / k / v^T come out of ONE edtr_igemm launch (transposed second output)?  Needs a 16-bit
+        output of the attention operand type (not the high mode, whose MFMA type is bf16 while attention runs on fp16) and V
+        columns that start on a column-tile boundary (every SD width: 2C is a multiple of 160 or 128)."""
+        if self.hp and not self.direct16:
+            return False
+        return N % 8 == 0 and C % 64 == 0 and ((2 * C) % 160 == 0 or (2 * C) % 128 == 0) and os.environ.get("EDTR_FUSED_QKV", "1") != "0"
+
+    def qkv_gemm(self, x, w, *, B: int, N: int, C: int, alpha: float, name: str = "attn1.qkv"):
+        """[Q; K; V] = x @ [Wq; Wk; Wv]^T in one launch: (qk [B*N, 2C] row-major with `alpha` applied, v^T [B*C, N] transposed
+        by the epilogue, unscaled).  reference model/attention.py:170-178 (to_q / to_k / to_v + the head rearranges)."""
+        M = B * N
+        parts = self.parts_for(name, M, 3 * C, C)
+        tmp = None
+        if self.hp:
+            x, tmp, parts = self._operand(x, M, C, parts)
+        wt = self._w(w, parts)
+        qk = self.arena.alloc((M, 2 * C), self.attn_dtype)
+        vt = self.arena.alloc((B * C, N), self.attn_dtype)
+        self.prog.add(ops.make_igemm(dtype=self.dtype, a1=x, w=wt, out=qk, M=M, N=3 * C, C1=parts * C, ld1=x.stride(0),
+                                     ldw=wt.stride(0), ldc=2 * C, alpha=alpha, rows_per_image=N, vt_out=vt, vt_col0=2 * C, vt_ld=N,
+                                     vt_alpha=1.0, name=name))
+        self.arena.free(tmp)
+        return qk, vt, N
+
     def conv(self, x: Act, prefix: str, *, taps=9, stride=1, pad_tl=1, ups=False, rowvec=None, residual=None,
              out=None, out_f32=False, alpha=1.0, name=None, stats=False) -> Act:
         """3x3 (or 1x1) convolution of an NHWC activation with the packed weight ``prefix``."""
@@ -615,14 +640,15 @@ class Emitter:
         return Act(out, x.B, OH, OW, N, gnp)
 
     # -- norms --------------------------------------------------------------------------------
-    def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, y: torch.Tensor,
-                 sums_zeroed: bool = False, parts: int = 1):
+    def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: Optional[torch.Tensor], y: torch.Tensor,
+                 sums_zeroed: bool = False, parts: int = 1, partial=None):
         gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
         c_real = self.store.params[prefix + "weight"].numel()
         if c_real != x.C:
             raise ValueError(f"GroupNorm {prefix}: activation has {x.C} channels, parameter has {c_real}")
         return ops.make_gn(dtype=self.op_fmt(parts) if self.hp else self.io, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C,
-                           sums=sums, gamma=gamma, beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed)
+                           sums=sums, gamma=gamma, beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed,
+                           partial=partial)
 
     def _norm_out(self, rows: int, C: int, parts: int):
         """(buffer the apply launch writes, what the caller carries): fp32-stream modes = the multi-part operand itself."""
@@ -640,16 +666,23 @@ class Emitter:
             y, carried = out, out
         else:
             y, carried = self._norm_out(x.rows, x.C, parts)
-        if x.gnp is not None:    # the producer's epilogue already reduced this tensor per 128-row tile
+        sums = None
+        if x.gnp is not None and ops.gn_foldable(x.H * x.W, x.C):
+            # the producer's epilogue already reduced this tensor per 128-row tile, and the tiles are few: the apply launch folds
+            # them itself (one launch per GroupNorm instead of two)
+            _, ap = self._gn_recs(x, prefix, eps, silu, None, y, parts=parts, partial=x.gnp)
+            st = None
+        elif x.gnp is not None:  # many tiles (the VAE's large levels): a finalize launch folds them once for all workgroups
             sums = self.arena.alloc((x.B, 32, 2), torch.float64)
             _, ap = self._gn_recs(x, prefix, eps, silu, sums, y, parts=parts)
             st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
         else:                    # atomically accumulated statistics: a pre-zeroed pool slot, never reused in this program
             sums = self.prog.sums_slot(self.arena, x.B)
             st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=True, parts=parts)
-        self.prog.add(st)
+        if st is not None:
+            self.prog.add(st)
         self.prog.add(ap)
-        if x.gnp is not None:
+        if x.gnp is not None and sums is not None:
             self.arena.free(sums)
         return Act(carried, x.B, x.H, x.W, x.C)
 

@@ -45,6 +45,7 @@ class IgemmParams(C.Structure):
         ("gn_partial", C.c_void_p),
         ("act_slope", C.c_float),
         ("residual_f32", C.c_int32),
+        ("vt_out", C.c_void_p), ("vt_col0", C.c_int32), ("vt_ld", C.c_int32), ("vt_alpha", C.c_float),
     ]
 
 
@@ -81,6 +82,7 @@ class GnParams(C.Structure):
         ("eps", C.c_float), ("silu", C.c_int32),
         ("y", C.c_void_p), ("ldy", C.c_int32),
         ("sums_zeroed", C.c_int32),
+        ("partial", C.c_void_p), ("tiles_per_image", C.c_int32),
     ]
 
 

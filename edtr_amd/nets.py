@@ -119,7 +119,14 @@ def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C:
     # c on the cross-attention's Q (its K comes from the per-prompt context program) — no extra rounding, one multiply
     # less per score in the attention kernel
     c = ATTN_PRESCALE
-    if ctx is None:   # self attention: fused [Wq;Wk] projection, V^T via the operand-swapped GEMM
+    if ctx is None and em.fused_qkv_ok(N, C):
+        # self attention: ONE launch for [Wq; Wk; Wv] — q / k row-major (scaled), v^T written transposed by the epilogue
+        wqkv, _ = em.store.linear([p + "to_q.weight", p + "to_k.weight", p + "to_v.weight"])
+        qk, vt, ldv = em.qkv_gemm(x, wqkv, B=B, N=N, C=C, alpha=math.sqrt(c))
+        o = em.flash(qk[:, :C], qk[:, C:], vt, B=B, H=heads, Nq=N, Nk=N, k_bs=N * qk.stride(0), vt_bs=C * ldv, vt_ld=ldv,
+                     prescaled=True)
+        em.free(qk, vt)
+    elif ctx is None:   # (high mode / odd shapes) fused [Wq;Wk] projection, V^T via the operand-swapped GEMM
         wqk, _ = em.store.linear([p + "to_q.weight", p + "to_k.weight"])
         qk = em.gemm(x, wqk, B * N, 2 * C, C, alpha=math.sqrt(c), name="attn1.qk", out16=True)
         wv, _ = em.store.linear([p + "to_v.weight"])
@@ -149,7 +156,7 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in")
     em.free(n)
     tb = p + "transformer_blocks.0."
-    l1 = em.layer_norm(t, rows, C, tb + "norm1.", feeds=("attn1.qk", "attn1.vT"))
+    l1 = em.layer_norm(t, rows, C, tb + "norm1.", feeds=("attn1.qkv",) if em.fused_qkv_ok(N, C) else ("attn1.qk", "attn1.vT"))
     t1 = emit_attention_core(em, tb + "attn1.", l1, B, N, C, l.heads, None, t)
     em.free(l1, t)
     l2 = em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",))

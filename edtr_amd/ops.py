@@ -66,6 +66,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                residual: Optional[torch.Tensor] = None, ldr: int = 0, out_f32: bool = False, n_valid: int = 0,
                tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None,
                gn_partial: Optional[torch.Tensor] = None, act_slope: float = 0.0, residual_f32: bool = False,
+               vt_out: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_ld: int = 0, vt_alpha: float = 1.0,
                name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
@@ -89,6 +90,8 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     p.gn_partial = ptr(gn_partial)
     p.act_slope = act_slope
     p.residual_f32 = int(residual_f32)
+    if vt_out is not None:
+        p.vt_out, p.vt_col0, p.vt_ld, p.vt_alpha = ptr(vt_out), vt_col0, vt_ld, vt_alpha
     flops = 2.0 * M * N * p.K * Z
     # algorithmic HBM bytes: every operand once (a conv reads its input image once, not once per tap)
     a_rows = (M // (p.OH * p.OW)) * p.IH * p.IW if spatial else M
@@ -96,7 +99,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     nbytes = Z * (2.0 * a_rows * (C1 + C2) + 2.0 * N * p.K + (4.0 if out_f32 else 2.0) * M * n_out
                   + ((4.0 if residual_f32 else 2.0) * M * n_out if residual is not None else 0.0))
     rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
-                                                    gn_partial), name, flops, nbytes)
+                                                    gn_partial, vt_out), name, flops, nbytes)
     rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
                + (" up2" if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
                + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else ""))
@@ -165,16 +168,27 @@ def make_zero(t: torch.Tensor, name: str = "zero") -> Rec:
     return Rec(L.load().edtr_zero_bytes, (ptr(t), nbytes), (t,), name, 0.0, float(nbytes))
 
 
+GN_FOLD_MAX_TILES = 64      # edtr_gn_apply folds the producer's per-tile partials itself up to this many 128-row tiles per image
+
+
+def gn_foldable(HW: int, C: int, groups: int = 32) -> bool:
+    """Can edtr_gn_apply fold the producing igemm's partials itself (no edtr_gn_finalize launch)?"""
+    return HW % 128 == 0 and HW // 128 <= GN_FOLD_MAX_TILES and C // groups <= 64
+
+
 def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, groups: int = 32, name="gn",
-            sums_zeroed: bool = False):
-    """Returns (stats_rec, apply_rec)."""
+            sums_zeroed: bool = False, partial=None):
+    """Returns (stats_rec, apply_rec).  ``partial``: the producing igemm's gn_partial tensor — the apply launch folds it
+    itself (gn_foldable) and ``sums`` may be None."""
     p = L.GnParams()
     p.dtype, p.B, p.HW, p.C, p.groups = dt_code(dtype), B, HW, C, groups
     p.x, p.ldx, p.sums = ptr(x), ldx, ptr(sums)
     p.gamma, p.beta, p.eps, p.silu = ptr(gamma), ptr(beta), eps, int(silu)
     p.y, p.ldy = ptr(y), ldy
     p.sums_zeroed = int(sums_zeroed)
-    keep = (p, x, sums, gamma, beta, y)
+    if partial is not None:
+        p.partial, p.tiles_per_image = ptr(partial), HW // 128
+    keep = (p, x, sums, gamma, beta, y, partial)
     lib = L.load()
     nb = 2.0 * B * HW * C
     return (Rec(lib.edtr_gn_stats, (ct.byref(p),), keep, name + ".stats", 0.0, nb),

@@ -142,6 +142,14 @@ typedef struct edtr_igemm_params {
     float act_slope;        /* negative-side slope of EDTR_ACT_LRELU (0 <= slope <= 1) */
     int32_t residual_f32;   /* nonzero: `residual` is fp32 (ldr in floats, multiple of 4): the fp32 activation stream of the
                                high / mixed precision modes adds its skip inside the epilogue instead of in a separate launch */
+    /* Transposed second output (optional): the fused [Wq; Wk; Wv] projection of a self-attention in ONE launch.  Output columns
+     * n >= vt_col0 are not stored at out[m][n] but TRANSPOSED, as the V^T operand edtr_flash_attn64 reads:
+     *   vt_out[(m / rows_per_image) * (N - vt_col0) + (n - vt_col0)][m % rows_per_image]   (row stride vt_ld, 16-bit)
+     * scaled by vt_alpha instead of alpha (the q / k halves carry the softmax scale, v does not); bias_n applies to all columns.
+     * Needs rows_per_image % 8 == 0, M % 8 == 0, vt_ld % 8 == 0, vt_col0 a multiple of the column-tile width (128, or 160 for
+     * tile 8: every SD width), Z == 1, no split-K / GEGLU / residual / rowvec, tile 0 / 1 / 3 / 8.  replaces: `to_v(x)` +
+     * the `b n (h d) -> (b h) n d` rearrange of v, reference model/attention.py:172-178. */
+    void* vt_out; int32_t vt_col0; int32_t vt_ld; float vt_alpha;
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -193,6 +201,10 @@ typedef struct edtr_gn_params {
     void* y; int32_t ldy;
     int32_t sums_zeroed;            /* edtr_gn_stats only: nonzero = the caller has already zeroed `sums` (e.g. one edtr_zero_bytes
                                        over a pool of them), so no per-call memset node is enqueued */
+    /* edtr_gn_apply only (optional): fold the per-tile column partials of the producing edtr_igemm (gn_partial,
+     * tiles_per_image = H*W/128 <= 64 tiles per image) inside the apply launch itself — `sums` is then ignored and the
+     * edtr_gn_finalize launch disappears (one launch less per GroupNorm of the UNet / ControlNet levels). */
+    const float* partial; int32_t tiles_per_image;
 } edtr_gn_params;
 
 int edtr_gn_stats(const edtr_gn_params* p, edtr_stream_t stream);

@@ -571,6 +571,66 @@ def test_fused_groupnorm_partials(dtype, cin, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,C,tile", [(2, 1024, 320, 0), (2, 256, 640, 0), (3, 64, 1280, 0), (1, 4096, 320, 8), (2, 64, 128, 3), (2, 200, 128, 1),
+                                        (1, 72, 64, 0)])
+def test_fused_qkv_projection_with_transposed_v(dtype, B, N, C, tile):
+    """One edtr_igemm launch for [Wq; Wk; Wv]: q / k row-major (scaled by alpha), v^T[image][channel][token] through the
+    transposed second output — against the separate products."""
+    ops = _ops()
+    d = dev()
+    M = B * N
+    x = rnd((M, C), 150).to(dtype)
+    w = rnd((3 * C, C), 151, 1 / math.sqrt(C))
+    wp = ops.pack_linear_weight(w, dtype).to(d)
+    qk = torch.full((M, 2 * C), 9.0, dtype=dtype, device=d)
+    vt = torch.full((B * C, N), 9.0, dtype=dtype, device=d)
+    rec = ops.make_igemm(dtype=dtype, a1=x.to(d), w=wp, out=qk, M=M, N=3 * C, C1=C, ld1=C, ldw=C, ldc=2 * C, alpha=0.37, rows_per_image=N,
+                         vt_out=vt, vt_col0=2 * C, vt_ld=N, vt_alpha=1.0, tile=tile)
+    if (2 * C) % 128 != 0 and (2 * C) % 160 != 0:
+        with pytest.raises(RuntimeError):
+            ops.launch(rec)
+        return
+    ops.launch(rec)
+    torch.cuda.synchronize()
+    full = x.float() @ w.to(dtype).float().t()
+    assert rel(qk.float(), 0.37 * full[:, :2 * C]) < TOL[dtype]
+    v_ref = full[:, 2 * C:].reshape(B, N, C).permute(0, 2, 1).reshape(B * C, N)
+    assert rel(vt.float(), v_ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,HW", [(320, 4096), (640, 1024), (1280, 256), (96, 384), (2560, 256), (512, 8192)])
+def test_gn_apply_folds_the_tile_partials_itself(dtype, C, HW):
+    """edtr_gn_apply with `partial`: the <= 64 per-tile column partials of the producing igemm are folded inside the apply
+    launch (no edtr_gn_finalize launch) — identical to finalize + apply, incl. widths whose groups (10 / 20 / 40 / 80 channels)
+    straddle the kernel's 256-channel chunks."""
+    ops = _ops()
+    d = dev()
+    B = 2
+    tiles = HW // 128
+    x = (rnd((B * HW, C), 140, 1.5) + 0.3).to(dtype).to(d)
+    xf = x.float().reshape(B, tiles, 128, C)
+    gnp = torch.stack([xf.sum(2), (xf * xf).sum(2)], dim=-1).reshape(B * tiles, C, 2).contiguous()     # what an igemm epilogue writes
+    gamma, beta = (1 + 0.1 * rnd((C,), 141)).to(d), (0.1 * rnd((C,), 142)).to(d)
+    if C // 32 > 64:
+        assert not ops.gn_foldable(HW, C)
+        return
+    assert ops.gn_foldable(HW, C)
+    sums = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    ops.launch(ops.make_gn_finalize(partial=gnp, tiles_per_image=tiles, B=B, C=C, sums=sums))
+    y_ref, y = torch.empty_like(x), torch.empty_like(x)
+    _, ap_ref = ops.make_gn(dtype=dtype, x=x, ldx=C, B=B, HW=HW, C=C, sums=sums, gamma=gamma, beta=beta, eps=1e-5, silu=True, y=y_ref, ldy=C)
+    _, ap = ops.make_gn(dtype=dtype, x=x, ldx=C, B=B, HW=HW, C=C, sums=None, gamma=gamma, beta=beta, eps=1e-5, silu=True, y=y, ldy=C,
+                        partial=gnp)
+    ops.launch(ap_ref)
+    ops.launch(ap)
+    torch.cuda.synchronize()
+    assert rel(y.float(), y_ref.float()) < 1e-6          # same fp64 totals up to summation order
+    want = F.silu(F.group_norm(x.float().reshape(B, HW, C).permute(0, 2, 1).cpu(), 32, gamma.cpu(), beta.cpu(), 1e-5)).permute(0, 2, 1).reshape(B * HW, C)
+    assert rel(y.float(), want) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,N", [(2, 2, 77), (1, 3, 200), (1, 1, 64), (2, 1, 129)])
 def test_flash_attn64_causal(dtype, B, H, N):
     """Causal mask of the CLIP text tower (key j <= query i), incl. ragged last tiles and fully masked key tiles."""

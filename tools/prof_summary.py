@@ -4,6 +4,10 @@
     python3 tools/prof_summary.py stats  <rocprof dir> <out.csv>        # --kernel-trace --stats: per-kernel time table
     python3 tools/prof_summary.py pmc    <rocprof dir> <out.json> [--passes N]
                                                                         # --pmc: per-kernel-family counter sums / per launch
+    python3 tools/prof_summary.py union  <rocprof dir> <out.json> [--passes N]
+                                                                        # --kernel-trace: per family, the UNION of the kernels'
+                                                                        # [start, end] intervals (in-situ busy time: overlapping
+                                                                        # lanes / batches counted once) next to the plain sum
 
 Kernel families: igemm (main loops + split-K reducers), flash_attn (v1 / v2 / v3), gn_apply, gn_stats, layernorm, other.
 PMC conventions (MI355X_MICROARCH.md): FETCH_SIZE is in KiB and counts wide coalesced reads at HALF their bytes on gfx950
@@ -94,7 +98,48 @@ def pmc(root, out, passes, by_grid=False):
     print(json.dumps(res, indent=1))
 
 
+def union(root, out, passes):
+    """In-situ figure of the timed region: inside the hipGraphs two lanes and two batches overlap, so the
+    sum of a family's kernel durations exceeds the wall time it occupies.  From the kernel trace: per family the union of its
+    dispatch intervals (time during which at least one kernel of the family was running), the plain sum, and the same over all
+    kernels (= GPU busy time) — per pass."""
+    files = find(root, "*kernel_trace.csv")
+    if not files:
+        raise SystemExit(f"no *kernel_trace.csv under {root}")
+    iv = {}
+    for f in files:
+        with open(f) as fh:
+            rd = csv.reader(fh)
+            header = next(rd)
+            kn, st, en = col(header, "Kernel_Name"), col(header, "Start_Timestamp"), col(header, "End_Timestamp")
+            for row in rd:
+                a, b = int(row[st]), int(row[en])
+                iv.setdefault(family(row[kn]), []).append((a, b))
+                iv.setdefault("ALL", []).append((a, b))
+
+    def merged(spans):
+        spans = sorted(spans)
+        tot, cs, ce = 0, None, None
+        for a, b in spans:
+            if ce is None or a > ce:
+                if ce is not None:
+                    tot += ce - cs
+                cs, ce = a, b
+            else:
+                ce = max(ce, b)
+        return tot + (ce - cs if ce is not None else 0)
+
+    res = {"passes": passes, "unit": "ms per pass", "families": {}}
+    for k, spans in sorted(iv.items()):
+        res["families"][k] = {"launches_per_pass": len(spans) / passes, "sum_ms": sum(b - a for a, b in spans) / passes / 1e6,
+                              "union_ms": merged(spans) / passes / 1e6}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == "__main__":
     mode, root, out = sys.argv[1:4]
     passes = int(sys.argv[sys.argv.index("--passes") + 1]) if "--passes" in sys.argv else 1
-    {"stats": lambda: stats(root, out), "pmc": lambda: pmc(root, out, passes, "--by-grid" in sys.argv)}[mode]()
+    {"stats": lambda: stats(root, out), "pmc": lambda: pmc(root, out, passes, "--by-grid" in sys.argv),
+     "union": lambda: union(root, out, passes)}[mode]()
