@@ -161,6 +161,30 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
+// ---- LayerNorm folded into the GEMMs around it (edtr_hip.h: row_stats / ln_stats) ------------------------------------------
+// One LDS array of per-row (mean, rstd) for the rows of the tile being finished (all igemm kernels have <= 256 rows per pass).
+__device__ __forceinline__ float2* ln_rows_lds() {
+    __shared__ float2 rows[256];
+    return rows;
+}
+// consumer side: fold the row's ln_slots (sum, sum of squares) slots into (mean, rstd); published by the caller's next barrier
+template <int BM, int THREADS>
+__device__ __forceinline__ void ln_rows_fill(const edtr_igemm_params& p, int m0) {
+    float2* dst = ln_rows_lds();
+    const float inv = 1.0f / (float)p.ln_C;
+    for (int r = threadIdx.x; r < BM; r += THREADS) {
+        const int m = m0 + r;
+        float s = 0.0f, q = 0.0f;
+        if (m < p.M) {
+            const f32x2* src = reinterpret_cast<const f32x2*>(p.ln_stats) + (int64_t)m * p.ln_slots;
+            for (int k = 0; k < p.ln_slots; ++k) { const f32x2 v = src[k]; s += v[0]; q += v[1]; }
+        }
+        const float mean = s * inv;
+        const float var = fmaxf(q * inv - mean * mean, 0.0f);
+        dst[r] = make_float2(mean, __builtin_amdgcn_rsqf(var + p.ln_eps));
+    }
+}
+
 // Transposed store of a staged tile whose columns are the V part of a fused [Q; K; V] projection: V^T[image][c][token], 8
 // consecutive tokens (rows of the tile) of one column per 16-byte store.  Lane (slot, cl): 16 adjacent columns per slot — the
 // LDS reads of a slot walk 16 adjacent banks (slots collide 4-way: 8 reads per lane, negligible), the 16-byte stores of the
@@ -176,16 +200,26 @@ __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float
         const int tg = u % TG, cb = u / TG;
         const int cloc = cb * 16 + cl, n = no0 + cloc, m = m0 + tg * 8;
         if (m >= p.M || n >= p.N) continue;
-        const float b = p.bias_n ? p.bias_n[n] : 0.0f;
+        float b = p.bias_n ? p.bias_n[n] : 0.0f;
         float f[8];
+        if (p.ln_stats) {        // folded LayerNorm of the tokens (rows): rstd (alpha acc - mean alpha c1) + alpha c2 + bias
+            const float c1a = p.vt_alpha * p.ln_c1[n];
+            b += p.vt_alpha * p.ln_c2[n];
+            const float2* lr = ln_rows_lds() + tg * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = __builtin_fmaf(stage[(tg * 8 + i) * PITCH + cloc], p.vt_alpha, b);
+            for (int i = 0; i < 8; ++i) f[i] = lr[i].y * (stage[(tg * 8 + i) * PITCH + cloc] * p.vt_alpha - lr[i].x * c1a) + b;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = __builtin_fmaf(stage[(tg * 8 + i) * PITCH + cloc], p.vt_alpha, b);
+        }
         const int img = m / p.rows_per_image, tok = m - img * p.rows_per_image;
         stg16(vt + ((int64_t)img * vt_rows + (n - p.vt_col0)) * p.vt_ld + tok, pack8<T>(f));
     }
 }
 
-template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false, int PITCH = BNO, typename Hook = NoHook>
+// FOLD = false compiles the folded-LayerNorm paths out (the halo kernels: their register budget is full and no LayerNorm sits next
+// to a 3x3 convolution)
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false, int PITCH = BNO, bool FOLD = true, typename Hook = NoHook>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8], Hook before_publish = Hook()) {
     // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
@@ -214,7 +248,9 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         return;
     }
 
+    const bool ln = FOLD && !GEGLU && !PATCH16 && p.ln_stats != nullptr;      // (GEGLU: the caller applied it before the gate product)
     if constexpr (!GEGLU && !PATCH16) {
+        if (ln) ln_rows_fill<BM, THREADS>(p, m0);        // visible after the barrier that publishes the staged tile
         if (p.vt_out != nullptr && no0 >= p.vt_col0) {    // a V tile of the fused [Q; K; V] projection: transposed store
             before_publish();
             __syncthreads();
@@ -252,9 +288,23 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         }
     }
     const float alpha = GEGLU ? 1.0f : p.alpha;
+    float c1a[8];                             // folded LayerNorm: alpha c1[n] (and alpha c2[n] joins the per-column addend)
+    if (ln && n_ok) {
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n), u1 = *reinterpret_cast<const f32x4*>(p.ln_c1 + n + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.ln_c2 + n), v1 = *reinterpret_cast<const f32x4*>(p.ln_c2 + n + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c1a[j] = alpha * u0[j]; c1a[j + 4] = alpha * u1[j];
+            cb[j] += alpha * v0[j]; cb[j + 4] += alpha * v1[j];
+        }
+    }
+    const bool stats_out = FOLD && !GEGLU && !PATCH16 && p.row_stats != nullptr;
+    float rsum[ITER], rsq[ITER];              // producer side of the fold: this thread's 8-column share of each row's sum / sum of squares
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) { rsum[it] = 0.0f; rsq[it] = 0.0f; }
     const bool silu = p.act == EDTR_ACT_SILU, gelu = p.act == EDTR_ACT_GELU, lrelu = p.act == EDTR_ACT_LRELU;
     before_publish();                         // the caller's last staging step runs under the flight of the loads above
-    __syncthreads();                          // staged tile visible
+    __syncthreads();                          // staged tile (and the folded LayerNorm's row scalars) visible
 
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -266,8 +316,14 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             s1 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8 + 4);
             float f[8];
             f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
+            if (ln) {
+                const float2 mr = ln_rows_lds()[ml];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], alpha, cb[j]);
+                for (int j = 0; j < 8; ++j) f[j] = mr.y * (f[j] * alpha - mr.x * c1a[j]) + cb[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], alpha, cb[j]);
+            }
             if (p.bias_m) {
                 const float bm = p.bias_m[m];
 #pragma unroll
@@ -314,6 +370,37 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
             }
+            if (stats_out) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { rsum[it] += f[j]; rsq[it] += f[j] * f[j]; }
+            }
+        }
+    }
+    if (stats_out) {
+        // per-row statistics of the tensor just written (the input of a LayerNorm that the NEXT GEMM folds in): the VPR threads
+        // that share a row meet in LDS (the staged tile is dead), one thread per row writes the tile's slot
+        __syncthreads();
+        float2* red = reinterpret_cast<float2*>(const_cast<float*>(stage));
+        if (EXACT || r0 < RPI) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int ml = r0 + RPI * it;
+                if (EXACT || ml < BM) red[ml * VPR + n8] = make_float2(rsum[it], rsq[it]);
+            }
+        }
+        __syncthreads();
+        const int nslots = p.N >> 5, slot0 = no0 >> 5;
+        for (int r = tid; r < BM; r += THREADS) {
+            const int m = m0 + r;
+            if (m < p.M) {
+                float a = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int k = 0; k < VPR; ++k) { const float2 v = red[r * VPR + k]; a += v.x; q += v.y; }
+                float* dst = p.row_stats + ((int64_t)m * nslots + slot0) * 2;
+                dst[0] = a;
+                dst[1] = q;
+                for (int k = 1; k < BNO / 32 && slot0 + k < nslots; ++k) { dst[2 * k] = 0.0f; dst[2 * k + 1] = 0.0f; }
+            }
         }
     }
 }
@@ -332,15 +419,30 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
     if (geglu) {
         if constexpr (NI == 2) {
             const int nv = n0 + wn * 64 + l31;  // packed column of the value half; gate = +32
-            const float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
-            const float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
+            float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
+            float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
+            const bool ln = p.ln_stats != nullptr;
+            float c1v = 0.0f, c1g = 0.0f;
+            if (ln) {                            // folded LayerNorm: row scalars through LDS, the two per-column vectors in registers
+                ln_rows_fill<BM, kThreads>(p, m0);
+                c1v = p.alpha * p.ln_c1[nv]; c1g = p.alpha * p.ln_c1[nv + 32];
+                bv += p.alpha * p.ln_c2[nv]; bg += p.alpha * p.ln_c2[nv + 32];
+                __syncthreads();
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float val = acc[mi][0][r] * p.alpha + bv;
-                    const float gate = acc[mi][1][r] * p.alpha + bg;
+                    float val, gate;
+                    if (ln) {
+                        const float2 mr = ln_rows_lds()[ml];
+                        val = mr.y * (acc[mi][0][r] * p.alpha - mr.x * c1v) + bv;
+                        gate = mr.y * (acc[mi][1][r] * p.alpha - mr.x * c1g) + bg;
+                    } else {
+                        val = acc[mi][0][r] * p.alpha + bv;
+                        gate = acc[mi][1][r] * p.alpha + bg;
+                    }
                     stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
                 }
         }
@@ -2295,25 +2397,38 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------------
 template <int V> using IC = std::integral_constant<int, V>;
 
-template <typename T, bool UP2>
+// GEO: 0 = 16 x 16 output patch of one image, 1 = the same with the nearest-2x upsample fused into the gather (UP2),
+//      2 = FOUR WHOLE 8 x 8 IMAGES per workgroup (IMG8; round 3): the 3x3 convolutions of the 8x8 latent level (M = 64 B rows
+//          against 1280 x 11520 .. 23040 weights).  The implicit-GEMM tiles run them at 380 - 470 TFLOP/s: each of 240 workgroups
+//          re-stages its activations nine times and crawls through 30 - 60 K-tiles alone on its CU.  Here the unit is 256 rows =
+//          4 images with their zero halo, a [4][10][10]-pixel patch per 64-channel chunk (50 KiB, staged once per chunk), the
+//          same nine-tap / ping-pong loop, split-K over chunks.  Patch pixel (i, py, px) at (100 i + 10 py + px) * 128 B, chunk
+//          slot c ^ ((px ^ (py & 1)) & 7): an MFMA row block is TWO image rows of 8 pixels, and the row parity in the key keeps
+//          the 16 lanes of a ds_read_b128 group on 16 distinct 16-byte bank slots (10 pixels per patch row is even, so the
+//          column key alone would put (y, x) and (y + 1, x) on the same slot).
+template <typename T, int GEO>
 __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_params p) {
+    constexpr bool UP2 = GEO == 1, IMG8 = GEO == 2;
     EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
     // UP2 (nearest-2x upsample fused into the gather, `Upsample` of the UNet / VAE decoder): output pixel (y, x), tap (ky, kx) reads
     // SOURCE pixel ((oy0 + y + ky - 1) >> 1, (ox0 + x + kx - 1) >> 1): the patch is 10 x 10 source pixels (12.5 KiB per chunk),
     // patch row of block row y and tap ky = (y + ky + 1) >> 1, patch column of lane x and tap kx = (x + kx + 1) >> 1.
-    constexpr int PW = UP2 ? 10 : 18, PROW = PW * 128;
-    constexpr int NPP = UP2 ? 2 : 6;           // patch pieces (1 KiB = 8 pixels) per wave and chunk
-    constexpr int PATCHB = UP2 ? 16 * 1024 : 48 * 1024;    // 324 (100) pixels x 128 B, filled by 48 (16) one-KiB pieces, the tail lands in padding
+    constexpr int PW = (UP2 || IMG8) ? 10 : 18, PROW = PW * 128;
+    constexpr int NPP = UP2 ? 2 : (IMG8 ? 7 : 6);           // patch pieces (1 KiB = 8 pixels) per wave and chunk
+    // 324 (100; IMG8: 400) pixels x 128 B, filled by 48 (16; 50) one-KiB pieces, the tail lands in padding (IMG8: pieces 50..55 land
+    // in a scratch KiB behind the weight ring, so that every wave issues the same number of DMAs and the vmcnt counts hold)
+    constexpr int PATCHB = UP2 ? 16 * 1024 : (IMG8 ? 50 * 1024 : 48 * 1024);
     constexpr int BTAP = 128 * BK * 2;         // 16 KiB
     constexpr int B_BASE = 2 * PATCHB;
+    constexpr int SCRATCH = B_BASE + 3 * BTAP; // IMG8 only
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    const int tw = p.OW >> 4, tpi = tw * (p.OH >> 4);              // patches per row / per image
-    const int nbm = (p.M / (p.OH * p.OW)) * tpi, nbn = (p.N + 127) / 128;
+    const int tw = IMG8 ? 1 : p.OW >> 4, tpi = IMG8 ? 1 : tw * (p.OH >> 4);              // patches per row / per image
+    const int nbm = IMG8 ? p.M >> 8 : (p.M / (p.OH * p.OW)) * tpi, nbn = (p.N + 127) / 128;
     int bid = blockIdx.x;
     {
         const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
@@ -2321,10 +2436,10 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     }
     int tm, tn;
     tile_coords(p, bid, nbm, nbn, tm, tn);
-    const int img = tm / tpi, tr = tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;
+    const int img = IMG8 ? tm * 4 : tm / tpi, tr = IMG8 ? 0 : tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;     // IMG8: first of the unit's 4 images
     const int oy0 = ty * 16, ox0 = tx * 16, n0 = tn * 128;
     const int sy0 = UP2 ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UP2 ? (ox0 >> 1) - 1 : ox0 - 1;     // source pixel of patch position (0, 0)
-    const int m0 = (img * p.OH + oy0) * p.OW + ox0;                 // first pixel of the patch
+    const int m0 = IMG8 ? tm * 256 : (img * p.OH + oy0) * p.OW + ox0;                 // first pixel of the patch
 
     const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
     const uint16_t* wp = static_cast<const uint16_t*>(p.w);
@@ -2339,6 +2454,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 
     // ---- staging geometry.  Patch piece q = wave + 8 j: LDS bytes [q KiB, +1 KiB) = pixels 8 q .. 8 q + 7, lane -> (pixel, slot)
     uint32_t voff_p[NPP], voff_w[2];
+    uint32_t lds_p[NPP];                       // LDS byte offset of patch piece j inside a patch buffer (IMG8: or the scratch KiB)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = (wave + 8 * j) * 8 + (lane >> 3), slot = lane & 7, n = n0 + r;
@@ -2354,11 +2470,21 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 #pragma unroll
     for (int j = 0; j < NPP; ++j) {
         const int u = (wave + 8 * j) * 64 + lane, pp = u >> 3, slot = u & 7;
-        const int py = pp / PW, px = pp - py * PW;
-        const int iy = sy0 + py, ix = sx0 + px;
-        const bool ok = pp < PW * PW && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const int c = slot ^ (px & 7);
-        voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOobOffset;
+        if constexpr (IMG8) {
+            const int i = pp / 100, rem = pp - i * 100, py = rem / 10, px = rem - py * 10;
+            const int iy = py - 1, ix = px - 1;
+            const bool ok = pp < 400 && iy >= 0 && iy < 8 && ix >= 0 && ix < 8;
+            const int c = slot ^ ((px ^ (py & 1)) & 7);
+            voff_p[j] = ok ? (uint32_t)(((((int64_t)(img + i) * 8 + iy) * 8 + ix) * p.ld1 + c * 8) * 2) : kOobOffset;
+            lds_p[j] = wave + 8 * j < 50 ? (uint32_t)((wave + 8 * j) * 1024) : 0xFFFFFFFFu;
+        } else {
+            const int py = pp / PW, px = pp - py * PW;
+            const int iy = sy0 + py, ix = sx0 + px;
+            const bool ok = pp < PW * PW && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const int c = slot ^ (px & 7);
+            voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOobOffset;
+            lds_p[j] = (uint32_t)((wave + 8 * j) * 1024);
+        }
     }
     auto stage_w = [&](int chunk, int tap, int j, int buf) {
         const uint32_t vo = chunk < cend ? voff_w[j] : kOobOffset;
@@ -2366,15 +2492,25 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     };
     auto stage_p = [&](int chunk, int j, int par) {
         const uint32_t vo = chunk < cend ? voff_p[j] : kOobOffset;
-        dma16_buf(vo, srd_a, (uint32_t)(chunk * BK * 2), smem_base + par * PATCHB + (wave + 8 * j) * 1024);
+        const uint32_t dst = (IMG8 && lds_p[j] == 0xFFFFFFFFu) ? (uint32_t)SCRATCH : (uint32_t)(par * PATCHB) + lds_p[j];
+        dma16_buf(vo, srd_a, (uint32_t)(chunk * BK * 2), smem_base + dst);
     };
 
     // ---- fragment read geometry: A block mb of tap (ky, kx) = patch row 8 wr + mb + ky, pixels l15 + kx, K chunk 4 g + lq
-    int a_rd[3];
+    // IMG8: block mb = image 2 wr + mb / 4, image rows 2 (mb % 4) + (l15 >> 3), pixel l15 & 7; the key needs the row parity, so
+    // there is one address per (kx, ky & 1): a_rd[kx + 3 (ky & 1)]
+    int a_rd[IMG8 ? 6 : 3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int px = UP2 ? (l15 + kx + 1) >> 1 : l15 + kx;
-        a_rd[kx] = (wr * (UP2 ? 4 : 8) * PW + px) * 128 + (((g * 4 + lq) ^ (px & 7)) << 4);
+        if constexpr (IMG8) {
+            const int yy = l15 >> 3, px = (l15 & 7) + kx;
+#pragma unroll
+            for (int kyp = 0; kyp < 2; ++kyp)
+                a_rd[kx + 3 * kyp] = (wr * 200 + yy * 10 + px) * 128 + (((g * 4 + lq) ^ ((px ^ ((yy + kyp) & 1)) & 7)) << 4);
+        } else {
+            const int px = UP2 ? (l15 + kx + 1) >> 1 : l15 + kx;
+            a_rd[kx] = (wr * (UP2 ? 4 : 8) * PW + px) * 128 + (((g * 4 + lq) ^ (px & 7)) << 4);
+        }
     }
     const int b_rd = tile_off(wc * 64 + l15, g * 4 + lq);            // + nb * 2048
 
@@ -2408,13 +2544,19 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
                 for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(pb + nb * 2048);
             }
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (UP2 ? (SUB * 4 + mb + KY + 1) >> 1 : SUB * 4 + mb + KY) * PROW);
+            for (int mb = 0; mb < 4; ++mb) {
+                if constexpr (IMG8)       // block SUB * 4 + mb: image SUB of this wave's two, image rows 2 mb + {0, 1}
+                    afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX + 3 * (KY & 1)] + (SUB * 100 + (2 * mb + KY) * 10) * 128);
+                else
+                    afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (UP2 ? (SUB * 4 + mb + KY + 1) >> 1 : SUB * 4 + mb + KY) * PROW);
+            }
             stage_w(c2, TAP2, SUB, BUF2);
             if constexpr (PH >= 2 && PH < 2 + NPP) stage_p(c + 1, PH - 2, par ^ 1);
             if constexpr (SUB == 1) {
                 // issued in this and the previous phase: 1 weight piece each, + 1 patch piece each in phases 2 .. 2 + NPP - 1
-                if constexpr (PH == 3 || (!UP2 && (PH == 5 || PH == 7))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                constexpr int INFLIGHT = 2 + (PH >= 2 && PH < 2 + NPP ? 1 : 0) + (PH - 1 >= 2 && PH - 1 < 2 + NPP ? 1 : 0);
+                if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (INFLIGHT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
@@ -2474,7 +2616,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    rows_phase<T, 256, 128, false, 512, true, SPITCH>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);
+    rows_phase<T, 256, 128, false, 512, !IMG8, SPITCH, false>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);   // IMG8: rows are consecutive
     if (gn_acc) {
         // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
 #pragma unroll
@@ -2503,16 +2645,18 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     EDTR_STAMP(4); EDTR_STAMP(7);
 }
 
-template <typename T, bool UP2>
+template <typename T, int GEO>
 int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = UP2 ? 256 * 132 * 4 : 2 * 48 * 1024 + 3 * 128 * BK * 2;     // 144 KiB; UP2: main loop 80 KiB, the epilogue's staging tile 132 KiB
+    constexpr bool UP2 = GEO == 1;
+    // 144 KiB; UP2: main loop 80 KiB, the epilogue's staging tile 132 KiB; IMG8: 2 x 50 KiB patches + 48 KiB weights + 1 KiB scratch
+    constexpr int lds = UP2 ? 256 * 132 * 4 : (GEO == 2 ? 2 * 50 * 1024 + 3 * 128 * BK * 2 + 1024 : 2 * 48 * 1024 + 3 * 128 * BK * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T, UP2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T, GEO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int nbm = (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4), nbn = (p.N + 127) / 128;
-    hipLaunchKernelGGL((igemm_halo_kernel<T, UP2>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
+    const int nbm = GEO == 2 ? p.M >> 8 : (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4), nbn = (p.N + 127) / 128;
+    hipLaunchKernelGGL((igemm_halo_kernel<T, GEO>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
     EDTR_LAUNCH_CHECK();
     if (p.splitk > 1) {
         const int64_t nvec = (int64_t)p.M * (p.N >> 3);
@@ -2691,11 +2835,16 @@ int launch_pp128(const edtr_igemm_params& p, hipStream_t stream) {
 }
 
 // the halo tile's shape requirements (the caller checks buffer addressability)
+// four whole 8 x 8 images per workgroup (GEO 2 of the halo kernel)
+static bool igemm_halo_img8(const edtr_igemm_params& p) {
+    return !p.upsample2x && p.OH == 8 && p.OW == 8 && p.IH == 8 && p.IW == 8 && (p.M & 255) == 0;
+}
+
 static bool igemm_halo_ok(const edtr_igemm_params& p, bool spatial) {
     const int up = p.upsample2x ? 2 : 1;
     return spatial && p.taps == 9 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.C2 == 0 && (p.C1 & 63) == 0 &&
-           p.OH == p.IH * up && p.OW == p.IW * up && (p.OH & 15) == 0 && (p.OW & 15) == 0 && p.Z == 1 && p.splitk <= p.C1 / 64 &&
-           p.act != EDTR_ACT_GEGLU && p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW;
+           p.OH == p.IH * up && p.OW == p.IW * up && (((p.OH & 15) == 0 && (p.OW & 15) == 0) || igemm_halo_img8(p)) && p.Z == 1 &&
+           p.splitk <= p.C1 / 64 && p.act != EDTR_ACT_GEGLU && p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW;
 }
 
 static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
@@ -2714,7 +2863,8 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
     }
     if (tile == 16) {      // halo tile for 3x3 / stride 1 convolutions
         if (!igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
-        return p.upsample2x ? launch_halo<T, true>(p, s) : launch_halo<T, false>(p, s);
+        if (igemm_halo_img8(p)) return launch_halo<T, 2>(p, s);
+        return p.upsample2x ? launch_halo<T, 1>(p, s) : launch_halo<T, 0>(p, s);
     }
     if (tile >= 3 && tile <= 14) {
         // buffer-addressed fast path: 32-bit byte offsets must cover the A and W operands (per z slice)
@@ -2849,6 +2999,18 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if ((p.vt_ld & 7) || p.vt_ld < p.rows_per_image || !aligned16(p.vt_out)) return EDTR_E_ALIGN;
     }
 
+    if (p.row_stats) {
+        if (p.Z != 1 || p.splitk > 1 || p.act == EDTR_ACT_GEGLU || p.vt_out) return EDTR_E_UNSUPPORTED;
+        if (p.N & 31) return EDTR_E_SHAPE;
+        if (!aligned16(p.row_stats)) return EDTR_E_ALIGN;
+    }
+    if (p.ln_stats) {
+        if (p.Z != 1 || p.splitk > 1 || p.taps != 1 || spatial || p.C2) return EDTR_E_UNSUPPORTED;
+        if (!p.ln_c1 || !p.ln_c2) return EDTR_E_NULL;
+        if (p.ln_slots <= 0 || p.ln_C != p.K || p.ln_slots * 32 != p.ln_C) return EDTR_E_SHAPE;
+        if (!aligned16(p.ln_stats) || !aligned16(p.ln_c1) || !aligned16(p.ln_c2)) return EDTR_E_ALIGN;
+    }
+
     // the LDS-DMA main loops need every 64-wide K-tile inside one tap of one source
     const bool dma_ok = p.C2 == 0 && (p.C1 & 63) == 0;
     int tile = p.tile;
@@ -2923,6 +3085,11 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         const int bn = tile == 8 ? 160 : 128;
         if (!(tile == 1 || tile == 3 || tile == 8) || p.vt_col0 % bn != 0) return EDTR_E_UNSUPPORTED;
     }
+    if (p.ln_stats && !(tile == 1 || tile == 3 || tile == 8)) {
+        if (p.tile != 0) return EDTR_E_UNSUPPORTED;       // the folded LayerNorm's epilogue exists in the 128-row tiles only
+        tile = dma_ok ? 3 : 1;
+    }
+    if ((p.row_stats || p.vt_out) && tile == 16) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
     const int c0 = blockIdx.y * GN_CC;
     const int cc = min(GN_CC, p.C - c0);
     const int cpg = p.C / p.groups;
-    const double cnt = (double)p.HW * cpg;
+    const double inv_cnt = 1.0 / ((double)p.HW * cpg);
     const int glo = (c0 / cpg) * cpg;                                   // first channel of the first group touching the chunk
     if (p.partial) {
         // every workgroup folds the <= 64 tiles x (its channels, extended to whole groups) itself — a few KB from L2 — instead
@@ -181,11 +181,12 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const edtr_gn_params p, i
             gsum[0] = srcd[0];
             gsum[1] = srcd[1];
         }
-        const double* src = gsum;
-        const double mean = src[0] / cnt;
-        double var = src[1] / cnt - mean * mean;
+        // mean / variance in fp64 (the sums are fp64: no cancellation), then ONE fp32 v_rsq instead of an fp64 division + square
+        // root + division per channel: with ~2048 small workgroups per launch this prologue was a third of a small tensor's time
+        const double mean = gsum[0] * inv_cnt;
+        double var = gsum[1] * inv_cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float rstd = __builtin_amdgcn_rsqf((float)var + p.eps);
         const float g = p.gamma[c0 + c] * rstd;
         sc[c] = g;
         sh[c] = p.beta[c0 + c] - (float)mean * g;

@@ -231,6 +231,33 @@ class WeightStore:
             b = self.cache[key]
         return ref, b
 
+    def ln_fold(self, kind: str, names: Sequence[str], biases, ln_prefix: str):
+        """A projection with the LayerNorm in front of it folded in (include/edtr_hip.h: ln_stats): the packed matrix is
+        W . gamma (columns scaled BEFORE the 16-bit rounding), c1[n] = sum_k of the PACKED values (so that the mean term cancels
+        exactly what the MFMA multiplied), c2[n] = sum_k beta[k] W[n][k] in fp32.  ``kind``: "linear" (row concatenation of
+        ``names``) or "geglu" (value / gate rows interleaved).  Fast modes only.  Returns (WRef, bias or None, c1, c2)."""
+        if self.dtype in (ops.F32S, ops.MIXED):
+            raise ValueError("the LayerNorm fold is a fast-mode optimisation (the parity modes keep the normalisation launch)")
+        names = tuple(names)
+        key = ("lnfold", kind, names, ln_prefix)
+        if key not in self.cache:
+            gamma, beta = self._p(ln_prefix + "weight").reshape(-1), self._p(ln_prefix + "bias").reshape(-1)
+            w = torch.cat([self._p(n).reshape(self.params[n].shape[0], -1) for n in names], dim=0)
+            b = None
+            if biases:
+                b = torch.cat([self._p(bn).reshape(-1) if bn else torch.zeros(self.params[n].shape[0], device=self.device)
+                               for n, bn in zip(names, biases)])
+            if kind == "geglu":
+                perm = ops.geglu_perm(w.shape[0] // 2).to(self.device)
+                w, b = w[perm], (b[perm] if b is not None else None)
+            packed = ops.pack_linear_weight(w * gamma[None, :], self.dtype)
+            npad = packed.shape[0]
+            c1 = packed[:, : w.shape[1]].float().sum(dim=1).contiguous()
+            c2 = ops.pad_bias(w @ beta, npad).contiguous()
+            self.cache[key] = (packed, ops.pad_bias(b, npad) if b is not None else None, c1, c2)
+        packed, b, c1, c2 = self.cache[key]
+        return packed, b, c1, c2
+
     def raw(self, name: str) -> torch.Tensor:
         """The fp32 parameter itself on the device (embedding tables)."""
         key = ("raw", name)
@@ -426,6 +453,14 @@ class OpN:
         return self.t.stride(dim)
 
 
+class LNRef:
+    """A LayerNorm that is not launched: its raw input rows ``x`` [rows, C] and the per-row statistics ``stats`` [rows, C / 32, 2]
+    the producing GEMM wrote; the consuming GEMMs fold the normalisation into their weights and epilogue (edtr_hip.h ln_stats)."""
+
+    def __init__(self, x: torch.Tensor, stats: torch.Tensor, C: int, prefix: str):
+        self.x, self.stats, self.C, self.prefix = x, stats, C, prefix
+
+
 @dataclass
 class Act:
     """NHWC activation: ``t`` is a 2-D view [B*H*W, C] (row stride ``ld`` >= C) of 16-bit storage — fp32 storage, or an OpN
@@ -477,6 +512,7 @@ class Emitter:
         self.io = ops.F32S if self.hp else dtype
         self.direct16 = precision == "mixed"      # a 16-bit GEMM output IS an attention / one-part operand (same fp16 type)
         self.last_gnp = None
+        self.last_row_stats = None
 
     # -- precision plumbing ---------------------------------------------------------------------
     def parts_for(self, name: str, M: int = 0, N: int = 0, K: int = 0) -> int:
@@ -505,6 +541,8 @@ class Emitter:
                 t = t.t
             if isinstance(t, OpN):
                 t = t.t
+            if isinstance(t, LNRef):
+                t = t.stats          # (the raw rows belong to the residual stream: their owner frees them)
             self.arena.free(t)
 
     # -- multi-part operands --------------------------------------------------------------------
@@ -534,16 +572,31 @@ class Emitter:
         return w.get(parts) if isinstance(w, WRef) else w
 
     # -- GEMM family ------------------------------------------------------------------------
+    def ln_fold_ok(self, C: int) -> bool:
+        """May a LayerNorm over C columns be folded into the GEMMs around it?  (fast modes; EDTR_LN_FOLD=0 switches it off)"""
+        return (not self.hp) and C % 32 == 0 and C % 8 == 0 and os.environ.get("EDTR_LN_FOLD", "1") != "0"
+
+    def _ln_kwargs(self, a, K: int, ln_vec):
+        """igemm arguments of a folded LayerNorm for operand ``a`` (an LNRef) -> (raw rows, extra keyword arguments)."""
+        if a.C != K or ln_vec is None:
+            raise ValueError("folded LayerNorm: the consumer needs K == C and the folded weight's (c1, c2)")
+        return a.x, dict(ln_stats=a.stats, ln_C=a.C, ln_eps=1e-5, ln_c1=ln_vec[0], ln_c2=ln_vec[1])
+
     def gemm(self, a, w, M: int, N: int, K: int, *, bias=None, out=None, act=0,
              residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,
-             out16=False, feeds=None, **kw) -> torch.Tensor:
+             out16=False, feeds=None, row_stats=False, ln_vec=None, **kw) -> torch.Tensor:
         """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld); ``w`` is a
         WRef of the store (or a ready packed tensor).  fp32-stream modes: the output is fp32 unless ``out16`` (an attention
         operand, mixed mode only) or ``feeds`` names a GEMM class that takes it as a one-part operand."""
         n_out = N // 2 if act == L.ACT_GEGLU else N
         self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
+        self.last_row_stats = None   # per-row statistics of this output for a LayerNorm folded into the next GEMMs (row_stats=True)
         parts = self.parts_for(name, M, N, K)
         tmp = None
+        if isinstance(a, LNRef):
+            a, lnkw = self._ln_kwargs(a, K, ln_vec)
+            kw.update(lnkw)
+            kw["tile"] = 0 if "tile" not in kw else kw["tile"]
         if self.hp:
             a, tmp, parts = self._operand(a, M, K, parts)
             if out is not None:
@@ -559,6 +612,9 @@ class Emitter:
             tile, splitk = kw.pop("tile"), 1
         else:
             tile, splitk = ops.choose_splitk(M, N, Ke, kw.get("Z", 1), act)
+        if row_stats and not self.hp and splitk == 1 and act != L.ACT_GEGLU and N % 32 == 0 and "Z" not in kw:
+            self.last_row_stats = self.arena.alloc((M, N // 32, 2), torch.float32)
+            kw["row_stats"] = self.last_row_stats
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         if (stats_hw and act == 0 and (self.hp or not out_f32) and out.stride(0) == N and "Z" not in kw
                 and ops.gn_fusable(M, N, Ke, stats_hw, splitk=splitk)):
@@ -582,12 +638,14 @@ class Emitter:
             return False
         return N % 8 == 0 and C % 64 == 0 and ((2 * C) % 160 == 0 or (2 * C) % 128 == 0) and os.environ.get("EDTR_FUSED_QKV", "1") != "0"
 
-    def qkv_gemm(self, x, w, *, B: int, N: int, C: int, alpha: float, name: str = "attn1.qkv"):
+    def qkv_gemm(self, x, w, *, B: int, N: int, C: int, alpha: float, name: str = "attn1.qkv", ln_vec=None):
         """[Q; K; V] = x @ [Wq; Wk; Wv]^T in one launch: (qk [B*N, 2C] row-major with `alpha` applied, v^T [B*C, N] transposed
         by the epilogue, unscaled).  reference model/attention.py:170-178 (to_q / to_k / to_v + the head rearranges)."""
         M = B * N
         parts = self.parts_for(name, M, 3 * C, C)
-        tmp = None
+        tmp, lnkw = None, {}
+        if isinstance(x, LNRef):
+            x, lnkw = self._ln_kwargs(x, C, ln_vec)
         if self.hp:
             x, tmp, parts = self._operand(x, M, C, parts)
         wt = self._w(w, parts)
@@ -595,7 +653,7 @@ class Emitter:
         vt = self.arena.alloc((B * C, N), self.attn_dtype)
         self.prog.add(ops.make_igemm(dtype=self.dtype, a1=x, w=wt, out=qk, M=M, N=3 * C, C1=parts * C, ld1=x.stride(0),
                                      ldw=wt.stride(0), ldc=2 * C, alpha=alpha, rows_per_image=N, vt_out=vt, vt_col0=2 * C, vt_ld=N,
-                                     vt_alpha=1.0, name=name))
+                                     vt_alpha=1.0, name=name, **lnkw))
         self.arena.free(tmp)
         return qk, vt, N
 
@@ -623,7 +681,8 @@ class Emitter:
         wt = self._w(w, parts)
         if out is None:
             out = self.new(M, N, torch.float32 if out_f32 else None)
-        tile, splitk = ops.choose_splitk(M, N, taps * Ce)
+        img8 = taps == 9 and stride == 1 and pad_tl == 1 and not ups and (x.H, x.W) == (8, 8) and Ce % 64 == 0
+        tile, splitk = ops.choose_splitk(M, N, taps * Ce, img8=img8)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
         if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk):
@@ -702,7 +761,11 @@ class Emitter:
             return Act(carried, x.B, x.H, x.W, x.C)
         return apply
 
-    def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str, feeds=None):
+    def layer_norm(self, x: torch.Tensor, rows: int, C: int, prefix: str, feeds=None, stats: Optional[torch.Tensor] = None):
+        """``stats``: the producing GEMM's per-row statistics of ``x`` (gemm(..., row_stats=True)) — no launch then: an LNRef
+        that the consuming GEMMs fold into their weights and epilogues."""
+        if stats is not None:
+            return LNRef(x, stats, C, prefix)
         parts = self.feeds_parts(feeds, rows)
         y, carried = self._norm_out(rows, C, parts)
         self.prog.add(ops.make_layernorm(dtype=self.op_fmt(parts) if self.hp else self.io, x=x, rows=rows, C=C, ldx=x.stride(0),

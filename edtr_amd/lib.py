@@ -46,6 +46,9 @@ class IgemmParams(C.Structure):
         ("act_slope", C.c_float),
         ("residual_f32", C.c_int32),
         ("vt_out", C.c_void_p), ("vt_col0", C.c_int32), ("vt_ld", C.c_int32), ("vt_alpha", C.c_float),
+        ("row_stats", C.c_void_p),
+        ("ln_stats", C.c_void_p), ("ln_slots", C.c_int32), ("ln_C", C.c_int32), ("ln_eps", C.c_float),
+        ("ln_c1", C.c_void_p), ("ln_c2", C.c_void_p),
     ]
 
 

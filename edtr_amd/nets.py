@@ -20,7 +20,7 @@ import torch
 from . import lib as L
 from . import ops
 from .arch import Layer, UNetArch, VaeLayer
-from .engine import Act, Emitter
+from .engine import Act, Emitter, LNRef
 from .ops import round_up
 
 
@@ -110,10 +110,14 @@ def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, of
     return y
 
 
-def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C: int, heads: int,
-                        ctx: Optional[Tuple[torch.Tensor, torch.Tensor, int, int, int, int]], residual: torch.Tensor) -> torch.Tensor:
-    """One attention layer on tokens x [B*N, C] (already layer-normed): projections, fused attention, output
-    projection with bias and residual.  model/attention.py:176-203."""
+def emit_attention_core(em: Emitter, p: str, x, B: int, N: int, C: int, heads: int,
+                        ctx: Optional[Tuple[torch.Tensor, torch.Tensor, int, int, int, int]], residual: torch.Tensor,
+                        row_stats: bool = False) -> torch.Tensor:
+    """One attention layer on tokens x [B*N, C] (already layer-normed, or an LNRef = the LayerNorm folded into the
+    projection): projections, fused attention, output projection with bias and residual.  ``row_stats``: the output
+    projection also writes the per-row statistics of its result (em.last_row_stats) for the next folded LayerNorm.
+    model/attention.py:176-203."""
+    fold = x.prefix if isinstance(x, LNRef) else None
     # softmax scale (1/sqrt(64)) and the exp -> exp2 factor log2(e) are folded into the projections' fp32 epilogues (q.k
     # products arrive "prescaled", include/edtr_hip.h q_prescaled): sqrt(c) on both halves of the fused [Q;K] projection,
     # c on the cross-attention's Q (its K comes from the per-prompt context program) — no extra rounding, one multiply
@@ -121,8 +125,13 @@ def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C:
     c = ATTN_PRESCALE
     if ctx is None and em.fused_qkv_ok(N, C):
         # self attention: ONE launch for [Wq; Wk; Wv] — q / k row-major (scaled), v^T written transposed by the epilogue
-        wqkv, _ = em.store.linear([p + "to_q.weight", p + "to_k.weight", p + "to_v.weight"])
-        qk, vt, ldv = em.qkv_gemm(x, wqkv, B=B, N=N, C=C, alpha=math.sqrt(c))
+        names = [p + "to_q.weight", p + "to_k.weight", p + "to_v.weight"]
+        if fold:
+            wqkv, _, c1, c2 = em.store.ln_fold("linear", names, None, fold)
+            qk, vt, ldv = em.qkv_gemm(x, wqkv, B=B, N=N, C=C, alpha=math.sqrt(c), ln_vec=(c1, c2))
+        else:
+            wqkv, _ = em.store.linear(names)
+            qk, vt, ldv = em.qkv_gemm(x, wqkv, B=B, N=N, C=C, alpha=math.sqrt(c))
         o = em.flash(qk[:, :C], qk[:, C:], vt, B=B, H=heads, Nq=N, Nk=N, k_bs=N * qk.stride(0), vt_bs=C * ldv, vt_ld=ldv,
                      prescaled=True)
         em.free(qk, vt)
@@ -136,12 +145,16 @@ def emit_attention_core(em: Emitter, p: str, x: torch.Tensor, B: int, N: int, C:
         em.free(qk, vt)
     else:
         k, vt, k_bs, vt_bs, ldv, nctx = ctx
-        wq, _ = em.store.linear([p + "to_q.weight"])
-        q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=True)
+        if fold:
+            wq, _, c1, c2 = em.store.ln_fold("linear", [p + "to_q.weight"], None, fold)
+            q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=True, ln_vec=(c1, c2))
+        else:
+            wq, _ = em.store.linear([p + "to_q.weight"])
+            q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=True)
         o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv, prescaled=True)
         em.free(q)
     wo, bo = em.store.linear([p + "to_out.0.weight"], [p + "to_out.0.bias"])
-    y = em.gemm(o, wo, B * N, C, C, bias=bo, residual=residual, name="attn.out")
+    y = em.gemm(o, wo, B * N, C, C, bias=bo, residual=residual, name="attn.out", row_stats=row_stats)
     em.free(o)
     return y
 
@@ -153,22 +166,33 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     rows = B * N
     n = em.group_norm(x, p + "norm.", 1e-6, False, feeds=("st.proj_in",))
     wi, bi = em.store.linear([p + "proj_in.weight"], [p + "proj_in.bias"])
-    t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in")
+    # The three LayerNorms of the block are not launched in the fast modes: the GEMM that writes their input also writes
+    # per-row statistics, the GEMMs that read them run on the raw rows with gamma folded into the weights (Emitter.layer_norm).
+    fold = em.ln_fold_ok(C)
+    fold1 = fold and em.fused_qkv_ok(N, C)        # (the operand-swapped V^T product would need per-COLUMN scalars)
+    t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in", row_stats=fold1)
+    st = em.last_row_stats
     em.free(n)
     tb = p + "transformer_blocks.0."
-    l1 = em.layer_norm(t, rows, C, tb + "norm1.", feeds=("attn1.qkv",) if em.fused_qkv_ok(N, C) else ("attn1.qk", "attn1.vT"))
-    t1 = emit_attention_core(em, tb + "attn1.", l1, B, N, C, l.heads, None, t)
+    l1 = em.layer_norm(t, rows, C, tb + "norm1.", feeds=("attn1.qkv",) if em.fused_qkv_ok(N, C) else ("attn1.qk", "attn1.vT"), stats=st)
+    t1 = emit_attention_core(em, tb + "attn1.", l1, B, N, C, l.heads, None, t, row_stats=fold)
+    st = em.last_row_stats
     em.free(l1, t)
-    l2 = em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",))
+    l2 = em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",), stats=st)
     off = kv.offs[l.prefix]
     k_view = kv.k_all[:, off:off + C]
     vt_view = kv.vt_all.view(B, kv.sumC, kv.ldv)[:, off:off + C, :]
     ctx = (k_view, vt_view, kv.Nctx * kv.sumC, kv.sumC * kv.ldv, kv.ldv, kv.Nctx)
-    t2 = emit_attention_core(em, tb + "attn2.", l2, B, N, C, l.heads, ctx, t1)
+    t2 = emit_attention_core(em, tb + "attn2.", l2, B, N, C, l.heads, ctx, t1, row_stats=fold)
+    st = em.last_row_stats
     em.free(l2, t1)
-    l3 = em.layer_norm(t2, rows, C, tb + "norm3.", feeds=("ff.geglu",))
-    wg, bg = em.store.geglu(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias")
-    g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out")
+    l3 = em.layer_norm(t2, rows, C, tb + "norm3.", feeds=("ff.geglu",), stats=st)
+    if isinstance(l3, LNRef):
+        wg, bg, c1, c2 = em.store.ln_fold("geglu", [tb + "ff.net.0.proj.weight"], [tb + "ff.net.0.proj.bias"], l3.prefix)
+        g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out", ln_vec=(c1, c2))
+    else:
+        wg, bg = em.store.geglu(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias")
+        g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out")
     em.free(l3)
     wf, bf = em.store.linear([tb + "ff.net.2.weight"], [tb + "ff.net.2.bias"])
     t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out")

@@ -67,6 +67,8 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None,
                gn_partial: Optional[torch.Tensor] = None, act_slope: float = 0.0, residual_f32: bool = False,
                vt_out: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_ld: int = 0, vt_alpha: float = 1.0,
+               row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0,
+               ln_eps: float = 1e-5, ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None,
                name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
@@ -92,6 +94,9 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     p.residual_f32 = int(residual_f32)
     if vt_out is not None:
         p.vt_out, p.vt_col0, p.vt_ld, p.vt_alpha = ptr(vt_out), vt_col0, vt_ld, vt_alpha
+    p.row_stats = ptr(row_stats)
+    if ln_stats is not None:
+        p.ln_stats, p.ln_slots, p.ln_C, p.ln_eps, p.ln_c1, p.ln_c2 = ptr(ln_stats), ln_C // 32, ln_C, ln_eps, ptr(ln_c1), ptr(ln_c2)
     flops = 2.0 * M * N * p.K * Z
     # algorithmic HBM bytes: every operand once (a conv reads its input image once, not once per tap)
     a_rows = (M // (p.OH * p.OW)) * p.IH * p.IW if spatial else M
@@ -99,14 +104,15 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     nbytes = Z * (2.0 * a_rows * (C1 + C2) + 2.0 * N * p.K + (4.0 if out_f32 else 2.0) * M * n_out
                   + ((4.0 if residual_f32 else 2.0) * M * n_out if residual is not None else 0.0))
     rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
-                                                    gn_partial, vt_out), name, flops, nbytes)
+                                                    gn_partial, vt_out, row_stats, ln_stats, ln_c1, ln_c2), name, flops, nbytes)
     rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
                + (" up2" if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
-               + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else ""))
+               + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else "") + (" vT" if vt_out is not None else "")
+               + (" ln" if ln_stats is not None else "") + (" rs" if row_stats is not None else ""))
     return rec
 
 
-def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int, int]:
+def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0, img8: bool = False) -> Tuple[int, int]:
     """(tile, splitk) heuristic for the 256-CU MI355X: when the 128x128 tile grid cannot fill the chip, cut K so
     that ~480 workgroups exist — but only while every split keeps enough K-tiles (of 64) to amortise the fp32 slab
     round trip of the reducer: >= 20 per split (>= 12 when fewer than 64 tiles exist at all).  Measured with
@@ -114,6 +120,12 @@ def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0) -> Tuple[int
     K=5120 gains (53.5 -> 42.3 us) and the 8x8-level convolutions (M=512, K=11520) gain 3.4x at 6 splits."""
     if Z != 1 or act == L.ACT_GEGLU:
         return 0, 1
+    if img8 and M % 256 == 0 and N % 128 == 0 and K % (9 * 64) == 0 and K // (9 * 64) >= 10 and (M // 256) * (N // 128) <= 64:
+        # 3x3 convolutions of the 8x8 latent level on the halo kernel's 4-images-per-workgroup geometry: split over the
+        # 64-channel chunks so that every workgroup multiplies 2 (K = 11520) .. 4 (K = 23040) chunks.  Measured
+        # (profiles/r03/ab_tiles_3_vs_16_smallm.log, one device): 31.1 us at 10 splits against 36.7 us for the 128x128 loop at its
+        # 6 splits (K = 11520), 42.2 against 59.3 us (K = 23040); batch 4: 27.1 against 33.1 us
+        return 0, 10
     nkt = (K + 63) // 64
     b128 = ((M + 127) // 128) * ((N + 127) // 128)
     if b128 >= 200 or nkt < 24:
@@ -168,7 +180,11 @@ def make_zero(t: torch.Tensor, name: str = "zero") -> Rec:
     return Rec(L.load().edtr_zero_bytes, (ptr(t), nbytes), (t,), name, 0.0, float(nbytes))
 
 
-GN_FOLD_MAX_TILES = 64      # edtr_gn_apply folds the producer's per-tile partials itself up to this many 128-row tiles per image
+# edtr_gn_apply folds the producer's per-tile partials itself up to this many 128-row tiles per image (the kernel accepts 64).
+# Every one of the apply launch's ~2000 workgroups repeats the fold for its channels, so it only pays while tiles x channels is
+# small next to a workgroup's own slab: the 16x16 and 32x32 latent levels (2 / 8 tiles); at 64x64 (32 tiles) the whole path
+# lost 6 % (profiles/r03/experiments_gn_fold.log) and the separate edtr_gn_finalize launch stays.
+GN_FOLD_MAX_TILES = int(__import__("os").environ.get("EDTR_GN_FOLD_MAX", "8"))
 
 
 def gn_foldable(HW: int, C: int, groups: int = 32) -> bool:

@@ -150,6 +150,22 @@ typedef struct edtr_igemm_params {
      * tile 8: every SD width), Z == 1, no split-K / GEGLU / residual / rowvec, tile 0 / 1 / 3 / 8.  replaces: `to_v(x)` +
      * the `b n (h d) -> (b h) n d` rearrange of v, reference model/attention.py:172-178. */
     void* vt_out; int32_t vt_col0; int32_t vt_ld; float vt_alpha;
+    /* LayerNorm folded into the GEMMs around it (fast modes; reference model/attention.py:222-224,230-234: x + attn(norm(x))).
+     * LayerNorm is affine per row, so  LN(x) W^T = rstd_r (x (gamma . W)^T - mean_r c1) + c2  with c1[n] = sum_k (gamma . W)[n][k]
+     * (of the packed 16-bit values) and c2[n] = sum_k beta[k] W[n][k]: the GEMM runs on the RAW rows against weights pre-multiplied
+     * by gamma, and its epilogue applies the two row scalars — the normalised tensor is never written or read, the edtr_layernorm
+     * launch disappears and one 16-bit rounding (of the normalised activations) with it.
+     *   producer side — row_stats (optional): the launch that WRITES x also writes, per row, the sum and the sum of squares of
+     *     the values it stores: row_stats[m][N / 32][2] fp32; a column tile fills the slot of its first 32 columns and zeroes
+     *     the other slots it covers, so the totals over a row's N / 32 slots are defined whatever tile ran (no atomics:
+     *     results stay bit-reproducible).  Needs N % 32 == 0, Z == 1, no split-K / GEGLU, a row-major tile (not tile 16).
+     *   consumer side — ln_stats (optional): row statistics of the A operand's rows (ln_slots = C / 32 slots per row, C = K =
+     *     ln_C columns, eps ln_eps); the epilogue computes out = rstd (alpha acc - mean alpha c1[n]) + alpha c2[n] + bias_n[n]
+     *     (vt_alpha for the transposed V columns), then GEGLU / activation / residual as usual.  Needs Z == 1, no split-K,
+     *     taps == 1, tile 0 / 1 / 3 / 8. */
+    float* row_stats;
+    const float* ln_stats; int32_t ln_slots; int32_t ln_C; float ln_eps;
+    const float* ln_c1; const float* ln_c2;
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);

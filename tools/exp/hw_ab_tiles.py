@@ -67,7 +67,8 @@ def main():
     cases = [("gemm", g, 1) for g in GEMMS] + [("gemm", (2048, 1280, 5120), 3), ("gemm", (512, 1280, 1280), 2)]
     cases += [("conv", c, 1) for c in CONVS] + [("conv", (8, 8, 8, 1280, 1280, 0), 6)]
     if args.cases == "smallm":      # the 8x8-latent convolutions: which split-K count?
-        cases = [("conv", (8, 8, 8, 1280, 1280, 0), k) for k in (4, 6, 8, 9, 10, 12, 15)] + [("conv", (8, 8, 8, 2560, 1280, 0), k) for k in (6, 8, 12, 16)]
+        cases = [("conv", (8, 8, 8, 1280, 1280, 0), k) for k in (4, 5, 6, 8, 10, 12, 20)] + [("conv", (8, 8, 8, 2560, 1280, 0), k) for k in (5, 6, 8, 10, 13, 20)]
+        cases += [("conv", (4, 8, 8, 1280, 1280, 0), k) for k in (6, 10, 20)] + [("conv", (4, 8, 8, 2560, 1280, 0), k) for k in (10, 20)]
     if args.cases == "smallgemm":   # plain GEMMs with at most ~one 128x128 tile per CU
         cases = [("gemm", g, 1) for g in [(2048, 1280, 1280), (1024, 1280, 1280), (512, 1280, 1280), (256, 1280, 1280), (2048, 2560, 1280), (2048, 1280, 2560),
                                            (2048, 1280, 5120), (4096, 640, 640), (4096, 640, 2560), (8192, 640, 640), (1000, 520, 1152), (130, 136, 128), (77, 640, 1024),
