@@ -573,8 +573,12 @@ class Emitter:
 
     # -- GEMM family ------------------------------------------------------------------------
     def ln_fold_ok(self, C: int) -> bool:
-        """May a LayerNorm over C columns be folded into the GEMMs around it?  (fast modes; EDTR_LN_FOLD=0 switches it off)"""
-        return (not self.hp) and C % 32 == 0 and C % 8 == 0 and os.environ.get("EDTR_LN_FOLD", "1") != "0"
+        """May a LayerNorm over C columns be folded into the GEMMs around it?  Built for VERDICT r02 item 4 (launch count), kept
+        OPT-IN (EDTR_LN_FOLD=1, fast modes): it removes 69 launches per denoise step and one 16-bit rounding, but in a same-device
+        A/B the whole path lost 0.7 % at batch 8 (104.99 -> 104.25 images/s) and gained 0.5 % at batch 4 / 50 steps (8.383 ->
+        8.426): the LayerNorm launches overlap with the other lane / batch, the two extra barriers in every producer epilogue and
+        the slot fold in every consumer epilogue sit on the GEMMs' critical path (profiles/r03/experiments_ln_fold.log)."""
+        return (not self.hp) and C % 32 == 0 and C % 8 == 0 and os.environ.get("EDTR_LN_FOLD", "0") == "1"
 
     def _ln_kwargs(self, a, K: int, ln_vec):
         """igemm arguments of a folded LayerNorm for operand ``a`` (an LNRef) -> (raw rows, extra keyword arguments)."""
