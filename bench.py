@@ -52,7 +52,7 @@ def main() -> None:
                     help="fast = 16-bit activation storage in --dtype (headline); mixed = the fast parity mode (fp32 stream, fp16 "
                          "operands, 1-3 products per layer class: edtr_amd/precision.py); high = the robust parity mode (fp32 stream, "
                          "bf16 split-3 products everywhere).  Both parity modes meet the 1e-3 north-star tolerance")
-    ap.add_argument("--parity-steps", type=int, default=3,
+    ap.add_argument("--parity-steps", type=int, default=8,
                     help="after the headline (fast) measurement, time this many passes of the parity mode (mixed) in the same run and "
                          "report them as \"parity_mode\" (0 = skip; skipped for N > 1 and for the non-default workloads)")
     ap.add_argument("--breakdown-json", default=None, help="write the per-launch-name time table of the roofline pass to this file")
