@@ -109,6 +109,9 @@ def main() -> None:
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:       # EDTR_BENCH_DIST=1 from a plain shell: a one-rank rendezvous on the loopback
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port()))):
+                os.environ.setdefault(k_, v_)
         dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
     rccl_ranks = count_ranks(dist, dev) if dist is not None else 1
     if rccl_ranks != world:
