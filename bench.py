@@ -55,6 +55,9 @@ def main() -> None:
     ap.add_argument("--parity-steps", type=int, default=8,
                     help="after the headline (fast) measurement, time this many passes of the parity mode (mixed) in the same run and "
                          "report them as \"parity_mode\" (0 = skip; skipped for N > 1 and for the non-default workloads)")
+    ap.add_argument("--also", default="det512s50,seg1024tiled",
+                    help="after the headline (default workload, N = 1): also time these BASELINE configurations briefly in the same run "
+                         "and report them under \"other_workloads\" (\"none\" = skip)")
     ap.add_argument("--breakdown-json", default=None, help="write the per-launch-name time table of the roofline pass to this file")
     ap.add_argument("--dup", default=None, help="measurement aid: issue every idempotent launch whose name contains this string twice "
                                                 "(marginal wall-clock cost of a kernel class inside the overlapped graphs)")
@@ -207,9 +210,11 @@ def main() -> None:
         if args.no_graph:
             return
         for e in cldm._cldm_engines.values():
-            e.step_prog.capture(parallel_lanes=not args.serial_lanes)
+            if e.step_prog.graph is None:
+                e.step_prog.capture(parallel_lanes=not args.serial_lanes)
         for e in cldm._vae_engines.values():
-            e.prog.capture()
+            if e.prog.graph is None:
+                e.prog.capture()
 
     capture_all()
     step_events = []
@@ -283,6 +288,15 @@ def main() -> None:
             result["pre_restoration"] = {"error": repr(e)}
     if rank == 0 and not args.no_roofline:
         result.update(roofline_pass(cldm, args, ms_per_step))
+    if (rank == 0 and world == 1 and args.also != "none" and args.precision == "fast" and args.workload == "det512" and args.config == "sd21"
+            and std_shape and not args.dup and not args.no_graph):
+        # ---- the other single-GPU BASELINE configurations, briefly, on the driver's record too
+        result["other_workloads"] = {}
+        for name in [w for w in args.also.split(",") if w in ("det512s50", "seg1024tiled")]:
+            try:
+                result["other_workloads"][name] = other_workload_leg(cldm, diffusion, sampler, name, dev, ctx_dim, args, capture_all, rel_err)
+            except Exception as e:       # never take the headline down
+                result["other_workloads"][name] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(finish_cpu_baseline(cpu_handle, inp, img.cpu(), z.cpu(), S, rel_err, tol_key))
     if rank == 0 and args.config == "sd21":     # rank 0's shard starts at image 0 of the global batch: same images as the golden's
@@ -402,6 +416,59 @@ def parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err) ->
     if gp:
         out.update(rel_err_latent=gp["rel_err_latent"], rel_err_image=gp["rel_err_image_samples"], fixture=gp["fixture"],
                    images=gp["images"], meets_north_star=bool(gp["rel_err_latent"] < NORTH_STAR and gp["rel_err_image_samples"] < NORTH_STAR), north_star=NORTH_STAR)
+    return out
+
+
+def other_workload_leg(cldm, diffusion, sampler, name, dev, ctx_dim, args, capture_all, rel_err) -> dict:
+    """A short measurement of another BASELINE configuration in the headline's process (same model, fast mode): configs[4] per GPU
+    (det512s50: batch 4, 50 steps from pure noise, fresh torch.randn_like per step) or configs[3] (seg1024tiled: one 1024x1024
+    image, tiled VAE encoder + latent-tiled sampler).  Timed like the headline (hipGraph replay, barrier-to-barrier wall clock);
+    `python bench.py --workload <name>` is the full-length form."""
+    from edtr_amd import workloads
+    B, S, _ = workloads.WORKLOADS[name]
+    inflight = 1 if name == "seg1024tiled" else args.inflight
+    steps = 6 if name == "seg1024tiled" else 2
+    inp = workloads.make_inputs(name, ctx_dim, dev, B, S)
+    untiled_forward = type(cldm).forward.__get__(cldm)      # (the tiled sampler monkey-patches cldm.forward and never restores it)
+
+    def one_pass():
+        img, z, _ = workloads.restore_pass(cldm, diffusion, sampler, inp, name, untiled_forward)
+        return img, z
+
+    streams = [torch.cuda.Stream() for _ in range(inflight)]
+
+    def run(n):
+        out = None
+        for i in range(n):
+            k = i % inflight
+            cldm.engine_slot = k
+            with torch.cuda.stream(streams[k]):
+                out = one_pass()
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        return out
+
+    for k in range(inflight):          # program build per buffer slot
+        cldm.engine_slot = k
+        one_pass()
+    torch.cuda.synchronize()
+    capture_all()
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    run(inflight)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img, z = run(steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    cldm.forward = untiled_forward
+    cldm.engine_slot = 0
+    out = {"images_per_s": round(B / ms * 1e3, 4), "ms_per_step": round(ms, 3), "steps": steps, "batch": B, "image_size": S,
+           "denoise_steps": workloads.WORKLOADS[name][2], "batches_in_flight": inflight,
+           "mfma_frac_whole_path": round(B / ms * 1e3 * FLOP_PER_IMAGE_BY_WORKLOAD[name] / (PEAK_TFLOPS * 1e12), 4)}
+    gp = golden_parity(name, img, z, rel_err, args.dtype).get("parity_vs_reference_golden")
+    if gp:
+        out.update(rel_err_latent=gp["rel_err_latent"], rel_err_image=gp["rel_err_image_samples"], parity_ok=gp["ok"])
     return out
 
 

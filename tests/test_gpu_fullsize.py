@@ -51,14 +51,16 @@ def _slice_inputs(inp, k):
                   [n[k:k + 1].contiguous() for n in inp.step_noises], inp.t_start[k:k + 1])
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "mixed"])
 def test_det512_batch8_every_image(golden_dir, dname):
-    """BASELINE configs[1] (and one GPU's share of configs[2]) exactly as bench.py runs it: B = 8."""
+    """BASELINE configs[1] (and one GPU's share of configs[2]) exactly as bench.py runs it: B = 8.  Every image of the batch is
+    also compared with the same image travelling alone: tile choice, split-K and GroupNorm fusion depend on M = B*H*W, so the
+    two agree to the mode's rounding, not bitwise (bf16 1.2e-2, fp16 1.5e-3, mixed: the printed value, inside the 1e-3 budget)."""
     from edtr_amd import workloads
     from edtr_amd.testing import rel_err
     dev = _need_gpu()
     g = np.load(os.path.join(golden_dir, "full_det512.npz"))
-    cldm, diffusion, sampler = _build(dev, DTYPES[dname])
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision="mixed" if dname == "mixed" else None)
     inp = workloads.make_inputs("det512", 1024, dev, 8, 512)
     img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "det512")
     torch.cuda.synchronize()
