@@ -3051,6 +3051,20 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (halo && dma_ok && (p.N & 127) == 0 && igemm_halo_ok(p, spatial) && igemm_fast_addressable(p, spatial) &&
             (int64_t)(p.M >> 8) * (p.N >> 7) * p.splitk >= 48)      // (p.splitk was normalised to >= 1 above)
             tile = 16;
+        // ... and where they DO pad N (N = 320 = 2.5 tiles) as long as the padded grid is at most ONE round of workgroups: the
+        // 64x64-latent convolutions at batch <= 4 (192 units), where the 128x160 tile's 256 workgroups crawl alone on their CUs.
+        // Measured (profiles/r03/halo_n320.log, one device): 37.0 / 63.1 / 88.9 us against 51.8 / 92.6 / 133.8 (K = 2880 / 5760 /
+        // 8640, batch 4: 1.40 - 1.50x), 33.1 against 48.7 at batch 2; at batch 8 (384 units = 1.5 rounds) the 128x160 tile wins by 8 %.
+        static int ragged = -1;
+        if (ragged < 0) {
+            const char* e6 = getenv("EDTR_IGEMM_HALO_RAGGED");
+            ragged = (e6 && e6[0] == '0') ? 0 : 1;
+        }
+        if (halo && ragged && dma_ok && (p.N & 127) != 0 && p.N > 128 && p.splitk <= 1 && igemm_halo_ok(p, spatial) &&
+            igemm_fast_addressable(p, spatial)) {
+            const int64_t units = (int64_t)(p.M >> 8) * ((p.N + 127) >> 7);
+            if (units >= 48 && units <= 256) tile = 16;
+        }
         // 8-wave ping-pong 128x128 tile: plain GEMMs whose tile grid leaves at most one workgroup per CU.  In isolation 1.20-1.32x over
         // tile 3 at 40-160 tiles (0.83x at 320: profiles/r02/ab_tiles_3_vs_15_small_gemm.log), but the whole path did not move in a
         // same-device A/B (det512 107.07 vs 106.65 images/s, det512s50 8.298 vs 8.291): these launches overlap with the other lane /
