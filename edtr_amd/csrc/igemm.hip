@@ -3007,7 +3007,9 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (p.ln_stats) {
         if (p.Z != 1 || p.splitk > 1 || p.taps != 1 || spatial || p.C2) return EDTR_E_UNSUPPORTED;
         if (!p.ln_c1 || !p.ln_c2) return EDTR_E_NULL;
-        if (p.ln_slots <= 0 || p.ln_C != p.K || p.ln_slots * 32 != p.ln_C) return EDTR_E_SHAPE;
+        // ln_C = the number of REAL columns the statistics run over (SwinIR keeps 180 channels in rows of 192 whose pad columns are
+        // exactly zero: they add nothing to the slots); the slots cover the K = ln_slots * 32 stored columns
+        if (p.ln_slots <= 0 || p.ln_slots * 32 != p.K || p.ln_C <= 0 || p.ln_C > p.K) return EDTR_E_SHAPE;
         if (!aligned16(p.ln_stats) || !aligned16(p.ln_c1) || !aligned16(p.ln_c2)) return EDTR_E_ALIGN;
     }
 

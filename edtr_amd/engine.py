@@ -457,8 +457,8 @@ class LNRef:
     """A LayerNorm that is not launched: its raw input rows ``x`` [rows, C] and the per-row statistics ``stats`` [rows, C / 32, 2]
     the producing GEMM wrote; the consuming GEMMs fold the normalisation into their weights and epilogue (edtr_hip.h ln_stats)."""
 
-    def __init__(self, x: torch.Tensor, stats: torch.Tensor, C: int, prefix: str):
-        self.x, self.stats, self.C, self.prefix = x, stats, C, prefix
+    def __init__(self, x: torch.Tensor, stats: torch.Tensor, C: int, prefix: str, c_valid: int = 0):
+        self.x, self.stats, self.C, self.prefix, self.c_valid = x, stats, C, prefix, c_valid or C
 
 
 @dataclass
@@ -584,7 +584,7 @@ class Emitter:
         """igemm arguments of a folded LayerNorm for operand ``a`` (an LNRef) -> (raw rows, extra keyword arguments)."""
         if a.C != K or ln_vec is None:
             raise ValueError("folded LayerNorm: the consumer needs K == C and the folded weight's (c1, c2)")
-        return a.x, dict(ln_stats=a.stats, ln_C=a.C, ln_eps=1e-5, ln_c1=ln_vec[0], ln_c2=ln_vec[1])
+        return a.x, dict(ln_stats=a.stats, ln_C=a.C, ln_valid=a.c_valid, ln_eps=1e-5, ln_c1=ln_vec[0], ln_c2=ln_vec[1])
 
     def gemm(self, a, w, M: int, N: int, K: int, *, bias=None, out=None, act=0,
              residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,

@@ -15,6 +15,7 @@ cyclic shift, window gather, relative-position bias, region mask, softmax, PV, s
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -22,7 +23,7 @@ import torch
 
 from .. import lib as L
 from .. import ops as ops_mod
-from ..engine import Act, Arena, Emitter, EngineCache, Program, WeightStore
+from ..engine import Act, Arena, Emitter, EngineCache, LNRef, Program, WeightStore
 from ..ops import round_up
 from .params import ParamTree, params_fingerprint
 
@@ -176,6 +177,21 @@ class _SwinEngine:
                                                  name="swin.layernorm"))
             return y
 
+        # LayerNorm folded into the GEMMs around it (include/edtr_hip.h: row_stats / ln_stats): proj and fc2 write the per-row
+        # statistics of their outputs, qkv and fc1 run on the raw rows against gamma-scaled weights.  Here — unlike in the UNet,
+        # where the launches it removes were hidden behind the other lane — every layer is a chain of launch-sized round trips
+        # and nothing runs beside it.  EDTR_SWIN_LN_FOLD=0 switches it off.
+        fold_ln = os.environ.get("EDTR_SWIN_LN_FOLD", "1") != "0" and CP % 32 == 0
+
+        def folded(key_kind: str, prefix: str, ln_prefix: str, wf: torch.Tensor, bf: torch.Tensor):
+            """(packed gamma-scaled matrix, bias, c1, c2) of an already padded fp32 [Npad, CP] matrix ``wf`` behind LayerNorm ``ln_prefix``."""
+            key = ("swin_lnfold", key_kind, prefix)
+            if key not in store.cache:
+                gamma, beta = store.vec(ln_prefix + "weight", CP), store.vec(ln_prefix + "bias", CP)       # pad entries are zero
+                packed = (wf * gamma[None, :]).to(dt).contiguous()
+                store.cache[key] = (packed, bf, packed.float().sum(dim=1).contiguous(), (wf @ beta).contiguous())
+            return store.cache[key]
+
         def linear(prefix: str, k_pad: int, n_pad: int):
             key = ("swin_linear", prefix, k_pad, n_pad)
             if key not in store.cache:
@@ -184,6 +200,12 @@ class _SwinEngine:
                 wp[: w.shape[0], : w.shape[1]] = w
                 store.cache[key] = (wp.to(dt).contiguous(), ops_mod.pad_bias(store._p(prefix + "bias"), n_pad))
             return store.cache[key]
+
+        def fc1_f32(p: str, n_pad: int) -> torch.Tensor:
+            w = store._p(p + "mlp.fc1.weight")
+            wp_ = torch.zeros((n_pad, CP), dtype=torch.float32, device=dev)
+            wp_[: w.shape[0], : w.shape[1]] = w
+            return wp_
 
         f0 = conv3(Act(f_in, B, th, tw, f_in.shape[1]), "conv_first.1.", CP, name="swin.conv_first")
         em.free(f_in)
@@ -195,18 +217,24 @@ class _SwinEngine:
                 raise NotImplementedError(f"SwinIR head width {d} > {HEAD_PAD}")
             QW = heads * HEAD_PAD
             r = t
+            r_stats = None                      # row statistics of r, when a GEMM of this group produced it
             for j in range(depth):
                 p = f"layers.{i}.residual_group.blocks.{j}."
                 shift = 0 if j % 2 == 0 else ws // 2
-                h = ln(r, p + "norm1.")
                 key = ("swin_qkv", p)
                 if key not in store.cache:
                     wq, bq = pack_qkv(store._p(p + "attn.qkv.weight"), store._p(p + "attn.qkv.bias"), heads, CP)
                     store.cache[key] = (wq.to(dt).contiguous(), bq.contiguous(),
-                                        expand_bias(store._p(p + "attn.relative_position_bias_table"), ws))
-                wq, bq, bias = store.cache[key]
-                qkv = em.gemm(h, wq, rows, 3 * QW, CP, bias=bq, name="swin.qkv")
-                em.free(h)
+                                        expand_bias(store._p(p + "attn.relative_position_bias_table"), ws), wq.contiguous())
+                wq, bq, bias, wq32 = store.cache[key]
+                if r_stats is not None:       # r came out of the previous layer's fc2 with its row statistics: no norm1 launch
+                    wqf, _, c1, c2 = folded("qkv", p, p + "norm1.", wq32, bq)
+                    qkv = em.gemm(LNRef(r, r_stats, CP, p + "norm1.", C), wqf, rows, 3 * QW, CP, bias=bq, name="swin.qkv", ln_vec=(c1, c2))
+                    em.free(r_stats)
+                else:
+                    h = ln(r, p + "norm1.")
+                    qkv = em.gemm(h, wq, rows, 3 * QW, CP, bias=bq, name="swin.qkv")
+                    em.free(h)
                 lab = None
                 if shift:
                     if shift not in labels:
@@ -218,16 +246,24 @@ class _SwinEngine:
                                                        scale=d ** -0.5))
                 em.free(qkv)
                 wp, bp = linear(p + "attn.proj.", CP, CP)
-                x1 = em.gemm(o, wp, rows, CP, CP, bias=bp, residual=r, name="swin.proj")
+                x1 = em.gemm(o, wp, rows, CP, CP, bias=bp, residual=r, name="swin.proj", row_stats=fold_ln)
+                x1_stats = em.last_row_stats
                 em.free(o)
                 if r is not t:
                     em.free(r)
-                h2 = ln(x1, p + "norm2.")
                 w1, b1 = linear(p + "mlp.fc1.", CP, HP)
-                g = em.gemm(h2, w1, rows, HP, CP, bias=b1, act=L.ACT_GELU, name="swin.fc1")
-                em.free(h2)
+                if x1_stats is not None:
+                    w1f, _, c1, c2 = folded("fc1", p, p + "norm2.", fc1_f32(p, HP), b1)
+                    g = em.gemm(LNRef(x1, x1_stats, CP, p + "norm2.", C), w1f, rows, HP, CP, bias=b1, act=L.ACT_GELU, name="swin.fc1", ln_vec=(c1, c2))
+                    em.free(x1_stats)
+                else:
+                    h2 = ln(x1, p + "norm2.")
+                    g = em.gemm(h2, w1, rows, HP, CP, bias=b1, act=L.ACT_GELU, name="swin.fc1")
+                    em.free(h2)
                 w2, b2 = linear(p + "mlp.fc2.", HP, CP)
-                r = em.gemm(g, w2, rows, CP, HP, bias=b2, residual=x1, name="swin.fc2")
+                last_of_group = j == depth - 1       # the group's last output feeds a 3x3 convolution, not a LayerNorm
+                r = em.gemm(g, w2, rows, CP, HP, bias=b2, residual=x1, name="swin.fc2", row_stats=fold_ln and not last_of_group)
+                r_stats = em.last_row_stats
                 em.free(g, x1)
             t2 = conv3(Act(r, B, th, tw, CP), f"layers.{i}.conv.", CP, residual=t, name="swin.rstb_conv")
             em.free(r)

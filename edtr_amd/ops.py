@@ -67,7 +67,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                tile: int = 0, splitk: int = 1, workspace: Optional[torch.Tensor] = None,
                gn_partial: Optional[torch.Tensor] = None, act_slope: float = 0.0, residual_f32: bool = False,
                vt_out: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_ld: int = 0, vt_alpha: float = 1.0,
-               row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0,
+               row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0, ln_valid: int = 0,
                ln_eps: float = 1e-5, ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None,
                name: str = "igemm") -> Rec:
     p = L.IgemmParams()
@@ -96,7 +96,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
         p.vt_out, p.vt_col0, p.vt_ld, p.vt_alpha = ptr(vt_out), vt_col0, vt_ld, vt_alpha
     p.row_stats = ptr(row_stats)
     if ln_stats is not None:
-        p.ln_stats, p.ln_slots, p.ln_C, p.ln_eps, p.ln_c1, p.ln_c2 = ptr(ln_stats), ln_C // 32, ln_C, ln_eps, ptr(ln_c1), ptr(ln_c2)
+        p.ln_stats, p.ln_slots, p.ln_C, p.ln_eps, p.ln_c1, p.ln_c2 = ptr(ln_stats), ln_C // 32, ln_valid or ln_C, ln_eps, ptr(ln_c1), ptr(ln_c2)
     flops = 2.0 * M * N * p.K * Z
     # algorithmic HBM bytes: every operand once (a conv reads its input image once, not once per tap)
     a_rows = (M // (p.OH * p.OW)) * p.IH * p.IW if spatial else M

@@ -159,8 +159,8 @@ typedef struct edtr_igemm_params {
      *     the values it stores: row_stats[m][N / 32][2] fp32; a column tile fills the slot of its first 32 columns and zeroes
      *     the other slots it covers, so the totals over a row's N / 32 slots are defined whatever tile ran (no atomics:
      *     results stay bit-reproducible).  Needs N % 32 == 0, Z == 1, no split-K / GEGLU, a row-major tile (not tile 16).
-     *   consumer side — ln_stats (optional): row statistics of the A operand's rows (ln_slots = C / 32 slots per row, C = K =
-     *     ln_C columns, eps ln_eps); the epilogue computes out = rstd (alpha acc - mean alpha c1[n]) + alpha c2[n] + bias_n[n]
+     *   consumer side — ln_stats (optional): row statistics of the A operand's rows (ln_slots = K / 32 slots per row; ln_C <= K
+     *     = the number of real columns the mean / variance run over — pad columns must be zero —, eps ln_eps); the epilogue computes out = rstd (alpha acc - mean alpha c1[n]) + alpha c2[n] + bias_n[n]
      *     (vt_alpha for the transposed V columns), then GEGLU / activation / residual as usual.  Needs Z == 1, no split-K,
      *     taps == 1, tile 0 / 1 / 3 / 8. */
     float* row_stats;
