@@ -343,7 +343,8 @@ class Program:
         return rec
 
     def duplicate_launches(self, substr: str, idempotent=("conv", "qk", "vT", "attn2.q", "geglu", "flash", "layernorm", ".apply",
-                                                          "proj_in", "time_embed", "emb_layers", "ctx_", "zero_conv")) -> int:
+                                                          "proj_in", "proj_out", "attn.out", "ff.out", "res.skip", "time_embed",
+                                                          "emb_layers", "ctx_", "zero_conv")) -> int:
         """Measurement aid for tools / bench.py --dup (never used by the product path): every launch whose name contains
         ``substr`` AND is known to be idempotent (writes only its own output, no in-place residual, no atomics) is issued twice.
         The slowdown of a whole-path run is the MARGINAL wall-clock cost of that kernel class inside the overlapped hipGraph

@@ -1,10 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-echo "# EDTR_EXP_DUP=<name>: every idempotent launch whose name contains <name> is issued twice; bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline (final code of round 2: halo tile incl. upsample variant, tile order rules)"
+echo "# bench.py --dup <name>: every idempotent launch whose name contains <name> is issued twice (Program.duplicate_launches); bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline --parity-steps 0 --also none"
 echo "# name            images/s   ms_per_step   marginal_ms"
 base=""
-for n in NONE vae.conv1 vae.conv2 vae.upsample res.conv1 res.conv2 upsample.conv ff.geglu ff.out flash gn.apply attn.out layernorm gn.stats st.proj attn1.qk attn1.vT NONE; do
-  if [ "$n" = "NONE" ]; then out=$(python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1); else out=$(EDTR_EXP_DUP=$n python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1); fi
+for n in NONE vae.conv1 vae.conv2 vae.upsample res.conv1 res.conv2 upsample.conv ff.geglu ff.out flash gn.apply attn.out layernorm st.proj attn1.qkv attn2.q zero_conv res.skip NONE; do
+  A="--steps 12 --warmup 3 --no-cpu-baseline --no-roofline --parity-steps 0 --also none"
+  if [ "$n" = "NONE" ]; then out=$(python bench.py $A 2>/dev/null | tail -1); else out=$(python bench.py $A --dup $n 2>/dev/null | tail -1); fi
   python3 - "$n" "$out" "$base" <<'PY'
 import json,sys
 n,o,b=sys.argv[1],sys.argv[2],sys.argv[3]
