@@ -29,8 +29,17 @@
             else sb__[i] = __builtin_amdgcn_s_memtime();                                                               \
         }                                                                                                              \
     } while (0)
+#define EDTR_STAMP_T(i)                                                                                                \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && p.workspace && p.splitk <= 1) {                                                        \
+            uint64_t* sb__ = static_cast<uint64_t*>(p.workspace) +                                                     \
+                             (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16;             \
+            sb__[i] = __builtin_amdgcn_s_memtime();                                                                    \
+        }                                                                                                              \
+    } while (0)
 #else
 #define EDTR_STAMP(i)
+#define EDTR_STAMP_T(i)
 #endif
 
 namespace {
@@ -161,6 +170,19 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
 // (measured with tools/exp/igemm_stamps.py: 9-15k cycles per tile before).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
+// Two workgroups share a CU in the 2-per-CU kernels, and the hardware starts blocks i and i + 256 on the same CU within the same
+// microsecond (tools/exp/igemm_stamps.py, EDTR_STAMP_PAIRS): they then run in LOCKSTEP — both in their K loop (VALU and the store
+// path idle), both in their epilogue (MFMA idle; the 512 simultaneous store bursts are bound by HBM write bandwidth: 6.5k of a
+// short-K tile's 20k cycles).  Holding the second block of each CU back by half a workgroup life at the START of the launch
+// interleaves the two for the rest of it.  stagger = cycles to wait (0 = off); only blocks 256..511 of the dispatch order wait.
+__device__ __forceinline__ void stagger_second_slot(const edtr_igemm_params& p) {
+    if (p.stagger <= 0) return;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin < 256u || lin >= 512u) return;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    while ((int64_t)(__builtin_amdgcn_s_memtime() - t0) < (int64_t)p.stagger) __builtin_amdgcn_s_sleep(32);
+}
+
 // ---- LayerNorm folded into the GEMMs around it (edtr_hip.h: row_stats / ln_stats) ------------------------------------------
 // One LDS array of per-row (mean, rstd) for the rows of the tile being finished (all igemm kernels have <= 256 rows per pass).
 __device__ __forceinline__ float2* ln_rows_lds() {
@@ -219,7 +241,11 @@ __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float
 
 // FOLD = false compiles the folded-LayerNorm paths out (the halo kernels: their register budget is full and no LayerNorm sits next
 // to a 3x3 convolution)
-template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false, int PITCH = BNO, bool FOLD = true, typename Hook = NoHook>
+// PF: how the staged vectors are read — 2 = all of this thread's vectors up front (needs 8 ITER free registers: the kernels whose
+// accumulators are all dead by now), 1 = one row iteration ahead (16 registers), 0 = inside the iteration (the 512-thread kernels,
+// whose register file is full)
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, bool PATCH16 = false, int PITCH = BNO, bool FOLD = true, int PF = 0,
+          typename Hook = NoHook>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8], Hook before_publish = Hook()) {
     // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
@@ -305,15 +331,93 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     const bool silu = p.act == EDTR_ACT_SILU, gelu = p.act == EDTR_ACT_GELU, lrelu = p.act == EDTR_ACT_LRELU;
     before_publish();                         // the caller's last staging step runs under the flight of the loads above
     __syncthreads();                          // staged tile (and the folded LayerNorm's row scalars) visible
+    EDTR_STAMP_T(13);
+
+    // All of this thread's staged vectors are requested up front, outside the row loop's control flow: inside it the compiler
+    // cannot move an iteration's ds_reads above the previous iteration's (predicated) stores, and the loop then pays one LDS
+    // round trip per iteration — 6.5k cycles of a 128 x 128 tile's 8.6k-cycle epilogue in the in-kernel stamps (round 3).  The
+    // accumulators are dead by now, so the 8 ITER registers are free.  (Rows beyond BM in the non-exact split are clamped: the read
+    // must stay inside the staged tile, its value is never used.)
+    constexpr int NPF = PF == 2 ? ITER : (PF == 1 ? 2 : 1);
+    f32x4 sv0[NPF], sv1[NPF];
+    auto stage_read = [&](int it, int slot) {
+        const int mlr = r0 + RPI * it, mlc = EXACT ? mlr : (mlr < BM ? mlr : BM - 1);
+        const int n8c = EXACT ? n8 : (n8 < VPR ? n8 : 0);
+        sv0[slot] = *reinterpret_cast<const f32x4*>(stage + mlc * PITCH + n8c * 8);
+        sv1[slot] = *reinterpret_cast<const f32x4*>(stage + mlc * PITCH + n8c * 8 + 4);
+    };
+    if constexpr (PF == 2) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) stage_read(it, it);
+    } else if constexpr (PF == 1) {
+        stage_read(0, 0);
+    }
+
+    // The common case — 16-bit output, bias (+ a uniform time-embedding row) in cb, optional 16-bit residual, optional GroupNorm
+    // partials, nothing else — gets its own loop: the general loop below tests ~10 launch-uniform options INSIDE every iteration
+    // (the compiler does not unswitch them), and with one wave per SIMD each of those scalar branches and the 64-bit address
+    // arithmetic they fence costs its full latency: 800 cycles per iteration, 6.4k of a 128 x 128 tile's 8.4k-cycle epilogue
+    // (tools/exp/igemm_stamps.py, round 3).  Here the only control flow is the store's predicate.
+    {
+        const bool fast = !ln && !p.bias_m && !rv_rows && !silu && !gelu && !lrelu && !p.out_f32 && !(p.residual && p.residual_f32) && !stats_out &&
+                          !(p.debug_flags & 1);
+        if (fast) {
+            uint16_t* const out16 = static_cast<uint16_t*>(p.out) + o_zoff + n;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
+                if constexpr (PF == 1) {
+                    if (it + 1 < ITER) stage_read(it + 1, (it + 1) & 1);
+                }
+                const bool ok = n_ok && m < p.M && (EXACT || ml < BM);
+                f32x4 s0, s1;
+                if constexpr (PF == 0) {
+                    const int mlc = EXACT ? ml : (ml < BM ? ml : BM - 1), n8c = EXACT ? n8 : (n8 < VPR ? n8 : 0);
+                    s0 = *reinterpret_cast<const f32x4*>(stage + mlc * PITCH + n8c * 8);
+                    s1 = *reinterpret_cast<const f32x4*>(stage + mlc * PITCH + n8c * 8 + 4);
+                } else {
+                    s0 = sv0[PF == 2 ? it : (it & 1)];
+                    s1 = sv1[PF == 2 ? it : (it & 1)];
+                }
+                float f[8];
+                f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], alpha, cb[j]);
+                if (res16) {
+                    float rf[8];
+                    unpack8<T>(res[it], rf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] += rf[j];
+                }
+                if (ok) {
+                    stg16(out16 + (int64_t)m * p.ldc, pack8<T>(f));
+                    if (gn_acc) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
+                    }
+                }
+            }
+            EDTR_STAMP_T(14);
+            return;
+        }
+    }
 
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         // PATCH16: the tile's rows are the pixels of a 16 x 16 output patch (row ml = 16 * y + x), m0 = its first pixel
         const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
+        if constexpr (PF == 1) {
+            if (it + 1 < ITER) stage_read(it + 1, (it + 1) & 1);       // the next iteration's vectors fly under this one's arithmetic
+        }
         if (m < p.M && n_ok && (EXACT || ml < BM)) {
             f32x4 s0, s1;
-            s0 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8);
-            s1 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8 + 4);
+            if constexpr (PF == 0) {
+                s0 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8);
+                s1 = *reinterpret_cast<const f32x4*>(stage + ml * PITCH + n8 * 8 + 4);
+            } else {
+                s0 = sv0[PF == 2 ? it : (it & 1)];
+                s1 = sv1[PF == 2 ? it : (it & 1)];
+            }
             float f[8];
             f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
             if (ln) {
@@ -376,6 +480,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             }
         }
     }
+    EDTR_STAMP_T(14);
     if (stats_out) {
         // per-row statistics of the tensor just written (the input of a LayerNorm that the NEXT GEMM folds in): the VPR threads
         // that share a row meet in LDS (the staged tile is dead), one thread per row writes the tile's slot
@@ -457,6 +562,7 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
                     stage[ml * BNO + wn * 32 * NI + ni * 32 + l31] = acc[mi][ni][r];
                 }
     }
+    EDTR_STAMP_T(12);
     const int n_out = geglu ? p.N / 2 : p.N;
     const int no0 = geglu ? n0 / 2 : n0;
     // fused GroupNorm statistics of the tensor being written (per-column sum / sum of squares over this tile's rows):
@@ -465,8 +571,8 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    if (geglu) rows_phase<T, BM, BN / 2, true>(p, stage, m0, no0, n_out, o_zoff, false, gs, gq);
-    else rows_phase<T, BM, BN, false>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
+    if (geglu) rows_phase<T, BM, BN / 2, true, 256, false, BN / 2, true, 2>(p, stage, m0, no0, n_out, o_zoff, false, gs, gq);
+    else rows_phase<T, BM, BN, false, 256, false, BN, true, 2>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
     if (gn_acc) {
         // lanes l, l+16, l+32, l+48 of a wave own the same columns: fold them, then fold the 4 waves through LDS
 #pragma unroll
@@ -702,6 +808,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
 template <typename T, bool SPATIAL, bool FAST>
 __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm_params p) {
     EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
+    stagger_second_slot(p);
     constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2085,6 +2192,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     constexpr int BM = 32 * MB, BN = 32 * NB;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    stagger_second_slot(p);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -2296,7 +2404,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
 #pragma unroll
                     for (int r = 0; r < 4; ++r) stage[(mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
         }
-        rows_phase<T, 16 * MB, BN, false, kThreads>(p, stage, m0 + h * (16 * MB), n0, p.N, o_zoff, gn_acc, gs, gq);
+        rows_phase<T, 16 * MB, BN, false, kThreads, false, BN, true, 1>(p, stage, m0 + h * (16 * MB), n0, p.N, o_zoff, gn_acc, gs, gq);
         __syncthreads();                       // every thread is done reading the staged rows
     }
     if (gn_acc) {
@@ -2616,7 +2724,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    rows_phase<T, 256, 128, false, 512, !IMG8, SPITCH, false>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);   // IMG8: rows are consecutive
+    rows_phase<T, 256, 128, false, 512, !IMG8, SPITCH, false, 0>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);   // IMG8: rows are consecutive
     if (gn_acc) {
         // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
 #pragma unroll
@@ -3111,6 +3219,30 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
     if (tile < 1 || tile > 16 || (tile >= 11 && tile <= 13)) return EDTR_E_DTYPE;     // 11-13: experiments, measured and removed (15 is opt-in)
+    // lockstep breaker of the two-workgroups-per-CU kernels (stagger_second_slot): only when the grid has more than one round
+    // (>= 768 workgroups: below that the second slot's blocks are the tail anyway) and the tile is short enough for the epilogue
+    // to matter.  EDTR_IGEMM_STAGGER = percent of the estimated half life (default 100; 0 = off).
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char* e8 = getenv("EDTR_IGEMM_GENERAL_EPILOGUE");
+        dbg = (e8 && e8[0] == '1') ? 1 : 0;
+    }
+    p.debug_flags = dbg;
+    p.stagger = 0;
+    if ((tile == 3 || tile == 8) && p.splitk <= 1) {
+        static int pct = -1;
+        if (pct < 0) {
+            const char* e7 = getenv("EDTR_IGEMM_STAGGER");
+            pct = e7 ? atoi(e7) : 0;       // measured: no gain in isolation (the two workgroups of a CU are not slowed by their lockstep), off
+        }
+        const int bm = 128, bn = tile == 8 ? 160 : 128;
+        const int64_t wgs = (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.Z;
+        const int nkt = (p.K + 63) / 64;
+        if (pct > 0 && wgs >= 768 && nkt <= 48) {
+            const int life = 4000 + nkt * 1350 + (p.act == EDTR_ACT_GEGLU ? 11000 : 9000);      // cycles, from the in-kernel stamps
+            p.stagger = (int)((int64_t)life * pct / 200);
+        }
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
 }

@@ -49,6 +49,7 @@ class IgemmParams(C.Structure):
         ("row_stats", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_slots", C.c_int32), ("ln_C", C.c_int32), ("ln_eps", C.c_float),
         ("ln_c1", C.c_void_p), ("ln_c2", C.c_void_p),
+        ("stagger", C.c_int32), ("debug_flags", C.c_int32),
     ]
 
 

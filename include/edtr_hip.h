@@ -166,6 +166,11 @@ typedef struct edtr_igemm_params {
     float* row_stats;
     const float* ln_stats; int32_t ln_slots; int32_t ln_C; float ln_eps;
     const float* ln_c1; const float* ln_c2;
+    int32_t stagger;        /* set by edtr_igemm itself (the caller's value is ignored): cycles by which the second workgroup of
+                               every CU starts late, so that the two resident workgroups of the 128-row tiles do not run their K
+                               loops and their store bursts in lockstep */
+    int32_t debug_flags;    /* set by edtr_igemm itself from the environment (A/B measurements on one device): bit 0 =
+                               EDTR_IGEMM_GENERAL_EPILOGUE=1, every launch takes the general epilogue row loop */
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);

@@ -84,6 +84,16 @@ def run():
         cu = (hw >> 8) & 0xF
         se = (hw >> 13) & 0x7
         slots = len(set(zip(xcc.tolist(), se.tolist(), cu.tolist())))
+        if os.environ.get("EDTR_STAMP_PAIRS"):      # which workgroups share a CU in the first round? (dispatch order)
+            first = np.nonzero(rt0 / 100.0 < 1.0)[0]
+            by_cu = {}
+            for i in first:
+                by_cu.setdefault((int(xcc[i]), int(se[i]), int(cu[i])), []).append(int(i))
+            pairs = sorted(v for v in by_cu.values())[:12]
+            diffs = sorted(set(abs(v[1] - v[0]) for v in by_cu.values() if len(v) == 2))
+            print(f"    first-round sharing of a CU (block indices): {pairs} ... index distances {diffs[:12]}")
+            order = np.argsort(rt0)[:16]
+            print(f"    first 16 workgroups to start: {[int(i) for i in order]} on (xcc, se, cu) {[(int(xcc[i]), int(se[i]), int(cu[i])) for i in order]}")
         starts = np.sort(rt0) / 100.0
         # how many workgroups start in the first microsecond = resident slots
         first_wave = int((starts < 1.0).sum())
@@ -92,6 +102,7 @@ def run():
               f"WG life {life_us:5.1f} us | cycles med: prologue {int(np.median(pro)):5d} first-tile {int(np.median(first)):5d} "
               + (f"[t16 epilogue: K-half-0 write {int(np.median(st[:, 8] - st[:, 3]))} K-half-1 add {int(np.median(st[:, 9] - st[:, 8]))} rows {int(np.median(st[:, 4] - st[:, 9]))}] " if tile == 16 else "")
               + (f"[t17: epi-setup {int(np.median(st[:, 8] - st[:, 3]))} mbloop {int(np.median(st[:, 9] - st[:, 8]))} gn+rest {int(np.median(st[:, 4] - st[:, 9]))} | unit2 loop {int(np.median(st[:, 10] - st[:, 4]))} epi {int(np.median(st[:, 11] - st[:, 10]))}] " if tile == 17 else "") +
+              (f"[epilogue: acc->LDS {int(np.median(st[:, 12] - st[:, 3]))} prefetch+barrier {int(np.median(st[:, 13] - st[:, 12]))} row loop {int(np.median(st[:, 14] - st[:, 13]))} tail {int(np.median(st[:, 4] - st[:, 14]))}] " if tile == 3 else "") +
               f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d} | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}",
               flush=True)
 
