@@ -359,16 +359,36 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     // arithmetic they fence costs its full latency: 800 cycles per iteration, 6.4k of a 128 x 128 tile's 8.4k-cycle epilogue
     // (tools/exp/igemm_stamps.py, round 3).  Here the only control flow is the store's predicate.
     {
-        const bool fast = !ln && !p.bias_m && !rv_rows && !silu && !gelu && !lrelu && !p.out_f32 && !(p.residual && p.residual_f32) && !stats_out &&
-                          !(p.debug_flags & 1);
-        if (fast) {
-            uint16_t* const out16 = static_cast<uint16_t*>(p.out) + o_zoff + n;
+        const bool fast = !ln && !p.bias_m && !rv_rows && !silu && !gelu && !lrelu && !stats_out && !(p.debug_flags & 1);
+        // OUT32: fp32 output (the fp32 activation stream of the mixed / high modes); RES32: fp32 residual, requested up front
+        // like the staged vectors where the registers allow (PF == 2), inside the iteration otherwise
+        auto fast_loop = [&](auto out32_c, auto res32_c) {
+            constexpr bool OUT32 = decltype(out32_c)::value, RES32 = decltype(res32_c)::value;
+            constexpr int NRF = (RES32 && PF == 2) ? ITER : 1;
+            f32x4 rf0[NRF], rf1[NRF];
+            auto res_read = [&](int it, int slot) {
+                const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
+                if (n_ok && m < p.M && (EXACT || ml < BM)) {
+                    const float* rp = static_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n;
+                    rf0[slot] = *reinterpret_cast<const f32x4*>(rp);
+                    rf1[slot] = *reinterpret_cast<const f32x4*>(rp + 4);
+                } else {
+                    rf0[slot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    rf1[slot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            };
+            if constexpr (RES32 && PF == 2) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) res_read(it, it);
+            }
+            char* const outp = static_cast<char*>(p.out) + (o_zoff + n) * (OUT32 ? 4 : 2);
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int ml = r0 + RPI * it, m = PATCH16 ? m0 + (ml >> 4) * p.OW + (ml & 15) : m0 + ml;
                 if constexpr (PF == 1) {
                     if (it + 1 < ITER) stage_read(it + 1, (it + 1) & 1);
                 }
+                if constexpr (RES32 && PF != 2) res_read(it, 0);
                 const bool ok = n_ok && m < p.M && (EXACT || ml < BM);
                 f32x4 s0, s1;
                 if constexpr (PF == 0) {
@@ -383,20 +403,42 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], alpha, cb[j]);
-                if (res16) {
+                if constexpr (RES32) {
+                    const f32x4 q0 = rf0[PF == 2 ? it : 0], q1 = rf1[PF == 2 ? it : 0];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { f[j] += q0[j]; f[j + 4] += q1[j]; }
+                } else if (res16) {
                     float rf[8];
                     unpack8<T>(res[it], rf);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) f[j] += rf[j];
                 }
                 if (ok) {
-                    stg16(out16 + (int64_t)m * p.ldc, pack8<T>(f));
+                    if constexpr (OUT32) {
+                        float* o = reinterpret_cast<float*>(outp) + (int64_t)m * p.ldc;
+                        f32x4 o0, o1;
+                        o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2]; o0[3] = f[3];
+                        o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
+                        *reinterpret_cast<f32x4*>(o) = o0;
+                        *reinterpret_cast<f32x4*>(o + 4) = o1;
+                    } else {
+                        stg16(reinterpret_cast<uint16_t*>(outp) + (int64_t)m * p.ldc, pack8<T>(f));
+                    }
                     if (gn_acc) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
                     }
                 }
             }
+        };
+        if (fast) {
+            using std::true_type;
+            using std::false_type;
+            const bool res32 = p.residual && p.residual_f32;
+            if (!p.out_f32 && !res32) fast_loop(false_type{}, false_type{});
+            else if (p.out_f32 && res32) fast_loop(true_type{}, true_type{});
+            else if (p.out_f32) fast_loop(true_type{}, false_type{});
+            else fast_loop(false_type{}, true_type{});
             EDTR_STAMP_T(14);
             return;
         }
