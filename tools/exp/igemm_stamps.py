@@ -45,7 +45,7 @@ def run():
         out = torch.empty(M, n_out, dtype=DT, device=dev)
         res = torch.randn(M, n_out, device=dev).to(DT) if residual else None
         bias = torch.zeros(N, device=dev)
-        nb = ((M + 127) // 128) * ((N + 127) // 128) if tile < 16 else min(256 if tile == 17 else 1 << 30, (M // 256) * ((N + 127) // 128))
+        nb = ((M + 127) // 128) * ((N + 127) // 128) if tile < 16 else min(256 if tile in (17, 18) else 1 << 30, (M // 256) * ((N + 127) // 128))
         stamps = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
         p = L.IgemmParams()
         p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = 0 if DT == torch.bfloat16 else 1, taps, M, N, K, 1, 1
@@ -100,15 +100,16 @@ def run():
         flops = 2.0 * M * N * K
         print(f"{label:34s} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF | WGs {nb:5d} first-us {first_wave:4d} CUs {slots:3d} | span {span_us:6.1f} us "
               f"WG life {life_us:5.1f} us | cycles med: prologue {int(np.median(pro)):5d} first-tile {int(np.median(first)):5d} "
-              + (f"[t16 epilogue: K-half-0 write {int(np.median(st[:, 8] - st[:, 3]))} K-half-1 add {int(np.median(st[:, 9] - st[:, 8]))} rows {int(np.median(st[:, 4] - st[:, 9]))}] " if tile == 16 else "")
+              + (f"[t16 epilogue: K-half write {int(np.median(st[:, 8] - st[:, 3]))} add+publish {int(np.median(st[:, 13] - st[:, 8]))} row loop {int(np.median(st[:, 14] - st[:, 13]))} tail {int(np.median(st[:, 4] - st[:, 14]))}] " if tile == 16 else "")
               + (f"[t17: epi-setup {int(np.median(st[:, 8] - st[:, 3]))} mbloop {int(np.median(st[:, 9] - st[:, 8]))} gn+rest {int(np.median(st[:, 4] - st[:, 9]))} | unit2 loop {int(np.median(st[:, 10] - st[:, 4]))} epi {int(np.median(st[:, 11] - st[:, 10]))}] " if tile == 17 else "") +
+              (f"[t18 LAST unit: coords+offsets {int(np.median(st[:, 15] - st[:, 12]))} a_rd+zero {int(np.median(st[:, 1] - st[:, 15]))} wait+barrier {int(np.median(st[:, 2] - st[:, 1]))} loop {int(np.median(st[:, 3] - st[:, 2]))} pass0 write+wait {int(np.median(st[:, 8] - st[:, 3]))} pass0 rest {int(np.median(st[:, 10] - st[:, 8]))} pass1 write {int(np.median(st[:, 9] - st[:, 10]))} pass1 rest {int(np.median(st[:, 11] - st[:, 9]))} (last row loop {int(np.median(st[:, 14] - st[:, 13]))}) gn {int(np.median(st[:, 4] - st[:, 11]))} | kernel life cycles {int(np.median(st[:, 4] - st[:, 0]))}] " if tile == 18 else "") +
               (f"[epilogue: acc->LDS {int(np.median(st[:, 12] - st[:, 3]))} prefetch+barrier {int(np.median(st[:, 13] - st[:, 12]))} row loop {int(np.median(st[:, 14] - st[:, 13]))} tail {int(np.median(st[:, 4] - st[:, 14]))}] " if tile == 3 else "") +
-              f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d} | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}",
+              f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d}" + ("" if tile != 3 else f" | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}"),
               flush=True)
 
     B = 8
     if len(sys.argv) > 2 and sys.argv[2] == "halo":
-        for t in (16,):
+        for t in (16, 18):
             case(f"t{t} conv 512^2 128->128", B * 512 * 512, 128, 128, taps=9, H=512, tile=t)
             case(f"t{t} conv 512^2 256->128", B * 512 * 512, 128, 256, taps=9, H=512, tile=t)
             case(f"t{t} conv 256^2 256->256", B * 256 * 256, 256, 256, taps=9, H=256, tile=t)
