@@ -53,7 +53,7 @@ def smoke(verbose: bool = True) -> dict:
         tag = f"precision={mode}" if mode != "fast" else str(dtype)
         out[tag] = (e_z, e_img)
         if verbose:
-            print(f"smoke[{tag}]: rel err latent {e_z:.2e}, image {e_img:.2e} (tolerance {tol:.0e})")
+            print(f"smoke[{tag}]: rel err latent {e_z:.2e}, image {e_img:.2e} (tolerance {tol:.2e})")
         if not (e_img < tol and e_z < tol):
             raise AssertionError(f"smoke parity failed for {tag}: latent {e_z:.3e}, image {e_img:.3e}")
     return out

@@ -10,12 +10,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$R/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-roofline --parity-steps 0"
+ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-roofline --parity-steps 0 --also none"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.log
 python3 $ROOT/tools/prof_summary.py stats $OUT/trace $OUT/kernel_stats.csv
 # warm-up (first pass per slot = 2) + 1 warm-up round (2) + 4 timed = 8 passes under the default two batches in flight
 python3 $ROOT/tools/prof_summary.py union $OUT/trace $OUT/kernel_busy_union.json --passes 8 > /dev/null
-PARGS="--steps 1 --warmup 1 --inflight 1 --no-graph --no-cpu-baseline --no-roofline --parity-steps 0"
+PARGS="--steps 1 --warmup 1 --inflight 1 --no-graph --no-cpu-baseline --no-roofline --parity-steps 0 --also none"
 export EDTR_SYNTH_DEVICE=cpu      # rocprofv3 --pmc FETCH_SIZE crashes inside torch's int64 elementwise kernels (weight hashing)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $PARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $PARGS > /dev/null 2> $OUT/pmc_write.log
