@@ -247,7 +247,7 @@ __device__ __forceinline__ void ln_rows_fill(const edtr_igemm_params& p, int m0)
 // consecutive tokens (rows of the tile) of one column per 16-byte store.  Lane (slot, cl): 16 adjacent columns per slot — the
 // LDS reads of a slot walk 16 adjacent banks (slots collide 4-way: 8 reads per lane, negligible), the 16-byte stores of the
 // lanes that share a column are adjacent in memory.
-template <typename T, int BM, int BNO, int THREADS, int PITCH>
+template <typename T, int BM, int BNO, int THREADS, int PITCH, bool FOLD = true>
 __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float* stage, int m0, int no0) {
     static_assert(BM % 8 == 0 && BNO % 16 == 0 && THREADS % 16 == 0, "vt_store tiling");
     constexpr int TG = BM / 8, NCB = BNO / 16, SLOTS = THREADS / 16, PAIRS = TG * NCB;
@@ -260,7 +260,7 @@ __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float
         if (m >= p.M || n >= p.N) continue;
         float b = p.bias_n ? p.bias_n[n] : 0.0f;
         float f[8];
-        if (p.ln_stats) {        // folded LayerNorm of the tokens (rows): rstd (alpha acc - mean alpha c1) + alpha c2 + bias
+        if (FOLD && p.ln_stats) {        // folded LayerNorm of the tokens (rows): rstd (alpha acc - mean alpha c1) + alpha c2 + bias
             const float c1a = p.vt_alpha * p.ln_c1[n];
             b += p.vt_alpha * p.ln_c2[n];
             const float2* lr = ln_rows_lds() + tg * 8;
@@ -324,7 +324,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         if (p.vt_out != nullptr && no0 >= p.vt_col0) {    // a V tile of the fused [Q; K; V] projection: transposed store
             before_publish();
             __syncthreads();
-            vt_store<T, BM, BNO, THREADS, PITCH>(p, stage, m0, no0);
+            vt_store<T, BM, BNO, THREADS, PITCH, FOLD>(p, stage, m0, no0);
             return;
         }
     }
@@ -2278,6 +2278,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
     constexpr int BM = 32 * MB, BN = 32 * NB;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
     stagger_second_slot(p);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2439,6 +2440,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         run_c0 = (kt0 / p.taps) * BK;
         run_tap = kt0 - (kt0 / p.taps) * p.taps;
     }
+    EDTR_STAMP(1);
     if (nkt > 0) issue_tile(kt0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -2454,6 +2456,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (kt == 0) EDTR_STAMP(2);
         const char* sa = smem + cur * STAGE;
         const char* sw = sa + A_BYTES;
 #pragma unroll
@@ -2473,25 +2476,44 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
         asm volatile("" ::: "memory");
     }
     if (nkt == 0) __syncthreads();
+    EDTR_STAMP(3);
 
-    // ---- epilogue: two passes of 16 MB rows x BN columns (the rows of the waves with wm == h)
+    // ---- epilogue: the whole BM x BN fp32 tile through LDS in ONE pass (round 3; 80 KiB for 128 x 160 — two workgroups are exactly
+    // the CU's 160 KiB).  Two passes of 64 rows in the main loop's 72 KiB cost a second set of barriers, a second round of
+    // bias / residual load latency and wrote with half of the waves at a time: 10.7k cycles of a K = 320 workgroup's 25k in the
+    // stamps, against 6.5k for the 128 x 128 tile.
     float* stage = reinterpret_cast<float*>(smem);
     const bool gn_acc = p.gn_partial != nullptr && p.splitk <= 1;
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
+    if (p.debug_flags & 2) {       // EDTR_IGEMM_N160_TWO_PASS=1: the former two-pass epilogue (rows of the waves wm == h), A/B on one device
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (wm == h) {
+        for (int h = 0; h < 2; ++h) {
+            if (wm == h) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) stage[(mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
+                        for (int r = 0; r < 4; ++r) stage[(mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
+            }
+            rows_phase<T, 16 * MB, BN, false, kThreads, false, BN, false, 1>(p, stage, m0 + h * (16 * MB), n0, p.N, o_zoff, gn_acc, gs, gq);
+            __syncthreads();
         }
-        rows_phase<T, 16 * MB, BN, false, kThreads, false, BN, true, 1>(p, stage, m0 + h * (16 * MB), n0, p.N, o_zoff, gn_acc, gs, gq);
-        __syncthreads();                       // every thread is done reading the staged rows
+    } else {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(wm * (16 * MB) + mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
+    EDTR_STAMP_T(12);
+    // (FOLD = false: the folded-LayerNorm paths keep 2 KiB of static LDS for the row scalars, which would push two 80 KiB workgroups
+    //  over the CU's 160 KiB; launches with ln_stats / row_stats take the 128 x 128 tiles)
+    rows_phase<T, BM, BN, false, kThreads, false, BN, false, 1>(p, stage, m0, n0, p.N, o_zoff, gn_acc, gs, gq);
+    __syncthreads();                       // every thread is done reading the staged rows
+    EDTR_STAMP_T(15);
     }
     if (gn_acc) {
         // thread (row group r0 = tid / VPR < RG, column group tid % VPR) -> LDS [r0][BN][2], then BN threads fold the row groups
@@ -2512,12 +2534,15 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
             dst[1] = q;
         }
     }
+    EDTR_STAMP(4); EDTR_STAMP(7);
 }
 
 template <typename T, bool SPATIAL, int MB, int NB>
 int launch_n160(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int BM = 32 * MB, BN = 32 * NB;
-    constexpr int lds = 2 * (BM + BN) * BK * 2;     // 72 KiB for 128 x 160, 48 KiB for 64 x 128
+    constexpr int loop_lds = 2 * (BM + BN) * BK * 2, stage_lds = BM * BN * 4;     // 72 KiB main loop / 80 KiB fp32 staging for 128 x 160
+    constexpr int lds = loop_lds > stage_lds ? loop_lds : stage_lds;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_n160_kernel<T, SPATIAL, MB, NB>),
@@ -3634,9 +3659,14 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         const int bn = tile == 8 ? 160 : 128;
         if (!(tile == 1 || tile == 3 || tile == 8) || p.vt_col0 % bn != 0) return EDTR_E_UNSUPPORTED;
     }
-    if (p.ln_stats && !(tile == 1 || tile == 3 || tile == 8)) {
-        if (p.tile != 0) return EDTR_E_UNSUPPORTED;       // the folded LayerNorm's epilogue exists in the 128-row tiles only
+    if (p.ln_stats && !(tile == 1 || tile == 3)) {
+        if (p.tile != 0) return EDTR_E_UNSUPPORTED;       // the folded LayerNorm's epilogue exists in the 128 x 128 tiles only
         tile = dma_ok ? 3 : 1;
+        if (p.vt_out && p.vt_col0 % 128 != 0) return EDTR_E_UNSUPPORTED;
+    }
+    if (p.row_stats && tile >= 8 && tile <= 14) {           // ... and the 16x16x32 template (tiles 8, 9, 10, 14) writes no row statistics
+        if (p.tile != 0) return EDTR_E_UNSUPPORTED;
+        tile = 3;
     }
     if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 18)) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
@@ -3650,7 +3680,8 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     static int dbg = -1;
     if (dbg < 0) {
         const char* e8 = getenv("EDTR_IGEMM_GENERAL_EPILOGUE");
-        dbg = (e8 && e8[0] == '1') ? 1 : 0;
+        const char* e10 = getenv("EDTR_IGEMM_N160_TWO_PASS");
+        dbg = ((e8 && e8[0] == '1') ? 1 : 0) | ((e10 && e10[0] == '1') ? 2 : 0);
     }
     p.debug_flags = dbg;
     p.stagger = 0;

@@ -165,7 +165,7 @@ typedef struct edtr_igemm_params {
      *   consumer side — ln_stats (optional): row statistics of the A operand's rows (ln_slots = K / 32 slots per row; ln_C <= K
      *     = the number of real columns the mean / variance run over — pad columns must be zero —, eps ln_eps); the epilogue computes out = rstd (alpha acc - mean alpha c1[n]) + alpha c2[n] + bias_n[n]
      *     (vt_alpha for the transposed V columns), then GEGLU / activation / residual as usual.  Needs Z == 1, no split-K,
-     *     taps == 1, tile 0 / 1 / 3 / 8. */
+     *     taps == 1, tile 0 / 1 / 3 (an automatic 128x160 choice falls back to tile 3). */
     float* row_stats;
     const float* ln_stats; int32_t ln_slots; int32_t ln_C; float ln_eps;
     const float* ln_c1; const float* ln_c2;
@@ -173,7 +173,8 @@ typedef struct edtr_igemm_params {
                                every CU starts late, so that the two resident workgroups of the 128-row tiles do not run their K
                                loops and their store bursts in lockstep */
     int32_t debug_flags;    /* set by edtr_igemm itself from the environment (A/B measurements on one device): bit 0 =
-                               EDTR_IGEMM_GENERAL_EPILOGUE=1, every launch takes the general epilogue row loop */
+                               EDTR_IGEMM_GENERAL_EPILOGUE=1, every launch takes the general epilogue row loop; bit 1 = EDTR_IGEMM_N160_TWO_PASS=1,
+                               the 128x160 tile stages its accumulators in two passes of 64 rows */
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);

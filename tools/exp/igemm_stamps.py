@@ -45,7 +45,7 @@ def run():
         out = torch.empty(M, n_out, dtype=DT, device=dev)
         res = torch.randn(M, n_out, device=dev).to(DT) if residual else None
         bias = torch.zeros(N, device=dev)
-        nb = ((M + 127) // 128) * ((N + 127) // 128) if tile < 16 else min(256 if tile in (17, 18) else 1 << 30, (M // 256) * ((N + 127) // 128))
+        nb = ((M + 127) // 128) * (N // 160) if tile == 8 else ((M + 127) // 128) * ((N + 127) // 128) if tile < 16 else min(256 if tile in (17, 18) else 1 << 30, (M // 256) * ((N + 127) // 128))
         stamps = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
         p = L.IgemmParams()
         p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = 0 if DT == torch.bfloat16 else 1, taps, M, N, K, 1, 1
@@ -103,6 +103,7 @@ def run():
               + (f"[t16 epilogue: K-half write {int(np.median(st[:, 8] - st[:, 3]))} add+publish {int(np.median(st[:, 13] - st[:, 8]))} row loop {int(np.median(st[:, 14] - st[:, 13]))} tail {int(np.median(st[:, 4] - st[:, 14]))}] " if tile == 16 else "")
               + (f"[t17: epi-setup {int(np.median(st[:, 8] - st[:, 3]))} mbloop {int(np.median(st[:, 9] - st[:, 8]))} gn+rest {int(np.median(st[:, 4] - st[:, 9]))} | unit2 loop {int(np.median(st[:, 10] - st[:, 4]))} epi {int(np.median(st[:, 11] - st[:, 10]))}] " if tile == 17 else "") +
               (f"[t18 LAST unit: coords+offsets {int(np.median(st[:, 15] - st[:, 12]))} a_rd+zero {int(np.median(st[:, 1] - st[:, 15]))} wait+barrier {int(np.median(st[:, 2] - st[:, 1]))} loop {int(np.median(st[:, 3] - st[:, 2]))} pass0 write+wait {int(np.median(st[:, 8] - st[:, 3]))} pass0 rest {int(np.median(st[:, 10] - st[:, 8]))} pass1 write {int(np.median(st[:, 9] - st[:, 10]))} pass1 rest {int(np.median(st[:, 11] - st[:, 9]))} (last row loop {int(np.median(st[:, 14] - st[:, 13]))}) gn {int(np.median(st[:, 4] - st[:, 11]))} | kernel life cycles {int(np.median(st[:, 4] - st[:, 0]))}] " if tile == 18 else "") +
+              (f"[t8 epilogue: pass-0 write {int(np.median(st[:, 12] - st[:, 3]))} pass 0 rows_phase+barrier {int(np.median(st[:, 15] - st[:, 12]))} pass 1 {int(np.median(st[:, 4] - st[:, 15]))} (last: prefetch+barrier {int(np.median(st[:, 13] - st[:, 15]))} row loop {int(np.median(st[:, 14] - st[:, 13]))})] " if tile == 8 else "") +
               (f"[epilogue: acc->LDS {int(np.median(st[:, 12] - st[:, 3]))} prefetch+barrier {int(np.median(st[:, 13] - st[:, 12]))} row loop {int(np.median(st[:, 14] - st[:, 13]))} tail {int(np.median(st[:, 4] - st[:, 14]))}] " if tile == 3 else "") +
               f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d}" + ("" if tile != 3 else f" | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}"),
               flush=True)
@@ -115,6 +116,14 @@ def run():
             case(f"t{t} conv 256^2 256->256", B * 256 * 256, 256, 256, taps=9, H=256, tile=t)
             case(f"t{t} conv 128^2 512->512", B * 128 * 128, 512, 512, taps=9, H=128, tile=t)
             case(f"t{t} conv 32^2 640->640", B * 1024, 640, 640, taps=9, H=32, tile=t)
+        return
+    if len(sys.argv) > 2 and sys.argv[2] == "t8":
+        for t in (3, 8):
+            case(f"t{t} proj 64^2 K320 N320 +res", B * 4096, 320, 320, residual=True, tile=t)
+            case(f"t{t} qkv 64^2 K320 N960", B * 4096, 960, 320, tile=t)
+            case(f"t{t} ff.out 64^2 K1280 N320 +res", B * 4096, 320, 1280, residual=True, tile=t)
+            case(f"t{t} proj 32^2 K640 N640 +res", B * 1024, 640, 640, residual=True, tile=t)
+            case(f"t{t} conv 64^2 320->320", B * 4096, 320, 320, taps=9, H=64, tile=t)
         return
     if len(sys.argv) > 2 and sys.argv[2] == "spatial1":
         case("1x1 spatial 64^2 K320 N320", B * 4096, 320, 320, taps=1, H=64)
