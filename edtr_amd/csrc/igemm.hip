@@ -638,6 +638,8 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
                 }
         }
     } else {
+        // (staging these inside rows_phase, as its pre-publish hook behind the operand loads — as the 128 x 160 tile does — was
+        //  tried here: the 128 x 128 kernels then spill 24 - 28 registers and the row loop triples)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -2502,16 +2504,18 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
             __syncthreads();
         }
     } else {
+    auto stage_acc = [&]() {               // rows_phase's pre-publish hook: its operand loads are in flight under this staging
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(wm * (16 * MB) + mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
-    EDTR_STAMP_T(12);
+                for (int r = 0; r < 4; ++r) stage[(wm * (16 * MB) + mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
+        EDTR_STAMP_T(12);
+    };
     // (FOLD = false: the folded-LayerNorm paths keep 2 KiB of static LDS for the row scalars, which would push two 80 KiB workgroups
     //  over the CU's 160 KiB; launches with ln_stats / row_stats take the 128 x 128 tiles)
-    rows_phase<T, BM, BN, false, kThreads, false, BN, false, 1>(p, stage, m0, n0, p.N, o_zoff, gn_acc, gs, gq);
+    rows_phase<T, BM, BN, false, kThreads, false, BN, false, 1>(p, stage, m0, n0, p.N, o_zoff, gn_acc, gs, gq, stage_acc);
     __syncthreads();                       // every thread is done reading the staged rows
     EDTR_STAMP_T(15);
     }
