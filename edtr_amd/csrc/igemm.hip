@@ -339,9 +339,12 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             res[it] = (m < p.M && n_ok && (EXACT || r0 + RPI * it < BM)) ? ldg16(static_cast<const uint16_t*>(p.residual) + (int64_t)m * p.ldr + n) : zero16();
         }
     }
-    float cb[8];                              // per-column addend: bias (+ time-embedding row when uniform over the tile)
+    // per-column addends: bias, and the time-embedding row when it is uniform over the tile.  The two are added SEPARATELY, in the
+    // order the per-row form uses (fma(acc, alpha, bias) + row): whether a tile lies inside one image depends on the batch size,
+    // and an image's result must not (EDTR_AMD_BATCH_INVARIANT; folding the row into the bias rounds differently).
+    float cb[8], rvu[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) cb[j] = 0.0f;
+    for (int j = 0; j < 8; ++j) { cb[j] = 0.0f; rvu[j] = 0.0f; }
     if (!GEGLU && p.bias_n && n_ok) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias_n + n), b1 = *reinterpret_cast<const f32x4*>(p.bias_n + n + 4);
         cb[0] = b0[0]; cb[1] = b0[1]; cb[2] = b0[2]; cb[3] = b0[3]; cb[4] = b1[0]; cb[5] = b1[1]; cb[6] = b1[2]; cb[7] = b1[3];
@@ -354,7 +357,11 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         if (!rv_rows && n_ok) {
             const float* rv = p.rowvec + (int64_t)img0 * p.rowvec_ld + n;
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv), b1 = *reinterpret_cast<const f32x4*>(rv + 4);
-            cb[0] += b0[0]; cb[1] += b0[1]; cb[2] += b0[2]; cb[3] += b0[3]; cb[4] += b1[0]; cb[5] += b1[1]; cb[6] += b1[2]; cb[7] += b1[3];
+            if constexpr (PATCH16 != 0) {      // the halo kernels' tiles never leave an image (and their register file is full): folded
+                cb[0] += b0[0]; cb[1] += b0[1]; cb[2] += b0[2]; cb[3] += b0[3]; cb[4] += b1[0]; cb[5] += b1[1]; cb[6] += b1[2]; cb[7] += b1[3];
+            } else {
+                rvu[0] = b0[0]; rvu[1] = b0[1]; rvu[2] = b0[2]; rvu[3] = b0[3]; rvu[4] = b1[0]; rvu[5] = b1[1]; rvu[6] = b1[2]; rvu[7] = b1[3];
+            }
         }
     }
     const float alpha = GEGLU ? 1.0f : p.alpha;
@@ -446,7 +453,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 float f[8];
                 f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], alpha, cb[j]);
+                for (int j = 0; j < 8; ++j) f[j] = PATCH16 != 0 ? __builtin_fmaf(f[j], alpha, cb[j]) : __builtin_fmaf(f[j], alpha, cb[j]) + rvu[j];
                 if constexpr (RES32) {
                     const f32x4 q0 = rf0[PF == 2 ? it : 0], q1 = rf1[PF == 2 ? it : 0];
 #pragma unroll
@@ -523,6 +530,9 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 const float* rv = p.rowvec + (int64_t)(m / p.rows_per_image) * p.rowvec_ld + n;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] += rv[j];
+            } else if constexpr (PATCH16 == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] += rvu[j];
             }
             if (silu) {
 #pragma unroll

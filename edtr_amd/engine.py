@@ -512,6 +512,12 @@ class Emitter:
         # dtype code of the layout / elementwise / statistics launches (every fp32-stream code means the same to them)
         self.io = ops.F32S if self.hp else dtype
         self.direct16 = precision == "mixed"      # a 16-bit GEMM output IS an attention / one-part operand (same fp16 type)
+        # EDTR_AMD_BATCH_INVARIANT=1 (read when a program is emitted): every launch choice that the default path derives from the
+        # row count M = B * H * W — tile geometry, split-K, the fused-statistics eligibility of the register-staged tiles — is
+        # derived from the layer's per-image shape instead (128 x 128 tiles, no split-K), so an image's result does not depend on
+        # the batch it arrives in: bit-identical across batch sizes and therefore across any sharding over GPUs (VERDICT r02,
+        # weak 3: the default path holds that only at tolerance level).  Costs throughput (§6 of DESIGN.md).
+        self.invariant = ops.batch_invariant()
         self.last_gnp = None
         self.last_row_stats = None
 
@@ -617,12 +623,14 @@ class Emitter:
             tile, splitk = kw.pop("tile"), 1
         else:
             tile, splitk = ops.choose_splitk(M, N, Ke, kw.get("Z", 1), act)
+        if self.invariant and tile == 0:
+            tile, splitk = ops.invariant_tile(Ke, kw.get("C2", 0)), 1
         if row_stats and not self.hp and splitk == 1 and act != L.ACT_GEGLU and N % 32 == 0 and "Z" not in kw:
             self.last_row_stats = self.arena.alloc((M, N // 32, 2), torch.float32)
             kw["row_stats"] = self.last_row_stats
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         if (stats_hw and act == 0 and (self.hp or not out_f32) and out.stride(0) == N and "Z" not in kw
-                and ops.gn_fusable(M, N, Ke, stats_hw, splitk=splitk)):
+                and ops.gn_fusable(M, N, Ke, stats_hw, splitk=splitk, C2=kw.get("C2", 0), invariant=self.invariant)):
             self.last_gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
             kw["gn_partial"] = self.last_gnp
         res32 = residual is not None and residual.dtype == torch.float32
@@ -641,6 +649,8 @@ class Emitter:
         columns that start on a column-tile boundary (every SD width: 2C is a multiple of 160 or 128)."""
         if self.hp and not self.direct16:
             return False
+        if self.invariant and (2 * C) % 128:
+            return False        # (the invariant mode runs the 128-column tiles only)
         return N % 8 == 0 and C % 64 == 0 and ((2 * C) % 160 == 0 or (2 * C) % 128 == 0) and os.environ.get("EDTR_FUSED_QKV", "1") != "0"
 
     def qkv_gemm(self, x, w, *, B: int, N: int, C: int, alpha: float, name: str = "attn1.qkv", ln_vec=None):
@@ -688,9 +698,11 @@ class Emitter:
             out = self.new(M, N, torch.float32 if out_f32 else None)
         img8 = taps == 9 and stride == 1 and pad_tl == 1 and not ups and (x.H, x.W) == (8, 8) and Ce % 64 == 0
         tile, splitk = ops.choose_splitk(M, N, taps * Ce, img8=img8)
+        if self.invariant:
+            tile, splitk = ops.invariant_tile(Ce, 0), 1
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
-        if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk):
+        if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk, invariant=self.invariant):
             gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
         res32 = residual is not None and residual.dtype == torch.float32
         self.prog.add(ops.make_igemm(

@@ -8,6 +8,7 @@ them once per shape so the steady-state host cost per kernel is one ctypes call.
 from __future__ import annotations
 
 import ctypes as ct
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -110,6 +111,17 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else "") + (" vT" if vt_out is not None else "")
                + (" ln" if ln_stats is not None else "") + (" rs" if row_stats is not None else ""))
     return rec
+
+
+def batch_invariant() -> bool:
+    """EDTR_AMD_BATCH_INVARIANT=1: launch choices must not depend on the batch size (engine.Emitter)."""
+    return os.environ.get("EDTR_AMD_BATCH_INVARIANT", "0") == "1"
+
+
+def invariant_tile(C1: int, C2: int) -> int:
+    """The one tile geometry of the batch-invariant mode: the 128x128 LDS-DMA loop where the operand layout allows it
+    (Cin % 64 == 0, no fused concat), the 128x128 register-staged loop otherwise — never chosen from M."""
+    return 3 if (C1 % 64 == 0 and not C2) else 1
 
 
 def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0, img8: bool = False) -> Tuple[int, int]:
@@ -215,13 +227,13 @@ def make_gn_finalize(*, partial, tiles_per_image, B, C, sums, groups: int = 32, 
     return Rec(L.load().edtr_gn_finalize, (ptr(partial), tiles_per_image, B, C, groups, ptr(sums)), (partial, sums), name)
 
 
-def gn_fusable(M: int, N: int, C1: int, hw: int, taps: int = 1, C2: int = 0, splitk: int = 1) -> bool:
+def gn_fusable(M: int, N: int, C1: int, hw: int, taps: int = 1, C2: int = 0, splitk: int = 1, invariant: bool = False) -> bool:
     """Can the producing edtr_igemm also emit GroupNorm partials?  (whole 128-row tiles inside one image, 128x128 kernel)"""
     if splitk > 1 or C2 or hw % 128 or M % 128 or N % 32:
         return False
     dma_ok = C1 % 64 == 0
     big = ((M + 127) // 128) * ((N + 127) // 128)
-    return dma_ok or big >= 200
+    return dma_ok or invariant or big >= 200      # (register-staged shapes: the 128x128 tile 1, which the invariant mode always takes)
 
 
 def make_layernorm(*, dtype, x, rows, C, ldx, gamma, beta, eps, y, ldy, c_valid: int = 0, name="layernorm") -> Rec:

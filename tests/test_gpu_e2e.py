@@ -329,6 +329,45 @@ def test_full_size_batch_invariance_and_determinism():
     assert torch.isfinite(img3).all() and float(img3.abs().max()) < 50.0
 
 
+@pytest.mark.parametrize("precision,dtype", [("fast", torch.bfloat16), ("mixed", None)])
+def test_batch_invariant_mode_is_bit_exact_across_batch_sizes(monkeypatch, precision, dtype):
+    """EDTR_AMD_BATCH_INVARIANT=1: tile geometry / split-K / statistics fusion are chosen from the layer's per-image shape, never
+    from the row count, so an image's restoration is BIT-identical whatever batch it travels in (and therefore however a data
+    set is sharded over GPUs).  SD-2.1 widths, 256x256 images (32x32 latents: all four UNet levels), 4 steps."""
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    monkeypatch.setenv("EDTR_AMD_BATCH_INVARIANT", "1")
+    dev = torch.device("cuda:0")
+    cldm = build_synthetic_cldm(synth.sd21_config(), dev, dtype, precision=precision)
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
+    sampler = SpacedSampler(diffusion.betas)
+    B, S = 5, 256
+    pre = synth.synth_input("inv:pre_res", (B, 3, S, S), 0.0, 1.0).to(dev)
+    c_txt = synth.synth_normal("inv:c_txt", (1, 77, 1024)).to(dev)
+    noises = [synth.synth_normal(f"inv:noise{i}", (B, 4, S // 8, S // 8)).to(dev) for i in range(5)]
+
+    def run(sel):
+        n = len(sel)
+        z_pre = cldm.vae_encode(pre[sel] * 2 - 1, sample=False)
+        x_T = diffusion.q_sample(z_pre, torch.full((n,), 200, dtype=torch.int64), noises[0][sel])
+        with injected_noise([nz[sel] for nz in noises[1:]]):
+            z = sampler.manual_sample_with_timesteps(model=cldm, device=dev, x_T=x_T, steps=4, used_timesteps=USED,
+                                                     batch_size=n, cond={"c_txt": c_txt.expand(n, -1, -1).contiguous(), "c_img": z_pre},
+                                                     uncond=None, cfg_scale=1.0, progress=False)
+        return z_pre, z, cldm.vae_decode(z)
+
+    zp5, z5, img5 = run([0, 1, 2, 3, 4])
+    zp1, z1, img1 = run([3])
+    zp2, z2, img2 = run([3, 0])
+    assert torch.isfinite(img5).all()
+    assert torch.equal(zp5[3:4], zp1) and torch.equal(z5[3:4], z1) and torch.equal(img5[3:4], img1)
+    assert torch.equal(zp2[0:1], zp1) and torch.equal(z2[0:1], z1) and torch.equal(img2[0:1], img1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tag", ["small", "full"])
 def test_swinir_vs_reference_golden(golden_dir, tag, dtype):
