@@ -166,6 +166,22 @@ def test_splitk_heuristic_and_arena():
     assert a.in_use == 0 and len(a.free_lists[0]) == 1
 
 
+def test_batch_invariant_launch_choices_do_not_depend_on_the_batch(monkeypatch):
+    """EDTR_AMD_BATCH_INVARIANT=1 (engine.Emitter): tile geometry comes from the operand layout, the fused-statistics
+    eligibility from the per-image shape — never from the row count M = B * H * W."""
+    from edtr_amd import ops
+    monkeypatch.delenv("EDTR_AMD_BATCH_INVARIANT", raising=False)
+    assert not ops.batch_invariant()
+    monkeypatch.setenv("EDTR_AMD_BATCH_INVARIANT", "1")
+    assert ops.batch_invariant()
+    assert ops.invariant_tile(320, 0) == 3 and ops.invariant_tile(4, 0) == 1 and ops.invariant_tile(320, 320) == 1
+    for hw, N, C1 in [(4096, 320, 320), (1024, 640, 8), (256, 1280, 1280), (16, 1280, 1280), (262144, 128, 3)]:
+        got = {ops.gn_fusable(B * hw, N, C1, hw, invariant=True) for B in (1, 2, 3, 8)}
+        assert len(got) == 1, (hw, N, C1, got)
+    # the default path DOES look at M for the register-staged shapes (documented: tolerance-level batch dependence)
+    assert ops.gn_fusable(8 * 1024, 640, 8, 1024) != ops.gn_fusable(1 * 1024, 640, 8, 1024)
+
+
 def test_batch_sharding_helpers():
     cover = []
     for r in range(8):
