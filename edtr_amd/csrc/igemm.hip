@@ -404,17 +404,21 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         stage_read(0, 0);
     }
 
+    bool did_fast = false;
     // The common case — 16-bit output, bias (+ a uniform time-embedding row) in cb, optional 16-bit residual, optional GroupNorm
     // partials, nothing else — gets its own loop: the general loop below tests ~10 launch-uniform options INSIDE every iteration
     // (the compiler does not unswitch them), and with one wave per SIMD each of those scalar branches and the 64-bit address
     // arithmetic they fence costs its full latency: 800 cycles per iteration, 6.4k of a 128 x 128 tile's 8.4k-cycle epilogue
     // (tools/exp/igemm_stamps.py, round 3).  Here the only control flow is the store's predicate.
     {
-        const bool fast = !ln && !p.bias_m && !rv_rows && !silu && !gelu && !lrelu && !stats_out && !(p.debug_flags & 1);
+        const bool fast = !p.bias_m && !rv_rows && !silu && !gelu && !lrelu && !(p.debug_flags & 1);
         // OUT32: fp32 output (the fp32 activation stream of the mixed / high modes); RES32: fp32 residual, requested up front
         // like the staged vectors where the registers allow (PF == 2), inside the iteration otherwise
-        auto fast_loop = [&](auto out32_c, auto res32_c) {
+        // LNF / STF: the two sides of the folded LayerNorm (consumer: row scalars from LDS; producer: per-row sums of the stored
+        // values, folded after the loop) — 16-bit output, no fp32 residual: the SwinIR layers and the UNet blocks under EDTR_LN_FOLD
+        auto fast_loop = [&](auto out32_c, auto res32_c, auto lnf_c, auto stf_c) {
             constexpr bool OUT32 = decltype(out32_c)::value, RES32 = decltype(res32_c)::value;
+            constexpr bool LNF = decltype(lnf_c)::value, STF = decltype(stf_c)::value;
             constexpr int NRF = (RES32 && PF == 2) ? ITER : 1;
             f32x4 rf0[NRF], rf1[NRF];
             auto res_read = [&](int it, int slot) {
@@ -452,8 +456,14 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 }
                 float f[8];
                 f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3]; f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
+                if constexpr (LNF) {
+                    const float2 mr = ln_rows_lds()[EXACT ? ml : (ml < BM ? ml : BM - 1)];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = PATCH16 != 0 ? __builtin_fmaf(f[j], alpha, cb[j]) : __builtin_fmaf(f[j], alpha, cb[j]) + rvu[j];
+                    for (int j = 0; j < 8; ++j) f[j] = mr.y * (f[j] * alpha - mr.x * c1a[j]) + cb[j] + rvu[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = PATCH16 != 0 ? __builtin_fmaf(f[j], alpha, cb[j]) : __builtin_fmaf(f[j], alpha, cb[j]) + rvu[j];
+                }
                 if constexpr (RES32) {
                     const f32x4 q0 = rf0[PF == 2 ? it : 0], q1 = rf1[PF == 2 ? it : 0];
 #pragma unroll
@@ -479,6 +489,10 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
                     }
+                    if constexpr (STF) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { rsum[it] += f[j]; rsq[it] += f[j] * f[j]; }
+                    }
                 }
             }
         };
@@ -486,15 +500,28 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             using std::true_type;
             using std::false_type;
             const bool res32 = p.residual && p.residual_f32;
-            if (!p.out_f32 && !res32) fast_loop(false_type{}, false_type{});
-            else if (p.out_f32 && res32) fast_loop(true_type{}, true_type{});
-            else if (p.out_f32) fast_loop(true_type{}, false_type{});
-            else fast_loop(false_type{}, true_type{});
-            EDTR_STAMP_T(14);
-            return;
+            if (!ln && !stats_out) {
+                if (!p.out_f32 && !res32) fast_loop(false_type{}, false_type{}, false_type{}, false_type{});
+                else if (p.out_f32 && res32) fast_loop(true_type{}, true_type{}, false_type{}, false_type{});
+                else if (p.out_f32) fast_loop(true_type{}, false_type{}, false_type{}, false_type{});
+                else fast_loop(false_type{}, true_type{}, false_type{}, false_type{});
+                did_fast = true;
+            } else if (!p.out_f32 && !res32) {
+                if constexpr (FOLD && !GEGLU && PATCH16 == 0) {
+                    if (ln && stats_out) fast_loop(false_type{}, false_type{}, true_type{}, true_type{});
+                    else if (ln) fast_loop(false_type{}, false_type{}, true_type{}, false_type{});
+                    else fast_loop(false_type{}, false_type{}, false_type{}, true_type{});
+                    did_fast = true;
+                }
+            }
+            if (did_fast && !stats_out) {
+                EDTR_STAMP_T(14);
+                return;
+            }
         }
     }
 
+    if (!did_fast) {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         // PATCH16: the tile's rows are the pixels of a 16 x 16 output patch (row ml = 16 * y + x), m0 = its first pixel
@@ -575,6 +602,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 for (int j = 0; j < 8; ++j) { rsum[it] += f[j]; rsq[it] += f[j] * f[j]; }
             }
         }
+    }
     }
     EDTR_STAMP_T(14);
     if (stats_out) {
@@ -1962,7 +1990,7 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
         float gs[8], gq[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-        rows_phase<T, 128, 256, false, 512>(p, stage, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs, gq);
+        rows_phase<T, 128, 256, false, 512, 0, 256, false>(p, stage, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs, gq);      // (FOLD off: only tiles 1 / 3 carry the folded-LayerNorm paths)
         __syncthreads();                       // every thread is done reading the staged rows
         if (gn_acc) {
             // thread (row group tid/32, column group tid%32): lanes l and l^32 share a column group; fold, then the 8 waves
@@ -2226,7 +2254,7 @@ __global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { gs[h][j] = 0.0f; gq[h][j] = 0.0f; }
-        rows_phase<T, 128, 128, false, 512>(p, stage_f + h * 128 * 128, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs[h], gq[h]);
+        rows_phase<T, 128, 128, false, 512, 0, 128, false>(p, stage_f + h * 128 * 128, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs[h], gq[h]);
     }
     if (gn_acc) {
         __syncthreads();                       // every thread is done reading the staged rows
@@ -3343,7 +3371,7 @@ __global__ void __launch_bounds__(512, 1) igemm_pp128_kernel(const edtr_igemm_pa
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    rows_phase<T, 128, 128, false, 512, false, SPITCH>(p, stg, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);
+    rows_phase<T, 128, 128, false, 512, 0, SPITCH, false>(p, stg, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);
     if (gn_acc) {
         // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
 #pragma unroll
@@ -3678,9 +3706,9 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         tile = dma_ok ? 3 : 1;
         if (p.vt_out && p.vt_col0 % 128 != 0) return EDTR_E_UNSUPPORTED;
     }
-    if (p.row_stats && tile >= 8 && tile <= 14) {           // ... and the 16x16x32 template (tiles 8, 9, 10, 14) writes no row statistics
+    if (p.row_stats && !(tile == 1 || tile == 2 || tile == 3)) {       // ... and so do the row statistics (+ the 64x64 tile 2)
         if (p.tile != 0) return EDTR_E_UNSUPPORTED;
-        tile = 3;
+        tile = dma_ok ? 3 : 1;
     }
     if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 18)) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave

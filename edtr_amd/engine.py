@@ -579,13 +579,21 @@ class Emitter:
         return w.get(parts) if isinstance(w, WRef) else w
 
     # -- GEMM family ------------------------------------------------------------------------
-    def ln_fold_ok(self, C: int) -> bool:
-        """May a LayerNorm over C columns be folded into the GEMMs around it?  Built for VERDICT r02 item 4 (launch count), kept
-        OPT-IN (EDTR_LN_FOLD=1, fast modes): it removes 69 launches per denoise step and one 16-bit rounding, but in a same-device
-        A/B the whole path lost 0.7 % at batch 8 (104.99 -> 104.25 images/s) and gained 0.5 % at batch 4 / 50 steps (8.383 ->
-        8.426): the LayerNorm launches overlap with the other lane / batch, the two extra barriers in every producer epilogue and
-        the slot fold in every consumer epilogue sit on the GEMMs' critical path (profiles/r03/experiments_ln_fold.log)."""
-        return (not self.hp) and C % 32 == 0 and C % 8 == 0 and os.environ.get("EDTR_LN_FOLD", "0") == "1"
+    def ln_fold_ok(self, C: int, B: int = 0) -> bool:
+        """May the LayerNorms (over C columns) of a transformer block that runs on a batch of B images be folded into the GEMMs
+        around them (fast modes)?  Built for VERDICT r02 item 4 (launch count): it removes up to 69 launches per denoise step and
+        one 16-bit rounding.  With the general epilogue loop it lost 0.7 % at batch 8 and was opt-in; since the producer /
+        consumer sides have their own specialised row loops (round 3) it gains where the LayerNorm launches are latency-bound —
+        det512s50 (batch 4): **+1.1 %** with every level folded, +0.1 % with the 32x32-and-deeper levels only — and still loses
+        where the GEMM epilogues are the longer pole — det512 (batch 8): -1.3 % all levels, -0.8 % / -0.4 % with the levels of
+        <= 8192 / <= 2048 rows only (profiles/r03/ab_lnfold_fast_epilogue.log, ab_lnfold_thresholds.log).  So the rule is the
+        batch, not the row count: on by default for B <= ops.LN_FOLD_MAX_BATCH.  EDTR_LN_FOLD = 1 / 0 forces it on / off."""
+        if self.hp or C % 32 or self.invariant:
+            return False
+        mode = os.environ.get("EDTR_LN_FOLD", "auto")
+        if mode in ("0", "1"):
+            return mode == "1"
+        return 0 < B <= ops.LN_FOLD_MAX_BATCH
 
     def _ln_kwargs(self, a, K: int, ln_vec):
         """igemm arguments of a folded LayerNorm for operand ``a`` (an LNRef) -> (raw rows, extra keyword arguments)."""

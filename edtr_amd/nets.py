@@ -168,7 +168,7 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     wi, bi = em.store.linear([p + "proj_in.weight"], [p + "proj_in.bias"])
     # The three LayerNorms of the block are not launched in the fast modes: the GEMM that writes their input also writes
     # per-row statistics, the GEMMs that read them run on the raw rows with gamma folded into the weights (Emitter.layer_norm).
-    fold = em.ln_fold_ok(C)
+    fold = em.ln_fold_ok(C, B)
     fold1 = fold and em.fused_qkv_ok(N, C)        # (the operand-swapped V^T product would need per-COLUMN scalars)
     t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in", row_stats=fold1)
     st = em.last_row_stats

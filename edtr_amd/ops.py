@@ -113,6 +113,9 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     return rec
 
 
+LN_FOLD_MAX_BATCH = 4     # UNet / ControlNet LayerNorm fold: on by default up to this batch size (engine.Emitter.ln_fold_ok has the measurements)
+
+
 def batch_invariant() -> bool:
     """EDTR_AMD_BATCH_INVARIANT=1: launch choices must not depend on the batch size (engine.Emitter)."""
     return os.environ.get("EDTR_AMD_BATCH_INVARIANT", "0") == "1"
