@@ -427,7 +427,7 @@ def other_workload_leg(cldm, diffusion, sampler, name, dev, ctx_dim, args, captu
     from edtr_amd import workloads
     B, S, _ = workloads.WORKLOADS[name]
     inflight = args.inflight
-    steps = 8 if name == "seg1024tiled" else 2
+    steps = 8 if name == "seg1024tiled" else 4
     inp = workloads.make_inputs(name, ctx_dim, dev, B, S)
     untiled_forward = type(cldm).forward.__get__(cldm)      # (the tiled sampler monkey-patches cldm.forward and never restores it)
 
