@@ -247,7 +247,7 @@ __device__ __forceinline__ void ln_rows_fill(const edtr_igemm_params& p, int m0)
 // consecutive tokens (rows of the tile) of one column per 16-byte store.  Lane (slot, cl): 16 adjacent columns per slot — the
 // LDS reads of a slot walk 16 adjacent banks (slots collide 4-way: 8 reads per lane, negligible), the 16-byte stores of the
 // lanes that share a column are adjacent in memory.
-template <typename T, int BM, int BNO, int THREADS, int PITCH, bool FOLD = true>
+template <typename T, int BM, int BNO, int THREADS, int PITCH, int FOLD = 3>
 __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float* stage, int m0, int no0) {
     static_assert(BM % 8 == 0 && BNO % 16 == 0 && THREADS % 16 == 0, "vt_store tiling");
     constexpr int TG = BM / 8, NCB = BNO / 16, SLOTS = THREADS / 16, PAIRS = TG * NCB;
@@ -260,7 +260,7 @@ __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float
         if (m >= p.M || n >= p.N) continue;
         float b = p.bias_n ? p.bias_n[n] : 0.0f;
         float f[8];
-        if (FOLD && p.ln_stats) {        // folded LayerNorm of the tokens (rows): rstd (alpha acc - mean alpha c1) + alpha c2 + bias
+        if ((FOLD & 1) && p.ln_stats) {        // folded LayerNorm of the tokens (rows): rstd (alpha acc - mean alpha c1) + alpha c2 + bias
             const float c1a = p.vt_alpha * p.ln_c1[n];
             b += p.vt_alpha * p.ln_c2[n];
             const float2* lr = ln_rows_lds() + tg * 8;
@@ -275,12 +275,13 @@ __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float
     }
 }
 
-// FOLD = false compiles the folded-LayerNorm paths out (the halo kernels: their register budget is full and no LayerNorm sits next
+// FOLD: bit 0 = the folded LayerNorm's consumer side (row scalars in 2 KiB of static LDS), bit 1 = its producer side (row statistics
+// of the output; no extra LDS).  FOLD = 0 compiles the folded-LayerNorm paths out (the halo kernels: their register budget is full and no LayerNorm sits next
 // to a 3x3 convolution)
 // PF: how the staged vectors are read — 2 = all of this thread's vectors up front (needs 8 ITER free registers: the kernels whose
 // accumulators are all dead by now), 1 = one row iteration ahead (16 registers), 0 = inside the iteration (the 512-thread kernels,
 // whose register file is full)
-template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, int PATCH16 = 0, int PITCH = BNO, bool FOLD = true, int PF = 0,
+template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, int PATCH16 = 0, int PITCH = BNO, int FOLD = 3, int PF = 0,
           typename Hook = NoHook>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
                                            int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8], Hook before_publish = Hook(),
@@ -318,7 +319,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         return;
     }
 
-    const bool ln = FOLD && !GEGLU && !PATCH16 && p.ln_stats != nullptr;      // (GEGLU: the caller applied it before the gate product)
+    const bool ln = (FOLD & 1) && !GEGLU && !PATCH16 && p.ln_stats != nullptr;      // (GEGLU: the caller applied it before the gate product)
     if constexpr (!GEGLU && !PATCH16) {
         if (ln) ln_rows_fill<BM, THREADS>(p, m0);        // visible after the barrier that publishes the staged tile
         if (p.vt_out != nullptr && no0 >= p.vt_col0) {    // a V tile of the fused [Q; K; V] projection: transposed store
@@ -375,7 +376,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             cb[j] += alpha * v0[j]; cb[j + 4] += alpha * v1[j];
         }
     }
-    const bool stats_out = FOLD && !GEGLU && !PATCH16 && p.row_stats != nullptr;
+    const bool stats_out = (FOLD & 2) && !GEGLU && !PATCH16 && p.row_stats != nullptr;
     float rsum[ITER], rsq[ITER];              // producer side of the fold: this thread's 8-column share of each row's sum / sum of squares
 #pragma unroll
     for (int it = 0; it < ITER; ++it) { rsum[it] = 0.0f; rsq[it] = 0.0f; }
@@ -507,11 +508,14 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 else fast_loop(false_type{}, true_type{}, false_type{}, false_type{});
                 did_fast = true;
             } else if (!p.out_f32 && !res32) {
-                if constexpr (FOLD && !GEGLU && PATCH16 == 0) {
-                    if (ln && stats_out) fast_loop(false_type{}, false_type{}, true_type{}, true_type{});
-                    else if (ln) fast_loop(false_type{}, false_type{}, true_type{}, false_type{});
-                    else fast_loop(false_type{}, false_type{}, false_type{}, true_type{});
-                    did_fast = true;
+                if constexpr (FOLD != 0 && !GEGLU && PATCH16 == 0) {
+                    if (ln && stats_out) {
+                        if constexpr (FOLD == 3) { fast_loop(false_type{}, false_type{}, true_type{}, true_type{}); did_fast = true; }
+                    } else if (ln) {
+                        if constexpr ((FOLD & 1) != 0) { fast_loop(false_type{}, false_type{}, true_type{}, false_type{}); did_fast = true; }
+                    } else {
+                        if constexpr ((FOLD & 2) != 0) { fast_loop(false_type{}, false_type{}, false_type{}, true_type{}); did_fast = true; }
+                    }
                 }
             }
             if (did_fast && !stats_out) {
@@ -697,8 +701,8 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    if (geglu) rows_phase<T, BM, BN / 2, true, 256, false, BN / 2, true, 2>(p, stage, m0, no0, n_out, o_zoff, false, gs, gq);
-    else rows_phase<T, BM, BN, false, 256, false, BN, true, 2>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
+    if (geglu) rows_phase<T, BM, BN / 2, true, 256, false, BN / 2, 3, 2>(p, stage, m0, no0, n_out, o_zoff, false, gs, gq);
+    else rows_phase<T, BM, BN, false, 256, false, BN, 3, 2>(p, stage, m0, no0, n_out, o_zoff, gn_acc, gs, gq);
     if (gn_acc) {
         // lanes l, l+16, l+32, l+48 of a wave own the same columns: fold them, then fold the 4 waves through LDS
 #pragma unroll
@@ -2551,9 +2555,9 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
                 for (int r = 0; r < 4; ++r) stage[(wm * (16 * MB) + mb * 16 + 4 * lq + r) * BN + wn * (16 * NB) + nb * 16 + l15] = acc[mb][nb][r];
         EDTR_STAMP_T(12);
     };
-    // (FOLD = false: the folded-LayerNorm paths keep 2 KiB of static LDS for the row scalars, which would push two 80 KiB workgroups
-    //  over the CU's 160 KiB; launches with ln_stats / row_stats take the 128 x 128 tiles)
-    rows_phase<T, BM, BN, false, kThreads, false, BN, false, 1>(p, stage, m0, n0, p.N, o_zoff, gn_acc, gs, gq, stage_acc);
+    // (FOLD = 2: the producer side of the LayerNorm fold only — the consumer side keeps 2 KiB of static LDS for the row scalars, which
+    //  would push two 80 KiB workgroups over the CU's 160 KiB; launches with ln_stats take the 128 x 128 tiles)
+    rows_phase<T, BM, BN, false, kThreads, false, BN, 2, 1>(p, stage, m0, n0, p.N, o_zoff, gn_acc, gs, gq, stage_acc);
     __syncthreads();                       // every thread is done reading the staged rows
     EDTR_STAMP_T(15);
     }
@@ -3438,6 +3442,17 @@ static bool igemm_fast_addressable(const edtr_igemm_params& p, bool spatial) {
     return a_bytes < 0xF0000000LL && w_bytes < 0xF0000000LL;
 }
 
+// A/B switches for measurements on one device (edtr_hip.h: debug_flags)
+static int dbg_flags() {
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char* e8 = getenv("EDTR_IGEMM_GENERAL_EPILOGUE");
+        const char* e10 = getenv("EDTR_IGEMM_N160_TWO_PASS");
+        dbg = ((e8 && e8[0] == '1') ? 1 : 0) | ((e10 && e10[0] == '1') ? 2 : 0);
+    }
+    return dbg;
+}
+
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
     if (tile == 15) {      // 8-wave ping-pong 128x128 tile for grids of at most one workgroup per CU
@@ -3706,7 +3721,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         tile = dma_ok ? 3 : 1;
         if (p.vt_out && p.vt_col0 % 128 != 0) return EDTR_E_UNSUPPORTED;
     }
-    if (p.row_stats && !(tile == 1 || tile == 2 || tile == 3)) {       // ... and so do the row statistics (+ the 64x64 tile 2)
+    if (p.row_stats && !(tile == 1 || tile == 2 || tile == 3 || (tile == 8 && !(dbg_flags() & 2)))) {   // ... the row statistics: + the 64x64 tile 2 and the 128x160 tile
         if (p.tile != 0) return EDTR_E_UNSUPPORTED;
         tile = dma_ok ? 3 : 1;
     }
@@ -3719,13 +3734,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     // lockstep breaker of the two-workgroups-per-CU kernels (stagger_second_slot): only when the grid has more than one round
     // (>= 768 workgroups: below that the second slot's blocks are the tail anyway) and the tile is short enough for the epilogue
     // to matter.  EDTR_IGEMM_STAGGER = percent of the estimated half life (default 100; 0 = off).
-    static int dbg = -1;
-    if (dbg < 0) {
-        const char* e8 = getenv("EDTR_IGEMM_GENERAL_EPILOGUE");
-        const char* e10 = getenv("EDTR_IGEMM_N160_TWO_PASS");
-        dbg = ((e8 && e8[0] == '1') ? 1 : 0) | ((e10 && e10[0] == '1') ? 2 : 0);
-    }
-    p.debug_flags = dbg;
+    p.debug_flags = dbg_flags();
     p.stagger = 0;
     if ((tile == 3 || tile == 8) && p.splitk <= 1) {
         static int pct = -1;

@@ -599,7 +599,7 @@ def test_fused_qkv_projection_with_transposed_v(dtype, B, N, C, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,tile", [(300, 320, 128, 0), (32768, 640, 320, 0), (512, 1280, 192, 3), (130, 96, 64, 1), (2048, 512, 1024, 0), (77, 160, 64, 2)])
+@pytest.mark.parametrize("M,N,K,tile", [(300, 320, 128, 0), (32768, 640, 320, 8), (4096, 320, 1280, 8), (512, 1280, 192, 3), (130, 96, 64, 1), (2048, 512, 1024, 0), (77, 160, 64, 2)])
 def test_gemm_writes_row_statistics_of_its_output(dtype, M, N, K, tile):
     """Producer side of the folded LayerNorm: per row, sum and sum of squares of the stored values in N / 32 slots (a column
     tile fills its first slot and zeroes the rest it covers), whatever tile runs; bias + residual included."""
