@@ -662,22 +662,33 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
                 bv += p.alpha * p.ln_c2[nv]; bg += p.alpha * p.ln_c2[nv + 32];
                 __syncthreads();
             }
+            // two straight-line loops, not one loop with the launch-uniform `ln` test inside: with the branch in every iteration each
+            // GELU (a dependent chain of ~16 instructions, two of them transcendental) sits in its own basic block and runs at its
+            // latency — 250 cycles per element, 8.2k of the tile's 20k cycles in the in-kernel stamps (round 3)
+            float* const st = stage + (wm * 32 * MI + 4 * lh) * BNO + wn * 32 + l31;
+            const float alpha = p.alpha;
+            if (ln) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float val, gate;
-                    if (ln) {
-                        const float2 mr = ln_rows_lds()[ml];
-                        val = mr.y * (acc[mi][0][r] * p.alpha - mr.x * c1v) + bv;
-                        gate = mr.y * (acc[mi][1][r] * p.alpha - mr.x * c1g) + bg;
-                    } else {
-                        val = acc[mi][0][r] * p.alpha + bv;
-                        gate = acc[mi][1][r] * p.alpha + bg;
+                    for (int r = 0; r < 16; ++r) {
+                        const int mo = mi * 32 + (r & 3) + 8 * (r >> 2);
+                        const float2 mr = ln_rows_lds()[wm * 32 * MI + 4 * lh + mo];
+                        const float val = mr.y * (acc[mi][0][r] * alpha - mr.x * c1v) + bv;
+                        const float gate = mr.y * (acc[mi][1][r] * alpha - mr.x * c1g) + bg;
+                        st[mo * BNO] = val * gelu_erf_f(gate);
                     }
-                    stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
-                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mo = mi * 32 + (r & 3) + 8 * (r >> 2);
+                        const float val = acc[mi][0][r] * alpha + bv;
+                        const float gate = acc[mi][1][r] * alpha + bg;
+                        st[mo * BNO] = val * gelu_erf_f(gate);
+                    }
+            }
         }
     } else {
         // (staging these inside rows_phase, as its pre-publish hook behind the operand loads — as the 128 x 160 tile does — was
@@ -956,6 +967,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
     int tm, tn;
     tile_coords(p, bid, nbm, nbn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    EDTR_STAMP_T(15);
 
     const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
     const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;

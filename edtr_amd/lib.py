@@ -7,7 +7,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
+LIB_PATH = os.environ.get("EDTR_AMD_LIB") or os.path.join(HERE, "libedtr_hip.so")     # (EDTR_AMD_LIB: another build of the same ABI, for A/B runs on one device)
 
 BF16, F16, F32_SPLIT, F32_H1, F32_H2, F32_H3 = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3, 4

@@ -104,7 +104,7 @@ def run():
               + (f"[t17: epi-setup {int(np.median(st[:, 8] - st[:, 3]))} mbloop {int(np.median(st[:, 9] - st[:, 8]))} gn+rest {int(np.median(st[:, 4] - st[:, 9]))} | unit2 loop {int(np.median(st[:, 10] - st[:, 4]))} epi {int(np.median(st[:, 11] - st[:, 10]))}] " if tile == 17 else "") +
               (f"[t18 LAST unit: coords+offsets {int(np.median(st[:, 15] - st[:, 12]))} a_rd+zero {int(np.median(st[:, 1] - st[:, 15]))} wait+barrier {int(np.median(st[:, 2] - st[:, 1]))} loop {int(np.median(st[:, 3] - st[:, 2]))} pass0 write+wait {int(np.median(st[:, 8] - st[:, 3]))} pass0 rest {int(np.median(st[:, 10] - st[:, 8]))} pass1 write {int(np.median(st[:, 9] - st[:, 10]))} pass1 rest {int(np.median(st[:, 11] - st[:, 9]))} (last row loop {int(np.median(st[:, 14] - st[:, 13]))}) gn {int(np.median(st[:, 4] - st[:, 11]))} | kernel life cycles {int(np.median(st[:, 4] - st[:, 0]))}] " if tile == 18 else "") +
               (f"[t8 epilogue: pass-0 write {int(np.median(st[:, 12] - st[:, 3]))} pass 0 rows_phase+barrier {int(np.median(st[:, 15] - st[:, 12]))} pass 1 {int(np.median(st[:, 4] - st[:, 15]))} (last: prefetch+barrier {int(np.median(st[:, 13] - st[:, 15]))} row loop {int(np.median(st[:, 14] - st[:, 13]))})] " if tile == 8 else "") +
-              (f"[epilogue: acc->LDS {int(np.median(st[:, 12] - st[:, 3]))} prefetch+barrier {int(np.median(st[:, 13] - st[:, 12]))} row loop {int(np.median(st[:, 14] - st[:, 13]))} tail {int(np.median(st[:, 4] - st[:, 14]))}] " if tile == 3 else "") +
+              (f"[prologue: to tile coords {int(np.median(st[:, 15] - st[:, 0]))}, rest {int(np.median(st[:, 1] - st[:, 15]))}] " if tile == 3 else "") + (f"[epilogue: acc->LDS {int(np.median(st[:, 12] - st[:, 3]))} prefetch+barrier {int(np.median(st[:, 13] - st[:, 12]))} row loop {int(np.median(st[:, 14] - st[:, 13]))} tail {int(np.median(st[:, 4] - st[:, 14]))}] " if tile == 3 else "") +
               f"loop {int(np.median(loop)):6d} ({int(np.median(loop)) // max(1, nkt):4d}/kt x{nkt}) epilogue {int(np.median(epi)):5d} total {int(np.median(tot)):6d}" + ("" if tile != 3 else f" | per kt: issue {int(np.median(st[:, 8])) // max(1, nkt - 1):4d} issue+vmwait {int(np.median(st[:, 9])) // nkt:4d} barrier {int(np.median(st[:, 10])) // nkt:4d} mfma-section {int(np.median(st[:, 11])) // nkt:4d}"),
               flush=True)
 
