@@ -293,8 +293,11 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     // staged row -> output row.  PATCH16 = 1: the rows are the pixels of a 16-pixel-wide patch (row ml = 16 y + x), m0 = its first
     // pixel; 2: two strips of 4 pixel rows that lie 8 rows apart in the image (tile 18: staged rows 0..63 = pixel rows 0..3, staged
     // rows 64..127 = pixel rows 8..11 of the 16 x 16 patch whose strip starts at m0)
+    // 3: one output PHASE of the sub-pixel upsample convolution — staged row ml = 16 y + x is SOURCE pixel (y, x) of a 16 x 16 source
+    // block, its output pixel lies at (2 y, 2 x) from m0 (the phase's first output pixel)
     auto row_m = [&](int ml) {
         if constexpr (PATCH16 == 0) return m0 + ml;
+        else if constexpr (PATCH16 == 3) return m0 + 2 * ((ml >> 4) * p.OW + (ml & 15));
         else return m0 + ((ml >> 4) + (PATCH16 == 2 ? 4 * (ml >> 6) : 0)) * p.OW + (ml & 15);
     };
     const int n8 = tid % VPR, r0 = tid / VPR;
@@ -352,7 +355,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     }
     bool rv_rows = false;                     // time-embedding row differs between this tile's rows
     if (p.rowvec) {
-        const int m_last = PATCH16 ? m0 + (PATCH16 == 2 ? 11 : 15) * p.OW + 15 : min(m0 + BM, p.M) - 1;      // (PATCH16: the patch's / strip pair's last pixel or a later one of the same image)
+        const int m_last = PATCH16 == 3 ? m0 + 30 * p.OW + 30 : PATCH16 ? m0 + (PATCH16 == 2 ? 11 : 15) * p.OW + 15 : min(m0 + BM, p.M) - 1;      // (PATCH16: the patch's / strip pair's last pixel or a later one of the same image)
         const int img0 = m0 / p.rows_per_image;
         rv_rows = (m_last / p.rows_per_image) != img0;
         if (!rv_rows && n_ok) {
@@ -1277,464 +1280,6 @@ int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
 
 
 // ------------------------------------------------------------------------------------------------------
-// 3-stage variant of the LDS-DMA main loop: 128x128 tile, K-tiles of 32, three 16 KiB LDS stages (48 KiB ->
-// three workgroups per CU), tile t+2 is issued while tile t is multiplied, ONE barrier per K-tile.  Buffer
-// addressing only (the host falls back to the 2-stage kernel otherwise).  The epilogue stages the fp32 tile
-// through LDS in two 64-row halves so that it also fits 48 KiB.
-// LDS rows are 64 bytes (4 chunks): chunk c of row r sits at slot c ^ ((r >> 2) & 3)  (conflict-free ds_read_b128).
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_off32(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
-
-template <typename T, bool SPATIAL>
-__global__ void __launch_bounds__(kThreads, 3) igemm_p3_kernel(const edtr_igemm_params p) {
-    constexpr int MI = 2, NI = 2, BM = 128, BN = 128, BKT = 32, NST = 3;
-    constexpr int A_BYTES = BM * BKT * 2, W_BYTES = BN * BKT * 2, STAGE = A_BYTES + W_BYTES;   // 16 KiB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x;
-    {
-        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    int tm, tn;
-    tile_coords(p, bid, nbm, nbn, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
-    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
-    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
-    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
-    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
-    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
-    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-
-    // one DMA instruction = 1 KiB = 16 tile rows of 64 bytes; a wave owns rows wave*32 + 16*j + (lane>>2), j = 0,1
-    const int rsub = lane >> 2, slot = lane & 3;
-    const int Cin = p.C1;
-    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
-    const int64_t bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
-    const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - bias);
-    const u32x4 srd_w = make_srd(wp);
-    uint32_t voff_a[2], voff_w[2], a_mask[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = wave * 32 + 16 * j + rsub;
-        const int coff = (slot ^ ((row >> 2) & 3)) * 8;
-        const int m = m0 + row;
-        const bool ok = m < p.M;
-        uint32_t mask = 0;
-        if (SPATIAL) {
-            const int hw = p.OH * p.OW;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-            const int64_t pc = (int64_t)b * p.IH * p.IW + (int64_t)(oy * p.stride) * p.IW + ox * p.stride;
-            voff_a[j] = (uint32_t)((pc * p.ld1 + coff) * 2);
-            const int ntap = p.taps;
-            for (int t = 0; t < ntap; ++t) {
-                const int ky = ntap == 9 ? (t * 11) >> 5 : p.pad_t, kx = ntap == 9 ? t - 3 * ky : p.pad_l;
-                const int iy = iy0 + ky, ix = ix0 + kx;
-                if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
-            }
-        } else {
-            voff_a[j] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
-            mask = 1u;
-        }
-        a_mask[j] = mask;
-        const int n = n0 + row;
-        voff_w[j] = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
-    }
-
-    int run_tap = 0, run_c0 = 0;
-    auto issue_tile = [&](int kt, int buf) {
-        const int tap = run_tap, c0 = run_c0;
-        run_c0 += BKT;
-        if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
-        uint32_t soff_a, tapbit = 1u;
-        if (SPATIAL) {
-            int ky = p.pad_t, kx = p.pad_l;
-            if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
-            soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + c0) * 2);
-        } else {
-            soff_a = (uint32_t)kt * (BKT * 2);
-        }
-        const uint32_t soff_w = (uint32_t)kt * (BKT * 2);
-        const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 64);
-        const uint32_t sw = sa + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t vo = SPATIAL ? ((a_mask[j] & tapbit) ? voff_a[j] : kOobOffset) : voff_a[j];
-            dma16_buf(vo, srd_a, soff_a, sa + j * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
-    };
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    const int nkt_all = p.K / BKT;
-    int kt0 = 0, nkt = nkt_all;
-    if (p.splitk > 1) {
-        const int per = (nkt_all + p.splitk - 1) / p.splitk;
-        kt0 = blockIdx.y * per;
-        nkt = min(per, nkt_all - kt0);
-        if (nkt < 0) nkt = 0;
-    }
-    if (SPATIAL && p.taps == 9) {
-        run_tap = (kt0 * BKT) / Cin;
-        run_c0 = kt0 * BKT - run_tap * Cin;
-    }
-    if (nkt > 0) issue_tile(kt0, 0);
-    if (nkt > 1) issue_tile(kt0 + 1, 1);
-
-    int cur = 0;                      // stage holding tile kt; tile kt+2 goes to (cur+2) % 3
-    for (int kt = 0; kt < nkt; ++kt) {
-        // this wave's 4 DMAs of tile kt are done when at most the 4 of tile kt+1 remain in flight
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everyone is past the reads of tile kt-1
-        asm volatile("" ::: "memory");
-        if (kt + 2 < nkt) issue_tile(kt0 + kt + 2, cur == 0 ? 2 : cur - 1);   // stage of tile kt-1, now free
-        const char* sa = smem + cur * STAGE;
-        const char* sw = sa + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BKT / 16; ++ks) {
-            const int c = 2 * ks + lh;
-            U4 af[MI], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const U4*>(sa + tile_off32(wm * 64 + mi * 32 + l31, c));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                bf[ni] = *reinterpret_cast<const U4*>(sw + tile_off32(wn * 64 + ni * 32 + l31, c));
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma(af[mi], bf[ni], acc[mi][ni]);
-        }
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-
-    // ---- epilogue in two 64-row halves (32 KiB of fp32 staging each)
-    const bool geglu = (p.act == EDTR_ACT_GEGLU);
-    const int BNO = geglu ? BN / 2 : BN;
-    float* stage = reinterpret_cast<float*>(smem);
-    const int n_out = geglu ? p.N / 2 : p.N;
-    const int no0 = geglu ? n0 / 2 : n0;
-    const int vec_per_row = BNO / 8;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();
-        if (wm == half) {
-            if (geglu) {
-                const int nv = n0 + wn * 64 + l31;
-                const float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
-                const float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float val = acc[mi][0][r] * p.alpha + bv;
-                        const float gate = acc[mi][1][r] * p.alpha + bg;
-                        stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
-                    }
-            } else {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            stage[ml * BNO + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
-                        }
-            }
-        }
-        __syncthreads();
-        for (int v = tid; v < 64 * vec_per_row; v += kThreads) {
-            const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
-            const int m = m0 + half * 64 + ml, n = no0 + n8 * 8;
-            if (m >= p.M || n >= n_out) continue;
-            float f[8];
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-            const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
-            f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
-            f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
-            if (p.splitk > 1) {
-                float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
-                *reinterpret_cast<f32x4*>(o) = s0;
-                *reinterpret_cast<f32x4*>(o + 4) = s1;
-                continue;
-            }
-            finish_vector<T>(p, f, m, n, !geglu, o_zoff);
-        }
-    }
-}
-
-template <typename T, bool SPATIAL>
-int launch_p3(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 3 * (128 + 128) * 32 * 2;   // 48 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_p3_kernel<T, SPATIAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
-    dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
-    hipLaunchKernelGGL((igemm_p3_kernel<T, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
-    EDTR_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
-        int64_t blocks = (nvec + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
-        EDTR_LAUNCH_CHECK();
-    }
-    return EDTR_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------------------
-// Large-tile variant: 256x128 block tile, K-tiles of 64, EIGHT waves (4 along M x 2 along N, 64x64 each), three
-// 48 KiB LDS stages (144 KiB, one workgroup per CU), tile t+2 in flight while tile t is multiplied, one barrier per
-// K-tile.  Per FLOP it pulls 25 % fewer operand bytes through L2 -> LDS than the 128x128 tile (the measured limiter
-// of that kernel on the large convolutions).  Buffer addressing only; the epilogue stages all 256x128 fp32 values.
-// ------------------------------------------------------------------------------------------------------
-template <typename T, bool SPATIAL>
-__global__ void __launch_bounds__(512, 2) igemm_big_kernel(const edtr_igemm_params p) {
-    constexpr int MI = 2, NI = 2, BM = 256, BN = 128, NT = 512;
-    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;   // 48 KiB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x;
-    {
-        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    int tm, tn;
-    tile_coords(p, bid, nbm, nbn, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
-    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
-    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
-    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
-    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
-    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
-    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-
-    // DMA ownership: A rows wave*32 + 8j + (lane>>3), j < 4;  W rows wave*16 + 8j + (lane>>3), j < 2
-    const int rsub = lane >> 3, slot = lane & 7;
-    const int Cin = p.C1;
-    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
-    const int64_t bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
-    const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - bias);
-    const u32x4 srd_w = make_srd(wp);
-    uint32_t voff_a[4], a_mask[4], voff_w[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + 8 * j + rsub;
-        const int coff = (slot ^ ((row >> 1) & 7)) * 8;
-        const int m = m0 + row;
-        const bool ok = m < p.M;
-        uint32_t mask = 0;
-        if (SPATIAL) {
-            const int hw = p.OH * p.OW;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-            const int64_t pc = (int64_t)b * p.IH * p.IW + (int64_t)(oy * p.stride) * p.IW + ox * p.stride;
-            voff_a[j] = (uint32_t)((pc * p.ld1 + coff) * 2);
-            const int ntap = p.taps;
-            for (int t = 0; t < ntap; ++t) {
-                const int ky = ntap == 9 ? (t * 11) >> 5 : p.pad_t, kx = ntap == 9 ? t - 3 * ky : p.pad_l;
-                const int iy = iy0 + ky, ix = ix0 + kx;
-                if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
-            }
-        } else {
-            voff_a[j] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
-            mask = 1u;
-        }
-        a_mask[j] = mask;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = wave * 16 + 8 * j + rsub;
-        const int coff = (slot ^ ((row >> 1) & 7)) * 8;
-        const int n = n0 + row;
-        voff_w[j] = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
-    }
-
-    int run_tap = 0, run_c0 = 0;
-    auto issue_tile = [&](int kt, int buf) {
-        const int tap = run_tap, c0 = run_c0;
-        run_c0 += BK;
-        if (run_c0 >= Cin) { run_c0 -= Cin; ++run_tap; }
-        uint32_t soff_a, tapbit = 1u;
-        if (SPATIAL) {
-            int ky = p.pad_t, kx = p.pad_l;
-            if (p.taps == 9) { ky = (tap * 11) >> 5; kx = tap - 3 * ky; tapbit = 1u << tap; }
-            soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + c0) * 2);
-        } else {
-            soff_a = (uint32_t)kt * (BK * 2);
-        }
-        const uint32_t soff_w = (uint32_t)kt * (BK * 2);
-        const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
-        const uint32_t sw = smem_base + buf * STAGE + A_BYTES + wave * (16 * 128);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t vo = SPATIAL ? ((a_mask[j] & tapbit) ? voff_a[j] : kOobOffset) : voff_a[j];
-            dma16_buf(vo, srd_a, soff_a, sa + j * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma16_buf(voff_w[j], srd_w, soff_w, sw + j * 1024);
-    };
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    const int nkt_all = p.K / BK;
-    int kt0 = 0, nkt = nkt_all;
-    if (p.splitk > 1) {
-        const int per = (nkt_all + p.splitk - 1) / p.splitk;
-        kt0 = blockIdx.y * per;
-        nkt = min(per, nkt_all - kt0);
-        if (nkt < 0) nkt = 0;
-    }
-    if (SPATIAL && p.taps == 9) {
-        run_tap = (kt0 * BK) / Cin;
-        run_c0 = kt0 * BK - run_tap * Cin;
-    }
-    if (nkt > 0) issue_tile(kt0, 0);
-    if (nkt > 1) issue_tile(kt0 + 1, 1);
-
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed; tile kt+1 (6 DMAs) may fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + 2 < nkt) issue_tile(kt0 + kt + 2, cur == 0 ? 2 : cur - 1);
-        const char* sa = smem + cur * STAGE;
-        const char* sw = sa + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int c = 2 * ks + lh;
-            U4 af[MI], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const U4*>(sa + tile_off(wm * 64 + mi * 32 + l31, c));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                bf[ni] = *reinterpret_cast<const U4*>(sw + tile_off(wn * 64 + ni * 32 + l31, c));
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma(af[mi], bf[ni], acc[mi][ni]);
-        }
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-
-    // ---- epilogue: the whole 256x128 fp32 tile through LDS (128 KiB), then 8-wide row vectors
-    const bool geglu = (p.act == EDTR_ACT_GEGLU);
-    const int BNO = geglu ? BN / 2 : BN;
-    float* stage = reinterpret_cast<float*>(smem);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (geglu) {
-        const int nv = n0 + wn * 64 + l31;
-        const float bv = p.bias_n ? p.bias_n[nv] : 0.0f;
-        const float bg = p.bias_n ? p.bias_n[nv + 32] : 0.0f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float val = acc[mi][0][r] * p.alpha + bv;
-                const float gate = acc[mi][1][r] * p.alpha + bg;
-                stage[ml * BNO + wn * 32 + l31] = val * gelu_erf_f(gate);
-            }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    stage[ml * BNO + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
-                }
-    }
-    __syncthreads();
-    const int n_out = geglu ? p.N / 2 : p.N;
-    const int no0 = geglu ? n0 / 2 : n0;
-    const int vec_per_row = BNO / 8;
-    for (int v = tid; v < BM * vec_per_row; v += NT) {
-        const int ml = v / vec_per_row, n8 = v - ml * vec_per_row;
-        const int m = m0 + ml, n = no0 + n8 * 8;
-        if (m >= p.M || n >= n_out) continue;
-        float f[8];
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + ml * BNO + n8 * 8 + 4);
-        f[0] = s0[0]; f[1] = s0[1]; f[2] = s0[2]; f[3] = s0[3];
-        f[4] = s1[0]; f[5] = s1[1]; f[6] = s1[2]; f[7] = s1[3];
-        if (p.splitk > 1) {
-            float* o = static_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
-            *reinterpret_cast<f32x4*>(o) = s0;
-            *reinterpret_cast<f32x4*>(o + 4) = s1;
-            continue;
-        }
-        finish_vector<T>(p, f, m, n, !geglu, o_zoff);
-    }
-}
-
-template <typename T, bool SPATIAL>
-int launch_big(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 3 * (256 + 128) * BK * 2;   // 144 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_big_kernel<T, SPATIAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
-    dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
-    hipLaunchKernelGGL((igemm_big_kernel<T, SPATIAL>), grid, dim3(512), lds, stream, p);
-    EDTR_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
-        int64_t blocks = (nvec + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
-        EDTR_LAUNCH_CHECK();
-    }
-    return EDTR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves, ping-pong schedule (tile = 6).  The structure the 128x128 two-barrier loop cannot
 // reach (its L2->LDS traffic is 64 B/clk/CU at MFMA peak and its DMA issue, LDS reads and MFMAs run back to back
 // in each wave): a workgroup of 8 waves per CU, waves w and w+4 share a SIMD and run HALF A PHASE APART (waves
@@ -2043,278 +1588,6 @@ int launch_256(const edtr_igemm_params& p, hipStream_t stream) {
     const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
     dim3 grid(nbm * nbn, 1, p.Z);
     hipLaunchKernelGGL((igemm_256_kernel<T, SPATIAL>), grid, dim3(512), lds, stream, p);
-    EDTR_LAUNCH_CHECK();
-    return EDTR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// 256x128 tile, 8 waves, ping-pong over a RING of six 32-deep K-slices (tile = 7; the N = 128 convolutions of the
-// 512x512 VAE level).  One phase = one 32-deep K-slice: every wave reads 4 A + 4 B fragments (its 64x64 sub-tile),
-// issues 16 v_mfma_f32_16x16x32 and stages 3 pieces (24 KiB per workgroup) of the slice four phases ahead; a slot
-// (16 KiB of A + 8 KiB of B, 64-byte rows, chunk XOR (row>>1)&3: conflict-free for the 16x16x32 operand reads) is
-// restaged two phases after its read and read four phases after its staging, behind vmcnt(9) = "all but the three
-// newest slices landed".  Balanced phases (the first 256x128 attempt alternated 12-read/4-DMA and 8-read/2-DMA
-// phases and lost to the 128x128 loop); L2->LDS demand 47 B/clk/CU at MFMA peak, between tile 3 (64) and tile 6 (32).
-// K order: (64-channel chunk, tap, 32-channel half) so that both halves of a 128-byte line are fetched back to back.
-// ------------------------------------------------------------------------------------------------------
-struct KState32 { int t, tap, c0, h; };
-
-template <typename T, bool SPATIAL>
-__global__ void __launch_bounds__(512, 1) igemm_256x128_kernel(const edtr_igemm_params p) {
-    constexpr int BKP = 32;                  // K depth of a phase
-    constexpr int A_SLOT = 256 * BKP * 2;    // 16 KiB
-    constexpr int SLOT = A_SLOT + 128 * BKP * 2;   // 24 KiB
-    constexpr int RING = 6;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;            // 4 x 2 waves of 64 x 64; waves w and w+4 share a SIMD
-    const int l15 = lane & 15, lq = lane >> 4;
-
-    const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
-    int bid = blockIdx.x;
-    {
-        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    int tm, tn;
-    tile_coords(p, bid, nbm, nbn, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 128;
-
-    const int z = blockIdx.z, zo = z / p.zdiv, zi = z - zo * p.zdiv;
-    const int64_t a_zoff = zo * p.a_zs_outer + zi * p.a_zs_inner;
-    const int64_t w_zoff = zo * p.w_zs_outer + zi * p.w_zs_inner;
-    const int64_t o_zoff = zo * p.o_zs_outer + zi * p.o_zs_inner;
-    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1) + a_zoff;
-    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + w_zoff;
-    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-
-    // ---- staging geometry: one piece = 16 rows x 64 bytes; lane -> (row = lane>>2, 16-byte slot = lane&3).
-    // This wave fills A rows wave*32 + 16j + (lane>>2), j = 0,1, and B row wave*16 + (lane>>2) of every slice.
-    const int rsub = lane >> 2, slot = lane & 3;
-    const int Cin = p.C1;
-    const int LH = p.upsample2x ? p.IH * 2 : p.IH, LW = p.upsample2x ? p.IW * 2 : p.IW;
-    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
-    uint32_t voff_a[2], a_mask[2], a_par[2], voff_w;
-    int b0 = 0, oy0 = 0, ox0 = 0;
-    float rcp_ow = 0.0f, rcp_oh = 0.0f;
-    if (SPATIAL) {
-        const int hw = p.OH * p.OW;
-        b0 = m0 / hw;
-        const int rem0 = m0 - b0 * hw;
-        oy0 = rem0 / p.OW;
-        ox0 = rem0 - oy0 * p.OW;
-        rcp_ow = 1.0f / (float)p.OW;
-        rcp_oh = 1.0f / (float)p.OH;
-    }
-    const int64_t a_bias = SPATIAL ? ((int64_t)p.pad_t * p.IW + p.pad_l) * p.ld1 * 2 : 0;
-    const u32x4 srd_a = make_srd(reinterpret_cast<const char*>(a1) - a_bias);
-    const u32x4 srd_w = make_srd(wp);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = wave * 32 + 16 * j + rsub;
-        const int coff = (slot ^ ((row >> 1) & 3)) * 8;               // logical 8-element chunk held by this LDS slot
-        const int m = m0 + row;
-        const bool ok = m < p.M;
-        uint32_t mask = 0;
-        a_par[j] = 0;
-        if (SPATIAL) {
-            const int x = ox0 + row;
-            int qx = (int)((float)x * rcp_ow), ox = x - qx * p.OW;
-            if (ox >= p.OW) { ++qx; ox -= p.OW; }
-            if (ox < 0) { --qx; ox += p.OW; }
-            const int y = oy0 + qx;
-            int qy = (int)((float)y * rcp_oh), oy = y - qy * p.OH;
-            if (oy >= p.OH) { ++qy; oy -= p.OH; }
-            if (oy < 0) { --qy; oy += p.OH; }
-            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-            const int ly = iy0 + p.pad_t, lx = ix0 + p.pad_l;
-            const int sy = p.upsample2x ? ly >> 1 : ly, sx = p.upsample2x ? lx >> 1 : lx;
-            a_par[j] = p.upsample2x ? (uint32_t)((ly & 1) | ((lx & 1) << 1)) : 0u;
-            const int64_t pc = (int64_t)(b0 + qy) * p.IH * p.IW + (int64_t)sy * p.IW + sx;
-            voff_a[j] = (uint32_t)((pc * p.ld1 + coff) * 2);
-            if (p.taps == 9) {
-                uint32_t rb = 0, cbits = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int iy = iy0 + k, ix = ix0 + k;
-                    rb |= (iy >= 0 && iy < LH) ? (1u << (3 * k)) : 0u;
-                    cbits |= (ix >= 0 && ix < LW) ? (1u << k) : 0u;
-                }
-                mask = ok ? rb * cbits : 0u;
-            } else {
-                mask = (ok && ly >= 0 && ly < LH && lx >= 0 && lx < LW) ? 1u : 0u;
-            }
-        } else {
-            voff_a[j] = ok ? (uint32_t)(((int64_t)m * p.ld1 + coff) * 2) : kOobOffset;
-            mask = 1u;
-        }
-        a_mask[j] = mask;
-    }
-    {
-        const int row = wave * 16 + rsub;
-        const int coff = (slot ^ ((row >> 1) & 3)) * 8;
-        const int n = n0 + row;
-        voff_w = n < nvalid ? (uint32_t)(((int64_t)n * p.ldw + coff) * 2) : kOobOffset;
-    }
-
-    const int nph = p.K / BKP;               // K % 64 == 0 -> even
-    auto advance1 = [&](KState32& s) {
-        s.t += 1;
-        if (s.h == 0) { s.h = 1; }
-        else {
-            s.h = 0;
-            if (++s.tap == p.taps) { s.tap = 0; s.c0 += 64; }
-        }
-    };
-    // stage the K-slice of `s` into ring slot `slot_i`
-    auto stage = [&](const KState32& s, int slot_i) {
-        const bool live = s.t < nph;
-        const int cc = s.c0 + s.h * BKP;                       // channel offset of this slice inside its tap
-        uint32_t soff_a = (uint32_t)(cc * 2), tapbit = 1u;
-        uint32_t dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
-        if (SPATIAL) {
-            int ky = p.pad_t, kx = p.pad_l;
-            if (p.taps == 9) { ky = (s.tap * 11) >> 5; kx = s.tap - 3 * ky; tapbit = 1u << s.tap; }
-            if (p.upsample2x) {
-                const int rowb = p.IW * p.ld1 * 2, colb = p.ld1 * 2;
-                dy0 = (uint32_t)((((0 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
-                dy1 = (uint32_t)((((1 + ky - p.pad_t) >> 1) + p.pad_t) * rowb);
-                dx0 = (uint32_t)((((0 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
-                dx1 = (uint32_t)((((1 + kx - p.pad_l) >> 1) + p.pad_l) * colb);
-            } else {
-                soff_a = (uint32_t)(((ky * p.IW + kx) * p.ld1 + cc) * 2);
-            }
-        }
-        if (!live) tapbit = 0u;
-        const uint32_t soff_w = (uint32_t)((s.tap * Cin + cc) * 2);
-        const uint32_t dst_a = smem_base + slot_i * SLOT + wave * 2048;
-        const uint32_t dst_w = smem_base + slot_i * SLOT + A_SLOT + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint32_t vo = voff_a[j];
-            if (SPATIAL && p.upsample2x) vo += ((a_par[j] & 1u) ? dy1 : dy0) + ((a_par[j] & 2u) ? dx1 : dx0);
-            vo = (a_mask[j] & tapbit) ? vo : kOobOffset;
-            dma16_buf(vo, srd_a, soff_a, dst_a + j * 1024);
-        }
-        dma16_buf(live ? voff_w : kOobOffset, srd_w, soff_w, dst_w);
-    };
-
-    // ---- fragment reads: 64-byte rows, byte offset of chunk c of row r = r*64 + ((c ^ ((r>>1)&3)) << 4); c = lane>>4
-    const int rd_sw = ((lq ^ ((l15 >> 1) & 3)) << 4);
-    const int a_rd = (wr * 64 + l15) * 64 + rd_sw;          // + mb * 1024 (16 rows)
-    const int b_rd = A_SLOT + (wc * 64 + l15) * 64 + rd_sw; // + nb * 1024
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    U4 af[4], bf[4];
-
-    // one phase: read slice `slot_i`, stage the slice four ahead into slot (slot_i + 4) % 6, rendezvous, multiply
-    auto phase = [&](int slot_i, KState32& s) {
-        const char* base = smem + slot_i * SLOT;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const U4*>(base + a_rd + mb * 1024);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) bf[nb] = *reinterpret_cast<const U4*>(base + b_rd + nb * 1024);
-        stage(s, (slot_i + 4) % RING);
-        advance1(s);
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = T::mfma16(af[mb], bf[nb], acc[mb][nb]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    // ---- prologue: slices 0..3
-    KState32 sS{0, 0, 0, 0};
-    stage(sS, 0); advance1(sS);
-    stage(sS, 1); advance1(sS);
-    stage(sS, 2); advance1(sS);
-    stage(sS, 3); advance1(sS);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wave >= 4) __builtin_amdgcn_s_barrier();        // waves 4-7 run half a phase behind their SIMD partners
-    asm volatile("" ::: "memory");
-
-    const int niter = (nph + RING - 1) / RING;
-    for (int it = 0; it < niter; ++it) {
-        phase(0, sS); phase(1, sS); phase(2, sS); phase(3, sS); phase(4, sS); phase(5, sS);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave < 4) __builtin_amdgcn_s_barrier();         // re-align the two wave groups
-    __syncthreads();
-
-    // ---- epilogue: the whole 256 x 128 fp32 tile (128 KiB) through LDS, then two 128-row row phases
-    float* stage_f = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                stage_f[(wr * 64 + mb * 16 + 4 * lq + r) * 128 + wc * 64 + nb * 16 + l15] = acc[mb][nb][r];
-    const bool gn_acc = p.gn_partial != nullptr;
-    float gs[2][8], gq[2][8];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { gs[h][j] = 0.0f; gq[h][j] = 0.0f; }
-        rows_phase<T, 128, 128, false, 512, 0, 128, false>(p, stage_f + h * 128 * 128, m0 + h * 128, n0, p.N, o_zoff, gn_acc, gs[h], gq[h]);
-    }
-    if (gn_acc) {
-        __syncthreads();                       // every thread is done reading the staged rows
-        // column group = tid % 16: lanes l, l+16, l+32, l+48 share it; fold them, then the 8 waves through LDS
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                gs[h][j] += __shfl_xor(gs[h][j], 16, 64); gs[h][j] += __shfl_xor(gs[h][j], 32, 64);
-                gq[h][j] += __shfl_xor(gq[h][j], 16, 64); gq[h][j] += __shfl_xor(gq[h][j], 32, 64);
-            }
-            if (lane < 16) {
-                float* dst = stage_f + ((h * 8 + wave) * 128 + lane * 8) * 2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[h][j]; dst[2 * j + 1] = gq[h][j]; }
-            }
-        }
-        __syncthreads();
-        if (tid < 256) {
-            const int h = tid >> 7, col = tid & 127;
-            if (n0 + col < p.N && m0 + h * 128 < p.M) {
-                float a = 0.0f, q = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) { a += stage_f[((h * 8 + w) * 128 + col) * 2]; q += stage_f[((h * 8 + w) * 128 + col) * 2 + 1]; }
-                float* dst = p.gn_partial + ((int64_t)((m0 >> 7) + h) * p.N + n0 + col) * 2;
-                dst[0] = a;
-                dst[1] = q;
-            }
-        }
-    }
-}
-
-template <typename T, bool SPATIAL>
-int launch_256x128(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 6 * (256 + 128) * 32 * 2;     // ring of six 24 KiB K-slices = 144 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_256x128_kernel<T, SPATIAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    const int nbm = (p.M + 255) / 256, nbn = (p.N + 127) / 128;
-    dim3 grid(nbm * nbn, 1, p.Z);
-    hipLaunchKernelGGL((igemm_256x128_kernel<T, SPATIAL>), grid, dim3(512), lds, stream, p);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }
@@ -2685,13 +1958,29 @@ template <int V> using IC = std::integral_constant<int, V>;
 //          column key alone would put (y, x) and (y + 1, x) on the same slot).
 template <typename T, int GEO>
 __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_params p) {
-    constexpr bool UP2 = GEO == 1, IMG8 = GEO == 2;
+    constexpr bool UP2 = GEO == 1, IMG8 = GEO == 2, SUBPIX = GEO == 3;
+    // SUBPIX (GEO 3, round 4): the nearest-2x upsample convolution in its SUB-PIXEL form.  The 2 x 2 blocks of the upsampled image are
+    // constant, so output pixel (2 s + py, 2 r + px) is a 2 x 2 convolution of the SOURCE image around (s, r) whose four weights are
+    // sums of the 3 x 3 kernel's (row py = 0: {w0 | w1 + w2} at source rows s - 1, s; py = 1: {w0 + w1 | w2} at rows s, s + 1; columns
+    // likewise): 4 taps instead of 9 per output pixel, 2.25 x fewer MACs than the UP2 gather, which multiplies the same source
+    // element by up to four taps separately.  The host packs the four phase matrices [2 py + px][N][2][2][C1] (sums in fp32, then the
+    // 16-bit / multi-part rounding) at p.w + phase * p.w_phase_stride.  A workgroup owns ONE phase of a 16 x 16 SOURCE block (256 output
+    // pixels of a 32 x 32 output block, stride 2) x 128 channels: the patch is the plain 18 x 18 geometry at source origin
+    // (16 ty + py - 1, 16 tx + px - 1), tap (dy, dx) reads patch pixel (y + dy, x + dx); the four phases of a block are consecutive
+    // units (their patches overlap in L2).  4 taps do not divide the ring of three weight slices, so the ring position is carried
+    // across chunks (rb) instead of being a compile-time function of the tap.
+    constexpr int NT = SUBPIX ? 4 : 9, TW = SUBPIX ? 2 : 3;         // taps per chunk, taps per kernel row
     EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
     // UP2 (nearest-2x upsample fused into the gather, `Upsample` of the UNet / VAE decoder): output pixel (y, x), tap (ky, kx) reads
     // SOURCE pixel ((oy0 + y + ky - 1) >> 1, (ox0 + x + kx - 1) >> 1): the patch is 10 x 10 source pixels (12.5 KiB per chunk),
     // patch row of block row y and tap ky = (y + ky + 1) >> 1, patch column of lane x and tap kx = (x + kx + 1) >> 1.
     constexpr int PW = (UP2 || IMG8) ? 10 : 18, PROW = PW * 128;
-    constexpr int NPP = UP2 ? 2 : (IMG8 ? 7 : 6);           // patch pieces (1 KiB = 8 pixels) per wave and chunk
+    // patch pieces (1 KiB = 8 pixels) per wave and chunk.  SUBPIX reads patch rows 0..16 only (306 pixels): 5 pieces per wave (320
+    // pixels) cover them, and they are issued in phases 1..5 of the chunk's 8 — the last one must be >= 2 phases before the chunk
+    // ends, because the counted waits only retire what was issued up to two phases ago and the next chunk reads the patch at once
+    // (with 9 taps the pieces of phases 2..7 have ten more phases to land)
+    constexpr int NPP = UP2 ? 2 : (IMG8 ? 7 : (SUBPIX ? 5 : 6));
+    constexpr int PP0 = SUBPIX ? 1 : 2;                     // first phase of a chunk that stages a piece of the next patch
     // 324 (100; IMG8: 400) pixels x 128 B, filled by 48 (16; 50) one-KiB pieces, the tail lands in padding (IMG8: pieces 50..55 land
     // in a scratch KiB behind the weight ring, so that every wave issues the same number of DMAs and the vmcnt counts hold)
     constexpr int PATCHB = UP2 ? 16 * 1024 : (IMG8 ? 50 * 1024 : 48 * 1024);
@@ -2704,7 +1993,8 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     const int g = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    const int tw = IMG8 ? 1 : p.OW >> 4, tpi = IMG8 ? 1 : tw * (p.OH >> 4);              // patches per row / per image
+    // patches per row / per image (SUBPIX: 16 x 16 source blocks per row, units = blocks x 4 phases per image)
+    const int tw = IMG8 ? 1 : (SUBPIX ? p.IW >> 4 : p.OW >> 4), tpi = IMG8 ? 1 : (SUBPIX ? tw * (p.IH >> 4) * 4 : tw * (p.OH >> 4));
     const int nbm = IMG8 ? p.M >> 8 : (p.M / (p.OH * p.OW)) * tpi, nbn = (p.N + 127) / 128;
     int bid = blockIdx.x;
     {
@@ -2713,13 +2003,17 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     }
     int tm, tn;
     tile_coords(p, bid, nbm, nbn, tm, tn);
-    const int img = IMG8 ? tm * 4 : tm / tpi, tr = IMG8 ? 0 : tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;     // IMG8: first of the unit's 4 images
-    const int oy0 = ty * 16, ox0 = tx * 16, n0 = tn * 128;
-    const int sy0 = UP2 ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UP2 ? (ox0 >> 1) - 1 : ox0 - 1;     // source pixel of patch position (0, 0)
-    const int m0 = IMG8 ? tm * 256 : (img * p.OH + oy0) * p.OW + ox0;                 // first pixel of the patch
+    const int img = IMG8 ? tm * 4 : tm / tpi, trp = IMG8 ? 0 : tm - img * tpi;     // IMG8: first of the unit's 4 images
+    const int phase_id = SUBPIX ? trp & 3 : 0, phy = phase_id >> 1, phx = phase_id & 1, tr = SUBPIX ? trp >> 2 : trp;
+    const int ty = tr / tw, tx = tr - ty * tw;
+    const int oy0 = ty * 16, ox0 = tx * 16, n0 = tn * 128;          // (SUBPIX: source block origin)
+    // source pixel of patch position (0, 0)
+    const int sy0 = UP2 ? (oy0 >> 1) - 1 : oy0 - 1 + phy, sx0 = UP2 ? (ox0 >> 1) - 1 : ox0 - 1 + phx;
+    // first pixel of the patch (SUBPIX: the phase's first output pixel, the others lie at even offsets from it)
+    const int m0 = IMG8 ? tm * 256 : SUBPIX ? (img * p.OH + 2 * oy0 + phy) * p.OW + 2 * ox0 + phx : (img * p.OH + oy0) * p.OW + ox0;
 
     const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
-    const uint16_t* wp = static_cast<const uint16_t*>(p.w);
+    const uint16_t* wp = static_cast<const uint16_t*>(p.w) + (SUBPIX ? (int64_t)phase_id * p.w_phase_stride : 0);
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const u32x4 srd_a = make_srd(a1);
     const u32x4 srd_w = make_srd(wp);
@@ -2778,7 +2072,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     // there is one address per (kx, ky & 1): a_rd[kx + 3 (ky & 1)]
     int a_rd[IMG8 ? 6 : 3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kx = 0; kx < TW; ++kx) {
         if constexpr (IMG8) {
             const int yy = l15 >> 3, px = (l15 & 7) + kx;
 #pragma unroll
@@ -2808,13 +2102,17 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     asm volatile("" ::: "memory");
     EDTR_STAMP(2);
 
+    int rb = 0;                                        // SUBPIX: ring slot of this chunk's tap 0 (4 taps per chunk over a ring of 3)
     for (int c = cbeg; c < cend; ++c) {
         const int par = (c - cbeg) & 1;
         const char* pa = smem + par * PATCHB;
+        const int rbuf[3] = {rb, rb == 2 ? 0 : rb + 1, rb == 0 ? 2 : rb - 1};        // (rb + k) % 3
         auto phase = [&](auto TAPc, auto SUBc) {
-            constexpr int TAP = decltype(TAPc)::value, SUB = decltype(SUBc)::value, KY = TAP / 3, KX = TAP % 3, BUF = TAP % 3;
-            constexpr int TAP2 = (TAP + 2) % 9, BUF2 = TAP2 % 3, PH = 2 * TAP + SUB;      // PH: phase inside the chunk, 0..17
-            const int c2 = TAP + 2 >= 9 ? c + 1 : c;
+            constexpr int TAP = decltype(TAPc)::value, SUB = decltype(SUBc)::value, KY = TAP / TW, KX = TAP % TW;
+            constexpr int TAP2 = (TAP + 2) % NT, PH = 2 * TAP + SUB;      // PH: phase inside the chunk, 0..2 NT - 1
+            // ring slots of tap TAP and of the slice staged now (tap TAP + 2): compile-time where 9 % 3 == 0 allows it
+            const int BUF = SUBPIX ? rbuf[TAP % 3] : TAP % 3, BUF2 = SUBPIX ? rbuf[(TAP + 2) % 3] : TAP2 % 3;
+            const int c2 = TAP + 2 >= NT ? c + 1 : c;
             if constexpr (SUB == 0) {
                 const char* pb = smem + B_BASE + BUF * BTAP + b_rd;
 #pragma unroll
@@ -2828,10 +2126,10 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
                     afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (UP2 ? (SUB * 4 + mb + KY + 1) >> 1 : SUB * 4 + mb + KY) * PROW);
             }
             stage_w(c2, TAP2, SUB, BUF2);
-            if constexpr (PH >= 2 && PH < 2 + NPP) stage_p(c + 1, PH - 2, par ^ 1);
+            if constexpr (PH >= PP0 && PH < PP0 + NPP) stage_p(c + 1, PH - PP0, par ^ 1);
             if constexpr (SUB == 1) {
-                // issued in this and the previous phase: 1 weight piece each, + 1 patch piece each in phases 2 .. 2 + NPP - 1
-                constexpr int INFLIGHT = 2 + (PH >= 2 && PH < 2 + NPP ? 1 : 0) + (PH - 1 >= 2 && PH - 1 < 2 + NPP ? 1 : 0);
+                // issued in this and the previous phase: 1 weight piece each, + 1 patch piece each in phases PP0 .. PP0 + NPP - 1
+                constexpr int INFLIGHT = 2 + (PH >= PP0 && PH < PP0 + NPP ? 1 : 0) + (PH - 1 >= PP0 && PH - 1 < PP0 + NPP ? 1 : 0);
                 if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else if constexpr (INFLIGHT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -2850,8 +2148,12 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
             asm volatile("" ::: "memory");
         };
         auto tap_body = [&](auto TAPc) { phase(TAPc, IC<0>{}); phase(TAPc, IC<1>{}); };
-        tap_body(IC<0>{}); tap_body(IC<1>{}); tap_body(IC<2>{}); tap_body(IC<3>{}); tap_body(IC<4>{});
-        tap_body(IC<5>{}); tap_body(IC<6>{}); tap_body(IC<7>{}); tap_body(IC<8>{});
+        tap_body(IC<0>{}); tap_body(IC<1>{}); tap_body(IC<2>{}); tap_body(IC<3>{});
+        if constexpr (!SUBPIX) {
+            tap_body(IC<4>{}); tap_body(IC<5>{}); tap_body(IC<6>{}); tap_body(IC<7>{}); tap_body(IC<8>{});
+        } else {
+            rb = rbuf[1];                                // 4 % 3 == 1
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (g == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave groups
@@ -2893,7 +2195,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    rows_phase<T, 256, 128, false, 512, !IMG8, SPITCH, false, 0>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);   // IMG8: rows are consecutive
+    rows_phase<T, 256, 128, false, 512, SUBPIX ? 3 : !IMG8, SPITCH, false, 0>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);   // IMG8: rows are consecutive
     if (gn_acc) {
         // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
 #pragma unroll
@@ -2925,7 +2227,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 template <typename T, int GEO>
 int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr bool UP2 = GEO == 1;
-    // 144 KiB; UP2: main loop 80 KiB, the epilogue's staging tile 132 KiB; IMG8: 2 x 50 KiB patches + 48 KiB weights + 1 KiB scratch
+    // 144 KiB (also SUBPIX); UP2: main loop 80 KiB, the epilogue's staging tile 132 KiB; IMG8: 2 x 50 KiB patches + 48 KiB weights + 1 KiB scratch
     constexpr int lds = UP2 ? 256 * 132 * 4 : (GEO == 2 ? 2 * 50 * 1024 + 3 * 128 * BK * 2 + 1024 : 2 * 48 * 1024 + 3 * 128 * BK * 2);
     static bool attr_set = false;
     if (!attr_set) {
@@ -3442,6 +2744,7 @@ static bool igemm_halo_img8(const edtr_igemm_params& p) {
 
 static bool igemm_halo_ok(const edtr_igemm_params& p, bool spatial) {
     const int up = p.upsample2x ? 2 : 1;
+    if (p.upsample2x == 2 && ((p.IH & 15) || (p.IW & 15) || p.w_phase_stride < (int64_t)p.N * p.ldw || p.ldw < 4 * p.C1)) return false;   // sub-pixel form: 16 x 16 source blocks
     return spatial && p.taps == 9 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.C2 == 0 && (p.C1 & 63) == 0 &&
            p.OH == p.IH * up && p.OW == p.IW * up && (((p.OH & 15) == 0 && (p.OW & 15) == 0) || igemm_halo_img8(p)) && p.Z == 1 &&
            p.splitk <= p.C1 / 64 && p.act != EDTR_ACT_GEGLU && p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW;
@@ -3479,6 +2782,7 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
     if (tile == 16) {      // halo tile for 3x3 / stride 1 convolutions
         if (!igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
         if (igemm_halo_img8(p)) return launch_halo<T, 2>(p, s);
+        if (p.upsample2x == 2) return launch_halo<T, 3>(p, s);
         return p.upsample2x ? launch_halo<T, 1>(p, s) : launch_halo<T, 0>(p, s);
     }
     if (tile >= 3 && tile <= 14) {
@@ -3489,29 +2793,12 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
             if (!fast || p.act == EDTR_ACT_GEGLU || p.gn_partial) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_n160<T, true, 8, 1>(p, s) : launch_n160<T, false, 8, 1>(p, s);
         }
-        if (tile == 4) {
-            if (!fast) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_p3<T, true>(p, s) : launch_p3<T, false>(p, s);
-        }
-        if (tile == 5) {
-            if (!fast) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_big<T, true>(p, s) : launch_big<T, false>(p, s);
-        }
-        if (tile == 10) {  // 128 x 128 with 16x16x32 MFMAs (experiment: same geometry as tile 3, other MFMA shape)
-            if (!fast || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_n160<T, true, 4, 4>(p, s) : launch_n160<T, false, 4, 4>(p, s);
-        }
-        if (tile == 9) {   // 64 x 128: twice the workgroups of tile 3 for small M
-            if (!fast || p.act == EDTR_ACT_GEGLU || p.gn_partial) return EDTR_E_UNSUPPORTED;
-            return spatial ? launch_n160<T, true, 2, 4>(p, s) : launch_n160<T, false, 2, 4>(p, s);
-        }
         if (tile == 8) {
             if (!fast || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
             return spatial ? launch_n160<T, true, 4, 5>(p, s) : launch_n160<T, false, 4, 5>(p, s);
         }
-        if (tile == 6 || tile == 7) {
+        if (tile == 6) {
             if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
-            if (tile == 7) return spatial ? launch_256x128<T, true>(p, s) : launch_256x128<T, false>(p, s);
             return spatial ? launch_256<T, true>(p, s) : launch_256<T, false>(p, s);
         }
         if (!spatial) return fast ? launch_dma<T, false, true>(p, s) : launch_dma<T, false, false>(p, s);
@@ -3578,6 +2865,7 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (p.OW <= 0 || p.IH <= 0 || p.IW <= 0 || p.stride <= 0) return EDTR_E_SHAPE;
         if (p.M % (p.OH * p.OW) != 0) return EDTR_E_SHAPE;
     }
+    if (p.upsample2x < 0 || p.upsample2x > 2) return EDTR_E_SHAPE;
     if (p.act < EDTR_ACT_NONE || p.act > EDTR_ACT_LRELU) return EDTR_E_DTYPE;
     if (p.act == EDTR_ACT_LRELU && !(p.act_slope >= 0.0f && p.act_slope <= 1.0f)) return EDTR_E_SHAPE;
     if (p.rowvec && p.rows_per_image <= 0) return EDTR_E_SHAPE;
@@ -3716,10 +3004,11 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (skinny && tile == 3 && p.N <= 32 && p.M >= 65536 && p.splitk <= 1 && !p.gn_partial && p.act != EDTR_ACT_GEGLU &&
             (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
             tile = 14;
-        // (tile 10 — the same 128x128 geometry with 16x16x32 MFMAs — is +9 % in isolation on the 512x512-level N = 128 VAE
-        //  convolutions but -0.5..-1 % on the whole path in the same A/B; opt-in)
-        // (the 64x128 tile 9 wins 10-30 % in isolation on the short-K GEMMs of the 16x16 / 8x8 latent levels but cost 1 % of
-        //  whole-path throughput in an A/B on one device — its 3 workgroups per CU crowd the concurrent stream — so it stays opt-in)
+    }
+    if (p.upsample2x == 2) {      // sub-pixel form of the upsample convolution: the halo kernel only (phase-major pre-summed weights)
+        if (p.tile != 0 && p.tile != 16) return EDTR_E_UNSUPPORTED;
+        if (!dma_ok || !igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
+        tile = 16;
     }
     if (p.vt_out) {     // the transposed V store needs whole column tiles of V: tiles 1 / 3 (128 columns) or 8 (160)
         if (p.tile == 0 && !((tile == 8 && p.vt_col0 % 160 == 0) || ((tile == 1 || tile == 3) && p.vt_col0 % 128 == 0)))
@@ -3740,9 +3029,11 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
     if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 18)) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
-    if (p.gn_partial && (tile == 2 || tile == 4 || tile == 5 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
+    if (p.gn_partial && (tile == 2 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    if (tile < 1 || tile > 18 || tile == 17 || (tile >= 11 && tile <= 13)) return EDTR_E_DTYPE;     // 11-13, 17: experiments, measured and removed (15 is opt-in)
+    // live tiles: 1, 2 (register-staged), 3 (LDS-DMA 128x128), 6 (256x256 ping-pong), 8 (128x160), 14 (256x32), 15 (opt-in), 16 (halo),
+    // 18 (persistent halo, opt-in); 4, 5, 7, 9 - 13, 17 were experiments, measured (profiles/r01 - r03) and removed
+    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || (tile >= 14 && tile <= 16) || tile == 18)) return EDTR_E_DTYPE;
     // lockstep breaker of the two-workgroups-per-CU kernels (stagger_second_slot): only when the grid has more than one round
     // (>= 768 workgroups: below that the second slot's blocks are the tail anyway) and the tile is short enough for the epilogue
     // to matter.  EDTR_IGEMM_STAGGER = percent of the estimated half life (default 100; 0 = off).

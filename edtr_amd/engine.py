@@ -186,6 +186,16 @@ class WeightStore:
                    (cop, kh * kw * cip))
         return ref, self.vec(prefix + "bias", cop, bias_scale)
 
+    def conv_subpixel(self, prefix: str, cin_pad: Optional[int] = None, bias_scale: float = 1.0) -> Tuple[WRef, torch.Tensor]:
+        """(WRef of the four pre-summed phase matrices [4 * Np, 4 * Cinp], bias f32 [Np]) of a nearest-2x upsample convolution in
+        its sub-pixel form (ops.pack_conv_weight_subpixel)."""
+        co, ci, kh, kw = self.shape_of(prefix + "weight")
+        cip, cop = cin_pad or round_up(ci, 8), round_up(co, 8)
+        ref = WRef(self, ("conv_subpixel", prefix, cin_pad),
+                   lambda parts: ops.pack_conv_weight_subpixel(self._p(prefix + "weight"), self.dtype, cin_pad=cin_pad, parts=parts),
+                   (4 * cop, 4 * cip))
+        return ref, self.vec(prefix + "bias", cop, bias_scale)
+
     def linear(self, names: Sequence[str], biases: Optional[Sequence[Optional[str]]] = None):
         """Row-concatenation of several [out, in] matrices (fused projections) + matching fp32 bias (or None)."""
         names = tuple(names)
@@ -701,6 +711,13 @@ class Emitter:
             a, tmp, parts = self._operand(x.t, x.rows, x.C, parts)
             out_f32 = True if out is None else out.dtype == torch.float32
         Ce = parts * x.C
+        # nearest-2x upsample convolutions run in their sub-pixel form (four 2x2 convolutions of the source image with pre-summed
+        # weights: 4 instead of 9 multiply-adds per output element) wherever the halo kernel's geometry takes them
+        subpix = (ups and taps == 9 and stride == 1 and pad_tl == 1 and not self.invariant
+                  and ops.subpixel_ok(x.H, x.W, Ce, N, x.B))
+        if subpix:
+            w, bias = self.store.conv_subpixel(prefix, cin_pad=x.C, bias_scale=alpha)
+            spatial = spatial[:7] + (2,)
         wt = self._w(w, parts)
         if out is None:
             out = self.new(M, N, torch.float32 if out_f32 else None)
@@ -708,6 +725,8 @@ class Emitter:
         tile, splitk = ops.choose_splitk(M, N, taps * Ce, img8=img8)
         if self.invariant:
             tile, splitk = ops.invariant_tile(Ce, 0), 1
+        if subpix:
+            tile, splitk = 16, 1
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
         if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk, invariant=self.invariant):
@@ -718,7 +737,7 @@ class Emitter:
             ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
             ldr=residual.stride(0) if residual is not None else 0, residual_f32=res32, out_f32=out_f32, alpha=alpha, tile=tile,
-            splitk=splitk, workspace=ws, gn_partial=gnp, name=name))
+            splitk=splitk, workspace=ws, gn_partial=gnp, name=name, w_phase_stride=(N * wt.stride(0)) if subpix else 0))
         self.arena.free(ws)
         self.arena.free(tmp)
         return Act(out, x.B, OH, OW, N, gnp)

@@ -50,6 +50,7 @@ class IgemmParams(C.Structure):
         ("ln_stats", C.c_void_p), ("ln_slots", C.c_int32), ("ln_C", C.c_int32), ("ln_eps", C.c_float),
         ("ln_c1", C.c_void_p), ("ln_c2", C.c_void_p),
         ("stagger", C.c_int32), ("debug_flags", C.c_int32),
+        ("w_phase_stride", C.c_int64),
     ]
 
 
@@ -147,7 +148,7 @@ def load() -> C.CDLL:
     lib.edtr_embed_tokens.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.edtr_window_attn.argtypes = [C.POINTER(WindowAttnParams), vp]
     lib.edtr_pixel_unshuffle.argtypes = [i32, vp, i32, i32, i32, i32, i32, vp, f32, vp, i32, i32, vp]
-    if lib.edtr_abi_version() != 6:
+    if lib.edtr_abi_version() != 7:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

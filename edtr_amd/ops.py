@@ -70,7 +70,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                vt_out: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_ld: int = 0, vt_alpha: float = 1.0,
                row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0, ln_valid: int = 0,
                ln_eps: float = 1e-5, ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None,
-               name: str = "igemm") -> Rec:
+               w_phase_stride: int = 0, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -79,6 +79,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     if spatial is not None:
         p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l, p.upsample2x = spatial
     p.w, p.ldw = ptr(w), ldw
+    p.w_phase_stride = w_phase_stride     # sub-pixel upsample convolution (spatial[7] == 2): four pre-summed phase matrices
     p.w_zs_outer, p.w_zs_inner = w_zs
     p.alpha = alpha
     p.bias_n, p.bias_m, p.rowvec = ptr(bias_n), ptr(bias_m), ptr(rowvec)
@@ -107,7 +108,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
                                                     gn_partial, vt_out, row_stats, ln_stats, ln_c1, ln_c2), name, flops, nbytes)
     rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
-               + (" up2" if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
+               + ((" up2" if p.upsample2x == 1 else " up2sp") if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
                + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else "") + (" vT" if vt_out is not None else "")
                + (" ln" if ln_stats is not None else "") + (" rs" if row_stats is not None else ""))
     return rec
@@ -392,6 +393,47 @@ def pack_conv_weight(w: torch.Tensor, dtype, cin_pad: Optional[int] = None,
     out[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
     dt16, parts = _weight_format(dtype, parts)
     return split3_weight(out, dt16, parts).reshape(cop, kh * kw * parts * cip)
+
+
+# sub-pixel form of nearest-2x upsample + 3x3 conv: which 3x3 taps add up on source offset d (0 / 1) of output parity p
+SUBPIXEL_TAPS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+
+
+def pack_conv_weight_subpixel(w: torch.Tensor, dtype, cin_pad: Optional[int] = None, parts: int = 1) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] fp32 -> four phase matrices [4 * Cout_pad][2 * 2 * parts * Cin_pad] of the sub-pixel form of
+    `interpolate(nearest, x2) -> conv3x3` (include/edtr_hip.h: w_phase_stride; reference model/unet.py:70-79, model/vae.py:35-39):
+    output pixel (2s + py, 2r + px) = sum over (dy, dx) in {0, 1}^2 of W[py, px][dy][dx] . src[s + py - 1 + dy, r + px - 1 + dx] with
+    W[py, px][dy][dx] = sum of w[ky][kx] over ky in SUBPIXEL_TAPS[py][dy], kx in SUBPIXEL_TAPS[px][dx].  The sums are taken in
+    fp32 BEFORE the 16-bit (or multi-part) rounding, so the packed operand is at least as close to the fp32 kernel as nine
+    separately rounded taps."""
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("the sub-pixel form is for 3x3 kernels")
+    cip = cin_pad or round_up(ci, 8)
+    cop = round_up(co, 8)
+    wf = w.float()
+    out = torch.zeros((4, cop, 2, 2, cip), dtype=torch.float32, device=w.device)
+    for py in (0, 1):
+        for px in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    acc = torch.zeros((co, ci), dtype=torch.float32, device=w.device)
+                    for ky in SUBPIXEL_TAPS[py][dy]:
+                        for kx in SUBPIXEL_TAPS[px][dx]:
+                            acc = acc + wf[:, :, ky, kx]
+                    out[2 * py + px, :co, dy, dx, :ci] = acc
+    dt16, parts = _weight_format(dtype, parts)
+    return split3_weight(out, dt16, parts).reshape(4 * cop, 4 * parts * cip)
+
+
+def subpixel_ok(H: int, W: int, Ce: int, N: int, B: int) -> bool:
+    """Does the halo kernel's sub-pixel geometry take this nearest-2x upsample convolution (source H x W, Ce operand channels incl.
+    parts, N output channels)?  16 x 16 source blocks, 64-channel chunks, 128-column tiles, and enough units to be worth a
+    146-KiB workgroup (the halo tile's own threshold).  EDTR_SUBPIXEL=0 keeps the 9-tap gather (A/B runs)."""
+    if os.environ.get("EDTR_SUBPIXEL", "1") == "0":
+        return False
+    units = B * (H // 16) * (W // 16) * 4 * ((N + 127) // 128)
+    return H % 16 == 0 and W % 16 == 0 and Ce % 64 == 0 and N % 128 == 0 and units >= 48
 
 
 def pack_linear_weight(w: torch.Tensor, dtype, n_pad: Optional[int] = None, parts: int = 1) -> torch.Tensor:

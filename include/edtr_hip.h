@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 6
+#define EDTR_ABI_VERSION 7
 
 enum edtr_dtype {
     EDTR_BF16 = 0, EDTR_F16 = 1,
@@ -84,7 +84,8 @@ int edtr_device_info(int* compute_units, int64_t* hbm_bytes, char* arch_name, in
  * A operand ("im2col on the fly"): k = tap * (C1 + C2) + c, tap = ky * 3 + kx for taps == 9.
  *   pixel (b, oy, ox) = unflatten(m; OH, OW);  iy = oy*stride + ky - pad_t;  ix likewise;
  *   out-of-range taps read 0;  upsample2x != 0 reads source pixel (iy>>1, ix>>1) of an
- *   (IH, IW) source (logical input is 2IH x 2IW);  channels c < C1 come from a1 (pixel stride
+ *   (IH, IW) source (logical input is 2IH x 2IW; upsample2x == 2: the same function in its sub-pixel
+ *   form, see w_phase_stride);  channels c < C1 come from a1 (pixel stride
  *   ld1), the rest from a2 (pixel stride ld2) — the fused channel concat.
  *   taps == 1 and OH == 0: plain row-major matrix, A(z, m, k) = a1[z][m*ld1 + k] (concat too).
  * W operand: row-major [N][K] (K contiguous, i.e. conv weights packed [Cout][ky][kx][Cin]).
@@ -119,8 +120,7 @@ typedef struct edtr_igemm_params {
     void* out; int32_t ldc; int32_t out_f32;
     int64_t o_zs_outer, o_zs_inner;
     int32_t tile;           /* 0 = auto; explicit main-loop choice (tests / A-B runs): 1 = 128x128 register-staged, 2 = 64x64,
-                               3 = 128x128 LDS-DMA (2 stages), 4 = 3-stage BK32, 5 = 256x128, 6 = 256x256 ping-pong, 7 = 256x128 ring,
-                               8 = 128x160, 9 = 64x128, 10 = 128x128 with 16x16x32 MFMAs, 14 = 256x32 for N <= 32 (automatic for
+                               3 = 128x128 LDS-DMA (2 stages), 6 = 256x256 ping-pong, 8 = 128x160, 14 = 256x32 for N <= 32 (automatic for
                                large-M skinny-N convolutions), 15 = 8-wave ping-pong 128x128 for plain GEMMs with at most one tile per CU (opt-in: faster in
                                isolation, no whole-path gain), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions, plain or nearest-2x upsampled, on outputs whose
                                height and width are multiples of 16: the 18x18 input patch of a 16x16 output patch stays in LDS for
@@ -128,8 +128,9 @@ typedef struct edtr_igemm_params {
                                other shape), 18 = the halo tile as a persistent kernel (workgroups walk units, the next unit's first
                                operands are fetched in the last chunk of the current one; needs an even number of 64-channel chunks,
                                no split-K, no upsample; opt-in: EDTR_IGEMM_HALO_PERSIST=1; outputs bit-identical to tile 16);
-                               11-13 and 17 were experiments (deeper LDS rings, bank-swizzled epilogue staging,
-                               two-workgroup halo variants), measured without gain and removed */
+                               4, 5, 7, 9 - 13 and 17 were experiments (3-stage BK32, 256x128 tiles, 64x128, 16x16x32 at 128x128, deeper
+                               LDS rings, bank-swizzled epilogue staging, two-workgroup halo variants), measured without a whole-path
+                               gain (profiles/r01 - r03) and removed: EDTR_E_DTYPE */
     /* split-K (small-M problems that cannot fill 256 CUs): K is cut into `splitk` runs of K-tiles, each
      * workgroup row writes an fp32 partial slab into `workspace` ([splitk][M][N] floats, caller-owned), and a
      * second launch sums the slabs and applies the epilogue.  splitk <= 1 disables it.  Needs Z == 1, no GEGLU. */
@@ -140,7 +141,7 @@ typedef struct edtr_igemm_params {
      * kernel's business — the halo tile fills slot 2k with a 256-pixel patch and zeroes slot 2k+1 — only the per-image
      * totals over an image's H*W/128 consecutive slots are defined).  edtr_gn_finalize folds them into
      * the fp64 sums edtr_gn_apply consumes, so the separate statistics pass over the tensor (edtr_gn_stats) disappears.
-     * Needs M % 128 == 0, no GEGLU / split-K / z-batching, tile 0/1/3/6/7/8/10/16/18 (16-bit or fp32 output). */
+     * Needs M % 128 == 0, no GEGLU / split-K / z-batching, tile 0/1/3/6/8/16/18 (16-bit or fp32 output). */
     float* gn_partial;
     float act_slope;        /* negative-side slope of EDTR_ACT_LRELU (0 <= slope <= 1) */
     int32_t residual_f32;   /* nonzero: `residual` is fp32 (ldr in floats, multiple of 4): the fp32 activation stream of the
@@ -175,6 +176,15 @@ typedef struct edtr_igemm_params {
     int32_t debug_flags;    /* set by edtr_igemm itself from the environment (A/B measurements on one device): bit 0 =
                                EDTR_IGEMM_GENERAL_EPILOGUE=1, every launch takes the general epilogue row loop; bit 1 = EDTR_IGEMM_N160_TWO_PASS=1,
                                the 128x160 tile stages its accumulators in two passes of 64 rows */
+    /* Sub-pixel form of `F.interpolate(x, scale_factor=2, mode="nearest")` + 3x3 conv (ABI 7; upsample2x == 2; reference
+     * model/unet.py:70-79, model/vae.py:35-39).  The 2 x 2 blocks of the upsampled image are constant, so output pixel
+     * (2s + py, 2r + px) is a 2 x 2 convolution of the SOURCE image whose weights are sums of the 3 x 3 kernel's rows / columns:
+     *   rows    py = 0: {w[0]} on source row s - 1, {w[1] + w[2]} on s;     py = 1: {w[0] + w[1]} on s, {w[2]} on s + 1   (columns alike)
+     * i.e. 4 multiply-adds per output element and input channel instead of 9.  `w` then holds FOUR phase matrices
+     * [2 py + px][N][dy][dx][C1] (K' = 4 C1 per row, row stride ldw >= 4 C1), `w_phase_stride` elements apart, summed in fp32 by
+     * the packer BEFORE the 16-bit (or multi-part) rounding.  taps stays 9 and K = 9 C1 (the algorithmic shape).  Halo kernel only
+     * (tile 0 / 16): IH, IW multiples of 16, C1 % 64 == 0, stride 1, pad 1; anything else is EDTR_E_UNSUPPORTED. */
+    int64_t w_phase_stride;
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);

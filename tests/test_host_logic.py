@@ -319,3 +319,36 @@ def test_clip_tokenizer_token_ids_vs_reference(golden_dir):
         assert tok.encode(prompt) == want, prompt
     got = tokenize(g["prompts"], 77, bpe_path=path)
     assert got.tolist() == g["tokenize_77"]
+
+
+def test_subpixel_weight_packing_equals_upsample_then_conv():
+    """ops.pack_conv_weight_subpixel (include/edtr_hip.h: w_phase_stride): four 2x2 convolutions of the source image with the
+    pre-summed weights reproduce `F.interpolate(x, 2, "nearest")` + 3x3 conv (reference model/unet.py:70-79, model/vae.py:35-39)
+    exactly in fp32 arithmetic — the index algebra the halo kernel's sub-pixel geometry relies on, incl. the image borders."""
+    import torch.nn.functional as F
+    from edtr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W, N = 2, 8, 5, 7, 16
+    x = torch.randn((B, C, H, W), generator=g, dtype=torch.float64)
+    w = torch.randn((N, C, 3, 3), generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    packed = ops.pack_conv_weight_subpixel(w.float(), ops.MIXED, cin_pad=C, parts=3)           # [4 N][2][2][hi | hi | lo] fp16
+    assert packed.shape == (4 * N, 4 * 3 * C)
+    p5 = packed.reshape(4, N, 2, 2, 3, C).double()
+    wsum = p5[..., 0, :] + p5[..., 2, :]                                                   # hi + lo = the fp32 sums to ~22 bits
+    out = torch.zeros_like(ref)
+    xp = F.pad(x, (1, 1, 1, 1))                                                            # source pixel (s, r) at xp[s + 1, r + 1]
+    for py in (0, 1):
+        for px in (0, 1):
+            acc = torch.zeros((B, N, H, W), dtype=torch.float64)
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    src = xp[:, :, py + dy:py + dy + H, px + dx:px + dx + W]               # src[s + py - 1 + dy, r + px - 1 + dx]
+                    acc += torch.einsum("bchw,nc->bnhw", src, wsum[2 * py + px, :, dy, dx])
+            out[:, :, py::2, px::2] = acc
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6
+    # one-part packing keeps the layout and rounds the SUMS once
+    p1 = ops.pack_conv_weight_subpixel(w.float(), torch.bfloat16, cin_pad=C).reshape(4, N, 2, 2, C)
+    want = (w[:, :, 1, 1] + w[:, :, 1, 2] + w[:, :, 2, 1] + w[:, :, 2, 2]).float().to(torch.bfloat16)   # phase (0, 0), tap (1, 1)
+    assert torch.equal(p1[0, :, 1, 1], want)
+    assert ops.subpixel_ok(64, 64, 512, 512, 8) and not ops.subpixel_ok(8, 8, 1280, 1280, 8) and not ops.subpixel_ok(64, 64, 320, 320, 8)

@@ -68,7 +68,7 @@ def bench_gemm(M, N, K, tile=0, act=0, residual=False, splitk=1):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     B = int(os.environ.get("B", "8"))
-    tiles = [int(t) for t in os.environ.get("TILES", "3,5").split(",")]
+    tiles = [int(t) for t in os.environ.get("TILES", "3,6").split(",")]
     if what == "one":      # python tools/bench_kernels.py one H Cin Cout tile [stride] [ups]   (for rocprofv3 --pmc runs)
         H, ci, co, t = (int(v) for v in sys.argv[2:6])
         st = int(sys.argv[6]) if len(sys.argv) > 6 else 1
