@@ -42,7 +42,9 @@ def log(*a):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=60,
+                    help="timed passes (default 60: >= 4 s of timed region at the headline workload, so that a few-percent kernel change "
+                         "is visible on the driver's record; the 50-step / tiled workloads default to 8 / 16 passes)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE config 2: 8)")
     ap.add_argument("--size", type=int, default=512)
@@ -88,12 +90,17 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     tiled = args.workload == "seg1024tiled"
     s50 = args.workload == "det512s50"
+    steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
     if tiled:
         args.batch, args.size = 1, 1024        # (two images in flight like the other workloads: 10.57 -> 11.52 images/s, same device, round 3)
         args.no_cpu_baseline = True
+        if not steps_given:
+            args.steps = 16
     if s50:
         args.batch, args.size = 4, 512
         args.no_cpu_baseline = True
+        if not steps_given:
+            args.steps = 8
     # ---- the CPU-baseline child is spawned before this process makes any HIP call; it builds its fp32 weights, reports "ready"
     #      and idles.  The GPU side waits for that "ready" before its warm-up, so the two never compete for the host cores.
     cpu_handle = None
@@ -162,8 +169,11 @@ def main() -> None:
     inp = workloads.make_inputs(args.workload, ctx_dim, dev, B, S, rank, world)
     untiled_forward = cldm.forward
 
-    def one_pass():
-        img, z, _ = workloads.restore_pass(cldm, diffusion, sampler, inp, args.workload, untiled_forward)
+    def one_pass(inject=False):
+        # inject=False: the sampler's per-step noise is drawn by torch.randn_like on the GPU INSIDE the pass, as the reference does
+        # (utils/sampler.py:199) — the timed region does that work; inject=True (the parity pass after the timed region) feeds
+        # the tensors the reference golden was made with
+        img, z, _ = workloads.restore_pass(cldm, diffusion, sampler, inp, args.workload, untiled_forward, inject=inject)
         return img, z
 
     def barrier():
@@ -247,6 +257,16 @@ def main() -> None:
     # HIP events around every pass on its own stream: the latency of ONE pass while `inflight` passes overlap (not a throughput)
     lat = sorted(a.elapsed_time(b) for a, b in step_events)
     pass_latency_ms = lat[len(lat) // 2] if lat else None
+    # completion-to-completion intervals of consecutive passes (HIP events, device clock): their median is the steady-state time
+    # per pass without the host's start-up / drain effects that the wall clock includes
+    ends = [b for _, b in step_events]
+    nf = args.inflight      # passes i and i + nf complete on the same stream
+    gaps = sorted(ends[i].elapsed_time(ends[i + nf]) / nf for i in range(len(ends) - nf)) if len(ends) > 2 * nf else []
+    ms_per_step_median = gaps[len(gaps) // 2] if gaps else None
+    # ---- parity pass (untimed): the same path once more with the reference golden's noise tensors injected
+    cldm.engine_slot = 0
+    img, z = one_pass(inject=True)
+    torch.cuda.synchronize()
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -273,6 +293,9 @@ def main() -> None:
                    "batches_in_flight": args.inflight, "precision": args.precision},
         "weight_broadcast": bcast, "rccl_ranks": rccl_ranks,
         "pass_latency_ms_median_hip_events": round(pass_latency_ms, 3) if pass_latency_ms is not None else None,
+        "ms_per_step_median_hip_events": round(ms_per_step_median, 3) if ms_per_step_median is not None else None,
+        "sampler_noise": "torch.randn_like on the GPU inside every timed pass (reference utils/sampler.py:199); the parity figures come "
+                         "from one extra untimed pass with the golden's noise injected",
         "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE_BY_WORKLOAD[args.workload] / (world * PEAK_TFLOPS * 1e12), 4)
         if (args.config == "sd21" and std_shape) else None,
     }
@@ -330,26 +353,44 @@ def _free_port() -> int:
 
 def launch_ranks(n: int) -> int:
     """Start `n` fresh child processes of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
-    127.0.0.1), wait for all of them and forward rank 0's JSON line.  The parent never touches the GPU (a process that has
-    initialised HIP must not be replaced or forked on this pool), never re-execs, and exits non-zero if any rank failed or if
-    the line does not report `n` ranks."""
+    127.0.0.1), and forward rank 0's JSON line.  The parent never touches the GPU (a process that has initialised HIP must not be
+    replaced or forked on this pool) and never re-execs.  All children are POLLED together: as soon as one exits non-zero the
+    others are killed (a rank that dies before or inside the rendezvous / a collective would otherwise leave its peers waiting
+    for their multi-minute timeouts) and that code is returned; the launcher also exits non-zero if the line does not report `n`
+    ranks.  Rank 0's stdout goes to a temporary file, so a full pipe can never stall it."""
     import subprocess
+    import tempfile
     port = _free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(codes):
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        log(f"bench.py launcher: rank exit codes {codes}; rank 0 printed (NOT forwarded as a result):\n{out0 or ''}")
-        return next(c for c in codes if c) or 1
-    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else sys.stderr))
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = (r, p.returncode)
+                    break
+            else:
+                time.sleep(0.2)
+        if failed is None:
+            failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+        if failed is not None:
+            for p in procs:                      # fail fast: the survivors would sit in the rendezvous / a collective
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            out0.seek(0)
+            log(f"bench.py launcher: rank {failed[0]} exited with code {failed[1]}; the other ranks were stopped; rank 0 printed "
+                f"(NOT forwarded as a result):\n{out0.read()}")
+            return failed[1] or 1
+        out0.seek(0)
+        text = out0.read()
+    lines = [ln for ln in text.splitlines() if ln.strip()]
     try:
         line = json.loads(lines[-1])
     except (IndexError, ValueError):
@@ -374,6 +415,8 @@ def dry_run_rank(rank: int, world: int) -> int:
     EDTR_BENCH_BACKEND=gloo.  Rank 0 prints a JSON line shaped like the real one."""
     import torch.distributed as dist
     backend = os.environ.get("EDTR_BENCH_BACKEND", "nccl")
+    if os.environ.get("EDTR_BENCH_DRY_FAIL_EARLY_RANK") == str(rank):  # the self-test's failure injection BEFORE the rendezvous:
+        return 4                                                       # the surviving ranks would wait in init_process_group
     if world > 1 or os.environ.get("EDTR_BENCH_DIST"):
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if backend == "nccl" else torch.device("cpu")
@@ -404,9 +447,12 @@ def parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err) ->
     torch.cuda.synchronize()
     build_s = time.time() - t0
     t0 = time.perf_counter()
-    img, z = run_steps(args.parity_steps)
+    run_steps(args.parity_steps)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.parity_steps * 1e3
+    cldm.engine_slot = 0
+    img, z = one_pass(inject=True)         # untimed parity pass: the golden's noise tensors
+    torch.cuda.synchronize()
     out = {"precision": "mixed", "policy": cldm._policy().describe(), "images_per_s": round(B / ms * 1e3, 3), "ms_per_step": round(ms, 3),
            "steps": args.parity_steps, "build_seconds": round(build_s, 1),
            "mfma_frac_whole_path": round(B / ms * 1e3 * FLOP_PER_IMAGE / (PEAK_TFLOPS * 1e12), 4),
@@ -415,6 +461,8 @@ def parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err) ->
     gp = golden_parity(args.workload, img, z, rel_err, "mixed").get("parity_vs_reference_golden")
     if gp:
         out.update(rel_err_latent=gp["rel_err_latent"], rel_err_image=gp["rel_err_image_samples"], fixture=gp["fixture"],
+                   max_err_latent=gp["max_err_latent"], max_err_image=gp["max_err_image_samples"],
+                   p9999_err_latent=gp["p9999_err_latent"], p9999_err_image=gp["p9999_err_image_samples"], max_norm_ok=gp["max_norm_ok"],
                    images=gp["images"], meets_north_star=bool(gp["rel_err_latent"] < NORTH_STAR and gp["rel_err_image_samples"] < NORTH_STAR), north_star=NORTH_STAR)
     return out
 
@@ -431,8 +479,8 @@ def other_workload_leg(cldm, diffusion, sampler, name, dev, ctx_dim, args, captu
     inp = workloads.make_inputs(name, ctx_dim, dev, B, S)
     untiled_forward = type(cldm).forward.__get__(cldm)      # (the tiled sampler monkey-patches cldm.forward and never restores it)
 
-    def one_pass():
-        img, z, _ = workloads.restore_pass(cldm, diffusion, sampler, inp, name, untiled_forward)
+    def one_pass(inject=False):
+        img, z, _ = workloads.restore_pass(cldm, diffusion, sampler, inp, name, untiled_forward, inject=inject)
         return img, z
 
     streams = [torch.cuda.Stream() for _ in range(inflight)]
@@ -448,27 +496,33 @@ def other_workload_leg(cldm, diffusion, sampler, name, dev, ctx_dim, args, captu
             torch.cuda.current_stream().wait_stream(st)
         return out
 
-    for k in range(inflight):          # program build per buffer slot
-        cldm.engine_slot = k
-        one_pass()
-    torch.cuda.synchronize()
-    capture_all()
-    for st in streams:
-        st.wait_stream(torch.cuda.current_stream())
-    run(inflight)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    img, z = run(steps)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    cldm.forward = untiled_forward
-    cldm.engine_slot = 0
+    try:
+        for k in range(inflight):          # program build per buffer slot
+            cldm.engine_slot = k
+            one_pass()
+        torch.cuda.synchronize()
+        capture_all()
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        run(inflight)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        cldm.engine_slot = 0
+        img, z = one_pass(inject=True)     # untimed parity pass
+        torch.cuda.synchronize()
+    finally:                               # whatever happened: the legs after this one must see the untiled forward again
+        cldm.forward = untiled_forward
+        cldm.engine_slot = 0
     out = {"images_per_s": round(B / ms * 1e3, 4), "ms_per_step": round(ms, 3), "steps": steps, "batch": B, "image_size": S,
            "denoise_steps": workloads.WORKLOADS[name][2], "batches_in_flight": inflight,
            "mfma_frac_whole_path": round(B / ms * 1e3 * FLOP_PER_IMAGE_BY_WORKLOAD[name] / (PEAK_TFLOPS * 1e12), 4)}
     gp = golden_parity(name, img, z, rel_err, args.dtype).get("parity_vs_reference_golden")
     if gp:
-        out.update(rel_err_latent=gp["rel_err_latent"], rel_err_image=gp["rel_err_image_samples"], parity_ok=gp["ok"])
+        out.update(rel_err_latent=gp["rel_err_latent"], rel_err_image=gp["rel_err_image_samples"], max_err_latent=gp["max_err_latent"],
+                   max_err_image=gp["max_err_image_samples"], parity_ok=gp["ok"])
     return out
 
 
@@ -635,6 +689,9 @@ def kernel_of(name: str) -> str:
 TOLERANCE = {"bf16": {"z_pre": 1.75e-2, "latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"z_pre": 2.2e-3, "latent": 1.3e-3, "image": 2.3e-3},
              "mixed": {"z_pre": 1e-3, "latent": 8.5e-4, "image": 9e-4}, "high": {"z_pre": 1.2e-4, "latent": 1.2e-4, "image": 1.5e-4}}
 NORTH_STAR = 1e-3
+# max-norm bound as a multiple of the L2 tolerance: measured max / L2 ratios of the shipped modes are 0.9 - 1.3 (the peak of a latent / image is a few times its RMS)
+# (profiles/r04/maxnorm_measured.log), a defect in one 16 x 16 tile of a 512 x 512 image with O(1) errors gives > 100
+MAX_OVER_L2 = 3.0
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r03", "pmc_hbm_traffic.json")
 
 
@@ -742,11 +799,15 @@ def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=42
     for name in ("first", "last"):
         if name in runs:
             sel, (dt, ref_img, ref_z) = runs[name]
-            ez, ei = rel_err(z[sel], ref_z), rel_err(img[sel], ref_img)
-            good = bool(ez == ez and ei == ei and ez < tol["latent"] and ei < tol["image"])          # NaN-safe
+            from edtr_amd.testing import err_stats
+            sz, si = err_stats(z[sel], ref_z), err_stats(img[sel], ref_img)
+            ez, ei = sz["l2"], si["l2"]
+            good = bool(ez == ez and ei == ei and ez < tol["latent"] and ei < tol["image"]           # NaN-safe
+                        and sz["max"] < MAX_OVER_L2 * tol["latent"] and si["max"] < MAX_OVER_L2 * tol["image"])
             ok = ok and good
             parity[f"{name}_image"] = {"index": sel.start, "rel_err_latent_vs_oracle": float(f"{ez:.3e}"),
-                                       "rel_err_image_vs_oracle": float(f"{ei:.3e}"), "ok": good}
+                                       "rel_err_image_vs_oracle": float(f"{ei:.3e}"), "max_err_latent_vs_oracle": float(f"{sz['max']:.3e}"),
+                                       "max_err_image_vs_oracle": float(f"{si['max']:.3e}"), "ok": good}
     if "batch" in runs:
         sel, (dt8, ref_img, ref_z) = runs["batch"]
         worst = max(max(rel_err(z[k:k + 1], ref_z[k:k + 1]), rel_err(img[k:k + 1], ref_img[k:k + 1])) for k in range(B))
@@ -783,14 +844,24 @@ def golden_parity(workload, img, z, rel_err, dtype_name) -> dict:
     sel = [int(k) for k in g["images"]] if "images" in g.files else [0]
     if max(sel) >= z.shape[0]:
         return {}
+    from edtr_amd.testing import err_stats
     zc, ic = z.cpu()[sel], img.cpu()[sel][:, :, 1::4, 2::4]
-    ez, ei = rel_err(zc, g["z"]), rel_err(ic, g["img_samples"].astype(np.float32))
+    sz, si = err_stats(zc, g["z"]), err_stats(ic, g["img_samples"].astype(np.float32))
+    ez, ei = sz["l2"], si["l2"]
     tol = TOLERANCE[dtype_name]
-    ok = bool(ez == ez and ei == ei and ez < tol["latent"] and ei < tol["image"])
+    # max-norm gate (BASELINE.md §3 "max relative error"): worst element / the signal's peak must stay below MAX_OVER_L2 x the L2
+    # tolerance — a localised defect (one wrong halo column, one bad tile seam) moves the max by orders of magnitude and the L2 norm hardly
+    max_ok = bool(sz["max"] < MAX_OVER_L2 * tol["latent"] and si["max"] < MAX_OVER_L2 * tol["image"])
+    ok = bool(ez == ez and ei == ei and ez < tol["latent"] and ei < tol["image"] and max_ok)
     if not ok:
-        log(f"!!! PARITY FAILURE vs the reference golden {name}: latent {ez:.3e}, image {ei:.3e} (tolerance {tol})")
-    return {"parity_vs_reference_golden": {"fixture": f"tests/golden/{name}", "images": sel, "rel_err_latent": float(f"{ez:.3e}"),
-                                           "rel_err_image_samples": float(f"{ei:.3e}"), "ok": ok, "tolerance": tol}}
+        log(f"!!! PARITY FAILURE vs the reference golden {name}: latent {sz}, image {si} (tolerance {tol}, max-norm bound {MAX_OVER_L2} x)")
+    r3 = lambda v: float(f"{v:.3e}")
+    return {"parity_vs_reference_golden": {"fixture": f"tests/golden/{name}", "images": sel, "rel_err_latent": r3(ez),
+                                           "rel_err_image_samples": r3(ei), "max_err_latent": r3(sz["max"]), "max_err_image_samples": r3(si["max"]),
+                                           "p9999_err_latent": r3(sz["p9999"]), "p9999_err_image_samples": r3(si["p9999"]),
+                                           "max_norm": "max|a - b| / max|b| (p9999: the 99.99th percentile of |a - b| / max|b|)",
+                                           "max_norm_bound": {"latent": MAX_OVER_L2 * tol["latent"], "image": MAX_OVER_L2 * tol["image"]},
+                                           "max_norm_ok": max_ok, "ok": ok, "tolerance": tol}}
 
 
 if __name__ == "__main__":

@@ -88,6 +88,25 @@ __global__ void __launch_bounds__(256) add_f32_kernel(const float* a, int lda, c
     }
 }
 
+// fp32 a (+ b) -> fp32 out AND its fp16 mirror (the one-part GEMM operand of the mixed-precision mode), 8 columns per thread
+__global__ void __launch_bounds__(256) add_f32_mirror_kernel(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
+                                                            uint16_t* out16, int ld16, int64_t rows, int CV) {
+    const int64_t total = rows * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / CV;
+        const int cv = (int)(i - r * CV);
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(a + r * lda + cv * 8), v1 = *reinterpret_cast<const f32x4*>(a + r * lda + cv * 8 + 4);
+        if (b) {
+            v0 += *reinterpret_cast<const f32x4*>(b + r * ldb + cv * 8);
+            v1 += *reinterpret_cast<const f32x4*>(b + r * ldb + cv * 8 + 4);
+        }
+        *reinterpret_cast<f32x4*>(out + r * ldo + cv * 8) = v0;
+        *reinterpret_cast<f32x4*>(out + r * ldo + cv * 8 + 4) = v1;
+        const float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        stg16(out16 + r * ld16 + cv * 8, pack8<F16>(f));
+    }
+}
+
 // [rows][C] (fp32 or 16-bit) -> bf16 [rows][3C]: hi | lo | hi (pattern 0) or hi | hi | lo (pattern 1)
 template <typename SRC>
 __global__ void __launch_bounds__(256) split3_kernel(const void* src, int64_t rows, int CV, int C, int64_t ld_src, int pattern,
@@ -353,6 +372,19 @@ extern "C" int edtr_nhwc_to_nchw(int dtype, const void* src, int src_f32, int B,
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<BF16>, grid, dim3(256), 0, s, src, src_f32, C, HW, ld, dst, scale);
     else
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<F16>, grid, dim3(256), 0, s, src, src_f32, C, HW, ld, dst, scale);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_add_mirror(const float* a, int lda, const float* b, int ldb, float* out, int ldo, void* out16, int ld16,
+                               int64_t rows, int C, edtr_stream_t stream) {
+    if (!a || !out || !out16) return EDTR_E_NULL;
+    if (rows <= 0 || C <= 0) return EDTR_E_SHAPE;
+    if ((C & 7) || (lda & 3) || (ldo & 3) || (ld16 & 7) || (b && (ldb & 3)) || !aligned16(a) || (b && !aligned16(b)) || !aligned16(out) ||
+        !aligned16(out16))
+        return EDTR_E_ALIGN;
+    hipLaunchKernelGGL(add_f32_mirror_kernel, dim3(blocks_for(rows * (C >> 3))), dim3(256), 0, static_cast<hipStream_t>(stream), a, lda,
+                       b, ldb, out, ldo, static_cast<uint16_t*>(out16), ld16, rows, C >> 3);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

@@ -135,6 +135,7 @@ __device__ __forceinline__ void finish_vector(const edtr_igemm_params& p, float 
         o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
         *reinterpret_cast<f32x4*>(o) = o0;
         *reinterpret_cast<f32x4*>(o + 4) = o1;
+        if (p.out16) stg16(static_cast<uint16_t*>(p.out16) + (int64_t)m * p.ld16 + n, pack8<T>(f));      // 16-bit mirror of the fp32 stream
     } else {
         stg16(static_cast<uint16_t*>(p.out) + oidx, pack8<T>(f));
     }
@@ -420,9 +421,10 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
         // like the staged vectors where the registers allow (PF == 2), inside the iteration otherwise
         // LNF / STF: the two sides of the folded LayerNorm (consumer: row scalars from LDS; producer: per-row sums of the stored
         // values, folded after the loop) — 16-bit output, no fp32 residual: the SwinIR layers and the UNet blocks under EDTR_LN_FOLD
-        auto fast_loop = [&](auto out32_c, auto res32_c, auto lnf_c, auto stf_c) {
+        // MIR: the fp32 stream's 16-bit MIRROR (p.out16: the one-part operand its 16-bit consumers read without a cast launch)
+        auto fast_loop = [&](auto out32_c, auto res32_c, auto lnf_c, auto stf_c, auto mir_c) {
             constexpr bool OUT32 = decltype(out32_c)::value, RES32 = decltype(res32_c)::value;
-            constexpr bool LNF = decltype(lnf_c)::value, STF = decltype(stf_c)::value;
+            constexpr bool LNF = decltype(lnf_c)::value, STF = decltype(stf_c)::value, MIR = decltype(mir_c)::value && OUT32;
             constexpr int NRF = (RES32 && PF == 2) ? ITER : 1;
             f32x4 rf0[NRF], rf1[NRF];
             auto res_read = [&](int it, int slot) {
@@ -486,6 +488,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                         o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
                         *reinterpret_cast<f32x4*>(o) = o0;
                         *reinterpret_cast<f32x4*>(o + 4) = o1;
+                        if constexpr (MIR) stg16(static_cast<uint16_t*>(p.out16) + (int64_t)m * p.ld16 + n, pack8<T>(f));
                     } else {
                         stg16(reinterpret_cast<uint16_t*>(outp) + (int64_t)m * p.ldc, pack8<T>(f));
                     }
@@ -494,8 +497,12 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                         for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
                     }
                     if constexpr (STF) {
+                        // statistics of the STORED 16-bit values (what the consuming GEMM multiplies), not of the fp32 ones
+                        // (the mismatch is of the order of the rounding itself on rows whose mean dwarfs their spread)
+                        float fr[8];
+                        unpack8<T>(pack8<T>(f), fr);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) { rsum[it] += f[j]; rsq[it] += f[j] * f[j]; }
+                        for (int j = 0; j < 8; ++j) { rsum[it] += fr[j]; rsq[it] += fr[j] * fr[j]; }
                     }
                 }
             }
@@ -505,19 +512,22 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
             using std::false_type;
             const bool res32 = p.residual && p.residual_f32;
             if (!ln && !stats_out) {
-                if (!p.out_f32 && !res32) fast_loop(false_type{}, false_type{}, false_type{}, false_type{});
-                else if (p.out_f32 && res32) fast_loop(true_type{}, true_type{}, false_type{}, false_type{});
-                else if (p.out_f32) fast_loop(true_type{}, false_type{}, false_type{}, false_type{});
-                else fast_loop(false_type{}, true_type{}, false_type{}, false_type{});
+                const bool mir = p.out16 != nullptr;
+                if (!p.out_f32 && !res32) fast_loop(false_type{}, false_type{}, false_type{}, false_type{}, false_type{});
+                else if (p.out_f32 && res32 && mir) fast_loop(true_type{}, true_type{}, false_type{}, false_type{}, true_type{});
+                else if (p.out_f32 && res32) fast_loop(true_type{}, true_type{}, false_type{}, false_type{}, false_type{});
+                else if (p.out_f32 && mir) fast_loop(true_type{}, false_type{}, false_type{}, false_type{}, true_type{});
+                else if (p.out_f32) fast_loop(true_type{}, false_type{}, false_type{}, false_type{}, false_type{});
+                else fast_loop(false_type{}, true_type{}, false_type{}, false_type{}, false_type{});
                 did_fast = true;
             } else if (!p.out_f32 && !res32) {
                 if constexpr (FOLD != 0 && !GEGLU && PATCH16 == 0) {
                     if (ln && stats_out) {
-                        if constexpr (FOLD == 3) { fast_loop(false_type{}, false_type{}, true_type{}, true_type{}); did_fast = true; }
+                        if constexpr (FOLD == 3) { fast_loop(false_type{}, false_type{}, true_type{}, true_type{}, false_type{}); did_fast = true; }
                     } else if (ln) {
-                        if constexpr ((FOLD & 1) != 0) { fast_loop(false_type{}, false_type{}, true_type{}, false_type{}); did_fast = true; }
+                        if constexpr ((FOLD & 1) != 0) { fast_loop(false_type{}, false_type{}, true_type{}, false_type{}, false_type{}); did_fast = true; }
                     } else {
-                        if constexpr ((FOLD & 2) != 0) { fast_loop(false_type{}, false_type{}, false_type{}, true_type{}); did_fast = true; }
+                        if constexpr ((FOLD & 2) != 0) { fast_loop(false_type{}, false_type{}, false_type{}, true_type{}, false_type{}); did_fast = true; }
                     }
                 }
             }
@@ -597,6 +607,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
                 *reinterpret_cast<f32x4*>(o) = o0;
                 *reinterpret_cast<f32x4*>(o + 4) = o1;
+                if (p.out16) stg16(static_cast<uint16_t*>(p.out16) + (int64_t)m * p.ld16 + n, pack8<T>(f));
             } else {
                 stg16(static_cast<uint16_t*>(p.out) + oidx, pack8<T>(f));
             }
@@ -605,8 +616,15 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
                 for (int j = 0; j < 8; ++j) { gs[j] += f[j]; gq[j] += f[j] * f[j]; }
             }
             if (stats_out) {
+                float fr[8];
+                if (p.out_f32) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rsum[it] += f[j]; rsq[it] += f[j] * f[j]; }
+                    for (int j = 0; j < 8; ++j) fr[j] = f[j];
+                } else {
+                    unpack8<T>(pack8<T>(f), fr);       // the stored 16-bit values
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { rsum[it] += fr[j]; rsq[it] += fr[j] * fr[j]; }
             }
         }
     }
@@ -806,7 +824,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
     auto load_tile = [&](int kt) {
         const int kg = kt * BK + kc * 8;
         const bool kvalid = kg < p.K;
-        int c = kg, ky = 0, kx = 0;
+        int c = (p.a_wrap > 0 && kg >= p.a_wrap) ? kg - p.a_wrap : kg, ky = 0, kx = 0;      // a_wrap: the A columns are read twice (K = 2 a_wrap)
         if (SPATIAL && p.taps == 9) {
             const int tap = kg / Cin;
             c = kg - tap * Cin;
@@ -1116,7 +1134,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
                 soff_w = (uint32_t)((run_tap * Cin + run_c0) * 2);   // the weight tile of (tap, chunk) in [Cout][ky][kx][Cin]
                 if (++run_tap == p.taps) { run_tap = 0; run_c0 += BK; }   // next tap of the same 64-channel chunk
             } else {
-                soff_a = (uint32_t)kt * (BK * 2);
+                soff_a = (uint32_t)((p.a_wrap > 0 && kt * BK >= p.a_wrap) ? kt * BK - p.a_wrap : kt * BK) * 2;      // a_wrap: A read twice
             }
             const uint32_t sa = smem_base + buf * STAGE + wave * (32 * 128);
             const uint32_t sw = sa + A_BYTES;
@@ -1127,7 +1145,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
             return;
         }
         const int k0 = kt * BK;
-        int c0 = k0, ky = 0, kx = 0;
+        int c0 = (p.a_wrap > 0 && k0 >= p.a_wrap) ? k0 - p.a_wrap : k0, ky = 0, kx = 0;
         if (SPATIAL && p.taps == 9) {
             const int tap = k0 / Cin;
             c0 = k0 - tap * Cin;
@@ -1739,7 +1757,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
             soff_w = (uint32_t)((run_tap * Cin + run_c0) * 2);
             if (++run_tap == p.taps) { run_tap = 0; run_c0 += BK; }      // K order: see igemm_256_kernel
         } else {
-            soff_a = (uint32_t)kt * (BK * 2);
+            soff_a = (uint32_t)((p.a_wrap > 0 && kt * BK >= p.a_wrap) ? kt * BK - p.a_wrap : kt * BK) * 2;          // a_wrap: A read twice
         }
         const uint32_t sa = smem_base + buf * STAGE + wave * (8 * MB * 128);
         const uint32_t sw = smem_base + buf * STAGE + A_BYTES + wave * (8 * NB * 128);
@@ -3004,6 +3022,15 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (skinny && tile == 3 && p.N <= 32 && p.M >= 65536 && p.splitk <= 1 && !p.gn_partial && p.act != EDTR_ACT_GEGLU &&
             (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
             tile = 14;
+    }
+    if (p.out16) {
+        if (!p.out_f32 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.vt_out) return EDTR_E_UNSUPPORTED;
+        if ((p.ld16 & 7) || !aligned16(p.out16)) return EDTR_E_ALIGN;
+    }
+    if (p.a_wrap != 0) {          // weights-exact two-part product: A[m][k mod a_wrap] against [Wh | Wl]; plain GEMMs on tiles 1 / 2 / 3 / 8
+        if (p.a_wrap < 0 || p.K != 2 * p.a_wrap || (p.a_wrap & 63) || spatial || p.taps != 1 || p.C2 || p.Z != 1 || p.ln_stats) return EDTR_E_UNSUPPORTED;
+        if (p.tile != 0 && !(p.tile == 1 || p.tile == 2 || p.tile == 3 || p.tile == 8)) return EDTR_E_UNSUPPORTED;
+        if (!(tile == 1 || tile == 2 || tile == 3 || tile == 8)) tile = 3;       // (an automatic 256x256 / ping-pong choice)
     }
     if (p.upsample2x == 2) {      // sub-pixel form of the upsample convolution: the halo kernel only (phase-major pre-summed weights)
         if (p.tile != 0 && p.tile != 16) return EDTR_E_UNSUPPORTED;

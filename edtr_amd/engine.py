@@ -528,6 +528,15 @@ class Emitter:
         # the batch it arrives in: bit-identical across batch sizes and therefore across any sharding over GPUs (VERDICT r02,
         # weak 3: the default path holds that only at tolerance level).  Costs throughput (§6 of DESIGN.md).
         self.invariant = ops.batch_invariant()
+        # mixed mode: tensors INSIDE a residual branch whose only consumer rounds them to fp16 anyway (conv1 -> GroupNorm -> conv2,
+        # ff.out -> proj_out) are stored as fp16, not fp32: only the residual stream and what feeds multi-part products stays wide
+        # (VERDICT r03 item 1b).  EDTR_AMD_BRANCH16=0 restores the all-fp32 stream of round 3 (A/B runs).
+        self.branch16 = self.direct16 and os.environ.get("EDTR_AMD_BRANCH16", "1") != "0"
+        # mixed mode: an fp32 stream tensor that a ONE-part product reads (zero / down / upsample convolutions, the weights-exact 1x1
+        # skips) gets an fp16 MIRROR written by its producer's epilogue (edtr_hip.h: out16) instead of a cast launch per consumer.
+        # (root fp32 tensor, fp16 mirror) pairs; a producer that writes a column slice of a root writes the same slice of the mirror.
+        self.mirrors_on = self.direct16 and os.environ.get("EDTR_AMD_MIRROR", "1") != "0"
+        self._mirrors: List[Tuple[torch.Tensor, torch.Tensor]] = []
         self.last_gnp = None
         self.last_row_stats = None
 
@@ -541,7 +550,7 @@ class Emitter:
             return 1
         if not feeds:
             return 3
-        return max(self.parts_for(f, M) for f in feeds)
+        return max(ops.op_parts(self.parts_for(f, M)) for f in feeds)
 
     def op_fmt(self, parts: int):
         """dtype code under which a norm / split launch writes a ``parts``-part operand."""
@@ -560,22 +569,67 @@ class Emitter:
                 t = t.t
             if isinstance(t, LNRef):
                 t = t.stats          # (the raw rows belong to the residual stream: their owner frees them)
+            self._drop_mirror(t)
             self.arena.free(t)
+
+    # -- fp16 mirrors of fp32 stream tensors (mixed mode) -----------------------------------------
+    def want_mirror(self, consumer: str) -> bool:
+        """Does the GEMM class ``consumer`` read its fp32 input as ONE fp16 part (so that a mirror written by the producer saves the
+        cast launch)?"""
+        return self.mirrors_on and ops.op_parts(self.parts_for(consumer)) == 1
+
+    def add_mirror(self, root: torch.Tensor) -> torch.Tensor:
+        m = self.arena.alloc(tuple(root.shape), self.dtype)
+        self._mirrors.append((root, m))
+        return m
+
+    def new_stream(self, rows: int, cols: int, mirror: bool = False) -> torch.Tensor:
+        """A stream buffer that several producers fill by column slices (the decoder's concat); ``mirror``: with its fp16 mirror."""
+        t = self.new(rows, cols)
+        if mirror and self.mirrors_on and t.dtype == torch.float32:
+            self.add_mirror(t)
+        return t
+
+    def mirror_view(self, v) -> Optional[torch.Tensor]:
+        """The fp16 mirror of fp32 tensor / column-slice view ``v`` (None when its root has none)."""
+        if not self._mirrors or not isinstance(v, torch.Tensor) or v.dtype != torch.float32 or v.dim() != 2:
+            return None
+        for root, m in self._mirrors:
+            off = v.data_ptr() - root.data_ptr()
+            if 0 <= off < root.numel() * 4 and v.stride(0) == root.stride(0) and v.stride(1) == 1:
+                row, col = divmod(off // 4, root.stride(0))
+                if row + v.shape[0] <= root.shape[0] and col + v.shape[1] <= root.shape[1]:
+                    return m[row:row + v.shape[0], col:col + v.shape[1]]
+        return None
+
+    def _drop_mirror(self, t) -> None:
+        if not self._mirrors or not isinstance(t, torch.Tensor):
+            return
+        for i, (root, m) in enumerate(self._mirrors):
+            if root.data_ptr() == t.data_ptr() and root.numel() == t.numel():
+                self.arena.free(m)
+                del self._mirrors[i]
+                return
 
     # -- multi-part operands --------------------------------------------------------------------
     def _operand(self, a, rows: int, C: int, parts: int):
         """(16-bit operand tensor, temporary to free or None, parts actually used) of an fp32 / 16-bit activation or of a
         ready OpN."""
+        ap = ops.op_parts(parts)          # (parts == ops.PARTS_2W: the weights-exact form reads ONE activation part twice)
         if isinstance(a, OpN):
-            if a.C != C or a.parts < parts:
-                raise ValueError(f"operand has {a.parts} part(s) of {a.C} columns, the GEMM wants {parts} of {C}")
+            if a.C != C or a.parts < ap:
+                raise ValueError(f"operand has {a.parts} part(s) of {a.C} columns, the GEMM wants {ap} of {C}")
             return a.t, None, parts
         if a.dtype == self.dtype:
             # already the MFMA operand type (mixed mode: an fp16 attention / GEGLU output): its low part is exactly zero, so
-            # more activation parts buy nothing — the one-part product
-            return a, None, 1
-        t = self.arena.alloc((rows, parts * C), self.dtype)
-        self.prog.add(ops.make_split_operand(src=a, rows=rows, C=C, dst=t, fmt=self.op_fmt(parts)))
+            # more activation parts buy nothing — the one-part product (or the weights-exact one)
+            return a, None, (parts if parts == ops.PARTS_2W else 1)
+        if ap == 1:
+            m = self.mirror_view(a)       # the producer's epilogue already wrote the fp16 copy
+            if m is not None:
+                return m, None, parts
+        t = self.arena.alloc((rows, ap * C), self.dtype)
+        self.prog.add(ops.make_split_operand(src=a, rows=rows, C=C, dst=t, fmt=self.op_fmt(ap)))
         return t, t, parts
 
     def to16(self, x: torch.Tensor, rows: int, C: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -613,7 +667,7 @@ class Emitter:
 
     def gemm(self, a, w, M: int, N: int, K: int, *, bias=None, out=None, act=0,
              residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,
-             out16=False, feeds=None, row_stats=False, ln_vec=None, **kw) -> torch.Tensor:
+             out16=False, feeds=None, row_stats=False, ln_vec=None, mirror=False, **kw) -> torch.Tensor:
         """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld); ``w`` is a
         WRef of the store (or a ready packed tensor).  fp32-stream modes: the output is fp32 unless ``out16`` (an attention
         operand, mixed mode only) or ``feeds`` names a GEMM class that takes it as a one-part operand."""
@@ -621,6 +675,8 @@ class Emitter:
         self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
         self.last_row_stats = None   # per-row statistics of this output for a LayerNorm folded into the next GEMMs (row_stats=True)
         parts = self.parts_for(name, M, N, K)
+        if parts == ops.PARTS_2W and (K % 64 or "Z" in kw or isinstance(a, LNRef) or kw.get("C2", 0)):
+            parts = 3           # (the weights-exact form needs whole 64-column K-tiles of a plain GEMM)
         tmp = None
         if isinstance(a, LNRef):
             a, lnkw = self._ln_kwargs(a, K, ln_vec)
@@ -631,12 +687,21 @@ class Emitter:
             if out is not None:
                 out_f32 = out.dtype == torch.float32
             else:
-                want16 = self.direct16 and (out16 or (feeds is not None and self.parts_for(feeds, M) == 1))
+                want16 = self.direct16 and (out16 or (feeds is not None and ops.op_parts(self.parts_for(feeds, M)) == 1))
                 out_f32 = not want16
+        m16 = None
         if out is None:
             out = self.new(M, n_out, torch.float32 if out_f32 else (self.dtype if self.hp else None))
+            if mirror and self.mirrors_on and out_f32:
+                m16 = self.add_mirror(out)
+        elif self.mirrors_on and out_f32:
+            m16 = self.mirror_view(out)       # a column slice of a mirrored stream buffer
+        if m16 is not None:
+            kw["out16"] = m16
         wt = self._w(w, parts)
-        Ke = parts * K
+        Ke = ops.k_mult(parts) * K
+        if parts == ops.PARTS_2W:
+            kw["a_wrap"] = K
         if "tile" in kw:
             tile, splitk = kw.pop("tile"), 1
         else:
@@ -676,6 +741,7 @@ class Emitter:
         by the epilogue, unscaled).  reference model/attention.py:170-178 (to_q / to_k / to_v + the head rearranges)."""
         M = B * N
         parts = self.parts_for(name, M, 3 * C, C)
+        parts = 3 if parts == ops.PARTS_2W else parts
         tmp, lnkw = None, {}
         if isinstance(x, LNRef):
             x, lnkw = self._ln_kwargs(x, C, ln_vec)
@@ -691,8 +757,10 @@ class Emitter:
         return qk, vt, N
 
     def conv(self, x: Act, prefix: str, *, taps=9, stride=1, pad_tl=1, ups=False, rowvec=None, residual=None,
-             out=None, out_f32=False, alpha=1.0, name=None, stats=False) -> Act:
-        """3x3 (or 1x1) convolution of an NHWC activation with the packed weight ``prefix``."""
+             out=None, out_f32=False, alpha=1.0, name=None, stats=False, feeds=None, mirror=False) -> Act:
+        """3x3 (or 1x1) convolution of an NHWC activation with the packed weight ``prefix``.  ``feeds`` (mixed mode): the output is
+        BRANCH-INTERNAL — its only consumer is a normalisation that feeds the named one-part GEMM classes, which round it to fp16
+        anyway — so it is stored as fp16 instead of joining the fp32 stream (Emitter.branch16)."""
         name = name or ("conv3x3" if taps == 9 else "conv1x1")
         w, bias = self.store.conv(prefix, cin_pad=x.C, bias_scale=alpha)      # the epilogue applies alpha before the bias
         N = w.shape[0]
@@ -706,11 +774,15 @@ class Emitter:
             OH, OW, spatial = x.H, x.W, None
         M = x.B * OH * OW
         parts = self.parts_for(name, M, N, taps * x.C)
+        if parts == ops.PARTS_2W and (taps != 1 or x.C % 64):
+            parts = 3           # (the weights-exact form exists for 1x1 convolutions = plain GEMMs)
         a, tmp = x.t, None
         if self.hp:
             a, tmp, parts = self._operand(x.t, x.rows, x.C, parts)
             out_f32 = True if out is None else out.dtype == torch.float32
-        Ce = parts * x.C
+            if out is None and self.branch16 and feeds and self.feeds_parts(feeds, M) == 1:
+                out_f32 = False
+        Ce = ops.k_mult(parts) * x.C
         # nearest-2x upsample convolutions run in their sub-pixel form (four 2x2 convolutions of the source image with pre-summed
         # weights: 4 instead of 9 multiply-adds per output element) wherever the halo kernel's geometry takes them
         subpix = (ups and taps == 9 and stride == 1 and pad_tl == 1 and not self.invariant
@@ -719,8 +791,13 @@ class Emitter:
             w, bias = self.store.conv_subpixel(prefix, cin_pad=x.C, bias_scale=alpha)
             spatial = spatial[:7] + (2,)
         wt = self._w(w, parts)
+        m16 = None
         if out is None:
-            out = self.new(M, N, torch.float32 if out_f32 else None)
+            out = self.new(M, N, torch.float32 if out_f32 else (self.dtype if self.hp else None))
+            if mirror and self.mirrors_on and out_f32:
+                m16 = self.add_mirror(out)
+        elif self.mirrors_on and out_f32:
+            m16 = self.mirror_view(out)
         img8 = taps == 9 and stride == 1 and pad_tl == 1 and not ups and (x.H, x.W) == (8, 8) and Ce % 64 == 0
         tile, splitk = ops.choose_splitk(M, N, taps * Ce, img8=img8)
         if self.invariant:
@@ -737,7 +814,8 @@ class Emitter:
             ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
             ldr=residual.stride(0) if residual is not None else 0, residual_f32=res32, out_f32=out_f32, alpha=alpha, tile=tile,
-            splitk=splitk, workspace=ws, gn_partial=gnp, name=name, w_phase_stride=(N * wt.stride(0)) if subpix else 0))
+            splitk=splitk, workspace=ws, gn_partial=gnp, name=name, w_phase_stride=(N * wt.stride(0)) if subpix else 0,
+            out16=m16, a_wrap=x.C if parts == ops.PARTS_2W else 0))
         self.arena.free(ws)
         self.arena.free(tmp)
         return Act(out, x.B, OH, OW, N, gnp)
@@ -749,7 +827,8 @@ class Emitter:
         c_real = self.store.params[prefix + "weight"].numel()
         if c_real != x.C:
             raise ValueError(f"GroupNorm {prefix}: activation has {x.C} channels, parameter has {c_real}")
-        return ops.make_gn(dtype=self.op_fmt(parts) if self.hp else self.io, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C,
+        in32 = x.t.dtype == torch.float32
+        return ops.make_gn(dtype=(self.op_fmt(parts) if in32 else self.dtype) if self.hp else self.io, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C,
                            sums=sums, gamma=gamma, beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed,
                            partial=partial)
 
@@ -765,6 +844,8 @@ class Emitter:
         """``feeds``: the GEMM classes that consume the result (their precision policy decides how many operand parts the
         apply launch writes in the fp32-stream modes)."""
         parts = self.feeds_parts(feeds, x.rows)
+        if self.hp and x.t.dtype != torch.float32:
+            parts = 1            # (a branch-internal fp16 tensor: its low parts are exactly zero)
         if out is not None:
             y, carried = out, out
         else:
@@ -794,6 +875,8 @@ class Emitter:
         """Statistics half only (tiled VAE: the caller pools `sums` across tiles before the apply half).
         Returns a closure that emits the apply half and yields the normalised activation."""
         parts = self.feeds_parts(feeds, x.rows)
+        if self.hp and x.t.dtype != torch.float32:
+            parts = 1
         y, carried = self._norm_out(x.rows, x.C, parts)
         st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=sums_zeroed, parts=parts)
         if x.gnp is not None:
@@ -821,6 +904,11 @@ class Emitter:
     def add(self, a: torch.Tensor, b: Optional[torch.Tensor], rows: int, C: int, out=None) -> torch.Tensor:
         if out is None:
             out = self.new(rows, C)
+        m16 = self.mirror_view(out) if (self.mirrors_on and C % 8 == 0) else None
+        if m16 is not None:
+            self.prog.add(ops.make_add_mirror(a=a, lda=a.stride(0), b=b, ldb=b.stride(0) if b is not None else 0, out=out,
+                                              ldo=out.stride(0), out16=m16, rows=rows, C=C))
+            return out
         self.prog.add(ops.make_add(dtype=self.io, a=a, lda=a.stride(0), b=b, ldb=b.stride(0) if b is not None else 0,
                                    out=out, ldo=out.stride(0), rows=rows, C=C))
         return out
@@ -876,6 +964,7 @@ class Emitter:
         Cout = wv.shape[0]
         ldv = round_up(Ntok, 8)
         parts = self.parts_for(name, Cout, ldv, Cin)
+        parts = 3 if parts == ops.PARTS_2W else parts
         tmp = None
         if self.hp:
             x, tmp, parts = self._operand(x, B * Ntok, Cin, parts)

@@ -18,7 +18,7 @@ DECLARED_SYMBOLS = [
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample", "edtr_split3", "edtr_cast16",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle",
-    "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample",
+    "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror",
 ]
 
 
@@ -51,6 +51,8 @@ class IgemmParams(C.Structure):
         ("ln_c1", C.c_void_p), ("ln_c2", C.c_void_p),
         ("stagger", C.c_int32), ("debug_flags", C.c_int32),
         ("w_phase_stride", C.c_int64),
+        ("out16", C.c_void_p), ("ld16", C.c_int32),
+        ("a_wrap", C.c_int32),
     ]
 
 
@@ -122,6 +124,7 @@ def load() -> C.CDLL:
     lib.edtr_nchw_to_nhwc.argtypes = [i32, vp, i32, i32, i64, vp, i32, i32, i32, f32, f32, vp]
     lib.edtr_nhwc_to_nchw.argtypes = [i32, vp, i32, i32, i32, i64, i32, vp, f32, vp]
     lib.edtr_add.argtypes = [i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]
+    lib.edtr_add_mirror.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]
     lib.edtr_timestep_embedding.argtypes = [i32, vp, i32, i32, vp, i32, vp]
     lib.edtr_sampler_update.argtypes = [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]
     lib.edtr_axpby.argtypes = [vp, vp, f32, f32, vp, i64, vp]

@@ -14,8 +14,13 @@ _ZERO_INIT_SUFFIXES = ("out_layers.3.weight", "out_layers.3.bias", "proj_out.wei
 _ZERO_INIT_PREFIXES = ("zero_convs.", "middle_block_out.", "out.2.")
 
 
+_STRUCT_EPOCH = [0]      # bumped whenever a Parameter OBJECT is (re)registered anywhere in a ParamTree (params_fingerprint)
+
+
 class _Node(nn.Module):
-    pass
+    def register_parameter(self, name, param):      # (nn.Module.__setattr__ of a Parameter and load_state_dict(assign=True) end here)
+        _STRUCT_EPOCH[0] += 1
+        super().register_parameter(name, param)
 
 
 _SKIP_INIT = False
@@ -39,7 +44,7 @@ def _is_zero_init(key: str, is_unet_like: bool) -> bool:
     return key.endswith(_ZERO_INIT_SUFFIXES) or key.startswith(_ZERO_INIT_PREFIXES)
 
 
-class ParamTree(nn.Module):
+class ParamTree(_Node):
     def __init__(self, spec: Iterable[Tuple[str, Tuple[int, ...]]], unet_like: bool = False):
         super().__init__()
         gen = torch.Generator().manual_seed(0)
@@ -72,14 +77,18 @@ def params_fingerprint(module: nn.Module) -> Tuple:
     """Changes whenever any parameter is rewritten in place (load_state_dict / copy_ on the parameter itself), replaced, or
     moved.  It is built from the tensors' version counters, so a write that goes through ``.data`` (``p.data.copy_(...)``, EMA
     swaps) is NOT seen: after such a write call ``ControlLDM.release_engines()`` (packed weights, programs and hipGraphs are
-    rebuilt on the next forward).  The parameter list of a ParamTree never changes shape, so it is collected once and the
-    per-forward cost is one pass over a cached list (~1300 integer reads) instead of a walk of the module tree."""
-    plist = module.__dict__.get("_fp_params")
-    if plist is None or not plist or next(module.parameters()) is not plist[0]:       # (first object swapped: load_state_dict(assign=True))
+    rebuilt on the next forward).  The parameter list is collected once and reused while no Parameter OBJECT has been
+    (re)registered in any ParamTree since (`_STRUCT_EPOCH`: `sub.weight = nn.Parameter(...)`, `load_state_dict(assign=True)` on
+    any sub-module — ADVICE r03: a cache keyed on the first parameter alone kept reading a replaced parameter's old version
+    counter), so the per-forward cost stays one pass over a cached list (~1300 integer reads), not a walk of the module tree.
+    (`module.to(device)` replaces ``.data`` in place, not the objects; the device of the first parameter is part of the result.)"""
+    hit = module.__dict__.get("_fp_params")
+    if hit is None or hit[0] != _STRUCT_EPOCH[0]:
         plist = list(module.parameters())
-        module.__dict__["_fp_params"] = plist
+        hit = (_STRUCT_EPOCH[0], plist, hash(tuple(id(p) for p in plist)))     # (the objects' identities: a replaced parameter may
+        module.__dict__["_fp_params"] = hit                                    #  carry the same version counter as the old one)
     ver, dev = 0, None
-    for p in plist:
+    for p in hit[1]:
         ver += p._version
         dev = p.device
-    return (str(dev), ver)
+    return (str(dev), ver, hit[2])

@@ -91,11 +91,11 @@ def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: in
 # ----------------------------------------------------------------------------------------------
 # UNet / ControlNet blocks
 # ----------------------------------------------------------------------------------------------
-def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, offs: Dict[str, int], out=None) -> Act:
+def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, offs: Dict[str, int], out=None, mirror=False) -> Act:
     """model/unet.py:203-223: GN-SiLU-conv (+bias +emb row) ; GN-SiLU-conv (+bias) + skip(x)."""
     p = P + l.prefix
     n1 = em.group_norm(x, p + "in_layers.0.", 1e-5, True, feeds=("res.conv1",))
-    h = em.conv(n1, p + "in_layers.2.", rowvec=table[:, offs[l.prefix]:], name="res.conv1", stats=True)
+    h = em.conv(n1, p + "in_layers.2.", rowvec=table[:, offs[l.prefix]:], name="res.conv1", stats=True, feeds=("res.conv2",))
     em.free(n1)
     n2 = em.group_norm(h, p + "out_layers.0.", 1e-5, True, feeds=("res.conv2",))
     em.free(h)
@@ -103,7 +103,7 @@ def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, of
         skip = em.conv(x, p + "skip_connection.", taps=1, name="res.skip1x1").t
     else:
         skip = x.t
-    y = em.conv(n2, p + "out_layers.3.", residual=skip, out=out, name="res.conv2", stats=out is None)
+    y = em.conv(n2, p + "out_layers.3.", residual=skip, out=out, name="res.conv2", stats=out is None, mirror=mirror)
     em.free(n2)
     if l.cin != l.cout:
         em.free(skip)
@@ -159,7 +159,7 @@ def emit_attention_core(em: Emitter, p: str, x, B: int, N: int, C: int, heads: i
     return y
 
 
-def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextKV, out=None) -> Act:
+def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextKV, out=None, mirror=False) -> Act:
     """model/attention.py:283-302 + :230-234 + :20-47 (use_linear, depth 1, gated FF)."""
     p = P + l.prefix
     B, N, C = x.B, x.H * x.W, x.C
@@ -195,30 +195,48 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
         g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out")
     em.free(l3)
     wf, bf = em.store.linear([tb + "ff.net.2.weight"], [tb + "ff.net.2.bias"])
-    t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out")
+    t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out", feeds="st.proj_out" if em.branch16 else None)
     em.free(g, t2)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
-    y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out", stats_hw=0 if out is not None else N)
+    y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out", stats_hw=0 if out is not None else N, mirror=mirror)
     em.free(t3)
     return Act(y, x.B, x.H, x.W, C, em.last_gnp)
 
 
-def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv, out=None, keep_input=True) -> Act:
+def mirror_for(em: Emitter, nxt: Optional[Layer]) -> bool:
+    """Does the layer that consumes a stream tensor next read it as a one-part GEMM operand (mixed mode: the producer then writes
+    the fp16 mirror, Emitter.want_mirror)?  Down / upsample convolutions read their input raw; a ResBlock reads it raw through its
+    1x1 skip convolution when the channel count changes; everything else reads it through a normalisation."""
+    if nxt is None:
+        return False
+    if nxt.kind == "down":
+        return em.want_mirror("downsample")
+    if nxt.kind == "up":
+        return em.want_mirror("upsample.conv")
+    if nxt.kind == "res" and nxt.cin != nxt.cout:
+        return em.want_mirror("res.skip1x1")
+    return False
+
+
+def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv, out=None, keep_input=True, mirror_out=False) -> Act:
     """TimestepEmbedSequential dispatch (model/unet.py:40-48).  ``out`` (a 2-D view) receives the LAST layer's
-    result; the block input is freed unless ``keep_input``."""
+    result; the block input is freed unless ``keep_input``.  ``mirror_out``: a consumer of the block's result reads it as a
+    one-part operand (mirror_for / the ControlNet's zero convolutions)."""
     h = x
     for i, l in enumerate(layers):
-        tgt = out if i == len(layers) - 1 else None
+        last = i == len(layers) - 1
+        tgt = out if last else None
+        mir = mirror_out if last else mirror_for(em, layers[i + 1])
         if l.kind == "conv":
-            y = em.conv(h, P + l.prefix, out=tgt, name="conv_in", stats=tgt is None)
+            y = em.conv(h, P + l.prefix, out=tgt, name="conv_in", stats=tgt is None, mirror=mir)
         elif l.kind == "res":
-            y = emit_resblock(em, P, l, h, table, offs, out=tgt)
+            y = emit_resblock(em, P, l, h, table, offs, out=tgt, mirror=mir)
         elif l.kind == "attn":
-            y = emit_spatial_transformer(em, P, l, h, kv, out=tgt)
+            y = emit_spatial_transformer(em, P, l, h, kv, out=tgt, mirror=mir)
         elif l.kind == "down":
-            y = em.conv(h, P + l.prefix + "op.", stride=2, out=tgt, name="downsample", stats=tgt is None)  # unet.py:99-108
+            y = em.conv(h, P + l.prefix + "op.", stride=2, out=tgt, name="downsample", stats=tgt is None, mirror=mir)  # unet.py:99-108
         elif l.kind == "up":
-            y = em.conv(h, P + l.prefix + "conv.", ups=True, out=tgt, name="upsample.conv", stats=tgt is None)  # unet.py:70-79
+            y = em.conv(h, P + l.prefix + "conv.", ups=True, out=tgt, name="upsample.conv", stats=tgt is None, mirror=mir)  # unet.py:70-79
         else:
             raise ValueError(l.kind)
         if h is not x or not keep_input:
@@ -232,11 +250,13 @@ def emit_controlnet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, 
     cat(x, hint) already in NHWC.  The control scale (model/cldm.py:189) is the tap's alpha."""
     outs: List[Act] = []
     h = x8
+    zmir = em.want_mirror("zero_conv")
     for i, layers in enumerate(a.input_blocks):
-        y = emit_block(em, P, layers, h, table, offs, kv, keep_input=(i == 0))
+        nxt = a.input_blocks[i + 1][0] if i + 1 < len(a.input_blocks) else a.middle[0]
+        y = emit_block(em, P, layers, h, table, offs, kv, keep_input=(i == 0), mirror_out=zmir or mirror_for(em, nxt))
         outs.append(em.conv(y, P + a.zero_convs[i][0], taps=1, alpha=scales[i], name="zero_conv"))
         h = y
-    y = emit_block(em, P, a.middle, h, table, offs, kv, keep_input=False)
+    y = emit_block(em, P, a.middle, h, table, offs, kv, keep_input=False, mirror_out=zmir)
     outs.append(em.conv(y, P + a.zero_convs[-1][0], taps=1, alpha=scales[12], name="zero_conv"))
     em.free(y)
     return outs
@@ -250,7 +270,8 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
     hs: List[Act] = []
     h = x8
     for i, layers in enumerate(a.input_blocks):
-        h = emit_block(em, P, layers, h, table, offs, kv, keep_input=True)
+        nxt = a.input_blocks[i + 1][0] if i + 1 < len(a.input_blocks) else a.middle[0]
+        h = emit_block(em, P, layers, h, table, offs, kv, keep_input=True, mirror_out=mirror_for(em, nxt))
         hs.append(h)
     mid = emit_block(em, P, a.middle, h, table, offs, kv, keep_input=True)
     if before_control is not None:
@@ -258,7 +279,8 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
 
     # first decoder input: cat([mid + control_mid, hs[-1] + control[-2]])
     skip = hs.pop()
-    cat = em.new(skip.rows, mid.C + skip.C)
+    # the decoder's concat buffers: every output block starts with a ResBlock whose 1x1 skip convolution reads the concat raw
+    cat = em.new_stream(skip.rows, mid.C + skip.C, mirror=em.want_mirror("res.skip1x1"))
     c = control.pop() if control is not None else None      # a None entry = no control at that tap (only_mid_control)
     if c is not None:
         em.add(mid.t, c.t, mid.rows, mid.C, out=cat[:, :mid.C])
@@ -282,7 +304,7 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
         if j + 1 < nblk:
             nskip = hs.pop()
             out_C = layers[-1].cout
-            ncat = em.new(nskip.rows, out_C + nskip.C)
+            ncat = em.new_stream(nskip.rows, out_C + nskip.C, mirror=em.want_mirror("res.skip1x1"))
             y = emit_block(em, P, layers, xin, table, offs, kv, out=ncat[:, :out_C], keep_input=True)
             em.free(cat)
             cat, skip, cur_C = ncat, nskip, out_C
@@ -313,7 +335,7 @@ def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool, feeds=None):
 def _g_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act):
     """model/vae.py:103-124 (tiled form: resblock2task, utils/tilevae/tilevae.py:86-106)."""
     n1 = yield from _g_norm(em, x, p + "norm1.", True, ("vae.conv1",))
-    h = em.conv(n1, p + "conv1.", name="vae.conv1", stats=True)
+    h = em.conv(n1, p + "conv1.", name="vae.conv1", stats=True, feeds=("vae.conv2",))
     em.free(n1)
     n2 = yield from _g_norm(em, h, p + "norm2.", True, ("vae.conv2",))
     em.free(h)

@@ -19,6 +19,7 @@ F32S = "f32_split"     # high-precision mode: fp32 activation stream, bf16 split
 # mixed-precision mode: fp32 activation stream, fp16 GEMM operands of 1 / 2 / 3 parts (edtr_hip.h EDTR_F32_H1 / H2 / H3)
 F32H = {1: "f32_h1", 2: "f32_h2", 3: "f32_h3"}
 MIXED = "f32_mixed"    # WeightStore dtype of the mixed mode: fp16 matrices packed per requested part count
+PARTS_2W = 4           # precision-policy code of the WEIGHTS-EXACT two-part product: x16 . [Wh | Wl] with the A columns read twice
 _DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, F32S: L.F32_SPLIT, F32H[1]: L.F32_H1, F32H[2]: L.F32_H2, F32H[3]: L.F32_H3}
 
 
@@ -70,7 +71,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                vt_out: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_ld: int = 0, vt_alpha: float = 1.0,
                row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0, ln_valid: int = 0,
                ln_eps: float = 1e-5, ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None,
-               w_phase_stride: int = 0, name: str = "igemm") -> Rec:
+               w_phase_stride: int = 0, out16: Optional[torch.Tensor] = None, a_wrap: int = 0, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -80,6 +81,9 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
         p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l, p.upsample2x = spatial
     p.w, p.ldw = ptr(w), ldw
     p.w_phase_stride = w_phase_stride     # sub-pixel upsample convolution (spatial[7] == 2): four pre-summed phase matrices
+    if out16 is not None:                 # fp16 mirror of an fp32 stream output (mixed mode)
+        p.out16, p.ld16 = ptr(out16), out16.stride(0)
+    p.a_wrap = a_wrap                     # weights-exact two-part product: A columns read twice against [Wh | Wl]
     p.w_zs_outer, p.w_zs_inner = w_zs
     p.alpha = alpha
     p.bias_n, p.bias_m, p.rowvec = ptr(bias_n), ptr(bias_m), ptr(rowvec)
@@ -106,11 +110,12 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     nbytes = Z * (2.0 * a_rows * (C1 + C2) + 2.0 * N * p.K + (4.0 if out_f32 else 2.0) * M * n_out
                   + ((4.0 if residual_f32 else 2.0) * M * n_out if residual is not None else 0.0))
     rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
-                                                    gn_partial, vt_out, row_stats, ln_stats, ln_c1, ln_c2), name, flops, nbytes)
+                                                    gn_partial, vt_out, row_stats, ln_stats, ln_c1, ln_c2, out16), name, flops, nbytes)
     rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
                + ((" up2" if p.upsample2x == 1 else " up2sp") if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
                + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else "") + (" vT" if vt_out is not None else "")
-               + (" ln" if ln_stats is not None else "") + (" rs" if row_stats is not None else ""))
+               + (" ln" if ln_stats is not None else "") + (" rs" if row_stats is not None else "")
+               + (" m16" if out16 is not None else "") + (" 2w" if a_wrap else ""))
     return rec
 
 
@@ -276,6 +281,12 @@ def make_add(*, dtype, a, lda, b, ldb, out, ldo, rows, C, name="add") -> Rec:
     return Rec(L.load().edtr_add, args, (a, b, out), name, 0.0, (6.0 if b is not None else 4.0) * rows * C)
 
 
+def make_add_mirror(*, a, lda, b, ldb, out, ldo, out16, rows, C, name="add") -> Rec:
+    """fp32 a (+ b) -> fp32 out and its fp16 mirror (edtr_hip.h: edtr_add_mirror)."""
+    args = (ptr(a), lda, ptr(b), ldb, ptr(out), ldo, ptr(out16), out16.stride(0), rows, C)
+    return Rec(L.load().edtr_add_mirror, args, (a, b, out, out16), name, 0.0, (14.0 if b is not None else 10.0) * rows * C)
+
+
 def make_timestep_embedding(*, dtype, t, B, dim, out, ld, name="timestep_embedding") -> Rec:
     return Rec(L.load().edtr_timestep_embedding, (dt_code(dtype), ptr(t), B, dim, ptr(out), ld), (t, out), name)
 
@@ -368,7 +379,19 @@ def split3_weight(w: torch.Tensor, dtype: torch.dtype = torch.bfloat16, parts: i
     if parts == 2:
         return torch.cat([hi, hi], dim=-1).contiguous()
     lo = (w - hi.float()).to(dtype)
+    if parts == PARTS_2W:       # [hi | lo] against the activation's one part read twice (edtr_hip.h: a_wrap): x16 . (Wh + Wl)
+        return torch.cat([hi, lo], dim=-1).contiguous()
     return torch.cat([hi, hi, lo], dim=-1).contiguous()
+
+
+def op_parts(parts: int) -> int:
+    """Parts the ACTIVATION operand of a `parts`-policy product has (the weights-exact form reads one part twice)."""
+    return 1 if parts == PARTS_2W else parts
+
+
+def k_mult(parts: int) -> int:
+    """K of a `parts`-policy product in units of the logical K."""
+    return 2 if parts == PARTS_2W else parts
 
 
 def _weight_format(dtype, parts: int):
@@ -376,8 +399,8 @@ def _weight_format(dtype, parts: int):
     if dtype == F32S:
         return torch.bfloat16, 3
     if dtype == MIXED:
-        if parts not in (1, 2, 3):
-            raise ValueError(f"mixed-precision weights have 1..3 parts, got {parts}")
+        if parts not in (1, 2, 3, PARTS_2W):
+            raise ValueError(f"mixed-precision weights have 1..3 parts (or {PARTS_2W} = weights-exact two-part), got {parts}")
         return torch.float16, parts
     return dtype, 1
 
@@ -392,7 +415,7 @@ def pack_conv_weight(w: torch.Tensor, dtype, cin_pad: Optional[int] = None,
     out = torch.zeros((cop, kh, kw, cip), dtype=torch.float32, device=w.device)
     out[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
     dt16, parts = _weight_format(dtype, parts)
-    return split3_weight(out, dt16, parts).reshape(cop, kh * kw * parts * cip)
+    return split3_weight(out, dt16, parts).reshape(cop, -1)
 
 
 # sub-pixel form of nearest-2x upsample + 3x3 conv: which 3x3 taps add up on source offset d (0 / 1) of output parity p
@@ -423,7 +446,7 @@ def pack_conv_weight_subpixel(w: torch.Tensor, dtype, cin_pad: Optional[int] = N
                             acc = acc + wf[:, :, ky, kx]
                     out[2 * py + px, :co, dy, dx, :ci] = acc
     dt16, parts = _weight_format(dtype, parts)
-    return split3_weight(out, dt16, parts).reshape(4 * cop, 4 * parts * cip)
+    return split3_weight(out, dt16, parts).reshape(4 * cop, -1)
 
 
 def subpixel_ok(H: int, W: int, Ce: int, N: int, B: int) -> bool:

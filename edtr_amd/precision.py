@@ -33,8 +33,8 @@ class PrecisionPolicy:
         self.table = dict(table or {})
         self.label = label
         for k, v in list(self.table.items()) + [("default", self.default)]:
-            if v not in (1, 2, 3):
-                raise ValueError(f"precision policy: {k} -> {v!r} (parts must be 1, 2 or 3)")
+            if v not in (1, 2, 3, 4):
+                raise ValueError(f"precision policy: {k} -> {v!r} (parts must be 1, 2, 3 or 4 = the weights-exact two-part product)")
 
     def parts(self, name: str, M: int = 0, N: int = 0, K: int = 0) -> int:
         hit = self.table.get(f"{name}@{M}")
@@ -64,8 +64,12 @@ class ConstPolicy(PrecisionPolicy):
 # 2.2e-4 for ALL their launches together).  So: three parts on the stream carriers, one part everywhere else.
 # Measured at full size (BASELINE configs[1], images 3 and 7 vs the reference): latent 5.2e-4, image 5.7e-4 at 81 images/s
 # (all-1: 7.5e-4 / 1.14e-3 at 91; all-2: 6.6e-4 / 8.8e-4 at 58; all-3: 1.0e-4 / 1.0e-4 at 44; fast bf16: 6.2e-3 / 1.2e-2 at 107).
+# Round 4: the UNet / ControlNet 1x1 skip convolutions run the WEIGHTS-EXACT two-part product (4 = ops.PARTS_2W: x16 . [Wh | Wl]
+# with the activation's fp16 mirror read twice — no operand-formation launch, 2/3 of the MFMA work): their weight rounding carried
+# 8.3e-8 of the 12.3e-8 variance they cost at one part (profiles/r03/precision_sensitivity.json), the activation rounding 2.9e-8.
+# Measured as a whole (profiles/r04/ab_mixed_policies.log): image error 5.8e-4 -> 6.0e-4, +1.4 % throughput.
 MIXED_TABLE: Dict[str, int] = {
-    "conv_in": 3, "res.skip1x1": 3, "unet.out_conv": 3,
+    "conv_in": 3, "res.skip1x1": 4, "unet.out_conv": 3,
     "time_embed.0": 3, "time_embed.2": 3, "emb_layers(all)": 3, "ctx_k(all)": 3, "ctx_vT(all)": 3,
     "vae.conv_in": 3, "vae.conv_out": 3, "vae.nin_shortcut": 3, "vae.upsample.conv": 3, "vae.downsample": 3,
     "vae.quant_conv": 3, "vae.post_quant_conv": 3,
@@ -77,6 +81,8 @@ def mixed_policy() -> PrecisionPolicy:
     env = os.environ.get("EDTR_AMD_POLICY")
     if env:
         spec = json.loads(env)
+        table = dict(MIXED_TABLE) if spec.pop("base", None) == "shipped" else {}      # {"base": "shipped", ...}: overrides of the shipped table
         default = int(spec.pop("default", MIXED_DEFAULT))
-        return PrecisionPolicy(default, {k: int(v) for k, v in spec.items()}, "env")
-    return PrecisionPolicy(MIXED_DEFAULT, MIXED_TABLE, "mixed-r03")
+        table.update({k: int(v) for k, v in spec.items()})
+        return PrecisionPolicy(default, table, "env")
+    return PrecisionPolicy(MIXED_DEFAULT, MIXED_TABLE, "mixed-r04")

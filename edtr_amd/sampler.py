@@ -126,6 +126,8 @@ class SpacedSampler(nn.Module):
             idx = index.reshape(-1).to(torch.int64)
             if idx.numel() == 1 and x.shape[0] > 1:
                 idx = idx.expand(x.shape[0])
+            if idx.numel() != x.shape[0]:       # the kernel reads index[image]: any other length would be an out-of-bounds device read
+                raise ValueError(f"p_sample: index has {idx.numel()} entries for a batch of {x.shape[0]} (1 or the batch size)")
             ops.launch(ops.make_sampler_update_indexed(x=x, eps=eps, noise=noise.contiguous().float(), index=idx.contiguous(),
                                                        coefs=self._coef_table(x.device), x_prev=x_prev, pred_x0=pred_x0))
             return x_prev, pred_x0

@@ -68,3 +68,18 @@ def rel_err(a, b) -> float:
     a = torch.as_tensor(a).double().cpu()
     b = torch.as_tensor(b).double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def err_stats(a, b) -> Dict[str, float]:
+    """Error of ``a`` against the reference ``b`` in the three norms the parity gates quote (BASELINE.md §3 asks for the "max
+    relative error"; the relative L2 norm alone would hide a localised defect — one wrong halo column, one bad tile seam):
+      l2     ||a - b||_2 / ||b||_2
+      max    max|a - b| / max|b|                      (the worst element, relative to the signal's peak)
+      p9999  99.99th percentile of |a - b| / max|b|   (the worst element outside 1e-4 of the tensor)"""
+    a = torch.as_tensor(a).double().cpu().reshape(-1)
+    b = torch.as_tensor(b).double().cpu().reshape(-1)
+    d = (a - b).abs()
+    peak = float(b.abs().max().clamp_min(1e-30))
+    k = max(1, int(round(d.numel() * 1e-4)))
+    p9999 = float(torch.topk(d, k).values[-1]) if d.numel() > 1 else float(d.max())
+    return {"l2": float(d.norm() / b.norm().clamp_min(1e-30)), "max": float(d.max()) / peak, "p9999": p9999 / peak}

@@ -55,8 +55,12 @@ def make_inputs(workload: str, ctx_dim: int, dev, batch: int, size: int, rank: i
     return Inputs(pre, c_txt, noises, step, torch.full((batch,), START_TIMESTEP, dtype=torch.int64))   # host t: no device sync
 
 
-def restore_pass(cldm, diffusion, sampler, inp: Inputs, workload: str, untiled_forward=None) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, torch.Tensor]]:
-    """One pass of the hot path over one batch.  Returns (decoded image in [-1, 1], final latent, {"z_pre": ...})."""
+def restore_pass(cldm, diffusion, sampler, inp: Inputs, workload: str, untiled_forward=None,
+                 inject: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, torch.Tensor]]:
+    """One pass of the hot path over one batch.  Returns (decoded image in [-1, 1], final latent, {"z_pre": ...}).
+    ``inject``: the sampler's per-step noise comes from ``inp.noises`` (parity runs: the tensors the reference golden was made with);
+    False = `torch.randn_like` draws it on the GPU inside the pass, as the reference does (utils/sampler.py:199) — what bench.py times."""
+    import contextlib
     dev = inp.pre_res.device
     B = inp.pre_res.shape[0]
     h, w = inp.pre_res.shape[2] // 8, inp.pre_res.shape[3] // 8
@@ -80,7 +84,7 @@ def restore_pass(cldm, diffusion, sampler, inp: Inputs, workload: str, untiled_f
             z = run()
         return cldm.vae_decode(z), z, {"z_pre": z_pre}
     x_T = diffusion.q_sample(z_pre, inp.t_start, inp.noises[0])
-    with injected_noise(inp.noises[1:]):
+    with (injected_noise(inp.noises[1:]) if inject else contextlib.nullcontext()):
         z = sampler.manual_sample_with_timesteps(
             model=cldm, device=dev, x_T=x_T, steps=4, used_timesteps=USED_TIMESTEPS, batch_size=B, cond=cond, uncond=None,
             cfg_scale=1.0, progress=False, tiled=tiled, tile_size=64, tile_stride=32)

@@ -185,6 +185,16 @@ typedef struct edtr_igemm_params {
      * the packer BEFORE the 16-bit (or multi-part) rounding.  taps stays 9 and K = 9 C1 (the algorithmic shape).  Halo kernel only
      * (tile 0 / 16): IH, IW multiples of 16, C1 % 64 == 0, stride 1, pad 1; anything else is EDTR_E_UNSUPPORTED. */
     int64_t w_phase_stride;
+    /* 16-bit MIRROR of an fp32 output (ABI 7; mixed-precision mode): when out_f32 != 0 and out16 != NULL the epilogue also stores
+     * the final values rounded to `dtype` at out16[m * ld16 + n] — the one-part GEMM operand that the 16-bit consumers of the fp32
+     * residual stream (1x1 skip / zero convolutions, down / upsample convolutions) read, instead of a separate cast launch per
+     * consumer (edtr_split_operand).  Needs Z == 1, no GEGLU / transposed output; ld16 % 8 == 0. */
+    void* out16; int32_t ld16;
+    /* Weights-exact two-part product (ABI 7): a_wrap > 0 reads the A operand's columns TWICE, A(m, k) = a1[m * ld1 + (k mod a_wrap)],
+     * K = 2 * a_wrap, against weights packed [Wh | Wl] (hi / lo halves of the fp32 weight): x16 . (Wh + Wl) — the weight rounding
+     * disappears at twice the MFMA work, with no low part of the activation to form.  Plain GEMMs (taps 1, non-spatial, no concat),
+     * a_wrap % 64 == 0, tiles 0 / 1 / 2 / 3 / 8. */
+    int32_t a_wrap;
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -326,6 +336,11 @@ int edtr_nhwc_to_nchw(int dtype, const void* src, int src_f32, int B, int C, int
  * replaces: `hs.pop() + control.pop()`, `h += control.pop()` and the torch.cat of model/controlnet.py:31,35,37. */
 int edtr_add(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C,
              edtr_stream_t stream);
+/* The fp32-stream form of edtr_add that also writes the result's fp16 MIRROR out16[r * ld16 + c] (ABI 7; see edtr_igemm_params.out16):
+ * the `hs.pop() + control.pop()` half of a decoder concat whose 1x1 skip convolution reads the mirror (model/controlnet.py:35-37,
+ * model/unet.py:189).  C % 8 == 0. */
+int edtr_add_mirror(const float* a, int lda, const float* b, int ldb, float* out, int ldo, void* out16, int ld16, int64_t rows, int C,
+                    edtr_stream_t stream);
 /* Sinusoidal timestep embedding [cos | sin] written as 16-bit rows of `dim` (even).
  * replaces: timestep_embedding, reference model/util.py:98-118. */
 int edtr_timestep_embedding(int dtype, const int64_t* t, int B, int dim, void* out, int ld,

@@ -223,3 +223,15 @@ def test_bench_self_launcher_fails_when_a_rank_fails():
     r = _run_bench_launcher({"EDTR_BENCH_DRY_FAIL_RANK": "1"})
     assert r.returncode != 0
     assert not r.stdout.strip(), "no result line may be forwarded when a rank failed"
+
+
+def test_bench_self_launcher_fails_fast_when_a_rank_dies_before_the_rendezvous():
+    """a rank that exits BEFORE init_process_group leaves its peer waiting in the rendezvous for minutes; the
+    launcher polls all children, kills the survivor and returns that rank's code at once."""
+    import time
+    t0 = time.time()
+    r = _run_bench_launcher({"EDTR_BENCH_DRY_FAIL_EARLY_RANK": "1"})
+    assert r.returncode == 4, (r.returncode, r.stderr[-1500:])
+    assert not r.stdout.strip()
+    assert "rank 1 exited with code 4" in r.stderr
+    assert time.time() - t0 < 120, "the launcher waited for the surviving rank's rendezvous timeout"

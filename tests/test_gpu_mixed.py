@@ -306,3 +306,90 @@ def test_det512_full_size_mixed_meets_the_north_star(golden_dir):
             "img": rel(img[:, :, 1::4, 2::4], g["img_samples"].astype(np.float32))}
     print(f"\n[mixed det512 full size] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     assert errs["z_pre"] < NORTH_STAR and errs["z"] < NORTH_STAR and errs["img"] < NORTH_STAR, errs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ABI 7 (round 4): the fp32 stream's fp16 mirror (out16), the weights-exact two-part product (a_wrap), edtr_add_mirror
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    # M, N, K, tile, residual, splitk, conv (3x3 on 16 x 16 images: the halo tile)
+    (300, 320, 192, 0, False, 1, False),      # general shapes, specialised loop without residual
+    (1024, 640, 640, 8, True, 1, False),      # 128x160 tile, fp32 residual
+    (512, 256, 1152, 3, True, 4, False),      # split-K: the reducer writes the mirror
+    (130, 136, 72, 1, True, 1, False),        # register-staged tile, ragged
+    (512, 128, 1152, 16, True, 1, True),      # halo tile (rows are patch pixels)
+])
+def test_igemm_fp32_output_with_fp16_mirror(case):
+    """out16: the epilogue stores the fp32 result AND its fp16 rounding (the one-part operand of the stream's 16-bit consumers);
+    the mirror must be bit-identical to casting the fp32 output."""
+    from edtr_amd import ops
+    d = dev()
+    M, N, K, tile, use_res, sk, conv = case
+    dt = torch.float16
+    if conv:
+        B, H, cin = M // 256, 16, K // 9
+        x = rnd((M, cin), 31).to(dt).to(d)
+        kw = dict(taps=9, C1=cin, ld1=cin, spatial=(H, H, H, H, 1, 1, 1, 0), rows_per_image=H * H)
+    else:
+        x = rnd((M, K), 31).to(dt).to(d)
+        kw = dict(C1=K, ld1=K)
+    w = rnd((N, K), 32, K ** -0.5).to(dt).to(d)
+    bias = rnd((N,), 33).to(d)
+    res = rnd((M, N), 34).to(d) if use_res else None
+    out = torch.full((M, N + 8), float("nan"), dtype=torch.float32, device=d)[:, :N]
+    mir = torch.full((M, N + 16), 9.0, dtype=dt, device=d)
+    ws = torch.empty((sk * M * N,), dtype=torch.float32, device=d) if sk > 1 else None
+    ops.launch(ops.make_igemm(dtype=dt, a1=x, w=w, out=out, M=M, N=N, ldw=K, ldc=out.stride(0), bias_n=bias, residual=res,
+                              ldr=N, residual_f32=use_res, out_f32=True, tile=tile, splitk=sk, workspace=ws, out16=mir[:, :N], **kw))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(mir[:, :N], out.to(dt))
+    assert bool((mir[:, N:] == 9.0).all())
+    if not conv:
+        ref = x.float().cpu() @ w.float().cpu().t() + bias.cpu() + (res.cpu() if use_res else 0.0)
+        assert rel(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,C,tile", [(300, 320, 192, 0), (2048, 640, 1280, 8), (512, 1280, 320, 3), (130, 136, 128, 1), (77, 72, 64, 2),
+                                        (64, 1280, 1536, 0)])
+def test_weights_exact_two_part_product(M, N, C, tile):
+    """a_wrap: x16 . [Wh | Wl] with the A columns read twice = x16 . W to ~22 bits of the weight (no weight rounding), against the
+    fp64 product of the SAME fp16 activation with the fp32 weight; the one-part product on the same operands shows the difference."""
+    from edtr_amd import ops
+    d = dev()
+    dt = torch.float16
+    x = rnd((M, C), 41).to(dt)
+    w32 = rnd((N, C), 42, C ** -0.5)
+    w2 = ops.split3_weight(w32, dt, ops.PARTS_2W)
+    assert w2.shape == (N, 2 * C)
+    xd = x.to(d)
+    out2 = torch.empty((M, N), dtype=torch.float32, device=d)
+    out1 = torch.empty((M, N), dtype=torch.float32, device=d)
+    sk = ops.choose_splitk(M, N, 2 * C)[1] if tile == 0 else 1
+    ws = torch.empty((sk * M * N,), dtype=torch.float32, device=d) if sk > 1 else None
+    ops.launch(ops.make_igemm(dtype=dt, a1=xd, w=w2.to(d), out=out2, M=M, N=N, C1=2 * C, ld1=C, ldw=2 * C, ldc=N, out_f32=True, tile=tile,
+                              a_wrap=C, splitk=sk, workspace=ws))
+    ops.launch(ops.make_igemm(dtype=dt, a1=xd, w=w32.to(dt).to(d), out=out1, M=M, N=N, C1=C, ld1=C, ldw=C, ldc=N, out_f32=True,
+                              tile=tile if tile != 0 else 0))
+    torch.cuda.synchronize()
+    ref = x.double() @ w32.double().t()
+    e2, e1 = rel(out2, ref), rel(out1, ref)
+    assert e2 < 2e-6, (e2, e1)          # fp32 accumulation only
+    assert e1 > 20 * e2                 # the one-part product carries the weights' fp16 rounding (~2.9e-4 / sqrt(3))
+    with pytest.raises(RuntimeError):   # tiles without the wrapped A walk refuse it
+        ops.launch(ops.make_igemm(dtype=dt, a1=xd, w=w2.to(d), out=out2, M=M, N=N, C1=2 * C, ld1=C, ldw=2 * C, ldc=N, out_f32=True, tile=6,
+                                  a_wrap=C))
+
+
+def test_add_mirror_bit_exact():
+    from edtr_amd import ops
+    d = dev()
+    rows, C = 1000, 320
+    a, b = rnd((rows, C + 8), 51).to(d), rnd((rows, C), 52).to(d)
+    out = torch.zeros((rows, 2 * C), dtype=torch.float32, device=d)
+    mir = torch.zeros((rows, 2 * C), dtype=torch.float16, device=d)
+    ops.launch(ops.make_add_mirror(a=a[:, :C], lda=a.stride(0), b=b, ldb=C, out=out[:, C:], ldo=2 * C, out16=mir[:, C:], rows=rows, C=C))
+    ops.launch(ops.make_add_mirror(a=a[:, :C], lda=a.stride(0), b=None, ldb=0, out=out[:, :C], ldo=2 * C, out16=mir[:, :C], rows=rows, C=C))
+    torch.cuda.synchronize()
+    want = torch.cat([a[:, :C], a[:, :C] + b], dim=1)
+    assert torch.equal(out, want) and torch.equal(mir, want.to(torch.float16))

@@ -584,7 +584,9 @@ def test_gemm_writes_row_statistics_of_its_output(dtype, M, N, K, tile):
     assert rel(out.float(), ref) < TOL[dtype]
     tot = stats.double().sum(1).cpu()
     assert torch.isfinite(tot).all()
-    assert rel(tot[:, 0], ref.double().sum(1)) < 1e-4 and rel(tot[:, 1], (ref.double() ** 2).sum(1)) < 1e-5
+    # (round 4) the statistics are those of the STORED 16-bit values — what the consuming GEMM multiplies — to fp32 summation accuracy
+    st = out.double().cpu()
+    assert rel(tot[:, 0], st.sum(1)) < 2e-6 and rel(tot[:, 1], (st ** 2).sum(1)) < 2e-6
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

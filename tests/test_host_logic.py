@@ -352,3 +352,23 @@ def test_subpixel_weight_packing_equals_upsample_then_conv():
     want = (w[:, :, 1, 1] + w[:, :, 1, 2] + w[:, :, 2, 1] + w[:, :, 2, 2]).float().to(torch.bfloat16)   # phase (0, 0), tap (1, 1)
     assert torch.equal(p1[0, :, 1, 1], want)
     assert ops.subpixel_ok(64, 64, 512, 512, 8) and not ops.subpixel_ok(8, 8, 1280, 1280, 8) and not ops.subpixel_ok(64, 64, 320, 320, 8)
+
+
+def test_params_fingerprint_sees_a_replaced_parameter_object():
+    """replacing a Parameter that is NOT the first one (`sub.weight = nn.Parameter(...)`, load_state_dict(assign=True)
+    on a sub-module) must change the fingerprint that invalidates packed weights / programs / hipGraphs."""
+    from edtr_amd.model.params import ParamTree, params_fingerprint
+    t = ParamTree([("a.weight", (4, 4)), ("a.bias", (4,)), ("b.c.weight", (2, 4))])
+    fp0 = params_fingerprint(t)
+    assert params_fingerprint(t) == fp0
+    t.b.c.weight = torch.nn.Parameter(torch.ones(2, 4), requires_grad=False)          # same shape, same version counter (0)
+    fp1 = params_fingerprint(t)
+    assert fp1 != fp0
+    t.a.load_state_dict({"weight": torch.zeros(4, 4), "bias": torch.zeros(4)}, assign=True)
+    fp2 = params_fingerprint(t)
+    assert fp2 != fp1
+    with torch.no_grad():
+        t.a.bias.add_(1.0)                                                             # in-place write: the version counter
+    assert params_fingerprint(t) != fp2
+    other = ParamTree([("x.weight", (2, 2))])                                          # another tree: this one's fingerprint is unchanged
+    assert other is not None and params_fingerprint(t) == params_fingerprint(t)
