@@ -216,6 +216,365 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
 }
 
 
+// =====================================================================================================================
+// Split-operand kernel (round 4): the ROBUST parity mode's attention.  On the heavy-tailed weight set (sharp attention) the fp16
+// rounding of q and k ALONE puts a denoiser evaluation 2.7e-3 from the reference (tests/heavy_attention_budget.py: fp32 oracle
+// with roundings injected; p 4.8e-4, v 4.4e-4, everything else exact 6e-6) — it bounded every GPU mode of rounds 1-3, whose
+// attention operands were one fp16 part.  Here the operands arrive as fp16 hi + lo PAIRS (x = hi + lo to ~22 bits, written by
+// edtr_split_operand from the fp32 projections) and each product runs as three MFMA products, the trick the GEMMs of the parity
+// modes use:   S = Qh Kh^T + Ql Kh^T + Qh Kl^T     and, with PV,     O = Ph Vh + Pl Vh + Ph Vl   (P split in registers).
+// Same structure as the generic kernel (one workgroup = 4 waves = 128 queries, 64-key tiles by LDS-DMA, online softmax in the exp2
+// domain, deferred rescale); 3 or 4 tiles per stage (K hi, K lo, V^T hi, V^T lo) and three times the MFMAs.  Correctness first:
+// this is the `precision="high"` path, not the throughput path.
+// =====================================================================================================================
+template <typename T, bool PV>
+__global__ void __launch_bounds__(kThreads, 1) flash_attn64_split_kernel(const edtr_attn_params p) {
+    constexpr int NTL = PV ? 4 : 3;                                      // tiles per stage: K hi | K lo | V^T hi | (V^T lo)
+    __shared__ __attribute__((aligned(16))) char smem[2 * NTL * TILE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_ok = q_row < p.Nq;
+
+    const int64_t qo = b * p.q_bs + h * 64, ko = b * p.k_bs + h * 64, vo = b * p.vt_bs + (int64_t)h * 64 * p.vt_ld;
+    const uint16_t* qph = static_cast<const uint16_t*>(p.q) + qo;
+    const uint16_t* qpl = static_cast<const uint16_t*>(p.q_lo) + qo;
+    U4 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qh[ks] = zero16();
+        ql[ks] = zero16();
+        if (q_ok) {
+            qh[ks] = ldg16(qph + (int64_t)q_row * p.q_ld + ks * 16 + lh * 8);
+            ql[ks] = ldg16(qpl + (int64_t)q_row * p.q_ld + ks * 16 + lh * 8);
+        }
+    }
+    const u32x4 srd_kh = srd_of(static_cast<const uint16_t*>(p.k) + ko), srd_kl = srd_of(static_cast<const uint16_t*>(p.k_lo) + ko);
+    const u32x4 srd_vh = srd_of(static_cast<const uint16_t*>(p.vt) + vo);
+    const u32x4 srd_vl = srd_of(static_cast<const uint16_t*>(PV ? p.vt_lo : p.vt) + vo);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem));
+    const int rsub = lane >> 3, slot = lane & 7;
+    uint32_t koff[2], voff[2];
+    int vkey[2], krow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wave * 16 + 8 * j + rsub;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        krow[j] = row;
+        koff[j] = (uint32_t)(((int64_t)row * p.k_ld + chunk * 8) * 2);
+        vkey[j] = chunk * 8;
+        voff[j] = (uint32_t)(((int64_t)row * p.vt_ld + chunk * 8) * 2);
+    }
+    auto issue_tile = [&](int t, int buf) {
+        const int kv0 = t * KV;
+        const uint32_t s0 = smem_base + buf * NTL * TILE_BYTES + wave * (16 * 128);
+        const uint32_t soff_k = (uint32_t)kv0 * (uint32_t)p.k_ld * 2u, soff_v = (uint32_t)kv0 * 2u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t ko_ = kv0 + krow[j] < p.Nk ? koff[j] : kOob, vo_ = kv0 + vkey[j] < p.Nk ? voff[j] : kOob;
+            dma16(ko_, srd_kh, soff_k, s0 + j * 1024);
+            dma16(ko_, srd_kl, soff_k, s0 + TILE_BYTES + j * 1024);
+            dma16(vo_, srd_vh, soff_v, s0 + 2 * TILE_BYTES + j * 1024);
+            if constexpr (PV) dma16(vo_, srd_vl, soff_v, s0 + 3 * TILE_BYTES + j * 1024);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+    float m_run = -1e30f, l_run = 0.0f;
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+    float mc = m_run * c;
+    const int nt = (p.Nk + KV - 1) / KV;
+    issue_tile(0, 0);
+    const int krd = swap23(l31);
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            issue_tile(t + 1, cur ^ 1);
+            if constexpr (PV) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* skh = smem + cur * NTL * TILE_BYTES;
+        const char* skl = skh + TILE_BYTES;
+        const char* svh = skh + 2 * TILE_BYTES;
+        const char* svl = skh + 3 * TILE_BYTES;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = tile_off(kb * 32 + krd, 2 * ks + lh);
+                const U4 kfh = *reinterpret_cast<const U4*>(skh + off), kfl = *reinterpret_cast<const U4*>(skl + off);
+                s[kb] = T::mfma(kfl, qh[ks], s[kb]);        // the small products first
+                s[kb] = T::mfma(kfh, ql[ks], s[kb]);
+                s[kb] = T::mfma(kfh, qh[ks], s[kb]);
+            }
+        }
+        if ((t + 1) * KV > p.Nk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KV + kb * 32 + 16 * (r >> 3) + 8 * lh + (r & 7);
+                    if (key >= p.Nk) s[kb][r] = -1e30f;
+                }
+        }
+        if (p.causal && (t + 1) * KV > blockIdx.x * 128 + wave * 32) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KV + kb * 32 + 16 * (r >> 3) + 8 * lh + (r & 7);
+                    if (key > q_row) s[kb][r] = -1e30f;
+                }
+        }
+        float mt = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        if (!__all((mt - m_run) * c <= kDeferLog2)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            mc = m_new * c;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
+        float psum = 0.0f;
+        U4 pfh[2][2], pfl[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float pr[16], pl[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c, -mc));
+                psum += pr[r];
+                pl[r] = pr[r] - T::to_f32(T::from_f32(pr[r]));          // the part the 16-bit rounding drops
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                pfh[kb][st].x = pack2<T>(pr[8 * st + 0], pr[8 * st + 1]); pfh[kb][st].y = pack2<T>(pr[8 * st + 2], pr[8 * st + 3]);
+                pfh[kb][st].z = pack2<T>(pr[8 * st + 4], pr[8 * st + 5]); pfh[kb][st].w = pack2<T>(pr[8 * st + 6], pr[8 * st + 7]);
+                if constexpr (PV) {
+                    pfl[kb][st].x = pack2<T>(pl[8 * st + 0], pl[8 * st + 1]); pfl[kb][st].y = pack2<T>(pl[8 * st + 2], pl[8 * st + 3]);
+                    pfl[kb][st].z = pack2<T>(pl[8 * st + 4], pl[8 * st + 5]); pfl[kb][st].w = pack2<T>(pl[8 * st + 6], pl[8 * st + 7]);
+                }
+            }
+        }
+        l_run += psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int off = tile_off(db * 32 + l31, kb * 4 + 2 * st + lh);
+                    const U4 vfh = *reinterpret_cast<const U4*>(svh + off);
+                    if constexpr (PV) {
+                        const U4 vfl = *reinterpret_cast<const U4*>(svl + off);
+                        o[db] = T::mfma(vfl, pfh[kb][st], o[db]);
+                        o[db] = T::mfma(vfh, pfl[kb][st], o[db]);
+                    }
+                    o[db] = T::mfma(vfh, pfh[kb][st], o[db]);
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        // the output feeds a multi-part GEMM (attn.out): fp32 when out_f32, else one 16-bit part
+        if (p.out_f32) {
+            float* op = static_cast<float*>(p.out) + b * p.o_bs + (int64_t)q_row * p.o_ld + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+                    v[0] = o[db][4 * g + 0] * inv; v[1] = o[db][4 * g + 1] * inv; v[2] = o[db][4 * g + 2] * inv; v[3] = o[db][4 * g + 3] * inv;
+                    *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g + 4 * lh) = v;
+                }
+        } else {
+            uint16_t* op = static_cast<uint16_t*>(p.out) + b * p.o_bs + (int64_t)q_row * p.o_ld + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 v;
+                    v.x = pack2<T>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+                    v.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = v;
+                }
+        }
+    }
+}
+
+
+// =====================================================================================================================
+// Small-Nk kernel (round 4): the cross-attention of every transformer block — Nk = 77 context tokens (any Nk <= 128) — 92 of the
+// 184 attention launches of a pass.  The generic kernel above treats it like any other shape: a workgroup per 128 queries stages
+// its two key tiles, runs the ONLINE softmax machinery (running maximum, deferred rescale, two barriers per tile) over them and
+// leaves; at 64x64 latents that is 1280 workgroups whose fixed costs (tile flight, barriers) exceed their 24 MFMAs per wave:
+// 18 us for a launch whose operands are 42 MB (7 us at the HBM rate).
+// Here K and V^T of the (image, head) are staged ONCE per workgroup (two 64-key tiles each, 32 KiB of LDS, one wait, one barrier)
+// and stay resident while every wave walks its 32-query blocks: all <= 128 scores of a query sit in registers, so the softmax is
+// the plain two-pass form (max, then exp2 / sum) with no running state, and a wave's loop has no barrier at all — the next block's
+// Q fragments are requested before the current block's products.  Key blocks that lie entirely beyond Nk are skipped (77 keys:
+// 3 of 4 blocks of 32; 5 of 8 key steps of the P.V product).
+// =====================================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(kThreads, 2) flash_attn64_smallk_kernel(const edtr_attn_params p, int blocks_per_wg) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [key tile t][K tile | V^T tile]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int nblk = (p.Nq + 31) >> 5;                                   // 32-query blocks of this (image, head)
+    const int blk0 = blockIdx.x * blocks_per_wg;
+
+    const uint16_t* qp = static_cast<const uint16_t*>(p.q) + b * p.q_bs + h * 64;
+    const uint16_t* kp = static_cast<const uint16_t*>(p.k) + b * p.k_bs + h * 64;
+    const uint16_t* vp = static_cast<const uint16_t*>(p.vt) + b * p.vt_bs + (int64_t)h * 64 * p.vt_ld;
+    uint16_t* ob = static_cast<uint16_t*>(p.out) + b * p.o_bs + h * 64;
+
+    // ---- K / V^T of this (image, head): both key tiles at once (keys >= Nk fail the range check and land as zeros)
+    const int nt = (p.Nk + KV - 1) / KV;                                  // 1 or 2
+    {
+        const u32x4 srd_k = srd_of(kp), srd_v = srd_of(vp);
+        const uint32_t smem_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem));
+        const int rsub = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < nt) {
+                const int kv0 = t * KV;
+                const uint32_t sk = smem_base + t * 2 * TILE_BYTES + wave * (16 * 128), sv = sk + TILE_BYTES;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wave * 16 + 8 * j + rsub, chunk = slot ^ ((row >> 1) & 7);
+                    const uint32_t koff = (uint32_t)(((int64_t)(kv0 + row) * p.k_ld + chunk * 8) * 2);
+                    const uint32_t voff = (uint32_t)(((int64_t)row * p.vt_ld + kv0 + chunk * 8) * 2);
+                    dma16(kv0 + row < p.Nk ? koff : kOob, srd_k, 0u, sk + j * 1024);
+                    dma16(kv0 + chunk * 8 < p.Nk ? voff : kOob, srd_v, 0u, sv + j * 1024);
+                }
+            }
+        }
+    }
+    auto load_q = [&](int blk, U4 (&qf)[4]) {
+        const int q_row = blk * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = zero16();
+            if (blk < nblk && q_row < p.Nq) qf[ks] = ldg16(qp + (int64_t)q_row * p.q_ld + ks * 16 + lh * 8);
+        }
+    };
+    U4 qf[4], qn[4];
+    int blk = blk0 + wave;
+    load_q(blk, qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+    const int krd = swap23(l31);
+    const int blk_end = min(blk0 + blocks_per_wg, nblk);
+    for (; blk < blk_end; blk += 4) {
+        load_q(blk + 4 < blk_end ? blk + 4 : nblk, qn);                   // (out-of-range block index: zeros, no load)
+        // ---- S^T[key][q]: up to 4 key blocks of 32
+        f32x16 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = -1e30f;
+            if (kb * 32 < p.Nk) {
+                const char* sk = smem + (kb >> 1) * 2 * TILE_BYTES;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const U4 kf = *reinterpret_cast<const U4*>(sk + tile_off((kb & 1) * 32 + krd, 2 * ks + lh));
+                    s[kb] = T::mfma(kf, qf[ks], s[kb]);
+                }
+                if (kb * 32 + 32 > p.Nk) {      // register r at lane half lh is key kb*32 + 16*(r>>3) + 8*lh + (r&7)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kb * 32 + 16 * (r >> 3) + 8 * lh + (r & 7) >= p.Nk) s[kb][r] = -1e30f;
+                }
+            }
+        }
+        float mt = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mc = mt * c;
+        float psum = 0.0f;
+        f32x16 o[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb * 32 < p.Nk) {
+                float pr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c, -mc));
+                    psum += pr[r];
+                }
+                U4 pf[2];
+                pf[0].x = pack2<T>(pr[0], pr[1]);   pf[0].y = pack2<T>(pr[2], pr[3]);
+                pf[0].z = pack2<T>(pr[4], pr[5]);   pf[0].w = pack2<T>(pr[6], pr[7]);
+                pf[1].x = pack2<T>(pr[8], pr[9]);   pf[1].y = pack2<T>(pr[10], pr[11]);
+                pf[1].z = pack2<T>(pr[12], pr[13]); pf[1].w = pack2<T>(pr[14], pr[15]);
+                const char* sv = smem + (kb >> 1) * 2 * TILE_BYTES + TILE_BYTES;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    if (kb * 32 + st * 16 < p.Nk) {
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const U4 vf = *reinterpret_cast<const U4*>(sv + tile_off(db * 32 + l31, (kb & 1) * 4 + 2 * st + lh));
+                            o[db] = T::mfma(vf, pf[st], o[db]);
+                        }
+                    }
+                }
+            }
+        }
+        const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
+        const int q_row = blk * 32 + l31;
+        if (q_row < p.Nq) {
+            uint16_t* op = ob + (int64_t)q_row * p.o_ld;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 v;
+                    v.x = pack2<T>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+                    v.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = v;
+                }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    }
+}
+
+
 constexpr int QB2 = 256;                  // queries per workgroup of the large-N kernel
 constexpr int NSTAGE = 4;
 
@@ -364,14 +723,31 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
     if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
     if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return EDTR_E_SHAPE;
     if (p.causal && p.Nq != p.Nk) return EDTR_E_SHAPE;
-    if ((p.q_ld & 7) || (p.k_ld & 7) || (p.vt_ld & 7) || (p.o_ld & 7) || (p.q_bs & 7) || (p.k_bs & 7) ||
-        (p.vt_bs & 7) || (p.o_bs & 7))
+    if ((p.q_ld & 7) || (p.k_ld & 7) || (p.vt_ld & 7) || (!p.out_f32 && (p.o_ld & 7)) || (p.q_bs & 7) || (p.k_bs & 7) ||
+        (p.vt_bs & 7) || (!p.out_f32 && (p.o_bs & 7)))
         return EDTR_E_ALIGN;
     if (p.vt_ld < ((p.Nk + 7) & ~7)) return EDTR_E_SHAPE;
     if (!aligned16(p.q) || !aligned16(p.k) || !aligned16(p.vt) || !aligned16(p.out)) return EDTR_E_ALIGN;
     // 32-bit byte offsets inside one (image, head) slice of K and of V^T (buffer addressing)
     if ((int64_t)(p.Nk + 64) * p.k_ld * 2 >= 0xF0000000LL || (int64_t)64 * p.vt_ld * 2 >= 0xF0000000LL) return EDTR_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((p.q_lo != nullptr) != (p.k_lo != nullptr)) return EDTR_E_NULL;        // q and k are split together
+    if (p.vt_lo && !p.q_lo) return EDTR_E_UNSUPPORTED;
+    if (p.out_f32 && !p.q_lo) return EDTR_E_UNSUPPORTED;                        // fp32 output: the split-operand kernel only
+    if (p.q_lo) {      // hi + lo operand pairs: three MFMA products per matrix product (the robust parity mode)
+        if (!aligned16(p.q_lo) || !aligned16(p.k_lo) || (p.vt_lo && !aligned16(p.vt_lo))) return EDTR_E_ALIGN;
+        if (p.out_f32 && ((p.o_ld & 3) || (p.o_bs & 3))) return EDTR_E_ALIGN;
+        dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+        if (p.dtype == EDTR_BF16) {
+            if (p.vt_lo) hipLaunchKernelGGL((flash_attn64_split_kernel<BF16, true>), grid, dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn64_split_kernel<BF16, false>), grid, dim3(kThreads), 0, s, p);
+        } else {
+            if (p.vt_lo) hipLaunchKernelGGL((flash_attn64_split_kernel<F16, true>), grid, dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn64_split_kernel<F16, false>), grid, dim3(kThreads), 0, s, p);
+        }
+        EDTR_LAUNCH_CHECK();
+        return EDTR_OK;
+    }
     static int v2_min_nq = -1;      // the large-N kernel takes over at this many queries (EDTR_ATTN_V3_MIN_NQ, 0 = never)
     if (v2_min_nq < 0) {
         const char* e = getenv("EDTR_ATTN_V3_MIN_NQ");
@@ -386,6 +762,23 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
         dim3 grid3(((p.Nq + QB2 - 1) / QB2) * p.H * p.B);
         if (p.dtype == EDTR_BF16) hipLaunchKernelGGL((flash_attn64_v3_kernel<BF16>), grid3, dim3(kThreads), 0, s, p);
         else hipLaunchKernelGGL((flash_attn64_v3_kernel<F16>), grid3, dim3(kThreads), 0, s, p);
+        EDTR_LAUNCH_CHECK();
+        return EDTR_OK;
+    }
+    static int smallk_on = -1;      // EDTR_ATTN_SMALLK=0: the generic kernel for the small-Nk (cross-attention) shapes too (A/B runs)
+    if (smallk_on < 0) {
+        const char* e = getenv("EDTR_ATTN_SMALLK");
+        smallk_on = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (smallk_on && !p.causal && p.Nk <= 128) {
+        // 32-query blocks per workgroup (4 waves): one per wave while that still gives every CU two workgroups, up to 4 per wave
+        const int64_t total = (int64_t)p.B * p.H * ((p.Nq + 31) / 32);
+        int per_wave = (int)(total / (4 * 512));
+        per_wave = per_wave < 1 ? 1 : (per_wave > 4 ? 4 : per_wave);
+        const int bpw = 4 * per_wave;
+        dim3 gridk(((p.Nq + 31) / 32 + bpw - 1) / bpw, p.H, p.B);
+        if (p.dtype == EDTR_BF16) hipLaunchKernelGGL((flash_attn64_smallk_kernel<BF16>), gridk, dim3(kThreads), 0, s, p, bpw);
+        else hipLaunchKernelGGL((flash_attn64_smallk_kernel<F16>), gridk, dim3(kThreads), 0, s, p, bpw);
         EDTR_LAUNCH_CHECK();
         return EDTR_OK;
     }

@@ -66,6 +66,8 @@ class AttnParams(C.Structure):
         ("scale", C.c_float),
         ("causal", C.c_int32),
         ("q_prescaled", C.c_int32),
+        ("q_lo", C.c_void_p), ("k_lo", C.c_void_p), ("vt_lo", C.c_void_p),
+        ("out_f32", C.c_int32),
     ]
 
 

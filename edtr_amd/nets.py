@@ -58,11 +58,12 @@ class ContextKV:
     """Per-net cross-attention keys / transposed values for every transformer layer, from c_txt."""
 
     def __init__(self):
-        self.k_all = None      # [B*Nctx, sumC]
-        self.vt_all = None     # [B*sumC, ldv]
+        self.k_all = None      # [B*Nctx, sumC]   (split attention, high mode: [B*Nctx, 2*sumC] = [hi | lo])
+        self.vt_all = None     # [B*sumC, ldv]    (split: [B*sumC, 2*ldv] = [hi | lo])
         self.sumC = 0
         self.ldv = 0
         self.Nctx = 0
+        self.split = 0         # Emitter.attn_split the context was prepared for
         self.offs: Dict[str, int] = {}
 
 
@@ -74,13 +75,19 @@ def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: in
     wk, _ = em.store.linear([P + l.prefix + t + "to_k.weight" for l in layers])
     wv, _ = em.store.linear([P + l.prefix + t + "to_v.weight" for l in layers])
     kv.sumC, kv.Nctx = wk.shape[0], Nctx
-    kv.k_all = em.gemm(ctx16, wk, B * Nctx, kv.sumC, a.context_dim, name="ctx_k(all)", out16=True)
-    kv.vt_all, kv.ldv = em.vt_gemm(wv, ctx16, B=B, Ntok=Nctx, Cin=a.context_dim, name="ctx_vT(all)")
-    if kv.k_all.dtype == torch.float32:      # high mode (bf16 MFMA type): the attention operands are fp16, cast once per prompt
-        k32, v32 = kv.k_all, kv.vt_all
-        kv.k_all = em.to16(k32, B * Nctx, kv.sumC)
-        kv.vt_all = em.to16(v32, B * kv.sumC, kv.ldv)
-        em.free(k32, v32)
+    kv.split = em.attn_split
+    kv.k_all = em.gemm(ctx16, wk, B * Nctx, kv.sumC, a.context_dim, name="ctx_k(all)", out16=kv.split < 1)
+    kv.vt_all, kv.ldv = em.vt_gemm(wv, ctx16, B=B, Ntok=Nctx, Cin=a.context_dim, name="ctx_vT(all)", out16=kv.split < 2)
+    # fp32 projections (high mode: bf16 MFMA type; split attention in any fp32-stream mode): the attention operands are fp16, cut
+    # once per prompt — hi + lo pairs ([hi | lo] columns) where the attention is split, one part otherwise
+    if kv.k_all.dtype == torch.float32:
+        k32 = kv.k_all
+        kv.k_all = em.split16(k32, B * Nctx, kv.sumC) if kv.split >= 1 else em.to16(k32, B * Nctx, kv.sumC)
+        em.free(k32)
+    if kv.vt_all.dtype == torch.float32:
+        v32 = kv.vt_all
+        kv.vt_all = em.split16(v32, B * kv.sumC, kv.ldv) if kv.split >= 2 else em.to16(v32, B * kv.sumC, kv.ldv)
+        em.free(v32)
     o = 0
     for l in layers:
         kv.offs[l.prefix] = o
@@ -137,21 +144,21 @@ def emit_attention_core(em: Emitter, p: str, x, B: int, N: int, C: int, heads: i
         em.free(qk, vt)
     elif ctx is None:   # (high mode / odd shapes) fused [Wq;Wk] projection, V^T via the operand-swapped GEMM
         wqk, _ = em.store.linear([p + "to_q.weight", p + "to_k.weight"])
-        qk = em.gemm(x, wqk, B * N, 2 * C, C, alpha=math.sqrt(c), name="attn1.qk", out16=True)
+        qk = em.gemm(x, wqk, B * N, 2 * C, C, alpha=math.sqrt(c), name="attn1.qk", out16=em.attn_split < 1)
         wv, _ = em.store.linear([p + "to_v.weight"])
-        vt, ldv = em.vt_gemm(wv, x, B=B, Ntok=N, Cin=C, name="attn1.vT")
+        vt, ldv = em.vt_gemm(wv, x, B=B, Ntok=N, Cin=C, name="attn1.vT", out16=em.attn_split < 2)
         o = em.flash(qk[:, :C], qk[:, C:], vt, B=B, H=heads, Nq=N, Nk=N, k_bs=N * qk.stride(0), vt_bs=C * ldv, vt_ld=ldv,
                      prescaled=True)
         em.free(qk, vt)
     else:
-        k, vt, k_bs, vt_bs, ldv, nctx = ctx
+        k, vt, k_bs, vt_bs, ldv, nctx, k_lo, vt_lo = ctx
         if fold:
             wq, _, c1, c2 = em.store.ln_fold("linear", [p + "to_q.weight"], None, fold)
             q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=True, ln_vec=(c1, c2))
         else:
             wq, _ = em.store.linear([p + "to_q.weight"])
-            q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=True)
-        o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv, prescaled=True)
+            q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=em.attn_split < 1)
+        o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv, prescaled=True, k_lo=k_lo, vt_lo=vt_lo)
         em.free(q)
     wo, bo = em.store.linear([p + "to_out.0.weight"], [p + "to_out.0.bias"])
     y = em.gemm(o, wo, B * N, C, C, bias=bo, residual=residual, name="attn.out", row_stats=row_stats)
@@ -181,8 +188,12 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     l2 = em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",), stats=st)
     off = kv.offs[l.prefix]
     k_view = kv.k_all[:, off:off + C]
-    vt_view = kv.vt_all.view(B, kv.sumC, kv.ldv)[:, off:off + C, :]
-    ctx = (k_view, vt_view, kv.Nctx * kv.sumC, kv.sumC * kv.ldv, kv.ldv, kv.Nctx)
+    k_lo = kv.k_all[:, kv.sumC + off:kv.sumC + off + C] if kv.split >= 1 else None
+    ldv_all = kv.vt_all.stride(0)          # (2 * ldv when the values are hi + lo pairs)
+    vt3 = kv.vt_all.view(B, kv.sumC, ldv_all)
+    vt_view = vt3[:, off:off + C, :kv.ldv]
+    vt_lo = vt3[:, off:off + C, kv.ldv:] if kv.split >= 2 else None
+    ctx = (k_view, vt_view, kv.Nctx * kv.k_all.stride(0), kv.sumC * ldv_all, ldv_all, kv.Nctx, k_lo, vt_lo)
     t2 = emit_attention_core(em, tb + "attn2.", l2, B, N, C, l.heads, ctx, t1, row_stats=fold)
     st = em.last_row_stats
     em.free(l2, t1)

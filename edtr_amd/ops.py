@@ -161,7 +161,9 @@ def choose_splitk(M: int, N: int, K: int, Z: int = 1, act: int = 0, img8: bool =
 # attention
 # --------------------------------------------------------------------------------------------
 def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld,
-                    scale: float, causal: bool = False, prescaled: bool = False, name: str = "flash_attn64") -> Rec:
+                    scale: float, causal: bool = False, prescaled: bool = False, q_lo=None, k_lo=None, vt_lo=None,
+                    out_f32: bool = False, name: str = "flash_attn64") -> Rec:
+    """``q_lo`` / ``k_lo`` (/ ``vt_lo``): low halves of hi + lo operand pairs, same strides as q / k / vt (edtr_hip.h: split operands)."""
     p = L.AttnParams()
     p.dtype, p.B, p.H, p.Nq, p.Nk = dt_code(dtype), B, H, Nq, Nk
     p.q, p.q_bs, p.q_ld = ptr(q), q_bs, q_ld
@@ -171,8 +173,13 @@ def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_l
     p.scale = scale
     p.causal = int(causal)
     p.q_prescaled = int(prescaled)
+    p.q_lo, p.k_lo, p.vt_lo, p.out_f32 = ptr(q_lo), ptr(k_lo), ptr(vt_lo), int(out_f32)
     flops = 4.0 * B * H * Nq * Nk * 64
-    return Rec(L.load().edtr_flash_attn64, (ct.byref(p),), (p, q, k, vt, out), name, flops)
+    # algorithmic HBM bytes: Q and O once, K and V^T once per (image, head)
+    nbytes = 2.0 * B * H * 64 * (2 * Nq + 2 * Nk)
+    rec = Rec(L.load().edtr_flash_attn64, (ct.byref(p),), (p, q, k, vt, out, q_lo, k_lo, vt_lo), name, flops, nbytes)
+    rec.tag = f"attn B{B} H{H} Nq{Nq} Nk{Nk}" + (" causal" if causal else "") + (" split" if q_lo is not None else "") + (" pv" if vt_lo is not None else "")
+    return rec
 
 
 def make_window_attn(*, dtype, qkv, ld_qkv, out, ld_out, B, H, W, heads, head_dim, c_pad, shift, bias, labels, scale,

@@ -222,6 +222,15 @@ typedef struct edtr_attn_params {
     int32_t q_prescaled;            /* nonzero: the q.k products already carry scale*log2(e) (the projection GEMMs that produced q
                                        and/or k applied it in fp32 before their single 16-bit rounding), so the kernel evaluates
                                        exp2(q.k - max) directly and ignores `scale`: one v_exp and no multiply per score */
+    /* Split operands (ABI 7; the robust parity mode): q_lo / k_lo (both or neither) and optionally vt_lo hold the LOW halves of
+     * hi + lo fp16 (bf16) pairs, laid out like q / k / vt (same strides): x = hi + lo to ~22 bits, as edtr_split_operand writes
+     * them ([hi | lo] columns: lo = hi + C elements).  The products then run as three MFMA products each,
+     *   S = Qh Kh^T + Ql Kh^T + Qh Kl^T,   O = Ph Vh + Pl Vh + Ph Vl  (P split in registers; PV only with vt_lo),
+     * which removes the 16-bit rounding of the attention operands — on sharp attention (tests/golden/heavy.npz) the rounding
+     * of q and k alone costs 2.7e-3 of a denoiser evaluation (tests/heavy_attention_budget.py).  out_f32 != 0 (split mode only):
+     * fp32 output (o_ld / o_bs in floats).  replaces: the same F.scaled_dot_product_attention call in fp32. */
+    const void* q_lo; const void* k_lo; const void* vt_lo;
+    int32_t out_f32;
 } edtr_attn_params;
 
 int edtr_flash_attn64(const edtr_attn_params* p, edtr_stream_t stream);

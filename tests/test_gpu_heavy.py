@@ -15,18 +15,24 @@ pytestmark = pytest.mark.gpu
 
 USED = [50, 100, 150, 200]
 # mode -> (compute dtype, precision, tolerances).  This network amplifies a perturbation ~10-30x more than the smooth set
-# (sharper attention: the fp32 oracle itself is 6.6e-5 from the reference here, 2e-5 there), and the attention operands are
-# fp16 in EVERY mode (as in the reference's own fp16-autocast GPU path), which is what bounds the parity modes on it.
+# (sharper attention: the fp32 oracle itself is 6.6e-5 from the reference here, 2e-5 there).  Rounds 1-3: the attention operands
+# were ONE fp16 part in every mode, and that bounded the parity modes (high: eps 2.6e-3).  Round 4:
+# tests/heavy_attention_budget.py shows on the CPU oracle that the fp16 rounding of q and k ALONE costs 2.7e-3 here (p 4.8e-4,
+# v 4.4e-4); the high mode now feeds the attention kernels hi + lo fp16 pairs (three MFMA products per product, edtr_hip.h q_lo /
+# k_lo / vt_lo): eps 2.6e-3 -> 6.6e-5 — the north-star 1e-3 holds on this weight set too (sd21_eps), with the fp32 oracle's
+# own distance as the floor.  The mixed mode keeps one-part attention operands (its projections write fp16 directly): it is the
+# FAST parity mode, validated on the smooth set; EDTR_AMD_ATTN_SPLIT=1 buys the split there at the cost of throughput.
 # Tolerances.  The VAE and single-evaluation figures are stable and held to <= 1.5 x measured; the 4-step PIPELINE on this
 # weight set is not: two builds of the same arithmetic (separate q / k / v^T launches vs the fused projection, v_rsq vs
 # 1 / sqrt in GroupNorm) moved its fp16 error from 6.9e-3 / 1.08e-2 to 1.37e-2 / 2.3e-2 (latent / image) — the amplification
-# is that of the network, not of a kernel — so the pipeline latents / images get 2.5 x the larger measurement.
-#   tiny pipeline (z_pre, z, img):  bf16 9.0e-3 5.9e-2 9.4e-2 | fp16 1.1e-3 1.4e-2 2.3e-2 | mixed 4.4e-4 1.03e-2 1.53e-2 | high 4.8e-5 2.2e-3 3.3e-3
-#   SD-2.1 widths (eps, vae_z, vae_dec): bf16 6.0e-2 1.1e-2 1.1e-2 | fp16 5.7e-3 1.4e-3 1.4e-3 | mixed 3.9e-3 4.7e-4 4.1e-4 | high 2.6e-3 1.2e-4 1.9e-4
-MODES = {"bf16": (torch.bfloat16, "fast", dict(z_pre=1.35e-2, z=1.5e-1, img=2.4e-1, eps=9e-2, vae=1.65e-2)),
-         "fp16": (torch.float16, "fast", dict(z_pre=1.65e-3, z=3.5e-2, img=5.8e-2, eps=8.5e-3, vae=2.1e-3)),
-         "mixed": (None, "mixed", dict(z_pre=6.6e-4, z=2.6e-2, img=3.9e-2, eps=5.8e-3, vae=7e-4)),
-         "high": (None, "high", dict(z_pre=7.2e-5, z=5.5e-3, img=8.3e-3, eps=3.9e-3, vae=2.9e-4))}
+# is that of the network, not of a kernel — so the pipeline latents / images get 2 - 2.5 x the measurement.
+# Measured (round 4):
+#   tiny pipeline (z_pre, z, img):  bf16 9.0e-3 6.2e-2 1.16e-1 | fp16 1.1e-3 1.34e-2 2.1e-2 | mixed 5.1e-4 3.4e-3 5.3e-3 | high 4.8e-5 7.0e-4 1.1e-3
+#   SD-2.1 widths (eps, vae_z, vae_dec): bf16 6.6e-2 1.2e-2 1.1e-2 | fp16 5.4e-3 1.3e-3 1.4e-3 | mixed 4.3e-3 5.7e-4 4.6e-4 | high 6.6e-5 1.2e-4 1.9e-4
+MODES = {"bf16": (torch.bfloat16, "fast", dict(z_pre=1.35e-2, z=1.5e-1, img=2.5e-1, eps=9.9e-2, vae=1.75e-2)),
+         "fp16": (torch.float16, "fast", dict(z_pre=1.65e-3, z=3.4e-2, img=5.3e-2, eps=8.2e-3, vae=2.1e-3)),
+         "mixed": (None, "mixed", dict(z_pre=7.6e-4, z=8.5e-3, img=1.35e-2, eps=6.4e-3, vae=8.6e-4)),
+         "high": (None, "high", dict(z_pre=7.2e-5, z=1.5e-3, img=2.4e-3, eps=1.0e-4, vae=2.9e-4))}
 
 def dev():
     if not torch.cuda.is_available():

@@ -291,6 +291,48 @@ def test_flash_attn64(dtype, B, H, Nq, Nk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Nq,Nk,prescaled,pipeline_layout", [
+    (2, 5, 4096, 77, True, True),       # the 64x64-latent cross-attention: two 32-query blocks per wave, keys 77 of 128
+    (8, 20, 256, 77, True, True),       # 16x16 latents: one block per wave
+    (3, 2, 1000, 128, False, False),    # Nk = 128 exactly (all four key blocks), ragged Nq, unscaled scores
+    (1, 3, 70, 64, False, False),       # one key tile; a workgroup whose last waves have no block
+    (2, 1, 33, 1, True, False),         # a single key: softmax == 1
+    (1, 20, 16384, 33, True, False),    # four blocks per wave (the per-workgroup walk), keys end inside the second block of 32
+])
+def test_flash_attn64_small_nk_resident_kv(dtype, B, H, Nq, Nk, prescaled, pipeline_layout):
+    """Nk <= 128 (the cross-attention over the 77 context tokens, reference model/attention.py:171-203): K / V^T resident in LDS,
+    two-pass softmax in registers.  pipeline_layout: keys are a column slice of a wider [B * Nk, sumC] matrix and V^T a row slice
+    of [B, sumC, ldv], as nets.emit_context_kv lays them out; EDTR_ATTN_SMALLK=0 is the generic kernel (A/B)."""
+    ops = _ops()
+    d = dev()
+    Cc = H * 64
+    sumC = Cc * 2 + 64 if pipeline_layout else Cc
+    off = 64 if pipeline_layout else 0
+    q = rnd((B, Nq, Cc), 230, 0.42 if prescaled else 1.0).to(dtype)
+    kall = rnd((B, Nk, sumC), 231, 0.42 if prescaled else 1.0).to(dtype)
+    vall = rnd((B, Nk, sumC), 232).to(dtype)
+    ldv = ops.round_up(Nk, 8)
+    vt = torch.zeros((B, sumC, ldv), dtype=dtype)
+    vt[:, :, :Nk] = vall.transpose(1, 2)
+    kd, vtd = kall.to(d), vt.to(d)
+    out = torch.full((B, Nq, Cc), float("nan"), dtype=dtype, device=d)
+    scale = 0.125
+    ops.launch(ops.make_flash_attn(dtype=dtype, q=q.to(d), k=kd[:, :, off:off + Cc], vt=vtd[:, off:off + Cc], out=out, B=B, H=H, Nq=Nq, Nk=Nk,
+                                   q_bs=Nq * Cc, q_ld=Cc, k_bs=Nk * sumC, k_ld=sumC, vt_bs=sumC * ldv, vt_ld=ldv, o_bs=Nq * Cc,
+                                   o_ld=Cc, scale=scale, prescaled=prescaled))
+    torch.cuda.synchronize()
+    k, v = kall[:, :, off:off + Cc], vall[:, :, off:off + Cc]
+
+    def heads(t):
+        return t.float().reshape(B, -1, H, 64).transpose(1, 2)
+
+    logits = heads(q) @ heads(k).transpose(-1, -2) * (math.log(2.0) if prescaled else scale)
+    ref = (torch.softmax(logits, dim=-1) @ heads(v)).transpose(1, 2).reshape(B, Nq, Cc)
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref) < TOL[dtype] * 1.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,Nq,Nk,growth", [(1, 5, 4096, 4096, 1.0),     # the hot shape: 64x64 latents, 5 heads (large-N kernel v3)
                                              (2, 3, 2100, 512, 1.0),      # ragged Nq (store predicate), 2 unrolled trips
                                              (1, 2, 2048, 1024, 5.0),     # later keys beat the first tile's row maximum by > 14 octaves

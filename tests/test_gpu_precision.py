@@ -220,3 +220,53 @@ def test_tiled_paths_meet_the_north_star(golden_dir):
     e_z = rel(z, g2["z_tiled"])
     print(f"\n[high precision tiled] tiled vae enc {e_enc:.2e} dec {e_dec:.2e}; latent-tiled sampler {e_z:.2e}")
     assert e_enc < 5e-5 and e_dec < 5e-5 and e_z < 5.5e-5      # measured 3.0e-5 / 1.7e-5 / 3.4e-5
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,causal,sharp", [(2, 3, 300, 300, False, 1.0), (1, 2, 1024, 77, False, 4.0), (1, 5, 256, 256, False, 8.0),
+                                                    (2, 1, 130, 130, True, 2.0), (1, 2, 64, 64, False, 1.0)])
+def test_flash_attention_split_operands(B, H, Nq, Nk, causal, sharp):
+    """ABI 7, the robust parity mode's attention: q / k (and p / v) as fp16 hi + lo pairs, three MFMA products per product
+    (include/edtr_hip.h: q_lo / k_lo / vt_lo), against fp64 attention of the UNROUNDED fp32 operands.  ``sharp`` scales the logits
+    (sharp softmax is where the fp16 rounding of q and k hurts: tests/heavy_attention_budget.py).  Errors must order as
+    one part > q, k split > everything split, and the fully split form must reach fp32-arithmetic accuracy."""
+    from edtr_amd import ops
+    d = dev()
+    Cc = H * 64
+    g = torch.Generator().manual_seed(11)
+    q32 = torch.randn((B * Nq, Cc), generator=g) * sharp
+    k32 = torch.randn((B * Nk, Cc), generator=g)
+    v32 = torch.randn((B * Nk, Cc), generator=g)
+    ldv = ops.round_up(Nk, 8)
+    vt32 = torch.zeros((B * Cc, ldv))
+    vt32.view(B, Cc, ldv)[:, :, :Nk] = v32.view(B, Nk, Cc).transpose(1, 2)
+    dt = torch.float16
+
+    def pair(x):            # [rows, C] fp32 -> [rows, 2C] fp16 = [hi | lo] on the device through the product's own kernel
+        y = torch.empty((x.shape[0], 2 * x.shape[1]), dtype=dt, device=d)
+        ops.launch(ops.make_split_operand(src=x.to(d), rows=x.shape[0], C=x.shape[1], dst=y, fmt=ops.F32H[2]))
+        return y
+
+    q2, k2, v2 = pair(q32), pair(k32), pair(vt32)
+    qf, kf, vf = (t.double().reshape(B, -1, H, 64).transpose(1, 2) for t in (q32, k32, v32))
+    logits = qf @ kf.transpose(-1, -2) / 8.0
+    if causal:
+        logits = logits + torch.triu(torch.full((Nq, Nk), float("-inf"), dtype=torch.float64), 1)
+    want = (torch.softmax(logits, dim=-1) @ vf).transpose(1, 2).reshape(B * Nq, Cc)
+    errs = {}
+    for mode in ("one", "qk", "qkpv"):
+        out = torch.full((B * Nq, Cc), float("nan"), dtype=torch.float32 if mode == "qkpv" else dt, device=d)
+        kw = {}
+        if mode != "one":
+            kw.update(q_lo=q2[:, Cc:], k_lo=k2[:, Cc:])
+        if mode == "qkpv":
+            kw.update(vt_lo=v2[:, ldv:], out_f32=True)
+        ops.launch(ops.make_flash_attn(dtype=dt, q=q2[:, :Cc], k=k2[:, :Cc], vt=v2[:, :ldv], out=out, B=B, H=H, Nq=Nq, Nk=Nk,
+                                       q_bs=Nq * 2 * Cc, q_ld=2 * Cc, k_bs=Nk * 2 * Cc, k_ld=2 * Cc, vt_bs=Cc * 2 * ldv, vt_ld=2 * ldv,
+                                       o_bs=Nq * Cc, o_ld=Cc, scale=0.125, causal=causal, **kw))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all(), mode
+        errs[mode] = rel(out.float(), want)
+    print(f"\n[split attention B{B} H{H} {Nq}x{Nk} sharp {sharp}] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert errs["qkpv"] < 3e-6, errs                       # fp32 accumulation + fp32 softmax only
+    assert errs["qk"] < 4.5e-4, errs                       # p and v carry one fp16 rounding each
+    assert errs["one"] > errs["qk"] > errs["qkpv"], errs
