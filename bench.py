@@ -684,10 +684,11 @@ def kernel_of(name: str) -> str:
 
 
 # relative-L2 tolerances against the fp32 reference at full size, each <= 1.5 x its measured value (bf16 6.2e-3 /
-# 1.2e-2, fp16 8.6e-4 / 1.5e-3, high 7.2e-5 / 7.4e-5) so that a 2x regression of a mode's numerics fails the run; the north-star
+# 1.2e-2, fp16 8.6e-4 / 1.5e-3, mixed 5.4e-4 / 6.0e-4, high — with split attention operands, round 4 — 2.9e-5 / 1.2e-5 / 2.4e-5
+# for z_pre / latent / image over the three workloads) so that a 2x regression of a mode's numerics fails the run; the north-star
 # 1e-3 is what the parity modes (mixed, high) must additionally meet
 TOLERANCE = {"bf16": {"z_pre": 1.75e-2, "latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"z_pre": 2.2e-3, "latent": 1.3e-3, "image": 2.3e-3},
-             "mixed": {"z_pre": 1e-3, "latent": 8.5e-4, "image": 9e-4}, "high": {"z_pre": 1.2e-4, "latent": 1.2e-4, "image": 1.5e-4}}
+             "mixed": {"z_pre": 1e-3, "latent": 8.2e-4, "image": 9e-4}, "high": {"z_pre": 4.4e-5, "latent": 1.8e-5, "image": 3.6e-5}}
 NORTH_STAR = 1e-3
 # max-norm bound as a multiple of the L2 tolerance: measured max / L2 ratios of the shipped modes are 0.9 - 1.3 (the peak of a latent / image is a few times its RMS)
 # (profiles/r04/maxnorm_measured.log), a defect in one 16 x 16 tile of a 512 x 512 image with O(1) errors gives > 100

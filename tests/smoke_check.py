@@ -36,8 +36,9 @@ def smoke(verbose: bool = True) -> dict:
     out = {}
     # the parity modes ("mixed": fp32 stream, fp16 1-3-part products; "high": bf16 split-3 everywhere) must meet the north-star
     # 1e-3 — and are held, like the two 16-bit storage modes, to 1.5 x their measured errors
-    # (measured: mixed 4.7e-4 / 5.2e-4, high 7.5e-5 / 7.6e-5, fp16 7.6e-4 / 1.45e-3, bf16 5.8e-3 / 1.12e-2; each bound <= 1.5 x)
-    for mode, dtype, tol in (("mixed", None, 7.8e-4), ("high", None, 1.15e-4), ("fast", torch.float16, 2.2e-3), ("fast", torch.bfloat16, 1.7e-2)):
+    # (measured: mixed 5.7e-4 / 6.4e-4, high 1.3e-5 / 3.4e-5 (round 4: split attention operands), fp16 7.6e-4 / 1.45e-3,
+    #  bf16 5.8e-3 / 1.12e-2; each bound <= 1.5 x)
+    for mode, dtype, tol in (("mixed", None, 9.5e-4), ("high", None, 5.1e-5), ("fast", torch.float16, 2.2e-3), ("fast", torch.bfloat16, 1.7e-2)):
         cldm = build_synthetic_cldm(cfg, dev, dtype, sds, precision=mode)
         diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
         sampler = SpacedSampler(diffusion.betas)

@@ -11,8 +11,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 NORTH_STAR = 1e-3
-# what the mode is held to: 1.5 x its largest measured error (per-step eps 2.1e-4; latents / images 2e-5 .. 7.5e-5)
-HIGH_TOL = 3.2e-4
+# what the mode is held to: 1.5 x its largest measured error (round 4, attention operands split: per-step eps 3.0e-5; latents /
+# images 1e-5 .. 2.9e-5; before the split: eps 2.1e-4, latents / images up to 7.5e-5)
+HIGH_TOL = 4.5e-5
 USED = [50, 100, 150, 200]
 
 
@@ -186,7 +187,7 @@ def test_det512_full_size_meets_the_north_star(golden_dir):
             "img": rel(img[:, :, 1::4, 2::4], g["img_samples"].astype(np.float32))}
     print(f"\n[high precision det512 full size] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     # the image golden is stored as fp16 samples (rounding 2^-11 relative per sample -> 2.8e-4 rms): budget it
-    assert errs["z_pre"] < 4e-5 and errs["z"] < 1.1e-4 and errs["img"] < 1.1e-4, errs      # measured 1.8e-5 / 7.2e-5 / 7.3e-5
+    assert errs["z_pre"] < 2.8e-5 and errs["z"] < 1.4e-5 and errs["img"] < 3.1e-5, errs      # measured 1.8e-5 / 9.2e-6 / 2.0e-5 (round 3: 7.2e-5 / 7.3e-5)
 
 
 def test_tiled_paths_meet_the_north_star(golden_dir):
