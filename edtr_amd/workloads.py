@@ -77,7 +77,7 @@ def restore_pass(cldm, diffusion, sampler, inp: Inputs, workload: str, untiled_f
         def run():
             return sampler.sample(model=cldm, device=dev, steps=50, batch_size=B, x_size=(4, h, w), cond=cond, uncond=None,
                                   cfg_scale=1.0, x_T=inp.noises[0], progress=False)
-        if inp.step_noises:
+        if inp.step_noises and inject:
             with injected_noise(inp.step_noises):
                 z = run()
         else:

@@ -372,3 +372,40 @@ def test_params_fingerprint_sees_a_replaced_parameter_object():
     assert params_fingerprint(t) != fp2
     other = ParamTree([("x.weight", (2, 2))])                                          # another tree: this one's fingerprint is unchanged
     assert other is not None and params_fingerprint(t) == params_fingerprint(t)
+
+
+def test_emitted_programs_of_the_precision_modes():
+    """The launch programs the three precision modes emit for one ControlNet + UNet evaluation (tiny config, built on the CPU: no
+    launch happens) carry the round-4 structure: fast = no operand-formation launches at all; mixed = the fp32 stream's one-part
+    consumers (zero / down / upsample convolutions) read fp16 mirrors written by their producers' epilogues (` m16`), the 1x1 skip
+    convolutions run the weights-exact two-part product on the mirror (` 2w`), conv1 -> GroupNorm -> conv2 and ff.out -> proj_out
+    stay 16-bit, and only the few multi-part stream carriers (conv_in, time path) still form operands by a launch; high = every
+    attention runs on hi + lo operand pairs (`attn.split` launches, ` split pv` kernels)."""
+    import collections
+    from edtr_amd import synth
+    from edtr_amd.model.cldm import CldmEngine
+    from edtr_amd.testing import build_synthetic_cldm
+    cfg = synth.tiny_config()
+    progs = {}
+    for prec in ("fast", "mixed", "high"):
+        cldm = build_synthetic_cldm(cfg, "cpu", torch.bfloat16, precision=prec)
+        eng = CldmEngine(cldm, 2, 32, 32, 77)
+        progs[prec] = eng.step_prog.recs
+    names = {k: collections.Counter(r.name for r in v) for k, v in progs.items()}
+    by = lambda prec, name: [r for r in progs[prec] if r.name == name]
+    # fast: nothing but the network's own launches
+    assert names["fast"]["split_operand"] == 0 and names["fast"]["attn.split"] == 0
+    assert not any(" m16" in r.tag or " 2w" in r.tag for r in progs["fast"])
+    # mixed
+    assert by("mixed", "res.skip1x1") and all(" 2w" in r.tag for r in by("mixed", "res.skip1x1"))
+    assert names["mixed"]["split_operand"] <= 8 < names["high"]["split_operand"]           # conv_in x 2 + the time path
+    assert sum(" m16" in r.tag for r in progs["mixed"]) >= len(by("mixed", "zero_conv"))   # every block output that a zero conv taps
+    assert all(" f32" not in r.tag for r in by("mixed", "res.conv1")), "conv1's output is branch-internal: fp16"
+    assert all(" f32" in r.tag for r in by("mixed", "res.conv2")), "conv2 writes the fp32 residual stream"
+    assert all(" f32" not in r.tag for r in by("mixed", "ff.out")) and all(" f32" in r.tag for r in by("mixed", "st.proj_out"))
+    assert names["mixed"]["attn.split"] == 0
+    # high: three launches cut q / k / v^T of a self-attention, one cuts q of a cross-attention (k / v^T of the context once per prompt)
+    n_attn = len(by("high", "flash_attn64"))
+    assert n_attn and names["high"]["attn.split"] == n_attn // 2 * 3 + n_attn // 2
+    assert all(" split pv" in r.tag for r in by("high", "flash_attn64"))
+    assert len(progs["fast"]) < len(progs["mixed"]) < len(progs["high"])

@@ -22,6 +22,10 @@ import sys
 def family(name: str) -> str:
     n = name.lower()
     if "flash_attn" in n:
+        if "smallk" in n:
+            return "flash_attn_smallk"
+        if "split" in n:
+            return "flash_attn_split"
         return "flash_attn_v3" if "v3" in n else ("flash_attn_v2" if "v2" in n else "flash_attn_v1")
     if "igemm" in n or "splitk_reduce" in n:
         return "igemm"
