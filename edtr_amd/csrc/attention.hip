@@ -46,6 +46,40 @@ __device__ __forceinline__ void dma16(uint32_t voff, const u32x4& srd, uint32_t 
                  : "memory");
 }
 
+// ---- coalesced store of a wave's O tile [32 queries][64 channels] (round 4) ------------------------------------------------
+// The accumulator layout of O^T = V^T P^T gives lane (query l31, half lh) the channels db*32 + 8g + 4*lh + (0..3): written straight
+// to memory that is 8 stores of 8 bytes per lane, each instruction touching 32 different rows with two adjacent 8-byte pieces
+// per row.  Measured on the cross-attention launches (tools/exp/r04_attn_shapes.py with the stores compiled out): 7 of 18 us at
+// 64x64 latents, 3 of 10.7 at 32x32 — the L2 sees 16-byte partial-line writes at its request rate, not 21 MB at its bandwidth.
+// Here the wave transposes the tile through a private 4.5 KiB LDS slab (144-byte rows: 16-byte aligned for the read-back) and
+// stores 16 bytes per lane with 8 lanes covering one row's 128 contiguous bytes: 4 store instructions of 8 whole row segments each.
+constexpr int OPITCH = 144, OSLAB = 32 * OPITCH;
+
+template <typename T, typename ACC>
+__device__ __forceinline__ void store_o_tile(char* slab, const ACC& o0, const ACC& o1, float inv, uint16_t* out_rows, int64_t o_ld,
+                                             int q0, int Nq, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint2 v;
+        v.x = pack2<T>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv);
+        v.y = pack2<T>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(slab + l31 * OPITCH + (8 * g + 4 * lh) * 2) = v;
+        v.x = pack2<T>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv);
+        v.y = pack2<T>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(slab + l31 * OPITCH + (32 + 8 * g + 4 * lh) * 2) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same wave: the LDS queue keeps the order, the compiler must too
+    const int r8 = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 8 + r8;
+        const U4 v = *reinterpret_cast<const U4*>(slab + row * OPITCH + ch * 16);
+        if (q0 + row < Nq) stg16(out_rows + (int64_t)row * o_ld + ch * 8, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slab may be rewritten by this wave's next tile
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_attn_params p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [2 buffers][K tile | V^T tile]
@@ -198,21 +232,13 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
         asm volatile("" ::: "memory");
     }
 
-    // ---- normalise and store: lane (q, half) holds d = db*32 + 8g + 4*half + (0..3) in regs 4g..4g+3
+    // ---- normalise and store: lane (q, half) holds d = db*32 + 8g + 4*half + (0..3) in regs 4g..4g+3; the tile goes through a
+    // wave-private slab of the (now dead: the loop's last barrier has passed) K / V^T buffers to whole-row stores
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q_ok) {
-        uint16_t* op = static_cast<uint16_t*>(p.out) + b * p.o_bs + (int64_t)q_row * p.o_ld + h * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v;
-                v.x = pack2<T>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
-                v.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = v;
-            }
-    }
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    store_o_tile<T>(smem + wave * OSLAB, o[0], o[1], inv, static_cast<uint16_t*>(p.out) + b * p.o_bs + (int64_t)q0 * p.o_ld + h * 64,
+                    p.o_ld, q0, p.Nq, lane);
 }
 
 
@@ -435,12 +461,16 @@ __global__ void __launch_bounds__(kThreads, 1) flash_attn64_split_kernel(const e
 // Here K and V^T of the (image, head) are staged ONCE per workgroup (two 64-key tiles each, 32 KiB of LDS, one wait, one barrier)
 // and stay resident while every wave walks its 32-query blocks: all <= 128 scores of a query sit in registers, so the softmax is
 // the plain two-pass form (max, then exp2 / sum) with no running state, and a wave's loop has no barrier at all — the next block's
-// Q fragments are requested before the current block's products.  Key blocks that lie entirely beyond Nk are skipped (77 keys:
+// Q rows are requested (coalesced) before the current block's products.  Key blocks that lie entirely beyond Nk are skipped (77 keys:
 // 3 of 4 blocks of 32; 5 of 8 key steps of the P.V product).
+// Measured (tools/exp/r04_attn_shapes.py, batch 8, pipeline layout, profiles/r04/attn_shapes.log): 18.3 -> 15.3 us at 64x64 latents,
+// 10.8 -> 9.3 at 32x32, 7.8 -> 6.9 at 16x16 — most of it from the whole-row stores (store_o_tile) and the coalesced Q loads, little
+// from the resident K / V^T: the launch is bound by ~2000 issue cycles per 32-query block (5120 blocks on 1024 SIMDs) plus the
+// first tiles' flight, not by its 42 MB of operands.
 // =====================================================================================================================
 template <typename T>
 __global__ void __launch_bounds__(kThreads, 2) flash_attn64_smallk_kernel(const edtr_attn_params p, int blocks_per_wg) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [key tile t][K tile | V^T tile]
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 4 * OSLAB];  // [key tile t][K tile | V^T tile], then a store slab per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
@@ -475,17 +505,31 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_smallk_kernel(const 
             }
         }
     }
-    auto load_q = [&](int blk, U4 (&qf)[4]) {
-        const int q_row = blk * 32 + l31;
+    // Q rows are LOADED coalesced (lane = (row, 16-byte chunk): 8 lanes cover a row's 128 bytes, one block ahead of its use) and
+    // turned into the MFMA's B-operand fragments — lane (query l31, half lh) holds Q[q][16 ks + 8 lh .. +7] — through the wave's
+    // store slab; the fragment layout read straight from memory is 32 rows x 32-byte pieces per instruction (2.7 of 18 us at
+    // 64x64 latents with the loads compiled out)
+    char* slab = smem + 4 * TILE_BYTES + wave * OSLAB;
+    const int r8 = lane >> 3, ch8 = lane & 7;
+    auto load_q = [&](int blk, U4 (&qr)[4]) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = zero16();
-            if (blk < nblk && q_row < p.Nq) qf[ks] = ldg16(qp + (int64_t)q_row * p.q_ld + ks * 16 + lh * 8);
+        for (int ps = 0; ps < 4; ++ps) {
+            const int q_row = blk * 32 + ps * 8 + r8;
+            qr[ps] = zero16();
+            if (blk < nblk && q_row < p.Nq) qr[ps] = ldg16(qp + (int64_t)q_row * p.q_ld + ch8 * 8);
         }
+    };
+    auto to_fragments = [&](const U4 (&qr)[4], U4 (&qf)[4]) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<U4*>(slab + (ps * 8 + r8) * OPITCH + ch8 * 16) = qr[ps];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const U4*>(slab + l31 * OPITCH + (2 * ks + lh) * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     U4 qf[4], qn[4];
     int blk = blk0 + wave;
-    load_q(blk, qf);
+    load_q(blk, qn);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -494,6 +538,7 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_smallk_kernel(const 
     const int krd = swap23(l31);
     const int blk_end = min(blk0 + blocks_per_wg, nblk);
     for (; blk < blk_end; blk += 4) {
+        to_fragments(qn, qf);
         load_q(blk + 4 < blk_end ? blk + 4 : nblk, qn);                   // (out-of-range block index: zeros, no load)
         // ---- S^T[key][q]: up to 4 key blocks of 32
         f32x16 s[4];
@@ -556,21 +601,7 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_smallk_kernel(const 
             }
         }
         const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
-        const int q_row = blk * 32 + l31;
-        if (q_row < p.Nq) {
-            uint16_t* op = ob + (int64_t)q_row * p.o_ld;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 v;
-                    v.x = pack2<T>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
-                    v.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-                    *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = v;
-                }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+        store_o_tile<T>(slab, o[0], o[1], inv, ob + (int64_t)blk * 32 * p.o_ld, p.o_ld, blk * 32, p.Nq, lane);
     }
 }
 
@@ -690,22 +721,11 @@ __global__ void __launch_bounds__(kThreads, 1) flash_attn64_v3_kernel(const edtr
 #endif
     const float invA = 1.0f / (la + __shfl_xor(la, 32, 64)), invB = 1.0f / (lb + __shfl_xor(lb, 32, 64));
     uint16_t* ob = static_cast<uint16_t*>(p.out) + b * p.o_bs + h * 64;
-    auto store = [&](int q_row, const float (&o0)[16], const float (&o1)[16], float inv) {
-        if (q_row >= p.Nq) return;
-        uint16_t* op = ob + (int64_t)q_row * p.o_ld;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 v;
-            v.x = pack2<T>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv);
-            v.y = pack2<T>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(op + 8 * g + 4 * lh) = v;
-            v.x = pack2<T>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv);
-            v.y = pack2<T>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(op + 32 + 8 * g + 4 * lh) = v;
-        }
-    };
-    store(q_rowA, oa0, oa1, invA);
-    store(q_rowB, ob0, ob1, invB);
+    // whole-row stores through a wave-private slab of the K / V^T ring (dead once every wave has left the tile loop)
+    __syncthreads();
+    const int q0 = qb * QB2 + wave * 64;
+    store_o_tile<T>(smem + wave * OSLAB, oa0, oa1, invA, ob + (int64_t)q0 * p.o_ld, p.o_ld, q0, p.Nq, lane);
+    store_o_tile<T>(smem + wave * OSLAB, ob0, ob1, invB, ob + (int64_t)(q0 + 32) * p.o_ld, p.o_ld, q0 + 32, p.Nq, lane);
 }
 
 }  // namespace

@@ -2213,6 +2213,9 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
+    // (PF = 0: the staged vectors are read inside the row iteration.  Round 4 measured PF = 1 — one iteration ahead, no spill at 246 - 250
+    //  VGPRs — in a same-device A/B of two builds: 108.69 / 108.42 vs 108.62 / 108.24 images/s, the K = 1152 convolutions 701 / 706 vs
+    //  699 / 695 us: no change, this epilogue is not bound by its LDS round trips; PF = 2 spills 107 - 128 registers)
     rows_phase<T, 256, 128, false, 512, SUBPIX ? 3 : !IMG8, SPITCH, false, 0>(p, stage, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);   // IMG8: rows are consecutive
     if (gn_acc) {
         // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
