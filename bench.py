@@ -166,7 +166,7 @@ def main() -> None:
 
     # ---- synthetic inputs for the GLOBAL batch, sliced per rank (results independent of the GPU count)
     GB = B * world
-    inp = workloads.make_inputs(args.workload, ctx_dim, dev, B, S, rank, world, with_step_noises=(s50 and world == 1))
+    inp = workloads.make_inputs(args.workload, ctx_dim, dev, B, S, rank, world, with_step_noises=s50)     # (the untimed parity pass injects them: rank 0 starts at image 0 = the golden's image)
     untiled_forward = cldm.forward
 
     def one_pass(inject=False):

@@ -285,21 +285,18 @@ __device__ __forceinline__ void vt_store(const edtr_igemm_params& p, const float
 template <typename T, int BM, int BNO, bool GEGLU, int THREADS = 256, int PATCH16 = 0, int PITCH = BNO, int FOLD = 3, int PF = 0,
           typename Hook = NoHook>
 __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const float* stage, int m0, int no0, int n_out,
-                                           int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8], Hook before_publish = Hook(),
-                                           int tid_in = -1) {
+                                           int64_t o_zoff, bool gn_acc, float (&gs)[8], float (&gq)[8], Hook before_publish = Hook()) {
     // VPR column groups; RPI rows per iteration (threads beyond RPI * VPR idle when VPR does not divide the block)
     constexpr int VPR = BNO / 8, RPI = THREADS / VPR, ITER = (BM + RPI - 1) / RPI;
     constexpr bool EXACT = (THREADS % VPR == 0) && (BM % RPI == 0);
-    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;        // (tid_in: the persistent kernels pass an opaque copy, see tile 18)
-    // staged row -> output row.  PATCH16 = 1: the rows are the pixels of a 16-pixel-wide patch (row ml = 16 y + x), m0 = its first
-    // pixel; 2: two strips of 4 pixel rows that lie 8 rows apart in the image (tile 18: staged rows 0..63 = pixel rows 0..3, staged
-    // rows 64..127 = pixel rows 8..11 of the 16 x 16 patch whose strip starts at m0)
+    const int tid = (int)threadIdx.x;
+    // staged row -> output row.  PATCH16 = 1: the rows are the pixels of a 16-pixel-wide patch (row ml = 16 y + x), m0 = its first pixel
     // 3: one output PHASE of the sub-pixel upsample convolution — staged row ml = 16 y + x is SOURCE pixel (y, x) of a 16 x 16 source
     // block, its output pixel lies at (2 y, 2 x) from m0 (the phase's first output pixel)
     auto row_m = [&](int ml) {
         if constexpr (PATCH16 == 0) return m0 + ml;
         else if constexpr (PATCH16 == 3) return m0 + 2 * ((ml >> 4) * p.OW + (ml & 15));
-        else return m0 + ((ml >> 4) + (PATCH16 == 2 ? 4 * (ml >> 6) : 0)) * p.OW + (ml & 15);
+        else return m0 + (ml >> 4) * p.OW + (ml & 15);
     };
     const int n8 = tid % VPR, r0 = tid / VPR;
     const int n = no0 + n8 * 8;
@@ -356,7 +353,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
     }
     bool rv_rows = false;                     // time-embedding row differs between this tile's rows
     if (p.rowvec) {
-        const int m_last = PATCH16 == 3 ? m0 + 30 * p.OW + 30 : PATCH16 ? m0 + (PATCH16 == 2 ? 11 : 15) * p.OW + 15 : min(m0 + BM, p.M) - 1;      // (PATCH16: the patch's / strip pair's last pixel or a later one of the same image)
+        const int m_last = PATCH16 == 3 ? m0 + 30 * p.OW + 30 : PATCH16 ? m0 + 15 * p.OW + 15 : min(m0 + BM, p.M) - 1;      // (PATCH16: the patch's last pixel or a later one of the same image)
         const int img0 = m0 / p.rows_per_image;
         rv_rows = (m_last / p.rows_per_image) != img0;
         if (!rv_rows && n_ok) {
@@ -1555,8 +1552,11 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
     // ---- epilogue: rows of A half `h` (128 x 256 fp32 = the whole 128 KiB) per pass
     float* stage = reinterpret_cast<float*>(smem);
     const bool gn_acc = p.gn_partial != nullptr;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    // (two passes written as two calls of one generic lambda with a compile-time pass index: as a `#pragma unroll` loop the body —
+    //  rows_phase and its specialised row loops — outgrew the unroller in round 4, the loop stayed rolled, `acc[h]` became a
+    //  dynamically indexed array and the 128 accumulators went through 528 bytes of scratch per lane)
+    auto epilogue_pass = [&](auto HPc) {
+        constexpr int h = decltype(HPc)::value;
 #pragma unroll
         for (int bh = 0; bh < 2; ++bh)
 #pragma unroll
@@ -1591,7 +1591,9 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
             }
             __syncthreads();
         }
-    }
+    };
+    epilogue_pass(H0{});
+    epilogue_pass(H1{});
 }
 
 template <typename T, bool SPATIAL>
@@ -2268,495 +2270,6 @@ int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Persistent halo tile (tile = 18, round 3): the halo kernel's 16 x 16-pixel unit with the set-up and the first slices' flight taken
-// off the critical path.  Stamps of tile 16 on the K = 1152 convolutions of the VAE's 512 x 512 level (8192 units, one workgroup
-// per CU): address set-up 2.6k + first patch / weight slices 3.2k + loop 22.7k + epilogue 7.4k cycles per unit — with one workgroup
-// per CU nothing runs under the first 5.8k.  Here a workgroup walks units u, u + G, u + 2 G, ... (G = 256 workgroups) as ONE
-// continuous stream of chunks: in the LAST chunk of a unit the slots that would fetch "chunk c + 1" fetch the NEXT unit's chunk 0
-// (its patch in phases 2..7, its weight slices of taps 0 and 1 in the phases of taps 7 and 8), so the next unit's operands are in
-// LDS when the epilogue ends.  The per-lane offsets are switched to the next unit inside the last chunk (patch offsets before
-// phase 2, weight offsets before tap 7); the unit's coordinates are wave-uniform scalars.
-// LDS map (146 KiB): W0 W1 | PA | PB | W2 | tail.  A unit with an EVEN number of chunks starts in PA and ends in PB, so at the
-// epilogue PB, W2 and the tail are dead and contiguous: the fp32 staging (128 rows x 528 B = 66 KiB) lives there and the epilogue
-// runs in two passes of 8 pixel rows (the rows of the waves wr == pass), while PA / W0 / W1 hold the next unit's first operands.
-// Requires what tile 16 requires, plus: no upsample, an even number of 64-channel chunks, no split-K.  Same K order as tile 16:
-// bit-identical results.
-// ------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(512, 1) igemm_halo_pers_kernel(const edtr_igemm_params p) {
-    constexpr int PW = 18, PROW = PW * 128, NPP = 6;
-    constexpr int PATCHB = 48 * 1024, BTAP = 128 * BK * 2;
-    constexpr int PA = 2 * BTAP, PB = PA + PATCHB, W2 = PB + PATCHB;
-    constexpr int SPITCH = 132;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    EDTR_STAMP(0); EDTR_STAMP(6); EDTR_STAMP(5);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
-
-    const int tw = p.OW >> 4, tpi = tw * (p.OH >> 4);
-    const int nbm = (p.M / (p.OH * p.OW)) * tpi, nbn = (p.N + 127) / 128, nunits = nbm * nbn;
-    const int G = (int)gridDim.x;
-    const int Cin = p.C1, nchunk = Cin / BK;
-    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
-
-    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
-    const uint16_t* wp = static_cast<const uint16_t*>(p.w);
-    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const u32x4 srd_a = make_srd(a1);
-    const u32x4 srd_w = make_srd(wp);
-
-    // Unit walk without divisions: unit u -> XCD-contiguous index bid (as every kernel here), column tile fastest (the <= 4 column
-    // tiles of a patch are neighbours on one XCD: its L2 serves the patch); u -> u + G moves bid by G / 8 (G is a multiple of 8), so
-    // (tn, tm) and then (img, ty, tx) advance by constant steps with carries.  (The general tile_coords() with its divisions cost
-    // 3.9k cycles per unit here: SALU work fed by VALU reciprocals, once per unit on the critical path.)
-    struct Unit { int img, ty, tx, tn, tm; };
-    const int th = p.OH >> 4;
-    Unit cur;
-    {
-        const int u0 = (int)blockIdx.x, q = nunits >> 3, r = nunits & 7, x = u0 & 7, j = u0 >> 3;
-        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-        cur.tm = bid / nbn; cur.tn = bid - cur.tm * nbn;
-        cur.img = cur.tm / tpi;
-        const int tr = cur.tm - cur.img * tpi;
-        cur.ty = tr / tw; cur.tx = tr - cur.ty * tw;
-    }
-    const int dbid = G >> 3, dtm = dbid / nbn, dtn = dbid - dtm * nbn;
-    auto advance = [&](const Unit& c) {
-        Unit n = c;
-        n.tn += dtn;
-        int dm = dtm;
-        if (n.tn >= nbn) { n.tn -= nbn; ++dm; }
-        n.tm += dm;
-        n.tx += dm;
-        while (n.tx >= tw) { n.tx -= tw; ++n.ty; }
-        while (n.ty >= th) { n.ty -= th; ++n.img; }
-        return n;
-    };
-    auto unit_m0 = [&](const Unit& c) { return (c.img * p.OH + c.ty * 16) * p.OW + c.tx * 16; };
-
-    // per-lane staging geometry.  Patch piece q = wave + 8 j: LDS bytes [q KiB, +1 KiB) = pixels 8 q .. 8 q + 7, lane -> (pixel, slot);
-    // the (py, px) of a lane's pixel never changes, only the unit's origin does
-    uint32_t voff_p[NPP], voff_w[2];          // this unit's
-    uint32_t voff_pn[NPP], voff_wn[2];        // the next unit's (computed at the top of a unit, used in its last chunk, then they become voff_p / voff_w)
-    // (32-bit arithmetic: igemm_fast_addressable() keeps every byte offset below 4 GiB; the 64-bit form spilled)
-    // (the lane index goes through an opaque asm in every per-unit computation: whatever depends only on the lane is loop-invariant
-    //  in the persistent loop, the compiler hoists it to kernel entry and then spills it around the main loop — 64 spilled registers)
-    auto set_w = [&](uint32_t (&voff_w)[2], const Unit& c, bool valid) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (wave + 8 * j) * 8 + (ln >> 3), slot = ln & 7, n = c.tn * 128 + r;
-            const int ch = slot ^ ((r >> 1) & 7);
-            const uint32_t val = ((uint32_t)n * (uint32_t)p.ldw + (uint32_t)(ch * 8)) * 2u;
-            voff_w[j] = ((int)valid & (int)(n < nvalid)) ? val : kOobOffset;            // (bitwise &: no short-circuit branches)
-        }
-    };
-    auto set_p = [&](uint32_t (&voff_p)[NPP], const Unit& c, bool valid) {
-        const int sy0 = c.ty * 16 - 1, sx0 = c.tx * 16 - 1;
-        const uint32_t base = (uint32_t)(c.img * p.IH + sy0) * (uint32_t)p.IW + (uint32_t)sx0;     // (wraps for sy0 / sx0 = -1: the sum below is exact mod 2^32)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int j = 0; j < NPP; ++j) {
-            const int pp = ((wave + 8 * j) * 64 + ln) >> 3, py = (pp * 3641) >> 16, px = pp - py * PW, slot = ln & 7;     // pp / 18 for pp < 1024
-            const int iy = sy0 + py, ix = sx0 + px;
-            const int ok = (int)valid & (int)(pp < PW * PW) & (int)((uint32_t)iy < (uint32_t)p.IH) & (int)((uint32_t)ix < (uint32_t)p.IW);
-            const int ch = slot ^ (px & 7);
-            const uint32_t val = ((base + (uint32_t)(py * p.IW + px)) * (uint32_t)p.ld1 + (uint32_t)(ch * 8)) * 2u;
-            voff_p[j] = ok ? val : kOobOffset;
-        }
-    };
-    auto wslot = [](int buf) { return buf < 2 ? buf * BTAP : W2; };
-    auto stage_w = [&](uint32_t vo, int chunk, int tap, int j, int buf) {
-        dma16_buf(vo, srd_w, (uint32_t)((tap * Cin + chunk * BK) * 2), smem_base + wslot(buf) + (wave + 8 * j) * 1024);
-    };
-    auto stage_p = [&](uint32_t vo, int chunk, int j, int par) {
-        dma16_buf(vo, srd_a, (uint32_t)(chunk * BK * 2), smem_base + PA + par * PATCHB + (wave + 8 * j) * 1024);
-    };
-
-    f32x4 acc[8][4];
-    U4 afr[4], bfr[4];
-
-    int u = (int)blockIdx.x;
-    set_w(voff_w, cur, true);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) stage_w(voff_w[j], 0, t, j, t);
-    set_p(voff_p, cur, true);
-#pragma unroll
-    for (int j = 0; j < NPP; ++j) stage_p(voff_p[j], 0, j, 0);
-    Unit nxt = advance(cur);
-    set_w(voff_wn, nxt, u + G < nunits);
-    set_p(voff_pn, nxt, u + G < nunits);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    for (;;) {
-        EDTR_STAMP_T(12);
-        const int un = u + G;
-        const bool has_next = un < nunits;
-        const int m0 = unit_m0(cur), n0 = cur.tn * 128;
-        // the fragment read geometry (as tile 16), recomputed per unit from an opaque lane index: nothing lane-derived but the
-        // staging offsets lives across the epilogue.  (The NEXT unit's staging offsets voff_*n were computed in the previous unit's
-        // epilogue, in the steps where this wave's group has nothing to do; inside a phase they would lengthen it for both groups.)
-        EDTR_STAMP_T(15);
-        int a_rd[3], b_rd;
-        {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int l15 = ln & 15, lq = ln >> 4;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int px = l15 + kx;
-                a_rd[kx] = (wr * 8 * PW + px) * 128 + (((g * 4 + lq) ^ (px & 7)) << 4);
-            }
-            b_rd = tile_off(wc * 64 + l15, g * 4 + lq);
-        }
-        EDTR_STAMP_T(1);
-        // (the first unit's operands were waited for above, the later units' before their predecessor's epilogue touched global
-        //  memory: no vmcnt(0) here, it would wait for the epilogue's stores)
-        __builtin_amdgcn_s_barrier();
-        if (g == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run half a phase behind their SIMD partners
-        asm volatile("" ::: "memory");
-        EDTR_STAMP_T(2);
-
-        auto run_chunk = [&](int c, auto LASTc, auto FIRSTc) {
-            constexpr bool LAST = decltype(LASTc)::value, FIRST = decltype(FIRSTc)::value;    // FIRST: tap 0 starts from C = 0 (no zeroing pass)
-            const int par = c & 1;
-            const char* pa = smem + PA + par * PATCHB;
-            auto phase = [&](auto TAPc, auto SUBc) {
-                constexpr int TAP = decltype(TAPc)::value, SUB = decltype(SUBc)::value, KY = TAP / 3, KX = TAP % 3, BUF = TAP % 3;
-                constexpr int TAP2 = (TAP + 2) % 9, BUF2 = TAP2 % 3, PH = 2 * TAP + SUB;
-                constexpr bool WRAP = TAP + 2 >= 9;
-                if constexpr (SUB == 0) {
-                    const char* pb = smem + (BUF < 2 ? BUF * BTAP : W2) + b_rd;
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(pb + nb * 2048);
-                }
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) afr[mb] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (SUB * 4 + mb + KY) * PROW);
-                stage_w((LAST && WRAP) ? voff_wn[SUB] : voff_w[SUB], WRAP ? (LAST ? 0 : c + 1) : c, TAP2, SUB, BUF2);
-                if constexpr (PH >= 2 && PH < 2 + NPP) stage_p(LAST ? voff_pn[PH - 2] : voff_p[PH - 2], LAST ? 0 : c + 1, PH - 2, par ^ 1);
-                if constexpr (SUB == 1) {
-                    constexpr int INFLIGHT = 2 + (PH >= 2 && PH < 2 + NPP ? 1 : 0) + (PH - 1 >= 2 && PH - 1 < 2 + NPP ? 1 : 0);
-                    if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else if constexpr (INFLIGHT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        acc[SUB * 4 + mb][nb] = T::mfma16(bfr[nb], afr[mb], (FIRST && TAP == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[SUB * 4 + mb][nb]);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            };
-            auto tap_body = [&](auto TAPc) { phase(TAPc, IC<0>{}); phase(TAPc, IC<1>{}); };
-            tap_body(IC<0>{}); tap_body(IC<1>{}); tap_body(IC<2>{}); tap_body(IC<3>{}); tap_body(IC<4>{});
-            tap_body(IC<5>{}); tap_body(IC<6>{}); tap_body(IC<7>{}); tap_body(IC<8>{});
-        };
-        run_chunk(0, std::false_type{}, std::true_type{});              // (nchunk is even: the first chunk is never the last)
-        for (int c = 1; c + 1 < nchunk; ++c) run_chunk(c, std::false_type{}, std::false_type{});
-        run_chunk(nchunk - 1, std::true_type{}, std::false_type{});
-        if (g == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave groups
-        __syncthreads();
-        EDTR_STAMP_T(3);
-
-        // ---- epilogue in two passes; the next unit's first operands are landing in PA / W0 / W1 meanwhile.  Pass q takes the pixel-row
-        // blocks 4 q .. 4 q + 3 of EVERY wave (image rows 8 wr + 4 q + i): all eight waves work in both passes, and only half of the
-        // accumulators is live while the first pass's row phase runs (with "the rows of the waves wr == pass" all 128 were: spills)
-        float* stage = reinterpret_cast<float*>(smem + PB);
-        int tid_e = tid;
-        asm volatile("" : "+v"(tid_e));
-        const int l15e = tid_e & 15, lqe = (tid_e >> 4) & 3;
-        auto sptr = [&](int i, int nb) { return stage + ((wr * 4 + i) * 16 + l15e) * SPITCH + wc * 64 + nb * 16 + 4 * lqe; };
-        const bool gn_acc = p.gn_partial != nullptr;
-        float gs[8], gq[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-        // the unit after the next one: its staging offsets are computed in pass 1, by each wave group in the step where the other
-        // group works (group 1 while group 0 writes its blocks, group 0 while group 1 adds its own)
-        const Unit nn = advance(nxt);
-        const bool has_nn = un + G < nunits;
-        auto roll_offsets = [&]() {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) voff_w[j] = voff_wn[j];
-#pragma unroll
-            for (int j = 0; j < NPP; ++j) voff_p[j] = voff_pn[j];
-            set_w(voff_wn, nn, has_nn);
-            set_p(voff_pn, nn, has_nn);
-        };
-        // A pass = rows_phase with the whole K-half exchange as its pre-publish hook, so that the row phase's global loads (bias,
-        // time-embedding row, residual) are in flight under BOTH steps: group 0 writes its blocks, barrier, group 1 adds its own.  In
-        // pass 1 each group also computes the staging offsets of the unit after the next one while the other group works.  Pass 0
-        // ends its hook with the wait for the next unit's DMAs (issued in the last chunk; every later wait would also cover stores).
-        auto pass = [&](auto Qc) {
-            constexpr int Q = decltype(Qc)::value;
-            auto exchange = [&]() {
-                if (g == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4*>(sptr(i, nb)) = acc[4 * Q + i][nb];
-                } else if constexpr (Q == 1) {
-                    roll_offsets();
-                }
-                __syncthreads();
-                if constexpr (Q == 0) EDTR_STAMP_T(8);
-                else EDTR_STAMP_T(9);
-                if (g == 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) {
-                            f32x4* q = reinterpret_cast<f32x4*>(sptr(i, nb));
-                            *q = *q + acc[4 * Q + i][nb];
-                        }
-                } else if constexpr (Q == 1) {
-                    roll_offsets();
-                }
-                if constexpr (Q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            };
-            rows_phase<T, 128, 128, false, 512, 2, SPITCH, false, (Q == 1 ? 2 : 0)>(p, stage, m0 + 4 * Q * p.OW, n0, p.N, 0, gn_acc, gs, gq, exchange, tid_e);
-            __syncthreads();                       // every thread is done reading the staged rows
-        };
-        pass(IC<0>{});
-        EDTR_STAMP_T(10);
-        pass(IC<1>{});
-        EDTR_STAMP_T(11);
-        if (gn_acc) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                gs[j] += __shfl_xor(gs[j], 16, 64); gs[j] += __shfl_xor(gs[j], 32, 64);
-                gq[j] += __shfl_xor(gq[j], 16, 64); gq[j] += __shfl_xor(gq[j], 32, 64);
-            }
-            if ((tid_e & 63) < 16) {
-                float* dst = stage + (wave * 128 + (tid_e & 63) * 8) * 2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
-            }
-            __syncthreads();
-            if (tid_e < 128 && n0 + tid_e < p.N) {
-                float a = 0.0f, q = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) { a += stage[(w * 128 + tid_e) * 2]; q += stage[(w * 128 + tid_e) * 2 + 1]; }
-                float* dst = p.gn_partial + ((int64_t)(2 * cur.tm) * p.N + n0 + tid_e) * 2;     // two 128-row slots per 256-pixel patch
-                dst[0] = a;
-                dst[1] = q;
-                dst[2 * p.N] = 0.0f;
-                dst[2 * p.N + 1] = 0.0f;
-            }
-            __syncthreads();
-        }
-        EDTR_STAMP_T(4); EDTR_STAMP(7);
-        if (!has_next) break;
-        u = un;
-        cur = nxt;
-        nxt = nn;
-    }
-}
-
-static bool igemm_halo_pers_ok(const edtr_igemm_params& p) {
-    return !p.upsample2x && (p.OH & 15) == 0 && (p.OW & 15) == 0 && ((p.C1 / 64) & 1) == 0 && p.splitk <= 1;
-}
-
-template <typename T>
-int launch_halo_pers(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 2 * 128 * BK * 2 + 48 * 1024 + 128 * 132 * 4;      // W0 W1 | PA | staging over PB, W2 and the tail: 146 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_pers_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    const int nunits = (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4) * ((p.N + 127) / 128);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EDTR_E_UNSUPPORTED;
-        cus = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount & ~7) : 256;     // a multiple of 8: unit u and u + G share an XCD
-        if (cus < 8) cus = 8;
-    }
-    hipLaunchKernelGGL((igemm_halo_pers_kernel<T>), dim3(nunits < cus ? nunits : cus, 1, 1), dim3(512), lds, stream, p);
-    EDTR_LAUNCH_CHECK();
-    return EDTR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// 128x128 tile for SMALL grids (tile = 15): plain GEMMs whose 128x128 tile grid leaves at most one workgroup per CU — the
-// short linears of the 16x16 / 8x8 latent levels (M = 512 .. 2048).  There the two-workgroups-per-CU loop of tile 3 has nobody
-// to overlap with: each wave issues its 8 DMAs, waits, multiplies (stamps: 1.4k cycles per K-tile for 512 of MFMA).  Here one
-// workgroup of EIGHT waves ping-pongs with itself, as tiles 6 / 16 do: wave (g, wr, wc) owns 64 rows x 64 columns x the K HALF g
-// of every 64-deep K-tile (16 v_mfma_f32_16x16x32 per K-tile); waves w and w+4 share a SIMD and run half a phase apart, so one
-// multiplies while its partner reads fragments and issues its 4 of the K-tile's 32 DMA pieces two K-tiles ahead.  Ring of four
-// 32 KiB K-tile slots (a slot is restaged two phases after its last read).  The two K halves meet in the epilogue's staging
-// tile, as in tile 16.  Non-spatial, C2 == 0, C1 % 64 == 0, Z == 1, no GEGLU; split-K over K-tiles (blockIdx.y).
-// ------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(512, 1) igemm_pp128_kernel(const edtr_igemm_params p) {
-    constexpr int HALF = 128 * BK * 2, SLOT = 2 * HALF, RING = 4;     // A rows then W rows of one K-tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
-    const int l15 = lane & 15, lq = lane >> 4;
-
-    const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
-    int bid = blockIdx.x;
-    {
-        const int nblk = nbm * nbn, q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    int tm, tn;
-    tile_coords(p, bid, nbm, nbn, tm, tn);
-    const int m0 = tm * 128, n0 = tn * 128;
-    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const u32x4 srd_a = make_srd(p.a1);
-    const u32x4 srd_w = make_srd(p.w);
-    const int nvalid = p.n_valid > 0 ? p.n_valid : p.N;
-    const int nsplit = p.splitk > 1 ? p.splitk : 1, nkt_all = p.K / BK;
-    const int kbeg = (int)blockIdx.y * nkt_all / nsplit, kend = ((int)blockIdx.y + 1) * nkt_all / nsplit;
-
-    // ---- staging: a K-tile is 32 one-KiB pieces (8 rows each): this wave's A rows (wave + 8 j) * 8 + (lane >> 3), j = 0, 1, and the same W rows
-    uint32_t voff_a[2], voff_w[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wave + 8 * j) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-        voff_a[j] = m0 + r < p.M ? (uint32_t)(((int64_t)(m0 + r) * p.ld1 + c * 8) * 2) : kOobOffset;
-        voff_w[j] = n0 + r < nvalid ? (uint32_t)(((int64_t)(n0 + r) * p.ldw + c * 8) * 2) : kOobOffset;
-    }
-    auto stage = [&](int kt, int slot) {
-        const bool live = kt < kend;
-        const uint32_t so = (uint32_t)kt * (BK * 2), dst = smem_base + slot * SLOT + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            dma16_buf(live ? voff_a[j] : kOobOffset, srd_a, so, dst + j * 8192);
-            dma16_buf(live ? voff_w[j] : kOobOffset, srd_w, so, dst + HALF + j * 8192);
-        }
-    };
-    const int a_rd = tile_off(wr * 64 + l15, g * 4 + lq);           // + mb * 2048
-    const int b_rd = HALF + tile_off(wc * 64 + l15, g * 4 + lq);    // + nb * 2048
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    U4 afr[4], bfr[4];
-
-    stage(kbeg, 0);
-    stage(kbeg + 1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // the first K-tile has landed (the second may still fly)
-    __builtin_amdgcn_s_barrier();
-    if (g == 1) __builtin_amdgcn_s_barrier();                      // waves 4-7 run half a phase behind their SIMD partners
-    asm volatile("" ::: "memory");
-
-    for (int kt = kbeg; kt < kend; ++kt) {
-        const char* sl = smem + ((kt - kbeg) & (RING - 1)) * SLOT;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(sl + b_rd + nb * 2048);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) afr[mb] = *reinterpret_cast<const U4*>(sl + a_rd + mb * 2048);
-        stage(kt + 2, (kt - kbeg + 2) & (RING - 1));
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // all but the four pieces just issued: K-tile kt + 1 has landed
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = T::mfma16(bfr[nb], afr[mb], acc[mb][nb]);   // transposed: D[column][row]
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (g == 0) __builtin_amdgcn_s_barrier();                      // re-align the two wave groups
-    __syncthreads();
-
-    // ---- epilogue: fp32 staging tile [128 rows][128 columns], 528-byte rows; a lane holds 4 consecutive columns of row l15 per block
-    constexpr int SPITCH = 132;
-    float* stg = reinterpret_cast<float*>(smem);
-    auto sptr = [&](int mb, int nb) { return stg + (wr * 64 + mb * 16 + l15) * SPITCH + wc * 64 + nb * 16 + 4 * lq; };
-    if (g == 0) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4*>(sptr(mb, nb)) = acc[mb][nb];
-    }
-    __syncthreads();
-    auto add_second_half = [&]() {
-        if (g == 1) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    f32x4* q = reinterpret_cast<f32x4*>(sptr(mb, nb));
-                    *q = *q + acc[mb][nb];
-                }
-        }
-    };
-    const bool gn_acc = p.gn_partial != nullptr && p.splitk <= 1;
-    float gs[8], gq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
-    rows_phase<T, 128, 128, false, 512, 0, SPITCH, false>(p, stg, m0, n0, p.N, 0, gn_acc, gs, gq, add_second_half);
-    if (gn_acc) {
-        // thread (row group tid / 16, column group tid % 16): lanes l, l+16, l+32, l+48 share a column group; fold, then the 8 waves
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            gs[j] += __shfl_xor(gs[j], 16, 64); gs[j] += __shfl_xor(gs[j], 32, 64);
-            gq[j] += __shfl_xor(gq[j], 16, 64); gq[j] += __shfl_xor(gq[j], 32, 64);
-        }
-        __syncthreads();
-        if (lane < 16) {
-            float* dst = stg + (wave * 128 + lane * 8) * 2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
-        }
-        __syncthreads();
-        if (tid < 128 && n0 + tid < p.N && m0 < p.M) {
-            float a = 0.0f, q = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { a += stg[(w * 128 + tid) * 2]; q += stg[(w * 128 + tid) * 2 + 1]; }
-            float* dst = p.gn_partial + ((int64_t)(m0 >> 7) * p.N + n0 + tid) * 2;
-            dst[0] = a;
-            dst[1] = q;
-        }
-    }
-}
-
-template <typename T>
-int launch_pp128(const edtr_igemm_params& p, hipStream_t stream) {
-    constexpr int lds = 4 * 2 * 128 * BK * 2;     // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pp128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
-    hipLaunchKernelGGL((igemm_pp128_kernel<T>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
-    EDTR_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
-        int64_t blocks = (nvec + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
-        EDTR_LAUNCH_CHECK();
-    }
-    return EDTR_OK;
-}
-
 // the halo tile's shape requirements (the caller checks buffer addressability)
 // four whole 8 x 8 images per workgroup (GEO 2 of the halo kernel)
 static bool igemm_halo_img8(const edtr_igemm_params& p) {
@@ -2791,15 +2304,6 @@ static int dbg_flags() {
 
 template <typename T>
 int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
-    if (tile == 15) {      // 8-wave ping-pong 128x128 tile for grids of at most one workgroup per CU
-        if (spatial || p.C2 != 0 || (p.C1 & 63) || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.bias_m || !igemm_fast_addressable(p, spatial))
-            return EDTR_E_UNSUPPORTED;
-        return launch_pp128<T>(p, s);
-    }
-    if (tile == 18) {      // persistent halo tile
-        if (!igemm_halo_ok(p, spatial) || !igemm_halo_pers_ok(p) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
-        return launch_halo_pers<T>(p, s);
-    }
     if (tile == 16) {      // halo tile for 3x3 / stride 1 convolutions
         if (!igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
         if (igemm_halo_img8(p)) return launch_halo<T, 2>(p, s);
@@ -2991,30 +2495,6 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             const int64_t units = (int64_t)(p.M >> 8) * ((p.N + 127) >> 7);
             if (units >= 48 && units <= 256) tile = 16;
         }
-        // Persistent form of the halo tile where a CU gets several units: the next unit's first patch / weight slices fly under the
-        // epilogue of the current one.  Measured (profiles/r03/halo_persistent.log, one device): 1.01 - 1.07x in isolation on the VAE
-        // convolutions with >= 2 units per CU (the two-pass epilogue that the next unit's resident operands force costs 5k of the
-        // 7k cycles the prefetch saves), -0.45 % on the whole path (with two batches in flight other launches already fill tile 16's
-        // set-up gaps, and a persistent grid holds every CU for the whole launch).  Opt-in: EDTR_IGEMM_HALO_PERSIST=1 (or tile = 18).
-        static int hpers = -1;
-        if (hpers < 0) {
-            const char* e9 = getenv("EDTR_IGEMM_HALO_PERSIST");
-            hpers = (e9 && e9[0] == '1') ? 1 : 0;
-        }
-        if (hpers && tile == 16 && (p.N & 127) == 0 && igemm_halo_pers_ok(p) && (int64_t)(p.M >> 8) * (p.N >> 7) >= 512)
-            tile = 18;
-        // 8-wave ping-pong 128x128 tile: plain GEMMs whose tile grid leaves at most one workgroup per CU.  In isolation 1.20-1.32x over
-        // tile 3 at 40-160 tiles (0.83x at 320: profiles/r02/ab_tiles_3_vs_15_small_gemm.log), but the whole path did not move in a
-        // same-device A/B (det512 107.07 vs 106.65 images/s, det512s50 8.298 vs 8.291): these launches overlap with the other lane /
-        // batch, and a 128 KiB workgroup leaves no room beside it.  Opt-in: EDTR_IGEMM_PP128=1 (or tile = 15).
-        static int pp128 = -1;
-        if (pp128 < 0) {
-            const char* e5 = getenv("EDTR_IGEMM_PP128");
-            pp128 = (e5 && e5[0] == '1') ? 1 : 0;
-        }
-        if (pp128 && tile == 3 && !spatial && p.Z == 1 && p.act != EDTR_ACT_GEGLU && !p.bias_m && p.K >= 320 &&
-            big * p.splitk <= 256 && igemm_fast_addressable(p, spatial))
-            tile = 15;
         // 256x32 tile for skinny-N convolutions (the VAE decoder's 3-channel output conv: 94 % of a 128-wide tile is padding);
         // validated against tile 3 on the MI355X (profiles/r02/ab_tiles_3_vs_14*.log).  EDTR_IGEMM_SKINNY=0 switches it off.
         static int skinny = -1;
@@ -3056,14 +2536,15 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (p.tile != 0) return EDTR_E_UNSUPPORTED;
         tile = dma_ok ? 3 : 1;
     }
-    if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 18)) return EDTR_E_UNSUPPORTED;
+    if ((p.row_stats || p.vt_out) && tile == 16) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
     if (p.gn_partial && (tile == 2 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    // live tiles: 1, 2 (register-staged), 3 (LDS-DMA 128x128), 6 (256x256 ping-pong), 8 (128x160), 14 (256x32), 15 (opt-in), 16 (halo),
-    // 18 (persistent halo, opt-in); 4, 5, 7, 9 - 13, 17 were experiments, measured (profiles/r01 - r03) and removed
-    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || (tile >= 14 && tile <= 16) || tile == 18)) return EDTR_E_DTYPE;
+    // live tiles: 1, 2 (register-staged), 3 (LDS-DMA 128x128), 6 (256x256 ping-pong), 8 (128x160), 14 (256x32), 16 (halo).
+    // 4, 5, 7, 9 - 13, 15, 17, 18 were experiments, measured (profiles/r01 - r03) and removed (15 = the 8-wave ping-pong 128x128 tile
+    // for small grids and 18 = the persistent halo tile were faster in isolation and neutral on the whole path: round 4 took them out)
+    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || tile == 14 || tile == 16)) return EDTR_E_DTYPE;
     // lockstep breaker of the two-workgroups-per-CU kernels (stagger_second_slot): only when the grid has more than one round
     // (>= 768 workgroups: below that the second slot's blocks are the tail anyway) and the tile is short enough for the epilogue
     // to matter.  EDTR_IGEMM_STAGGER = percent of the estimated half life (default 100; 0 = off).

@@ -121,16 +121,14 @@ typedef struct edtr_igemm_params {
     int64_t o_zs_outer, o_zs_inner;
     int32_t tile;           /* 0 = auto; explicit main-loop choice (tests / A-B runs): 1 = 128x128 register-staged, 2 = 64x64,
                                3 = 128x128 LDS-DMA (2 stages), 6 = 256x256 ping-pong, 8 = 128x160, 14 = 256x32 for N <= 32 (automatic for
-                               large-M skinny-N convolutions), 15 = 8-wave ping-pong 128x128 for plain GEMMs with at most one tile per CU (opt-in: faster in
-                               isolation, no whole-path gain), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions, plain or nearest-2x upsampled, on outputs whose
+                               large-M skinny-N convolutions), 16 = halo tile (3x3 / stride 1 / pad 1 convolutions — plain, nearest-2x
+                               upsampled as a gather or in the sub-pixel form, or four whole 8x8 images per workgroup — on outputs whose
                                height and width are multiples of 16: the 18x18 input patch of a 16x16 output patch stays in LDS for
-                               the nine taps; automatic for N % 128 == 0 and >= 48 units incl. split-K; EDTR_E_UNSUPPORTED for any
-                               other shape), 18 = the halo tile as a persistent kernel (workgroups walk units, the next unit's first
-                               operands are fetched in the last chunk of the current one; needs an even number of 64-channel chunks,
-                               no split-K, no upsample; opt-in: EDTR_IGEMM_HALO_PERSIST=1; outputs bit-identical to tile 16);
-                               4, 5, 7, 9 - 13 and 17 were experiments (3-stage BK32, 256x128 tiles, 64x128, 16x16x32 at 128x128, deeper
-                               LDS rings, bank-swizzled epilogue staging, two-workgroup halo variants), measured without a whole-path
-                               gain (profiles/r01 - r03) and removed: EDTR_E_DTYPE */
+                               all taps; automatic for N % 128 == 0 and >= 48 units incl. split-K; EDTR_E_UNSUPPORTED for any other
+                               shape).  4, 5, 7, 9 - 13, 15, 17 and 18 were experiments (3-stage BK32, 256x128 tiles, 64x128,
+                               16x16x32 at 128x128, deeper LDS rings, bank-swizzled epilogue staging, an 8-wave ping-pong 128x128 tile
+                               for small grids, two-workgroup and persistent halo variants), measured without a whole-path gain
+                               (profiles/r01 - r03) and removed: EDTR_E_DTYPE */
     /* split-K (small-M problems that cannot fill 256 CUs): K is cut into `splitk` runs of K-tiles, each
      * workgroup row writes an fp32 partial slab into `workspace` ([splitk][M][N] floats, caller-owned), and a
      * second launch sums the slabs and applies the epilogue.  splitk <= 1 disables it.  Needs Z == 1, no GEGLU. */
@@ -141,7 +139,7 @@ typedef struct edtr_igemm_params {
      * kernel's business — the halo tile fills slot 2k with a 256-pixel patch and zeroes slot 2k+1 — only the per-image
      * totals over an image's H*W/128 consecutive slots are defined).  edtr_gn_finalize folds them into
      * the fp64 sums edtr_gn_apply consumes, so the separate statistics pass over the tensor (edtr_gn_stats) disappears.
-     * Needs M % 128 == 0, no GEGLU / split-K / z-batching, tile 0/1/3/6/8/16/18 (16-bit or fp32 output). */
+     * Needs M % 128 == 0, no GEGLU / split-K / z-batching, tile 0/1/3/6/8/16 (16-bit or fp32 output). */
     float* gn_partial;
     float act_slope;        /* negative-side slope of EDTR_ACT_LRELU (0 <= slope <= 1) */
     int32_t residual_f32;   /* nonzero: `residual` is fp32 (ldr in floats, multiple of 4): the fp32 activation stream of the

@@ -62,3 +62,19 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         lib.load()
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every gfx950 kernel of libedtr_hip.so keeps its state in registers / LDS: no scratch (private-segment) memory, no VGPR
+    spills.  Round 4 found the 256x256 ping-pong kernel staging its 128 accumulators through 528 bytes of scratch per lane — a
+    `#pragma unroll` loop around the shared epilogue had silently stopped unrolling when the epilogue grew — and nothing had
+    looked.  Reads the code objects' notes (tools/kernel_resources.py); needs the ROCm LLVM tools, no GPU."""
+    import importlib.util
+    tool = os.path.join(ROOT, "tools", "kernel_resources.py")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("ROCm LLVM tools not installed")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tail = r.stdout.strip().splitlines()[-1]
+    assert tail.endswith(" 0 with scratch / spills"), r.stdout[-3000:]
+    assert int(tail.split()[0]) >= 100, tail          # the library's kernels were actually enumerated

@@ -4,6 +4,6 @@ run default A=1
 run ln_fold EDTR_LN_FOLD=1
 run gn_fold16 EDTR_GN_FOLD_MAX=16
 run gn_fold64 EDTR_GN_FOLD_MAX=64
-run pp128 EDTR_IGEMM_PP128=1
+# (run pp128 EDTR_IGEMM_PP128=1: tile 15 was removed in round 4; its result is in profiles/r03/ab_s50.log)
 run ln_fold+gn64 EDTR_LN_FOLD=1 EDTR_GN_FOLD_MAX=64
 run default A=1
