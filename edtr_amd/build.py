@@ -51,7 +51,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS + EXTRA_DEPS.get(src, [])):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+            # -Werror=pass-failed: a `#pragma unroll` the optimizer could not honour is an ERROR — in round 4 such a loop around the
+            # shared epilogue silently stayed rolled and sent a kernel's accumulators through scratch memory
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Werror=pass-failed", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
