@@ -910,7 +910,9 @@ class Emitter:
     def add(self, a: torch.Tensor, b: Optional[torch.Tensor], rows: int, C: int, out=None) -> torch.Tensor:
         if out is None:
             out = self.new(rows, C)
-        m16 = self.mirror_view(out) if (self.mirrors_on and C % 8 == 0) else None
+        m16 = self.mirror_view(out) if self.mirrors_on else None
+        if m16 is not None and C % 8:
+            raise ValueError(f"add into a mirrored stream buffer needs C % 8 == 0 (got {C}): its fp16 mirror would go stale")
         if m16 is not None:
             self.prog.add(ops.make_add_mirror(a=a, lda=a.stride(0), b=b, ldb=b.stride(0) if b is not None else 0, out=out,
                                               ldo=out.stride(0), out16=m16, rows=rows, C=C))
