@@ -54,7 +54,7 @@ def main() -> None:
                     help="fast = 16-bit activation storage in --dtype (headline); mixed = the fast parity mode (fp32 stream, fp16 "
                          "operands, 1-3 products per layer class: edtr_amd/precision.py); high = the robust parity mode (fp32 stream, "
                          "bf16 split-3 products everywhere).  Both parity modes meet the 1e-3 north-star tolerance")
-    ap.add_argument("--parity-steps", type=int, default=8,
+    ap.add_argument("--parity-steps", type=int, default=24,
                     help="after the headline (fast) measurement, time this many passes of the parity mode (mixed) in the same run and "
                          "report them as \"parity_mode\" (0 = skip; skipped for N > 1 and for the non-default workloads)")
     ap.add_argument("--also", default="det512s50,seg1024tiled",
@@ -475,7 +475,7 @@ def other_workload_leg(cldm, diffusion, sampler, name, dev, ctx_dim, args, captu
     from edtr_amd import workloads
     B, S, _ = workloads.WORKLOADS[name]
     inflight = args.inflight
-    steps = 8 if name == "seg1024tiled" else 4
+    steps = 16 if name == "seg1024tiled" else 6      # (the last pass of a leg runs without a partner in flight: short legs under-read by half a pass)
     inp = workloads.make_inputs(name, ctx_dim, dev, B, S, with_step_noises=(name == "det512s50"))     # (the parity pass injects them)
     untiled_forward = type(cldm).forward.__get__(cldm)      # (the tiled sampler monkey-patches cldm.forward and never restores it)
 
