@@ -118,6 +118,22 @@ __device__ __forceinline__ float wave_max(float v) {
 // MFMA operand read, chunk fixed) hit 16 distinct 16-byte bank slots of the 256-byte bank row.
 __device__ __forceinline__ int tile_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
+// One global_load_lds_dwordx4: lane i's 16 bytes land at LDS byte address lds_addr + 16*i (lds_addr wave-uniform, in
+// M0).  Inline asm on purpose: hipcc neither counts it in its own vmcnt bookkeeping nor serialises later ds_reads
+// behind it with a vmcnt(0), so the prefetch can stay in flight across the barrier; completion is waited for by
+// the hand-placed counted s_waitcnt in the main loop.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
+    return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define EDTR_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

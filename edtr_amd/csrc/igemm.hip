@@ -918,18 +918,6 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
 // 16 bytes of zeros in device memory: the LDS-DMA source of every out-of-range chunk (conv halo, M / N tails).
 __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4];
 
-// One global_load_lds_dwordx4: lane i's 16 bytes land at LDS byte address lds_addr + 16*i (lds_addr wave-uniform, in
-// M0).  Inline asm on purpose: hipcc neither counts it in its own vmcnt bookkeeping nor serialises later ds_reads
-// behind it with a vmcnt(0), so the prefetch can stay in flight across the barrier; completion is waited for by
-// the hand-placed counted s_waitcnt in the main loop.
-__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-}
-
 // Buffer-addressed LDS-DMA: address = SRD base + voff (per lane) + soff (wave uniform); lanes whose voff fails the
 // descriptor's range check write zeros.
 constexpr uint32_t kOobOffset = 0xFFFFFF00u;     // >= num_records - 15 -> always out of range
@@ -950,10 +938,6 @@ __device__ __forceinline__ void dma16_buf(uint32_t voff, const u32x4& srd, uint3
                  :
                  : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
                  : "memory");   // M0 is free here: hipcc keeps no value in it across statements on gfx950
-}
-
-__device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
-    return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
 
 // ------------------------------------------------------------------------------------------------------

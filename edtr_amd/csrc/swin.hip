@@ -13,6 +13,7 @@
 // V is token-major in memory but the V^T operand needs 8 consecutive keys of one channel per lane: each wave transposes its
 // 64 x 32 V block through a private 4.5 KiB LDS slab (ds_write_b16 columns, ds_read_b128 rows).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -189,6 +190,331 @@ __global__ void __launch_bounds__(256) window_attn_kernel(const edtr_window_attn
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// edtr_swin_mlp — x + fc2(GELU(fc1(LayerNorm(x)))) of one Swin layer in ONE launch (reference model/swinir.py:24-37 Mlp,
+// :281-283 `x = x + self.drop_path(self.mlp(self.norm2(x)))`).  The two GEMMs are K = 192 / K = 384 deep: as separate
+// launches each is a 20 - 28 us round trip of the 12.6 MB token tensor (plus the 25 MB hidden tensor in between) through
+// HBM / L2 for 2 - 3 us of matrix work.  Here a workgroup owns 128 tokens; the hidden activations never leave registers.
+//
+// Both products run TRANSPOSED so that the first one's accumulators are the second one's B operand:
+//   h^T[u][t]   = sum_k  W1g[u][k] x[t][k]         A = W1g rows (LDS), B = x^T fragments (registers)
+//   out^T[c][t] = sum_u  W2[c][u]  h[u][t]         A = W2 rows (LDS),  B = GELU(...) packed from the accumulators
+// Both weight matrices are fed with bits 2,3 of the row index swapped (as attention.hip does with its keys), which makes
+// accumulator registers 8s..8s+7 of lane (token, half) hold rows 16s + 8*half + 0..7: for h^T that is the k order of the
+// next MFMA's B operand, for out^T it is the channel order of the x fragment the lane already holds — the residual comes
+// from registers and the result goes back into the token tile's LDS image in place.
+// LayerNorm is folded (include/edtr_hip.h, "LayerNorm folded into the GEMMs around it"): W1g = gamma . W1, the row mean and
+// rstd come from the x fragments, pre = rstd (acc - mean c1[u]) + c2b[u].
+//
+// The kernel is as much VALU as MFMA work: the erf-GELU costs ~70 VALU cycles per hidden activation and wave (two
+// quarter-rate transcendentals), 1.2k cycles per 32 x 32 hidden tile against 768 for the tile's 24 MFMAs.  So the eight
+// waves PING-PONG: wave (t4, hg) owns tokens 32 t4 .. + 31 and hidden HALF hg (six tiles), the two waves of a SIMD are one
+// of each half, and the workgroup runs in barrier-separated PERIODS in which half hg = t & 1 multiplies
+// (second product of its tile j - 1, first product of tile j) while the other half evaluates the GELU of the tile it
+// multiplied a period earlier: 14 periods of max(MFMA, VALU) instead of 6 steps of their sum (measured: DESIGN.md).
+// Hidden halves rather than more tokens per workgroup so that 32768 tokens (batch 8) are 256 workgroups, one per CU.  The
+// halves' partial outputs meet once, after the loop: each wave keeps three of the six 32-channel output tiles and hands the
+// other three to its partner through LDS (fp32, lane-linear: conflict-free both ways).
+// Everything arrives by LDS-DMA: the weights as pre-swizzled 12 KiB images (packed by the host, layout in the header), a
+// "unit" = [W2 slice j - 1 | W1 tile j] of one half per period, two periods ahead, into that half's other buffer; the token
+// tile with the same XOR swizzle applied on the source side, so that rows are fetched and stored as whole 384-byte runs.
+// gelu_erf_f (common.h) over 8 values in LOCKSTEP: one stage of the evaluation for all eight before the next.  Left alone, hipcc
+// evaluates value after value (least register pressure) and the wave — alone or with one partner on its SIMD — then runs a
+// 13-deep dependency chain per value at the VALU latency (measured in this kernel: 2.5k cycles for 16 values, 11 cycles per
+// instruction) instead of at the issue rate.  An empty asm that takes a stage's eight results as read-write operands pins the
+// order (__builtin_amdgcn_sched_barrier does not: the arithmetic is moved across it before the scheduler runs).
+__device__ __forceinline__ void pin8(float (&v)[8]) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+// in: h = x / 2 (the caller folds the half into its affine constants); out: gelu(x) = h + |h| erf(|x| / sqrt 2)
+__device__ __forceinline__ void gelu_erf_lockstep(float (&h)[8]) {
+    float d[8], u[8], poly[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_fmaf(fabsf(h[i]), 0.3275911f * 1.41421356237309504880f, 1.0f);
+    pin8(d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_rcpf(d[i]);                    // t = 1 / (1 + p |x| / sqrt 2)
+    pin8(d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = h[i] * h[i];
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = u[i] * (-2.0f * 1.4426950408889634f);
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_exp2f(u[i]);                   // exp(-x^2 / 2)
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(1.061405429f, d[i], -1.453152027f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], 1.421413741f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], -0.284496736f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], 0.254829592f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = u[i] * d[i];
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = __builtin_fmaf(-poly[i], u[i], 1.0f);           // erf(|x| / sqrt 2)
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = __builtin_fmaf(fabsf(h[i]), u[i], h[i]);
+    pin8(h);
+}
+
+constexpr int MLP_CT = 6, MLP_HT = 12;                       // 32-wide tiles of the token width 192 and of the hidden width 384
+constexpr int MLP_IMG = 32 * 32 * MLP_CT * 2;                // 12288 B: one W1 tile (32 units x 192 k) or one W2 slice (192 c x 32 units)
+constexpr int MLP_THREADS = 512, MLP_TOKENS = 128;
+constexpr int MLP_WBUF = 4 * 2 * MLP_IMG;                    // [half][buffer][W2 slice | W1 tile]
+constexpr int MLP_XT = MLP_TOKENS * 32 * MLP_CT * 2;         // token tile, rows of 384 B with the W1 image's swizzle
+constexpr int MLP_CONST_FLOATS = 2 * 32 * MLP_HT + 32 * MLP_CT;   // c1 | c2b | b2
+constexpr int MLP_LDS = MLP_WBUF + MLP_XT + MLP_CONST_FLOATS * 4;
+
+template <typename T>
+__global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_mlp_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int t4 = wave & 3, hg = wave >> 2;
+    char* xt = smem + MLP_WBUF;
+    float* cst = reinterpret_cast<float*>(smem + MLP_WBUF + MLP_XT);
+    const uint32_t lds0 = lds_addr_of(smem);
+    constexpr int C = 32 * MLP_CT, HID = 32 * MLP_HT, NJ = MLP_HT / 2, KS = 2 * MLP_CT, PERIODS = 2 * NJ + 2;
+    const int tok_base = blockIdx.x * MLP_TOKENS;
+
+    for (int i = tid; i < HID; i += MLP_THREADS) { cst[i] = 0.5f * p.c1[i]; cst[HID + i] = 0.5f * p.c2b[i]; }     // halves: see gelu_erf_lockstep
+    if (tid < C) cst[2 * HID + tid] = p.b2[tid];
+
+    // ---- token tile: 48 DMA instructions of 1 KiB, six per wave (instruction Q = 6 wave + q covers rows 8 (Q / 3) .. + 7 in three
+    // parts); LDS slot (row, c') holds chunk c' ^ key(row) of the row
+    auto tile_slot = [&](int q, int ln, int& r, int& c) {       // row and SOURCE chunk of lane ln's 16 bytes of instruction 6 wave + q
+        const int e = 64 * (q % 3) + ln, rl = e / 24;
+        r = 8 * (2 * wave + q / 3) + rl;
+        c = (e - 24 * rl) ^ ((r >> 1) & 7);
+    };
+    {
+        const uint16_t* xg = static_cast<const uint16_t*>(p.x);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            int r, c;
+            tile_slot(q, lane, r, c);
+            dma16(xg + (int64_t)min(tok_base + r, p.rows - 1) * p.ldx + c * 8, lds0 + MLP_WBUF + (wave * 6 + q) * 1024);
+        }
+    }
+    // ---- weight units: unit(t) = half t & 1, tile j = t >> 1: [W2 slice j - 1 | W1 tile j] -> buffer j & 1 of the half; 24 KiB = three
+    // instructions per wave (chunk e = wave, wave + 8, wave + 16 of 24; the absent parts of j = 0 / j = 6 fetch a neighbour)
+    const char* w1g = static_cast<const char*>(p.w1) + lane * 16;
+    const char* w2g = static_cast<const char*>(p.w2) + lane * 16;
+    auto stage_unit = [&](int t) {
+        const int g = t & 1, j = t >> 1;
+        const int i2 = g * NJ + max(j - 1, 0), i1 = g * NJ + min(j, NJ - 1);
+        const uint32_t dst = lds0 + (uint32_t)((g * 2 + (j & 1)) * 2 * MLP_IMG);
+        dma16(w2g + (int64_t)i2 * MLP_IMG + wave * 1024, dst + wave * 1024);
+        if (wave < 4) dma16(w2g + (int64_t)i2 * MLP_IMG + (wave + 8) * 1024, dst + (wave + 8) * 1024);
+        else dma16(w1g + (int64_t)i1 * MLP_IMG + (wave - 4) * 1024, dst + MLP_IMG + (wave - 4) * 1024);
+        dma16(w1g + (int64_t)i1 * MLP_IMG + (wave + 4) * 1024, dst + MLP_IMG + (wave + 4) * 1024);
+    };
+    stage_unit(0);
+    stage_unit(1);
+
+    const int tok = tok_base + t4 * 32 + l31;
+    const bool live = tok < p.rows;
+    const int xrow = t4 * 32 + l31;
+    const int x_off = xrow * (C * 2), xkey = (xrow >> 1) & 7;
+    const int rs = (l31 & 16) | swap23(l31 & 15);              // the weight row this lane feeds to MFMA row l31
+    const int w1_row = MLP_IMG + rs * (C * 2), key1 = (rs >> 1) & 7;
+    const int key2 = (rs >> 2) & 3;
+    const int w2_o0 = rs * 64 + ((lh ^ key2) << 4), w2_o1 = rs * 64 + (((2 + lh) ^ key2) << 4);
+
+    U4 xf[KS];
+    U4 hb0 = zero16(), hb1 = zero16();
+    float k0 = 0.0f, k1 = 0.0f;
+    f32x16 hacc;
+    f32x16 oacc[MLP_CT];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < MLP_CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[ct][r] = 0.0f;
+
+#pragma unroll 1
+    for (int t = 0; t < PERIODS; ++t) {
+        // unit(t) (and, at t = 0, the token tile) has landed: everything this wave issued except unit(t + 1)'s three
+        if (t + 1 < PERIODS) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < PERIODS) stage_unit(t + 2);                 // into the buffer period t - 2 read
+        if (t == 0) {
+            // x^T fragments: lane (token, half) holds channels 16 ks + 8 half .. + 7; LayerNorm statistics over the stored values
+            // (pad columns are zero): pre / 2 = k0 acc + (k1 c1[u] / 2 + c2b[u] / 2), k0 = rstd / 2, k1 = -rstd mean
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const U4*>(xt + x_off + (((2 * ks + lh) ^ xkey) << 4));
+            float s = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float f[8];
+                unpack8<T>(xf[ks], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s += f[j]; q = __builtin_fmaf(f[j], f[j], q); }
+            }
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            const float inv_c = 1.0f / (float)p.c_valid;
+            const float mean = s * inv_c;
+            const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
+            const float rstd = __builtin_amdgcn_rsqf(var + p.eps);
+            k0 = 0.5f * rstd;
+            k1 = -rstd * mean;
+        }
+        const int j = t >> 1;
+        if ((t & 1) == hg) {
+            // ---- multiply: second product of tile j - 1, first product of tile j
+            const char* unit = smem + (hg * 2 + (j & 1)) * 2 * MLP_IMG;
+            // each product's fragment reads run two groups of four ahead of the MFMAs that use them (nothing else hides the LDS
+            // latency: the partner wave is busy in its VALU stream); the empty asms pin that order, which hipcc otherwise undoes
+            // — two reads, two MFMAs — to save registers
+            auto pin4 = [](u32x4 (&f)[4]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); };
+            if (j >= 1) {
+                // fragment e = 2 ct + s: output tile ct, k-step s
+                auto rd = [&](int e) { return *reinterpret_cast<const u32x4*>(unit + (e >> 1) * 2048 + ((e & 1) ? w2_o1 : w2_o0)); };
+                u32x4 f0[4], f1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f0[e] = rd(e);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f1[e] = rd(4 + e);
+                pin4(f0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[e >> 1] = T::mfma(__builtin_bit_cast(U4, f0[e]), (e & 1) ? hb1 : hb0, oacc[e >> 1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f0[e] = rd(8 + e);
+                pin4(f1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[2 + (e >> 1)] = T::mfma(__builtin_bit_cast(U4, f1[e]), (e & 1) ? hb1 : hb0, oacc[2 + (e >> 1)]);
+                pin4(f0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[4 + (e >> 1)] = T::mfma(__builtin_bit_cast(U4, f0[e]), (e & 1) ? hb1 : hb0, oacc[4 + (e >> 1)]);
+            }
+            if (j < NJ) {
+                auto rd = [&](int ks) { return *reinterpret_cast<const u32x4*>(unit + w1_row + (((2 * ks + lh) ^ key1) << 4)); };
+                u32x4 f0[4], f1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f0[e] = rd(e);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f1[e] = rd(4 + e);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
+                pin4(f0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hacc = T::mfma(__builtin_bit_cast(U4, f0[e]), xf[e], hacc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f0[e] = rd(8 + e);
+                pin4(f1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hacc = T::mfma(__builtin_bit_cast(U4, f1[e]), xf[4 + e], hacc);
+                pin4(f0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hacc = T::mfma(__builtin_bit_cast(U4, f0[e]), xf[8 + e], hacc);
+            }
+        } else if (t >= 1 && ((t - 1) >> 1) < NJ) {
+            // ---- LayerNorm fold + bias + GELU of the tile multiplied a period ago; registers 8s..8s+7 are hidden units u0 + 16 s + 0..7
+            const int jv = (t - 1) >> 1;
+            const float* cu = cst + (hg * NJ + jv) * 32 + 8 * lh;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4 ca = *reinterpret_cast<const f32x4*>(cu + 16 * s), cb = *reinterpret_cast<const f32x4*>(cu + 16 * s + 4);
+                const f32x4 da = *reinterpret_cast<const f32x4*>(cu + HID + 16 * s), db = *reinterpret_cast<const f32x4*>(cu + HID + 16 * s + 4);
+                const float c1v[8] = {ca[0], ca[1], ca[2], ca[3], cb[0], cb[1], cb[2], cb[3]};
+                const float c2v[8] = {da[0], da[1], da[2], da[3], db[0], db[1], db[2], db[3]};
+                float g[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = __builtin_fmaf(k0, hacc[8 * s + e], __builtin_fmaf(k1, c1v[e], c2v[e]));
+                gelu_erf_lockstep(g);
+                if (s == 0) hb0 = pack8<T>(g); else hb1 = pack8<T>(g);
+            }
+        }
+    }
+
+    // ---- the two hidden halves meet: wave (t4, hg) keeps output tiles 3 hg .. 3 hg + 2 and hands over the other three
+    __syncthreads();                                            // the weight buffers are dead: they become the exchange area
+    constexpr int XCH = 3 * 16 * 64;                            // floats per wave
+    float* mine = reinterpret_cast<float*>(smem) + wave * XCH;
+    const float* theirs = reinterpret_cast<const float*>(smem) + (wave ^ 4) * XCH;
+    auto hand_over = [&](auto HG) {
+        constexpr int give0 = 3 * (1 - decltype(HG)::value);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& a = oacc[give0 + k];
+                const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(mine + ((k * 4 + g) * 64 + lane) * 4) = v;
+            }
+    };
+    if (hg == 0) hand_over(std::integral_constant<int, 0>{}); else hand_over(std::integral_constant<int, 1>{});
+    __syncthreads();
+
+    auto finish = [&](auto HG) {
+        constexpr int keep0 = 3 * decltype(HG)::value;
+        float s = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                       // registers 8h .. 8h+7: channels 32 ct + 16 h + 8 lh + 0..7 = x fragment 2 ct + h
+                const int ct = keep0 + k;
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(theirs + ((k * 4 + 2 * h) * 64 + lane) * 4);
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(theirs + ((k * 4 + 2 * h + 1) * 64 + lane) * 4);
+                const float* bp = cst + 2 * HID + 32 * ct + 16 * h + 8 * lh;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                float xr[8];
+                unpack8<T>(xf[2 * ct + h], xr);
+                const f32x16& a = oacc[ct];
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (a[8 * h + e] + o0[e]) + b0[e] + xr[e];
+                    v[4 + e] = (a[8 * h + 4 + e] + o1[e]) + b1[e] + xr[4 + e];
+                }
+                const U4 w = pack8<T>(v);
+                *reinterpret_cast<U4*>(xt + x_off + (((2 * (2 * ct + h) + lh) ^ xkey) << 4)) = w;       // in place: this lane's own chunk
+                float f[8];
+                unpack8<T>(w, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s += f[e]; q = __builtin_fmaf(f[e], f[e], q); }
+            }
+        if (p.row_stats) {           // this wave's 96 columns: slot 3 hg carries the sums, the two after it are zero
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (live && lh == 0) {
+                f32x2* dst = reinterpret_cast<f32x2*>(p.row_stats) + (int64_t)tok * MLP_CT + keep0;
+                const f32x2 sv = {s, q}, z = {0.0f, 0.0f};
+                dst[0] = sv; dst[1] = z; dst[2] = z;
+            }
+        }
+    };
+    if (hg == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 1>{});
+    __syncthreads();
+
+    // ---- the finished tile leaves as whole rows: lane-linear LDS reads, 16-byte stores, 128-byte runs per 8 lanes
+    {
+        uint16_t* og = static_cast<uint16_t*>(p.out);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));        // (recompute the slot arithmetic here instead of carrying the prologue's through the loop)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            int r, c;
+            tile_slot(q, ln, r, c);
+            const U4 v = *reinterpret_cast<const U4*>(xt + (wave * 6 + q) * 1024 + ln * 16);
+            if (tok_base + r < p.rows) stg16(og + (int64_t)(tok_base + r) * p.ldo + c * 8, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // pixel-unshuffle front end: one thread = one (token, channel, dy) run of r source pixels
 template <typename T>
 __global__ void __launch_bounds__(256) pixel_unshuffle_kernel(const float* src, int B, int C, int H, int W, int r, const float* sub,
@@ -244,6 +570,38 @@ extern "C" int edtr_window_attn(const edtr_window_attn_params* pp, edtr_stream_t
         hipLaunchKernelGGL(window_attn_kernel<BF16>, grid, dim3(256), 0, s, p, (int)tasks);
     else
         hipLaunchKernelGGL(window_attn_kernel<F16>, grid, dim3(256), 0, s, p, (int)tasks);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_swin_mlp(const edtr_swin_mlp_params* pp, edtr_stream_t stream) {
+    if (!pp) return EDTR_E_NULL;
+    const edtr_swin_mlp_params& p = *pp;
+    if (!p.x || !p.w1 || !p.w2 || !p.c1 || !p.c2b || !p.b2 || !p.out) return EDTR_E_NULL;
+    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (p.rows <= 0 || p.c_valid <= 0 || p.c_valid > p.C) return EDTR_E_SHAPE;
+    if (p.C != 32 * MLP_CT || p.hidden != 32 * MLP_HT) return EDTR_E_UNSUPPORTED;      // the shipped SwinIR width (180 -> 192, 360 -> 384)
+    if (p.ldx < p.C || p.ldo < p.C) return EDTR_E_SHAPE;
+    if ((p.ldx & 7) || (p.ldo & 7)) return EDTR_E_ALIGN;
+    if (!aligned16(p.x) || !aligned16(p.w1) || !aligned16(p.w2) || !aligned16(p.out) || !aligned16(p.c1) || !aligned16(p.c2b) ||
+        !aligned16(p.b2) || (p.row_stats && !aligned16(p.row_stats)))
+        return EDTR_E_ALIGN;
+    static bool attr_set[2] = {false, false};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((p.rows + MLP_TOKENS - 1) / MLP_TOKENS));
+    if (p.dtype == EDTR_BF16) {
+        if (!attr_set[0]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_mlp_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL(swin_mlp_kernel<BF16>, grid, dim3(MLP_THREADS), MLP_LDS, s, p);
+    } else {
+        if (!attr_set[1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_mlp_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL(swin_mlp_kernel<F16>, grid, dim3(MLP_THREADS), MLP_LDS, s, p);
+    }
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

@@ -17,7 +17,7 @@ DECLARED_SYMBOLS = [
     "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample", "edtr_split3", "edtr_cast16",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
-    "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle",
+    "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp",
     "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror",
 ]
 
@@ -79,6 +79,18 @@ class WindowAttnParams(C.Structure):
         ("out", C.c_void_p), ("ld_out", C.c_int32), ("c_pad", C.c_int32),
         ("bias", C.c_void_p), ("labels", C.c_void_p),
         ("scale", C.c_float),
+    ]
+
+
+class SwinMlpParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("rows", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("c_valid", C.c_int32),
+        ("eps", C.c_float),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("w1", C.c_void_p), ("w2", C.c_void_p),
+        ("c1", C.c_void_p), ("c2b", C.c_void_p), ("b2", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("row_stats", C.c_void_p),
     ]
 
 
@@ -153,7 +165,8 @@ def load() -> C.CDLL:
     lib.edtr_embed_tokens.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.edtr_window_attn.argtypes = [C.POINTER(WindowAttnParams), vp]
     lib.edtr_pixel_unshuffle.argtypes = [i32, vp, i32, i32, i32, i32, i32, vp, f32, vp, i32, i32, vp]
-    if lib.edtr_abi_version() != 7:
+    lib.edtr_swin_mlp.argtypes = [C.POINTER(SwinMlpParams), vp]
+    if lib.edtr_abi_version() != 8:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

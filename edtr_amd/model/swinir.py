@@ -201,6 +201,25 @@ class _SwinEngine:
                 store.cache[key] = (wp.to(dt).contiguous(), ops_mod.pad_bias(store._p(prefix + "bias"), n_pad))
             return store.cache[key]
 
+        # The MLP half of a layer as ONE launch (edtr_swin_mlp: LayerNorm fold + fc1 + GELU + fc2 + residual, the hidden
+        # activations never leave registers) at the shipped width; EDTR_SWIN_MLP_FUSE=0 issues the two GEMMs instead.
+        fuse_mlp = (os.environ.get("EDTR_SWIN_MLP_FUSE", "1") != "0" and (CP, HP) == (ops_mod.SWIN_MLP_C, ops_mod.SWIN_MLP_HIDDEN))
+
+        def mlp_images(p: str):
+            key = ("swin_mlp", p)
+            if key not in store.cache:
+                gamma, beta = store.vec(p + "norm2.weight", CP), store.vec(p + "norm2.bias", CP)       # pad entries are zero
+                w1f = fc1_f32(p, HP)
+                w2 = store._p(p + "mlp.fc2.weight")
+                w2f = torch.zeros((CP, HP), dtype=torch.float32, device=dev)
+                w2f[: w2.shape[0], : w2.shape[1]] = w2
+                w1g = w1f * gamma[None, :]
+                img1, img2 = ops_mod.pack_swin_mlp_weights(w1g, w2f, dt)
+                c1 = w1g.to(dt).float().sum(dim=1).contiguous()
+                c2b = (w1f @ beta + ops_mod.pad_bias(store._p(p + "mlp.fc1.bias"), HP)).contiguous()
+                store.cache[key] = (img1, img2, c1, c2b, ops_mod.pad_bias(store._p(p + "mlp.fc2.bias"), CP))
+            return store.cache[key]
+
         def fc1_f32(p: str, n_pad: int) -> torch.Tensor:
             w = store._p(p + "mlp.fc1.weight")
             wp_ = torch.zeros((n_pad, CP), dtype=torch.float32, device=dev)
@@ -246,11 +265,20 @@ class _SwinEngine:
                                                        scale=d ** -0.5))
                 em.free(qkv)
                 wp, bp = linear(p + "attn.proj.", CP, CP)
-                x1 = em.gemm(o, wp, rows, CP, CP, bias=bp, residual=r, name="swin.proj", row_stats=fold_ln)
+                x1 = em.gemm(o, wp, rows, CP, CP, bias=bp, residual=r, name="swin.proj", row_stats=fold_ln and not fuse_mlp)
                 x1_stats = em.last_row_stats
                 em.free(o)
                 if r is not t:
                     em.free(r)
+                last_of_group = j == depth - 1       # the group's last output feeds a 3x3 convolution, not a LayerNorm
+                if fuse_mlp:
+                    img1, img2, c1, c2b, b2 = mlp_images(p)
+                    r = em.new(rows, CP)
+                    r_stats = self.arena.alloc((rows, CP // 32, 2), torch.float32) if fold_ln and not last_of_group else None
+                    self.prog.add(ops_mod.make_swin_mlp(dtype=dt, x=x1, ldx=x1.stride(0), rows=rows, c_valid=C, eps=1e-5, w1=img1, w2=img2,
+                                                        c1=c1, c2b=c2b, b2=b2, out=r, ldo=CP, row_stats=r_stats))
+                    em.free(x1)
+                    continue
                 w1, b1 = linear(p + "mlp.fc1.", CP, HP)
                 if x1_stats is not None:
                     w1f, _, c1, c2 = folded("fc1", p, p + "norm2.", fc1_f32(p, HP), b1)
@@ -261,7 +289,6 @@ class _SwinEngine:
                     g = em.gemm(h2, w1, rows, HP, CP, bias=b1, act=L.ACT_GELU, name="swin.fc1")
                     em.free(h2)
                 w2, b2 = linear(p + "mlp.fc2.", HP, CP)
-                last_of_group = j == depth - 1       # the group's last output feeds a 3x3 convolution, not a LayerNorm
                 r = em.gemm(g, w2, rows, CP, HP, bias=b2, residual=x1, name="swin.fc2", row_stats=fold_ln and not last_of_group)
                 r_stats = em.last_row_stats
                 em.free(g, x1)

@@ -195,6 +195,40 @@ def make_window_attn(*, dtype, qkv, ld_qkv, out, ld_out, B, H, W, heads, head_di
     return Rec(L.load().edtr_window_attn, (ct.byref(p),), (p, qkv, out, bias, labels), name, flops, nbytes)
 
 
+SWIN_MLP_C, SWIN_MLP_HIDDEN = 192, 384          # the one shape edtr_swin_mlp is built for (include/edtr_hip.h)
+
+
+def pack_swin_mlp_weights(w1g: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 [384, 192] (gamma-scaled fc1) and [192, 384] (fc2), both already zero-padded -> the two LDS-image tensors
+    edtr_swin_mlp copies by LDS-DMA (layout: include/edtr_hip.h, edtr_swin_mlp_params.w1 / .w2)."""
+    C, HID = SWIN_MLP_C, SWIN_MLP_HIDDEN
+    assert tuple(w1g.shape) == (HID, C) and tuple(w2.shape) == (C, HID)
+    dev = w1g.device
+    a = w1g.to(dtype).reshape(HID // 32, 32, C // 8, 8)                       # [tile][r][c][j]
+    r = torch.arange(32, device=dev)[:, None]
+    c = torch.arange(C // 8, device=dev)[None, :]
+    img1 = torch.empty_like(a)
+    img1[:, r, c ^ ((r >> 1) & 7)] = a[:, r, c]                               # chunk c of row r sits in slot c ^ key(r)
+    b = w2.to(dtype).reshape(C, HID // 32, 4, 8).permute(1, 0, 2, 3)          # [tile][r][c][j]
+    r2 = torch.arange(C, device=dev)[:, None]
+    c2 = torch.arange(4, device=dev)[None, :]
+    img2 = torch.empty((HID // 32, C, 4, 8), dtype=dtype, device=dev)
+    img2[:, r2, c2 ^ ((r2 >> 2) & 3)] = b[:, r2, c2]
+    return img1.reshape(-1).contiguous(), img2.reshape(-1).contiguous()
+
+
+def make_swin_mlp(*, dtype, x, ldx, rows, c_valid, eps, w1, w2, c1, c2b, b2, out, ldo, row_stats=None, name="swin.mlp") -> Rec:
+    """One Swin layer's x + fc2(GELU(fc1(LayerNorm(x)))) (edtr_hip.h: edtr_swin_mlp)."""
+    p = L.SwinMlpParams()
+    p.dtype, p.rows, p.C, p.hidden, p.c_valid, p.eps = dt_code(dtype), rows, SWIN_MLP_C, SWIN_MLP_HIDDEN, c_valid, eps
+    p.x, p.ldx, p.w1, p.w2 = ptr(x), ldx, ptr(w1), ptr(w2)
+    p.c1, p.c2b, p.b2 = ptr(c1), ptr(c2b), ptr(b2)
+    p.out, p.ldo, p.row_stats = ptr(out), ldo, ptr(row_stats)
+    flops = 4.0 * rows * SWIN_MLP_C * SWIN_MLP_HIDDEN
+    nbytes = 2.0 * rows * 2 * SWIN_MLP_C + 4.0 * SWIN_MLP_C * SWIN_MLP_HIDDEN
+    return Rec(L.load().edtr_swin_mlp, (ct.byref(p),), (p, x, w1, w2, c1, c2b, b2, out, row_stats), name, flops, nbytes)
+
+
 # --------------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 7
+#define EDTR_ABI_VERSION 8
 
 enum edtr_dtype {
     EDTR_BF16 = 0, EDTR_F16 = 1,
@@ -302,6 +302,40 @@ typedef struct edtr_window_attn_params {
 } edtr_window_attn_params;
 
 int edtr_window_attn(const edtr_window_attn_params* p, edtr_stream_t stream);
+
+/* The MLP half of a Swin layer in one launch (ABI 8):  out = x + fc2(GELU(fc1(LayerNorm(x)))) on 16-bit token rows.
+ * replaces: `x = x + self.drop_path(self.mlp(self.norm2(x)))`, reference model/swinir.py:281-283 with Mlp.forward :31-37
+ *           (nn.LayerNorm eps 1e-5, nn.GELU exact, both dropouts are p = 0).
+ * Specialised for the shipped pre-restorer (configs/det/demo.yaml:2-18: embed_dim 180, mlp_ratio 2): C = 192 padded token
+ * columns, hidden = 384 padded hidden units; anything else is EDTR_E_UNSUPPORTED and the caller issues the two edtr_igemm
+ * launches instead.  Pad columns of x must be zero and stay zero (zero weight rows / bias entries).
+ *   x      : [rows][ldx] 16-bit; LayerNorm statistics run over the first c_valid columns' stored values
+ *   w1     : fc1 weights pre-multiplied by the LayerNorm gamma, rounded to `dtype`, as hidden/32 LDS images of 12288 bytes:
+ *            image t, byte r*384 + ((c ^ ((r >> 1) & 7)) << 4) + 2 j  =  (gamma . W1)[32 t + r][8 c + j]    (r < 32, c < 24, j < 8)
+ *   w2     : fc2 weights as hidden/32 images of 12288 bytes:
+ *            image t, byte r*64 + ((c ^ ((r >> 2) & 3)) << 4) + 2 j   =  W2[r][32 t + 8 c + j]                (r < 192, c < 4, j < 8)
+ *            (the XOR keys make every ds_read_b128 of an MFMA operand conflict-free; the images are copied by LDS-DMA as they are)
+ *   c1     : fp32 [hidden], row sums of the PACKED 16-bit (gamma . W1)    c2b : fp32 [hidden], W1 beta + fc1 bias
+ *            pre[u] = rstd (acc[u] - mean c1[u]) + c2b[u]   — the folded LayerNorm of edtr_igemm's ln_stats, with the row
+ *            statistics taken inside the kernel from the x rows it already holds
+ *   b2     : fp32 [C] fc2 bias (pad entries zero)
+ *   out    : [rows][ldo] 16-bit (may not alias x)
+ *   row_stats : optional fp32 [rows][C/32][2], the (sum, sum of squares) slots of the stored output rows in edtr_igemm's
+ *            row_stats format (slots 0 and 3 carry the sums of columns 0..95 / 96..191, the others are zero), for the
+ *            LayerNorm folded into the next layer's qkv projection.
+ * ldx % 8 == 0, ldo % 8 == 0, all pointers 16-byte aligned. */
+typedef struct edtr_swin_mlp_params {
+    int32_t dtype;
+    int32_t rows, C, hidden, c_valid;
+    float eps;
+    const void* x; int32_t ldx;
+    const void* w1; const void* w2;
+    const float* c1; const float* c2b; const float* b2;
+    void* out; int32_t ldo;
+    float* row_stats;
+} edtr_swin_mlp_params;
+
+int edtr_swin_mlp(const edtr_swin_mlp_params* p, edtr_stream_t stream);
 
 /* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p); columns cols..cols_pad-1
  * of every output row are written as zeros (so the row can feed a GEMM whose K is padded to a multiple of 8).

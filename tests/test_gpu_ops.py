@@ -898,6 +898,49 @@ def test_window_attention(dtype, B, H, W, heads, d, cp, shift):
     assert float(got[:, heads * d:].abs().max()) == 0.0 if cp > heads * d else True
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows", [128, 4096 + 64, 300, 32768])
+def test_swin_mlp_one_launch(dtype, rows):
+    """edtr_swin_mlp: x + fc2(GELU(fc1(LayerNorm(x)))) of a Swin layer in one launch (reference model/swinir.py:24-37, :281-283)
+    vs torch fp32 on the same 16-bit inputs: 180 real of 192 columns, 360 real of 384 hidden units, ragged row counts
+    (a partial last workgroup, a partial 32-token tile); pad columns stay exactly zero; the row statistics it writes for the
+    next layer's folded LayerNorm are those of the stored values."""
+    ops = _ops()
+    d = dev()
+    C, HID, CP, HP = 180, 360, ops.SWIN_MLP_C, ops.SWIN_MLP_HIDDEN
+    x = torch.zeros((rows, CP))
+    x[:, :C] = rnd((rows, C), 190, 1.5) + 0.4
+    x = x.to(dtype)
+    gamma, beta = 1 + 0.2 * rnd((C,), 191), 0.3 * rnd((C,), 192)
+    w1, b1 = rnd((HID, C), 193, 1 / math.sqrt(C)), 0.2 * rnd((HID,), 194)
+    w2, b2 = rnd((C, HID), 195, 1 / math.sqrt(HID)), 0.2 * rnd((C,), 196)
+    w1g = torch.zeros((HP, CP))
+    w1g[:HID, :C] = w1 * gamma[None, :]
+    w2p = torch.zeros((CP, HP))
+    w2p[:C, :HID] = w2
+    img1, img2 = ops.pack_swin_mlp_weights(w1g, w2p, dtype)
+    c1 = w1g.to(dtype).float().sum(1).contiguous()
+    c2b = torch.zeros(HP)
+    c2b[:HID] = w1 @ beta + b1
+    b2p = torch.zeros(CP)
+    b2p[:C] = b2
+    out = torch.full((rows, CP), float("nan"), dtype=dtype, device=d)
+    stats = torch.full((rows, CP // 32, 2), float("nan"), dtype=torch.float32, device=d)
+    ops.launch(ops.make_swin_mlp(dtype=dtype, x=x.to(d), ldx=CP, rows=rows, c_valid=C, eps=1e-5, w1=img1.to(d), w2=img2.to(d), c1=c1.to(d),
+                                 c2b=c2b.to(d), b2=b2p.to(d), out=out, ldo=CP, row_stats=stats))
+    torch.cuda.synchronize()
+    xf = x.float()[:, :C]
+    h = F.gelu(F.layer_norm(xf, (C,), gamma, beta, 1e-5) @ w1.t() + b1)
+    ref = xf + h @ w2.t() + b2
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel(got[:, :C], ref) < TOL[dtype]
+    assert float(got[:, C:].abs().max()) == 0.0
+    tot = stats.double().sum(1).cpu()
+    st = out.double().cpu()
+    assert rel(tot[:, 0], st.sum(1)) < 2e-6 and rel(tot[:, 1], (st ** 2).sum(1)) < 2e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # tile 14 (256 x 32, skinny-N convolutions: the VAE decoder's 3-channel output conv) is selected automatically for N <= 32 at
 # large M; tiles 11-13 (round-1 experiments) were measured on the MI355X without gain and removed.

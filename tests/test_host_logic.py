@@ -286,6 +286,34 @@ def test_swinir_packing_helpers(golden_dir):
     assert bias.shape == (heads, 64, 64) and float(bias[3, 10, 50]) == float(table[idx[10, 50], 3])
 
 
+def test_swin_mlp_weight_images():
+    """pack_swin_mlp_weights writes the LDS images edtr_swin_mlp documents (include/edtr_hip.h): chunk c of row r at slot
+    c ^ key(r), element for element, and every MFMA operand read of the kernel (16 lanes = 16 rows, one chunk) touches 16
+    different 16-byte bank slots."""
+    from edtr_amd import ops
+    C, HID = ops.SWIN_MLP_C, ops.SWIN_MLP_HIDDEN
+    w1 = (torch.arange(HID * C, dtype=torch.float32).reshape(HID, C) % 2039) / 8.0          # exactly representable in fp16
+    w2 = (torch.arange(C * HID, dtype=torch.float32).reshape(C, HID) % 2029) / 8.0
+    i1, i2 = ops.pack_swin_mlp_weights(w1, w2, torch.float16)
+    assert i1.numel() == HID * C and i2.numel() == C * HID
+    b1, b2 = i1.view(torch.uint8).numpy(), i2.view(torch.uint8).numpy()
+    h1, h2 = w1.to(torch.float16).numpy(), w2.to(torch.float16).numpy()
+    rng = np.random.default_rng(0)
+    for _ in range(400):
+        t, r, c, j = rng.integers(HID // 32), rng.integers(32), rng.integers(C // 8), rng.integers(8)
+        off = t * 12288 + r * 384 + ((c ^ ((r >> 1) & 7)) << 4) + 2 * j
+        assert b1[off:off + 2].view(np.float16)[0] == h1[32 * t + r, 8 * c + j]
+        r2, c2 = rng.integers(C), rng.integers(4)
+        off = t * 12288 + r2 * 64 + ((c2 ^ ((r2 >> 2) & 3)) << 4) + 2 * j
+        assert b2[off:off + 2].view(np.float16)[0] == h2[r2, 32 * t + 8 * c2 + j]
+    for c in range(C // 8):          # W1 tile: the 16 rows a lane group reads (any permutation of 16 consecutive rows), chunk c
+        for r0 in (0, 16):
+            assert len({((r * 384 + ((c ^ ((r >> 1) & 7)) << 4)) >> 4) & 15 for r in range(r0, r0 + 16)}) == 16
+    for c in range(4):               # W2 slice
+        for r0 in range(0, C, 16):
+            assert len({((r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) >> 4) & 15 for r in range(r0, r0 + 16)}) == 16
+
+
 def test_engine_cache_lru():
     """Shape-keyed engine cache: hits refresh recency, the least recently used entry is evicted and released past capacity."""
     from edtr_amd.engine import EngineCache
