@@ -102,6 +102,61 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x + 0.5f * fabsf(x) * e;                 // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
 }
 
+// gelu_erf_f over 8 values in LOCKSTEP: one stage of the evaluation for all eight before the next.  Left alone, hipcc evaluates
+// value after value (least register pressure), and a wave with at most one partner on its SIMD — every MFMA kernel here —
+// then runs the 13-deep dependency chain of each value at the VALU latency (measured in edtr_swin_mlp: 2.5k cycles for 16
+// values, 11 cycles per instruction) instead of at the issue rate.  An empty asm that takes a stage's eight results as
+// read-write operands pins the order (__builtin_amdgcn_sched_barrier does not: the arithmetic is moved across it before the
+// scheduler runs).  HALF_IN: the caller passes h = x / 2 (folded into its affine constants) — one stage less.
+__device__ __forceinline__ void pin8(float (&v)[8]) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+template <bool HALF_IN>
+__device__ __forceinline__ void gelu_erf_lockstep(float (&h)[8]) {
+    float d[8], u[8], poly[8];
+    if constexpr (!HALF_IN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = 0.5f * h[i];
+        pin8(h);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_fmaf(fabsf(h[i]), 0.3275911f * 1.41421356237309504880f, 1.0f);
+    pin8(d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_rcpf(d[i]);                    // t = 1 / (1 + p |x| / sqrt 2)
+    pin8(d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = h[i] * h[i];
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = u[i] * (-2.0f * 1.4426950408889634f);
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_exp2f(u[i]);                   // exp(-x^2 / 2)
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(1.061405429f, d[i], -1.453152027f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], 1.421413741f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], -0.284496736f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], 0.254829592f);
+    pin8(poly);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = u[i] * d[i];
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = __builtin_fmaf(-poly[i], u[i], 1.0f);           // erf(|x| / sqrt 2)
+    pin8(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = __builtin_fmaf(fabsf(h[i]), u[i], h[i]);        // x/2 (1 + sign(x) erf(|x| / sqrt 2))
+    pin8(h);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

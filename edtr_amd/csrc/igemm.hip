@@ -109,8 +109,7 @@ __device__ __forceinline__ void finish_vector(const edtr_igemm_params& p, float 
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
     } else if (p.act == EDTR_ACT_GELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = gelu_erf_f(f[j]);
+        gelu_erf_lockstep<false>(f);
     } else if (p.act == EDTR_ACT_LRELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], f[j] * p.act_slope);   // slope in [0, 1]
@@ -579,8 +578,7 @@ __device__ __forceinline__ void rows_phase(const edtr_igemm_params& p, const flo
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
             } else if (gelu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = gelu_erf_f(f[j]);
+                gelu_erf_lockstep<false>(f);
             } else if (lrelu) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], f[j] * p.act_slope);
@@ -685,26 +683,69 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
             // latency — 250 cycles per element, 8.2k of the tile's 20k cycles in the in-kernel stamps (round 3)
             float* const st = stage + (wm * 32 * MI + 4 * lh) * BNO + wn * 32 + l31;
             const float alpha = p.alpha;
-            if (ln) {
+            // (round 4) ... and eight gates at a time through gelu_erf_lockstep: even in straight-line code hipcc runs each value's
+            // chain to its end before the next (EDTR_IGEMM_GEGLU_SERIAL=1 — debug_flags bit 2 — is the A/B)
+            if (p.debug_flags & 4) {
+                if (ln) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int mo = mi * 32 + (r & 3) + 8 * (r >> 2);
+                            const float2 mr = ln_rows_lds()[wm * 32 * MI + 4 * lh + mo];
+                            const float val = mr.y * (acc[mi][0][r] * alpha - mr.x * c1v) + bv;
+                            const float gate = mr.y * (acc[mi][1][r] * alpha - mr.x * c1g) + bg;
+                            st[mo * BNO] = val * gelu_erf_f(gate);
+                        }
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int mo = mi * 32 + (r & 3) + 8 * (r >> 2);
+                            const float val = acc[mi][0][r] * alpha + bv;
+                            const float gate = acc[mi][1][r] * alpha + bg;
+                            st[mo * BNO] = val * gelu_erf_f(gate);
+                        }
+                }
+            } else if (ln) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int mo = mi * 32 + (r & 3) + 8 * (r >> 2);
-                        const float2 mr = ln_rows_lds()[wm * 32 * MI + 4 * lh + mo];
-                        const float val = mr.y * (acc[mi][0][r] * alpha - mr.x * c1v) + bv;
-                        const float gate = mr.y * (acc[mi][1][r] * alpha - mr.x * c1g) + bg;
-                        st[mo * BNO] = val * gelu_erf_f(gate);
+                    for (int rg = 0; rg < 2; ++rg) {
+                        float val[8], gate[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = 8 * rg + e, mo = mi * 32 + (r & 3) + 8 * (r >> 2);
+                            const float2 mr = ln_rows_lds()[wm * 32 * MI + 4 * lh + mo];
+                            val[e] = mr.y * (acc[mi][0][r] * alpha - mr.x * c1v) + bv;
+                            gate[e] = mr.y * (acc[mi][1][r] * alpha - mr.x * c1g) + bg;
+                        }
+                        gelu_erf_lockstep<false>(gate);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = 8 * rg + e, mo = mi * 32 + (r & 3) + 8 * (r >> 2);
+                            st[mo * BNO] = val[e] * gate[e];
+                        }
                     }
             } else {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int mo = mi * 32 + (r & 3) + 8 * (r >> 2);
-                        const float val = acc[mi][0][r] * alpha + bv;
-                        const float gate = acc[mi][1][r] * alpha + bg;
-                        st[mo * BNO] = val * gelu_erf_f(gate);
+                    for (int rg = 0; rg < 2; ++rg) {
+                        float val[8], gate[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = 8 * rg + e;
+                            val[e] = acc[mi][0][r] * alpha + bv;
+                            gate[e] = acc[mi][1][r] * alpha + bg;
+                        }
+                        gelu_erf_lockstep<false>(gate);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = 8 * rg + e, mo = mi * 32 + (r & 3) + 8 * (r >> 2);
+                            st[mo * BNO] = val[e] * gate[e];
+                        }
                     }
             }
         }
@@ -2281,7 +2322,8 @@ static int dbg_flags() {
     if (dbg < 0) {
         const char* e8 = getenv("EDTR_IGEMM_GENERAL_EPILOGUE");
         const char* e10 = getenv("EDTR_IGEMM_N160_TWO_PASS");
-        dbg = ((e8 && e8[0] == '1') ? 1 : 0) | ((e10 && e10[0] == '1') ? 2 : 0);
+        const char* e12 = getenv("EDTR_IGEMM_GEGLU_SERIAL");
+        dbg = ((e8 && e8[0] == '1') ? 1 : 0) | ((e10 && e10[0] == '1') ? 2 : 0) | ((e12 && e12[0] == '1') ? 4 : 0);
     }
     return dbg;
 }

@@ -217,55 +217,6 @@ __global__ void __launch_bounds__(256) window_attn_kernel(const edtr_window_attn
 // Everything arrives by LDS-DMA: the weights as pre-swizzled 12 KiB images (packed by the host, layout in the header), a
 // "unit" = [W2 slice j - 1 | W1 tile j] of one half per period, two periods ahead, into that half's other buffer; the token
 // tile with the same XOR swizzle applied on the source side, so that rows are fetched and stored as whole 384-byte runs.
-// gelu_erf_f (common.h) over 8 values in LOCKSTEP: one stage of the evaluation for all eight before the next.  Left alone, hipcc
-// evaluates value after value (least register pressure) and the wave — alone or with one partner on its SIMD — then runs a
-// 13-deep dependency chain per value at the VALU latency (measured in this kernel: 2.5k cycles for 16 values, 11 cycles per
-// instruction) instead of at the issue rate.  An empty asm that takes a stage's eight results as read-write operands pins the
-// order (__builtin_amdgcn_sched_barrier does not: the arithmetic is moved across it before the scheduler runs).
-__device__ __forceinline__ void pin8(float (&v)[8]) {
-    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-}
-// in: h = x / 2 (the caller folds the half into its affine constants); out: gelu(x) = h + |h| erf(|x| / sqrt 2)
-__device__ __forceinline__ void gelu_erf_lockstep(float (&h)[8]) {
-    float d[8], u[8], poly[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = __builtin_fmaf(fabsf(h[i]), 0.3275911f * 1.41421356237309504880f, 1.0f);
-    pin8(d);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_rcpf(d[i]);                    // t = 1 / (1 + p |x| / sqrt 2)
-    pin8(d);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = h[i] * h[i];
-    pin8(u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = u[i] * (-2.0f * 1.4426950408889634f);
-    pin8(u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_exp2f(u[i]);                   // exp(-x^2 / 2)
-    pin8(u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(1.061405429f, d[i], -1.453152027f);
-    pin8(poly);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], 1.421413741f);
-    pin8(poly);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], -0.284496736f);
-    pin8(poly);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) poly[i] = __builtin_fmaf(poly[i], d[i], 0.254829592f);
-    pin8(poly);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = u[i] * d[i];
-    pin8(u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = __builtin_fmaf(-poly[i], u[i], 1.0f);           // erf(|x| / sqrt 2)
-    pin8(u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = __builtin_fmaf(fabsf(h[i]), u[i], h[i]);
-    pin8(h);
-}
-
 constexpr int MLP_CT = 6, MLP_HT = 12;                       // 32-wide tiles of the token width 192 and of the hidden width 384
 constexpr int MLP_IMG = 32 * 32 * MLP_CT * 2;                // 12288 B: one W1 tile (32 units x 192 k) or one W2 slice (192 c x 32 units)
 constexpr int MLP_THREADS = 512, MLP_TOKENS = 128;
@@ -286,7 +237,7 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
     constexpr int C = 32 * MLP_CT, HID = 32 * MLP_HT, NJ = MLP_HT / 2, KS = 2 * MLP_CT, PERIODS = 2 * NJ + 2;
     const int tok_base = blockIdx.x * MLP_TOKENS;
 
-    for (int i = tid; i < HID; i += MLP_THREADS) { cst[i] = 0.5f * p.c1[i]; cst[HID + i] = 0.5f * p.c2b[i]; }     // halves: see gelu_erf_lockstep
+    for (int i = tid; i < HID; i += MLP_THREADS) { cst[i] = 0.5f * p.c1[i]; cst[HID + i] = 0.5f * p.c2b[i]; }     // halves: see gelu_erf_lockstep<true> (common.h)
     if (tid < C) cst[2 * HID + tid] = p.b2[tid];
 
     // ---- token tile: 48 DMA instructions of 1 KiB, six per wave (instruction Q = 6 wave + q covers rows 8 (Q / 3) .. + 7 in three
@@ -433,7 +384,7 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
                 float g[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = __builtin_fmaf(k0, hacc[8 * s + e], __builtin_fmaf(k1, c1v[e], c2v[e]));
-                gelu_erf_lockstep(g);
+                gelu_erf_lockstep<true>(g);
                 if (s == 0) hb0 = pack8<T>(g); else hb1 = pack8<T>(g);
             }
         }

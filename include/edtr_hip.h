@@ -173,7 +173,8 @@ typedef struct edtr_igemm_params {
                                loops and their store bursts in lockstep */
     int32_t debug_flags;    /* set by edtr_igemm itself from the environment (A/B measurements on one device): bit 0 =
                                EDTR_IGEMM_GENERAL_EPILOGUE=1, every launch takes the general epilogue row loop; bit 1 = EDTR_IGEMM_N160_TWO_PASS=1,
-                               the 128x160 tile stages its accumulators in two passes of 64 rows */
+                               the 128x160 tile stages its accumulators in two passes of 64 rows; bit 2 = EDTR_IGEMM_GEGLU_SERIAL=1, the GEGLU epilogue evaluates
+                               its gates one value after the other (the form before the eight-value lockstep evaluation) */
     /* Sub-pixel form of `F.interpolate(x, scale_factor=2, mode="nearest")` + 3x3 conv (ABI 7; upsample2x == 2; reference
      * model/unet.py:70-79, model/vae.py:35-39).  The 2 x 2 blocks of the upsampled image are constant, so output pixel
      * (2s + py, 2r + px) is a 2 x 2 convolution of the SOURCE image whose weights are sums of the 3 x 3 kernel's rows / columns:
