@@ -466,6 +466,373 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// edtr_swin_attn — x + proj(WindowAttention(LayerNorm(x))) of one Swin layer in ONE launch (reference model/swinir.py:254-279:
+// norm1, cyclic shift, window partition, WindowAttention.forward :120-148 incl. the qkv and proj linears, window reverse,
+// shift back, residual).  As three launches (qkv GEMM, edtr_window_attn, proj GEMM) the half layer is 26 + 29 + 15 us of
+// launch-sized round trips of the token tensor and of the 3.1 x wider qkv tensor; here a workgroup owns TWO windows (128
+// tokens, gathered into an LDS tile by LDS-DMA with the shift and window arithmetic applied to the row address) and nothing
+// but the tile and the weight images ever moves.
+//
+// Wave (t4, g) of the eight owns token tile t4 (window t4 >> 1, its queries 32 (t4 & 1) .. + 31) and head group g (three
+// heads).  Per head, in four barrier-separated parts that follow the weight stream (one 12 KiB image per group and part,
+// LDS-DMA one part ahead):
+//   q: q^T[d][t] = Wq x^T (A = weight rows, bits 2,3 of the row index swapped; B = x fragments)  -> folded LayerNorm -> B fragments
+//   k: k^T likewise                                                    -> A fragments of S^T = K Q^T, published in LDS
+//   v: v[t][d]  = x Wv^T (A = x fragments, B = weight rows)            -> A fragments of O^T = V^T P^T, published in LDS
+//   o: S^T for both key tiles of the window (the partner tile's K / V come from LDS), + relative-position bias, + region mask,
+//      softmax in registers (a query's 64 keys are 32 registers here and 32 in lane ^ 32), O^T, and the head's share of
+//      proj: out^T[c][t] += Wp[c][h, d] O[t][d].
+// The accumulator layout of one product is the operand layout of the next throughout (attention.hip's trick): keys sit on
+// the MFMA rows of S^T in the same register pattern in which tokens sit on the rows of v, so P^T and V^T meet without a
+// shuffle; the swapped weight rows make q, k, O and the output leave their accumulators in operand / storage order.
+// The two head groups' partial outputs meet once, after the loop, as in edtr_swin_mlp; the result replaces x in the LDS tile
+// and leaves as whole rows, scattered back through the same row map.
+constexpr int SA_HEADS = 6, SA_CT = 6;                       // 6 heads x 32 (padded) columns; 6 x 32 token columns
+constexpr int SA_IMG = 12288;                                // one weight image: 32 rows x 192 k (q / k / v of a head) or 192 rows x 32 k (proj)
+constexpr int SA_THREADS = 512, SA_TOKENS = 128;
+constexpr int SA_WBUF = 2 * 2 * SA_IMG;                      // [buffer][head group]
+constexpr int SA_XT = SA_TOKENS * 384;
+constexpr int SA_XCH = 48 * 1024;                            // loop: K / V fragments [window][group][key tile][k | v][step] x 1 KiB (32 KiB); after it, with WBUF: the partial outputs
+constexpr int SA_CONST_FLOATS = 2 * 3 * SA_HEADS * 32 + 32 * SA_CT + 2 * SA_TOKENS;      // c1 | c2b | bproj | per-token (rstd, -rstd mean)
+constexpr int SA_LDS = SA_WBUF + SA_XCH + SA_XT + SA_CONST_FLOATS * 4 + SA_TOKENS;       // + one region label per token
+
+template <typename T>
+__global__ void __launch_bounds__(SA_THREADS) swin_attn_kernel(const edtr_swin_attn_params p, int total_windows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int t4 = wave & 3, g = wave >> 2, ww = t4 >> 1, tt = t4 & 1;
+    char* xch = smem + SA_WBUF;
+    char* xt = smem + SA_WBUF + SA_XCH;
+    float* cst = reinterpret_cast<float*>(smem + SA_WBUF + SA_XCH + SA_XT);
+    constexpr int NQKV = 3 * SA_HEADS * 32, C = 32 * SA_CT, KS = 2 * SA_CT;
+    float* ts = cst + 2 * NQKV + C;
+    uint8_t* lab = reinterpret_cast<uint8_t*>(ts + 2 * SA_TOKENS);
+    const uint32_t lds0 = lds_addr_of(smem);
+    const int nwx = p.W / WS, nwy = p.H / WS;
+
+    // token n of window `win` -> row of the unshifted token matrix (the window is cut from the cyclically shifted image)
+    auto token_row = [&](int win, int n) -> int64_t {
+        const int wx = win % nwx, r = win / nwx, wy = r % nwy, b = r / nwy;
+        int y = wy * WS + (n >> 3) + p.shift, x = wx * WS + (n & 7) + p.shift;
+        if (y >= p.H) y -= p.H;
+        if (x >= p.W) x -= p.W;
+        return ((int64_t)b * p.H + y) * p.W + x;
+    };
+    const int win0 = blockIdx.x * 2;
+    // LDS tile row r holds token (r & ~31) | swap(r & 31) of the tile (swap = bits 2,3 exchanged: an involution), so that a lane's
+    // token row and the weight row it feeds carry the SAME swizzle key and share their twelve chunk offsets
+    auto tile_token = [](int r) { return (r & ~15) | swap23(r & 15); };
+    auto tile_slot = [&](int q, int ln, int& r, int& c) {       // tile row and SOURCE chunk of lane ln's 16 bytes of DMA instruction 6 wave + q
+        const int e = 64 * (q % 3) + ln, rl = e / 24;
+        r = 8 * (2 * wave + q / 3) + rl;
+        c = (e - 24 * rl) ^ ((r >> 1) & 7);
+    };
+
+    for (int i = tid; i < NQKV; i += SA_THREADS) { cst[i] = p.c1[i]; cst[NQKV + i] = p.c2b[i]; }
+    if (tid < C) cst[2 * NQKV + tid] = p.bproj[tid];
+    if (tid < SA_TOKENS) {
+        uint8_t v = 0;
+        if (p.labels) {
+            const int win = min(win0 + (tid >> 6), total_windows - 1), n = tid & 63;
+            const int wx = win % nwx, wy = (win / nwx) % nwy;
+            v = p.labels[(int64_t)(wy * WS + (n >> 3)) * p.W + wx * WS + (n & 7)];
+        }
+        lab[tid] = v;
+    }
+    {
+        const uint16_t* xg = static_cast<const uint16_t*>(p.x);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            int r, c;
+            tile_slot(q, lane, r, c);
+            const int64_t row = token_row(min(win0 + (r >> 6), total_windows - 1), tile_token(r) & 63);
+            dma16(xg + row * p.ldx + c * 8, lds0 + SA_WBUF + SA_XCH + (wave * 6 + q) * 1024);
+        }
+    }
+    // weight unit n = 4 i + part (head 3 g' + i of each group g'; part 0 / 1 / 2 = the q / k / v image, 3 = the proj slice): 24 KiB,
+    // three instructions per wave (chunk e = wave, wave + 8, wave + 16 of 24: e < 12 belongs to group 0)
+    const int lane16 = lane * 16;
+    auto stage_unit = [&](int n) {
+        const int i = n >> 2, part = n & 3;
+        const uint32_t dst = lds0 + (uint32_t)(n & 1) * (2 * SA_IMG);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int e = wave + 8 * k, gg = e >= 12 ? 1 : 0, off = (e - 12 * gg) * 1024;
+            const int h = 3 * gg + i;
+            const char* src = part < 3 ? static_cast<const char*>(p.wqkv) + (int64_t)(h * 3 + part) * SA_IMG : static_cast<const char*>(p.wproj) + (int64_t)h * SA_IMG;
+            dma16(src + off + lane16, dst + e * 1024);
+        }
+    };
+    stage_unit(0);
+
+    const int rs = (l31 & 16) | swap23(l31 & 15);              // the weight row this lane feeds to MFMA row / column l31 ...
+    const int xrow = t4 * 32 + l31;                             // this lane's token in the tile ...
+    const int w1_row = rs * (C * 2), key1 = (rs >> 1) & 7;     // ... which sits in tile row t4 * 32 + rs: same key
+    char* const xt4 = xt + t4 * 32 * (C * 2);                  // this wave's 32 rows of the tile (uniform)
+    // chunk 2 ks + lh of a 384-byte row: the XOR key touches the low three chunk bits only and 2 ks + lh = 2 ks ^ lh, so ONE
+    // offset serves all twelve k-steps: (ks >> 2) * 128 + (perm0 ^ 32 (ks & 3))
+    const int perm0 = (lh ^ key1) << 4;
+    auto chunk = [&](int ks) { return (ks >> 2) * 128 + (perm0 ^ (32 * (ks & 3))); };
+    auto xfrag = [&](int ks) { return *reinterpret_cast<const U4*>(xt4 + w1_row + chunk(ks)); };
+    auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const U4*>(img + w1_row + chunk(ks)); };
+    // a 32 x 32 x 192 product of a weight image with this wave's token tile: fragment reads run one group of four k-steps ahead of
+    // the MFMAs (pinned: hipcc would otherwise issue all 24 reads up front — 96 registers at the kernel's pressure peak);
+    // W_ROWS: the weight rows are the MFMA rows (q^T, k^T), else the tokens are (v)
+    auto pin8f = [](u32x4 (&f)[8]) {
+        asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+    };
+    auto project = [&](const char* img, f32x16& acc, auto W_ROWS) {
+        u32x4 f0[8], f1[8];          // [0..3] weight, [4..7] token fragments of four k-steps
+        auto load4 = [&](u32x4 (&f)[8], int ks0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = *reinterpret_cast<const u32x4*>(img + w1_row + chunk(ks0 + e));
+                f[4 + e] = *reinterpret_cast<const u32x4*>(xt4 + w1_row + chunk(ks0 + e));
+            }
+        };
+        auto mul4 = [&](u32x4 (&f)[8]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const U4 w = __builtin_bit_cast(U4, f[e]), x = __builtin_bit_cast(U4, f[4 + e]);
+                if constexpr (decltype(W_ROWS)::value) acc = T::mfma(w, x, acc);
+                else acc = T::mfma(x, w, acc);
+            }
+        };
+        load4(f0, 0);
+        load4(f1, 4);
+        pin8f(f0);
+        mul4(f0);
+        load4(f0, 8);
+        pin8f(f1);
+        mul4(f1);
+        pin8f(f0);
+        mul4(f0);
+    };
+    const int key2 = (rs >> 2) & 3;
+    const int w2_o0 = rs * 64 + ((lh ^ key2) << 4);           // k-step 1 is the chunk two further: offset ^ 32
+    const int qn = 32 * tt + l31;                               // this lane's query within its window
+    char* const my_x0 = xch + (((ww * 2 + g) * 2 + tt) * 4) * 1024;               // [k s0, k s1, v s0, v s1] (uniform; + lane16)
+    const char* const win_x0 = xch + ((ww * 2 + g) * 2) * 4 * 1024;               // + key tile * 4096 + (k | v) * 2048 + step * 1024
+
+    float k0 = 0.0f, k1 = 0.0f;
+    U4 qf[2] = {zero16(), zero16()};
+    f32x16 oacc[SA_CT];
+#pragma unroll
+    for (int ct = 0; ct < SA_CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[ct][r] = 0.0f;
+
+#pragma unroll 1
+    for (int n = 0; n < 4 * 3; ++n) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of unit n (and, at n = 0, of the token tile) has landed
+        __syncthreads();                                        // ... everyone's, and the other buffer is free
+        if (n + 1 < 12) stage_unit(n + 1);
+        if (n == 0) {
+            // LayerNorm statistics of this lane's token over the stored values (pad columns are zero)
+            float s = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float f[8];
+                unpack8<T>(xfrag(ks), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s += f[j]; q = __builtin_fmaf(f[j], f[j], q); }
+            }
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            // (through an SGPR: as a hoisted VGPR value the reciprocal is one more register carried through the loop)
+            const float inv_c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / (float)p.c_valid)));
+            const float mean = s * inv_c;
+            const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
+            k0 = __builtin_amdgcn_rsqf(var + p.eps);
+            k1 = -k0 * mean;
+            if (g == 0 && lh == 0) { ts[2 * xrow] = k0; ts[2 * xrow + 1] = k1; }      // (read in the v parts: two barriers from here)
+        }
+        const int i = n >> 2, part = n & 3, h = 3 * g + i;
+        const char* img = smem + (n & 1) * (2 * SA_IMG) + g * SA_IMG;
+        if (part < 2) {
+            // ---- q^T / k^T [d][t]: folded LayerNorm per lane (token), constants per register (d = 16 s + 8 lh + j)
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            project(img, acc, std::true_type{});
+            const float* cu = cst + (part * SA_HEADS + h) * 32 + 8 * lh;
+            U4 f2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4 ca = *reinterpret_cast<const f32x4*>(cu + 16 * s), cb = *reinterpret_cast<const f32x4*>(cu + 16 * s + 4);
+                const f32x4 da = *reinterpret_cast<const f32x4*>(cu + NQKV + 16 * s), db = *reinterpret_cast<const f32x4*>(cu + NQKV + 16 * s + 4);
+                const float c1v[8] = {ca[0], ca[1], ca[2], ca[3], cb[0], cb[1], cb[2], cb[3]};
+                const float c2v[8] = {da[0], da[1], da[2], da[3], db[0], db[1], db[2], db[3]};
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(k0, acc[8 * s + e], __builtin_fmaf(k1, c1v[e], c2v[e]));
+                f2[s] = pack8<T>(v);
+            }
+            if (part == 0) { qf[0] = f2[0]; qf[1] = f2[1]; }
+            else { *reinterpret_cast<U4*>(my_x0 + lane16) = f2[0]; *reinterpret_cast<U4*>(my_x0 + lane16 + 1024) = f2[1]; }
+        } else if (part == 2) {
+            // ---- v [t][d]: tokens on the rows (per register), this lane's column is head channel rs
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            project(img, acc, std::false_type{});
+            const float c1v = cst[(2 * SA_HEADS + h) * 32 + rs], c2v = cst[NQKV + (2 * SA_HEADS + h) * 32 + rs];
+            const float* tsw = ts + 2 * (t4 * 32 + 4 * lh);
+            U4 f2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {               // registers 8 s + 4 gq + e: tokens 16 s + 8 gq + 4 lh + e
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(tsw + 2 * (16 * s + 8 * gq));
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(tsw + 2 * (16 * s + 8 * gq) + 4);
+                    const float r0[4] = {a[0], a[2], b[0], b[2]}, r1[4] = {a[1], a[3], b[1], b[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * gq + e] = __builtin_fmaf(r0[e], acc[8 * s + 4 * gq + e], __builtin_fmaf(r1[e], c1v, c2v));
+                }
+                f2[s] = pack8<T>(v);
+            }
+            *reinterpret_cast<U4*>(my_x0 + lane16 + 2048) = f2[0];
+            *reinterpret_cast<U4*>(my_x0 + lane16 + 3072) = f2[1];
+        } else {
+            // ---- scores of this tile's 32 queries against the window's 64 keys; register r of sc[kt] is key 32 kt + 8 (r >> 2) + 4 lh + (r & 3)
+            f32x16 sc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt][r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) sc[kt] = T::mfma(*reinterpret_cast<const U4*>(win_x0 + lane16 + kt * 4096 + s * 1024), qf[s], sc[kt]);
+            }
+            int qo = qn;
+            asm volatile("" : "+v"(qo));                        // (the per-lane bias address is formed here, not carried through the loop)
+            const float* bias_h = p.bias + ((int64_t)h * 16 * 64 + qo) * 4;
+            const uint32_t qlab = lab[ww * 64 + qo];
+            float m = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int kg = 8 * kt + 2 * gq + lh;                          // keys 4 kg .. 4 kg + 3
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + kg * 64 * 4);
+                    const uint32_t kl = *reinterpret_cast<const uint32_t*>(lab + ww * 64 + 4 * kg);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = sc[kt][4 * gq + e] + b[e];
+                        if (p.labels && ((kl >> (8 * e)) & 0xffu) != qlab) v -= 100.0f;
+                        sc[kt][4 * gq + e] = v;
+                        m = fmaxf(m, v);
+                    }
+                }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float mc = m * 1.4426950408889634f;
+            float l = 0.0f;
+            U4 pf[2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                float pr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], 1.4426950408889634f, -mc));
+                    l += pr[r];
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float v[8] = {pr[8 * s], pr[8 * s + 1], pr[8 * s + 2], pr[8 * s + 3], pr[8 * s + 4], pr[8 * s + 5], pr[8 * s + 6], pr[8 * s + 7]};
+                    pf[kt][s] = pack8<T>(v);
+                }
+            }
+            l += __shfl_xor(l, 32, 64);
+            const float inv_l = 1.0f / l;
+            // ---- O^T[d][q] = V^T P^T, then this head's share of proj
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) o = T::mfma(*reinterpret_cast<const U4*>(win_x0 + lane16 + kt * 4096 + 2048 + s * 1024), pf[kt][s], o);
+            U4 of[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = o[8 * s + e] * inv_l;
+                of[s] = pack8<T>(v);
+            }
+#pragma unroll
+            for (int ct = 0; ct < SA_CT; ++ct) {
+                oacc[ct] = T::mfma(*reinterpret_cast<const U4*>(img + ct * 2048 + w2_o0), of[0], oacc[ct]);
+                oacc[ct] = T::mfma(*reinterpret_cast<const U4*>(img + ct * 2048 + (w2_o0 ^ 32)), of[1], oacc[ct]);
+            }
+        }
+    }
+
+    // ---- the two head groups meet: wave (t4, g) keeps output tiles 3 g .. 3 g + 2 and hands over the other three
+    __syncthreads();                                            // weight buffers and K / V slots are dead: they become the exchange area
+    constexpr int XCH = 3 * 16 * 64;                            // floats per wave
+    int l4 = lane16 >> 2;
+    asm volatile("" : "+v"(l4));
+    float* mine = reinterpret_cast<float*>(smem) + wave * XCH + l4;
+    const float* theirs = reinterpret_cast<const float*>(smem) + (wave ^ 4) * XCH + l4;
+    auto hand_over = [&](auto G) {
+        constexpr int give0 = 3 * (1 - decltype(G)::value);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x16& a = oacc[give0 + k];
+                const f32x4 v = {a[4 * gq], a[4 * gq + 1], a[4 * gq + 2], a[4 * gq + 3]};
+                *reinterpret_cast<f32x4*>(mine + (k * 4 + gq) * 256) = v;
+            }
+    };
+    if (g == 0) hand_over(std::integral_constant<int, 0>{}); else hand_over(std::integral_constant<int, 1>{});
+    __syncthreads();
+    auto finish = [&](auto G) {
+        constexpr int keep0 = 3 * decltype(G)::value;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {                    // registers 8 hh .. 8 hh + 7: channels 32 ct + 16 hh + 8 lh + 0..7 = x fragment 2 ct + hh
+                const int ct = keep0 + k;
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(theirs + (k * 4 + 2 * hh) * 256);
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(theirs + (k * 4 + 2 * hh + 1) * 256);
+                const float* bp = cst + 2 * NQKV + 32 * ct + 16 * hh + 8 * (l4 >> 7);      // (lane half from the re-derived lane offset)
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                char* slot = xt4 + w1_row + chunk(2 * ct + hh);
+                float xr[8];
+                unpack8<T>(*reinterpret_cast<const U4*>(slot), xr);
+                const f32x16& a = oacc[ct];
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (a[8 * hh + e] + o0[e]) + b0[e] + xr[e];
+                    v[4 + e] = (a[8 * hh + 4 + e] + o1[e]) + b1[e] + xr[4 + e];
+                }
+                *reinterpret_cast<U4*>(slot) = pack8<T>(v);    // in place: this lane's own chunk
+            }
+    };
+    if (g == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 1>{});
+    __syncthreads();
+
+    // ---- the finished tile leaves as whole rows, scattered back through the row map
+    {
+        uint16_t* og = static_cast<uint16_t*>(p.out);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));        // (recompute the slot arithmetic here instead of carrying the prologue's through the loop)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            int r, c;
+            tile_slot(q, ln, r, c);
+            const U4 v = *reinterpret_cast<const U4*>(xt + (wave * 6 + q) * 1024 + ln * 16);
+            const int win = win0 + (r >> 6);
+            if (win < total_windows) stg16(og + token_row(win, tile_token(r) & 63) * p.ldo + c * 8, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // pixel-unshuffle front end: one thread = one (token, channel, dy) run of r source pixels
 template <typename T>
 __global__ void __launch_bounds__(256) pixel_unshuffle_kernel(const float* src, int B, int C, int H, int W, int r, const float* sub,
@@ -552,6 +919,43 @@ extern "C" int edtr_swin_mlp(const edtr_swin_mlp_params* pp, edtr_stream_t strea
             attr_set[1] = true;
         }
         hipLaunchKernelGGL(swin_mlp_kernel<F16>, grid, dim3(MLP_THREADS), MLP_LDS, s, p);
+    }
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_swin_attn(const edtr_swin_attn_params* pp, edtr_stream_t stream) {
+    if (!pp) return EDTR_E_NULL;
+    const edtr_swin_attn_params& p = *pp;
+    if (!p.x || !p.wqkv || !p.wproj || !p.c1 || !p.c2b || !p.bproj || !p.bias || !p.out) return EDTR_E_NULL;
+    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (p.B <= 0 || p.H <= 0 || p.W <= 0 || (p.H % WS) || (p.W % WS) || p.c_valid <= 0 || p.c_valid > p.C) return EDTR_E_SHAPE;
+    if (p.C != 32 * SA_CT || p.heads != SA_HEADS || p.head_dim > HP || p.head_dim <= 0) return EDTR_E_UNSUPPORTED;   // the shipped SwinIR width
+    if (p.shift < 0 || p.shift >= WS) return EDTR_E_SHAPE;
+    if (p.shift > 0 && !p.labels) return EDTR_E_NULL;
+    if (p.x == p.out) return EDTR_E_UNSUPPORTED;               // other workgroups gather rows this one scatters
+    if (p.ldx < p.C || p.ldo < p.C) return EDTR_E_SHAPE;
+    if ((p.ldx & 7) || (p.ldo & 7) || (p.W & 3)) return EDTR_E_ALIGN;
+    if (!aligned16(p.x) || !aligned16(p.wqkv) || !aligned16(p.wproj) || !aligned16(p.out) || !aligned16(p.c1) || !aligned16(p.c2b) ||
+        !aligned16(p.bproj) || !aligned16(p.bias) || (p.labels && (reinterpret_cast<uintptr_t>(p.labels) & 3u)))
+        return EDTR_E_ALIGN;
+    const int64_t windows = (int64_t)p.B * (p.H / WS) * (p.W / WS);
+    if (windows > 0x3fffffffLL) return EDTR_E_UNSUPPORTED;
+    static bool attr_set[2] = {false, false};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((windows + 1) / 2));
+    if (p.dtype == EDTR_BF16) {
+        if (!attr_set[0]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS);
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL(swin_attn_kernel<BF16>, grid, dim3(SA_THREADS), SA_LDS, s, p, (int)windows);
+    } else {
+        if (!attr_set[1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS);
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL(swin_attn_kernel<F16>, grid, dim3(SA_THREADS), SA_LDS, s, p, (int)windows);
     }
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;

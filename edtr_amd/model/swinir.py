@@ -220,6 +220,30 @@ class _SwinEngine:
                 store.cache[key] = (img1, img2, c1, c2b, ops_mod.pad_bias(store._p(p + "mlp.fc2.bias"), CP))
             return store.cache[key]
 
+        # The attention half of a layer as ONE launch (edtr_swin_attn: LayerNorm + qkv + shifted-window attention + proj + residual on
+        # an LDS tile of two windows) at the shipped structure; EDTR_SWIN_ATTN_FUSE=0 issues the three launches instead.
+        fuse_attn = (os.environ.get("EDTR_SWIN_ATTN_FUSE", "1") != "0" and CP == ops_mod.SWIN_MLP_C and ws == 8 and tw % 4 == 0
+                     and all(h == ops_mod.SWIN_ATTN_HEADS and C // h <= HEAD_PAD for h in cfg["num_heads"]))
+
+        def attn_images(p: str, heads: int):
+            key = ("swin_attn", p)
+            if key not in store.cache:
+                d = C // heads
+                wq32, bq32 = pack_qkv(store._p(p + "attn.qkv.weight"), store._p(p + "attn.qkv.bias"), heads, CP)     # rows (s, h, e)
+                gamma, beta = store.vec(p + "norm1.weight", CP), store.vec(p + "norm1.bias", CP)                    # pad entries are zero
+                scale = torch.ones(3 * heads * HEAD_PAD, dtype=torch.float32, device=dev)
+                scale[: heads * HEAD_PAD] = d ** -0.5                                                               # q * scale (model/swinir.py:128)
+                wg = wq32 * gamma[None, :] * scale[:, None]
+                c2b = ((wq32 @ beta + bq32) * scale).contiguous()
+                wp = store._p(p + "attn.proj.weight")
+                wpp = torch.zeros((CP, heads, HEAD_PAD), dtype=torch.float32, device=dev)
+                wpp[:C, :, :d] = wp.reshape(C, heads, d)
+                img_qkv, img_proj = ops_mod.pack_swin_attn_weights(wg, wpp.reshape(CP, heads * HEAD_PAD), dt)
+                c1 = wg.to(dt).float().sum(dim=1).contiguous()
+                bias = ops_mod.swin_attn_bias(expand_bias(store._p(p + "attn.relative_position_bias_table"), ws))
+                store.cache[key] = (img_qkv, img_proj, c1, c2b, ops_mod.pad_bias(store._p(p + "attn.proj.bias"), CP), bias)
+            return store.cache[key]
+
         def fc1_f32(p: str, n_pad: int) -> torch.Tensor:
             w = store._p(p + "mlp.fc1.weight")
             wp_ = torch.zeros((n_pad, CP), dtype=torch.float32, device=dev)
@@ -240,6 +264,23 @@ class _SwinEngine:
             for j in range(depth):
                 p = f"layers.{i}.residual_group.blocks.{j}."
                 shift = 0 if j % 2 == 0 else ws // 2
+                last_of_group = j == depth - 1       # the group's last output feeds a 3x3 convolution, not a LayerNorm
+                if fuse_attn and fuse_mlp:
+                    if shift and shift not in labels:
+                        labels[shift] = torch.from_numpy(region_labels(th, tw, ws, shift)).to(dev).contiguous()
+                    img_qkv, img_proj, ac1, ac2b, abp, abias = attn_images(p, heads)
+                    x1 = em.new(rows, CP)
+                    self.prog.add(ops_mod.make_swin_attn(dtype=dt, x=r, ldx=r.stride(0), out=x1, ldo=CP, B=B, H=th, W=tw, head_dim=d, shift=shift,
+                                                         c_valid=C, eps=1e-5, wqkv=img_qkv, wproj=img_proj, c1=ac1, c2b=ac2b, bproj=abp, bias=abias,
+                                                         labels=labels[shift] if shift else None))
+                    if r is not t:
+                        em.free(r)
+                    img1, img2, c1, c2b, b2 = mlp_images(p)
+                    r = em.new(rows, CP)
+                    self.prog.add(ops_mod.make_swin_mlp(dtype=dt, x=x1, ldx=x1.stride(0), rows=rows, c_valid=C, eps=1e-5, w1=img1, w2=img2,
+                                                        c1=c1, c2b=c2b, b2=b2, out=r, ldo=CP, row_stats=None))
+                    em.free(x1)
+                    continue
                 key = ("swin_qkv", p)
                 if key not in store.cache:
                     wq, bq = pack_qkv(store._p(p + "attn.qkv.weight"), store._p(p + "attn.qkv.bias"), heads, CP)
@@ -270,7 +311,6 @@ class _SwinEngine:
                 em.free(o)
                 if r is not t:
                     em.free(r)
-                last_of_group = j == depth - 1       # the group's last output feeds a 3x3 convolution, not a LayerNorm
                 if fuse_mlp:
                     img1, img2, c1, c2b, b2 = mlp_images(p)
                     r = em.new(rows, CP)

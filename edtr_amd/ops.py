@@ -198,23 +198,65 @@ def make_window_attn(*, dtype, qkv, ld_qkv, out, ld_out, B, H, W, heads, head_di
 SWIN_MLP_C, SWIN_MLP_HIDDEN = 192, 384          # the one shape edtr_swin_mlp is built for (include/edtr_hip.h)
 
 
+def _swin_image_rows(w: torch.Tensor) -> torch.Tensor:
+    """16-bit [32 t, 192] -> t LDS images of a 32-row tile: chunk c of row r in slot c ^ ((r >> 1) & 7) (edtr_hip.h: edtr_swin_mlp w1)."""
+    T, C = w.shape[0] // 32, w.shape[1]
+    a = w.reshape(T, 32, C // 8, 8)
+    r = torch.arange(32, device=w.device)[:, None]
+    c = torch.arange(C // 8, device=w.device)[None, :]
+    img = torch.empty_like(a)
+    img[:, r, c ^ ((r >> 1) & 7)] = a[:, r, c]
+    return img.reshape(-1).contiguous()
+
+
+def _swin_image_slices(w: torch.Tensor) -> torch.Tensor:
+    """16-bit [192, 32 t] -> t LDS images of a 32-column slice: chunk c of row r in slot c ^ ((r >> 2) & 3) (edtr_swin_mlp w2)."""
+    C, T = w.shape[0], w.shape[1] // 32
+    b = w.reshape(C, T, 4, 8).permute(1, 0, 2, 3)
+    r = torch.arange(C, device=w.device)[:, None]
+    c = torch.arange(4, device=w.device)[None, :]
+    img = torch.empty((T, C, 4, 8), dtype=w.dtype, device=w.device)
+    img[:, r, c ^ ((r >> 2) & 3)] = b[:, r, c]
+    return img.reshape(-1).contiguous()
+
+
 def pack_swin_mlp_weights(w1g: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
     """fp32 [384, 192] (gamma-scaled fc1) and [192, 384] (fc2), both already zero-padded -> the two LDS-image tensors
     edtr_swin_mlp copies by LDS-DMA (layout: include/edtr_hip.h, edtr_swin_mlp_params.w1 / .w2)."""
-    C, HID = SWIN_MLP_C, SWIN_MLP_HIDDEN
-    assert tuple(w1g.shape) == (HID, C) and tuple(w2.shape) == (C, HID)
-    dev = w1g.device
-    a = w1g.to(dtype).reshape(HID // 32, 32, C // 8, 8)                       # [tile][r][c][j]
-    r = torch.arange(32, device=dev)[:, None]
-    c = torch.arange(C // 8, device=dev)[None, :]
-    img1 = torch.empty_like(a)
-    img1[:, r, c ^ ((r >> 1) & 7)] = a[:, r, c]                               # chunk c of row r sits in slot c ^ key(r)
-    b = w2.to(dtype).reshape(C, HID // 32, 4, 8).permute(1, 0, 2, 3)          # [tile][r][c][j]
-    r2 = torch.arange(C, device=dev)[:, None]
-    c2 = torch.arange(4, device=dev)[None, :]
-    img2 = torch.empty((HID // 32, C, 4, 8), dtype=dtype, device=dev)
-    img2[:, r2, c2 ^ ((r2 >> 2) & 3)] = b[:, r2, c2]
-    return img1.reshape(-1).contiguous(), img2.reshape(-1).contiguous()
+    assert tuple(w1g.shape) == (SWIN_MLP_HIDDEN, SWIN_MLP_C) and tuple(w2.shape) == (SWIN_MLP_C, SWIN_MLP_HIDDEN)
+    return _swin_image_rows(w1g.to(dtype)), _swin_image_slices(w2.to(dtype))
+
+
+SWIN_ATTN_HEADS = 6          # the one structure edtr_swin_attn is built for: 6 heads of <= 32 columns, 192 token columns, window 8
+
+
+def pack_swin_attn_weights(wqkv: torch.Tensor, wproj: torch.Tensor, dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 [3 * heads * 32, 192] (the head-padded, gamma- and q-scaled qkv matrix, rows (s, h, e) as model.swinir.pack_qkv orders
+    them) and [192, heads * 32] (proj with head-padded input columns) -> the LDS images of edtr_swin_attn (edtr_hip.h)."""
+    H = SWIN_ATTN_HEADS
+    assert tuple(wqkv.shape) == (3 * H * 32, SWIN_MLP_C) and tuple(wproj.shape) == (SWIN_MLP_C, H * 32)
+    by_head = wqkv.reshape(3, H, 32, SWIN_MLP_C).permute(1, 0, 2, 3).reshape(3 * H * 32, SWIN_MLP_C)        # image 3 h + s
+    return _swin_image_rows(by_head.to(dtype)), _swin_image_slices(wproj.to(dtype))
+
+
+def swin_attn_bias(bias: torch.Tensor) -> torch.Tensor:
+    """[heads, 64 queries, 64 keys] (model.swinir.expand_bias) -> [heads, 16 key groups, 64 queries, 4] for edtr_swin_attn."""
+    h = bias.shape[0]
+    return bias.reshape(h, 64, 16, 4).permute(0, 2, 1, 3).contiguous()
+
+
+def make_swin_attn(*, dtype, x, ldx, out, ldo, B, H, W, head_dim, shift, c_valid, eps, wqkv, wproj, c1, c2b, bproj, bias, labels,
+                   name="swin.attn") -> Rec:
+    """One Swin layer's x + proj(WindowAttention(LayerNorm(x))) (edtr_hip.h: edtr_swin_attn)."""
+    p = L.SwinAttnParams()
+    p.dtype, p.B, p.H, p.W, p.heads, p.head_dim, p.shift = dt_code(dtype), B, H, W, SWIN_ATTN_HEADS, head_dim, shift
+    p.C, p.c_valid, p.eps = SWIN_MLP_C, c_valid, eps
+    p.x, p.ldx, p.out, p.ldo = ptr(x), ldx, ptr(out), ldo
+    p.wqkv, p.wproj, p.c1, p.c2b, p.bproj, p.bias, p.labels = ptr(wqkv), ptr(wproj), ptr(c1), ptr(c2b), ptr(bproj), ptr(bias), ptr(labels)
+    tokens = B * H * W
+    flops = 2.0 * tokens * SWIN_MLP_C * 4 * SWIN_ATTN_HEADS * 32 + 4.0 * tokens * 64 * SWIN_ATTN_HEADS * head_dim
+    nbytes = 2.0 * tokens * 2 * SWIN_MLP_C + 2.0 * 4 * SWIN_ATTN_HEADS * 32 * SWIN_MLP_C
+    return Rec(L.load().edtr_swin_attn, (ct.byref(p),), (p, x, out, wqkv, wproj, c1, c2b, bproj, bias, labels), name, flops, nbytes)
 
 
 def make_swin_mlp(*, dtype, x, ldx, rows, c_valid, eps, w1, w2, c1, c2b, b2, out, ldo, row_stats=None, name="swin.mlp") -> Rec:

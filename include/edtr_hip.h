@@ -338,6 +338,41 @@ typedef struct edtr_swin_mlp_params {
 
 int edtr_swin_mlp(const edtr_swin_mlp_params* p, edtr_stream_t stream);
 
+/* The attention half of a Swin layer in one launch (ABI 8):  out = x + proj(WindowAttention(LayerNorm(x))) on 16-bit token rows.
+ * replaces: `shortcut + window_reverse(attn(window_partition(roll(norm1(x)))))`, reference model/swinir.py:254-279 with
+ *           WindowAttention.forward :120-148 (qkv linear, q * scale, relative-position bias, shift mask, softmax, proj linear; the
+ *           dropouts are p = 0) — i.e. the qkv edtr_igemm, edtr_window_attn and the proj edtr_igemm of the three-launch form.
+ * Specialised for the shipped pre-restorer (embed_dim 180 -> C = 192 padded columns, 6 heads of width 30 -> 32, window 8); anything
+ * else is EDTR_E_UNSUPPORTED and the caller issues the three launches.  Pad columns of x must be zero and stay zero.
+ *   x, out : [B*H*W][ld] 16-bit, token (b, y, x) at row (b*H + y)*W + x; out must not alias x (workgroups gather rows others scatter)
+ *   wqkv   : heads * 3 LDS images of 12288 bytes, image 3 h + s (s = 0 / 1 / 2: q / k / v), layout as edtr_swin_mlp's w1 images:
+ *            byte r*384 + ((c ^ ((r >> 1) & 7)) << 4) + 2 j = (gamma . Wqkv)[s*C' + h*d + r][8 c + j] for r < d, zero rows above
+ *            (C' = heads*d, d = head_dim); the q rows are pre-multiplied by the softmax scale d^-1/2
+ *   wproj  : heads images of 12288 bytes, image h, layout as edtr_swin_mlp's w2 images:
+ *            byte r*64 + ((c ^ ((r >> 2) & 3)) << 4) + 2 j = Wproj[r][h*d + 8 c + j]   (zero for 8 c + j >= d, r >= C')
+ *   c1, c2b: fp32 [3][heads][32]: row sums of the packed 16-bit (gamma . Wqkv) rows / Wqkv beta + bias (q entries scaled), zero pads
+ *   bproj  : fp32 [C] (pad entries zero)
+ *   bias   : fp32 [heads][16][64][4]: bias[h][kg][i][e] is added to the score of query i and key 4 kg + e (the gathered
+ *            relative_position_bias_table, key-group major so that the 32 queries of a wave read contiguous 16-byte entries)
+ *   labels : as edtr_window_attn (NULL when shift == 0)
+ * LayerNorm statistics come from the gathered rows themselves (c_valid real columns, eps).  ld % 8 == 0, W % 4 == 0, pointers
+ * 16-byte aligned. */
+typedef struct edtr_swin_attn_params {
+    int32_t dtype;
+    int32_t B, H, W;                /* token grid; H % 8 == 0, W % 8 == 0 */
+    int32_t heads, head_dim, shift;
+    int32_t C, c_valid;
+    float eps;
+    const void* x; int32_t ldx;
+    const void* wqkv; const void* wproj;
+    const float* c1; const float* c2b; const float* bproj;
+    const float* bias;
+    const uint8_t* labels;
+    void* out; int32_t ldo;
+} edtr_swin_attn_params;
+
+int edtr_swin_attn(const edtr_swin_attn_params* p, edtr_stream_t stream);
+
 /* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p); columns cols..cols_pad-1
  * of every output row are written as zeros (so the row can feed a GEMM whose K is padded to a multiple of 8).
  * replaces: the softmax inside F.scaled_dot_product_attention of the d=512 single-head VAE

@@ -899,6 +899,56 @@ def test_window_attention(dtype, B, H, W, heads, d, cp, shift):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,shift", [(2, 16, 24, 0), (2, 16, 24, 4), (1, 8, 8, 4), (3, 24, 8, 3), (1, 64, 64, 4), (1, 8, 24, 0)])
+def test_swin_attention_half_one_launch(dtype, B, H, W, shift):
+    """edtr_swin_attn: x + proj(WindowAttention(LayerNorm(x))) of a Swin layer in one launch (reference model/swinir.py:254-279,
+    :120-148) vs torch fp32 on the same 16-bit inputs: LayerNorm, the qkv linear, q * scale, relative-position bias, the shift
+    mask, softmax, proj and the residual; non-square token grids, one-window images, an odd window count (the last workgroup
+    owns one window), odd shift; pad columns stay exactly zero."""
+    from edtr_amd.model import swinir as S
+    ops = _ops()
+    dv = dev()
+    heads, d, C, CP = 6, 30, 180, ops.SWIN_MLP_C
+    rows = B * H * W
+    x = torch.zeros((rows, CP))
+    x[:, :C] = rnd((rows, C), 200, 1.5) + 0.3
+    x = x.to(dtype)
+    gamma, beta = 1 + 0.2 * rnd((C,), 201), 0.3 * rnd((C,), 202)
+    wqkv, bqkv = rnd((3 * C, C), 203, 1.5 / math.sqrt(C)), 0.2 * rnd((3 * C,), 204)
+    wp, bp = rnd((C, C), 205, 1 / math.sqrt(C)), 0.2 * rnd((C,), 206)
+    table = rnd((225, heads), 207, 0.7)
+    bias = S.expand_bias(table, 8)
+    # packing exactly as model/swinir.py does it
+    wq32, bq32 = S.pack_qkv(wqkv, bqkv, heads, CP)                  # [(s, h, e), CP] with zero pad rows / columns
+    g_pad, b_pad = torch.zeros(CP), torch.zeros(CP)
+    g_pad[:C], b_pad[:C] = gamma, beta
+    scale = torch.ones(3 * heads * 32)
+    scale[: heads * 32] = d ** -0.5
+    wg = wq32 * g_pad[None, :] * scale[:, None]
+    c2b = ((wq32 @ b_pad) + bq32) * scale
+    wpp = torch.zeros((CP, heads, 32))
+    wpp[:C, :, :d] = wp.reshape(C, heads, d)
+    img_qkv, img_proj = ops.pack_swin_attn_weights(wg, wpp.reshape(CP, heads * 32), dtype)
+    c1 = wg.to(dtype).float().sum(1).contiguous()
+    bpp = torch.zeros(CP)
+    bpp[:C] = bp
+    out = torch.full((rows, CP), float("nan"), dtype=dtype, device=dv)
+    lab = torch.from_numpy(S.region_labels(H, W, 8, shift)).to(dv) if shift else None
+    ops.launch(ops.make_swin_attn(dtype=dtype, x=x.to(dv), ldx=CP, out=out, ldo=CP, B=B, H=H, W=W, head_dim=d, shift=shift, c_valid=C, eps=1e-5,
+                                  wqkv=img_qkv.to(dv), wproj=img_proj.to(dv), c1=c1.to(dv), c2b=c2b.contiguous().to(dv), bproj=bpp.to(dv),
+                                  bias=ops.swin_attn_bias(bias).to(dv), labels=lab))
+    torch.cuda.synchronize()
+    xf = x.float()[:, :C]
+    qkv = F.layer_norm(xf, (C,), gamma, beta, 1e-5) @ wqkv.t() + bqkv
+    att = _window_attn_reference(qkv.reshape(B, H, W, 3, heads, d), bias, H, W, heads, d, shift).reshape(rows, C)
+    ref = xf + att @ wp.t() + bp
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel(got[:, :C], ref) < TOL[dtype]
+    assert float(got[:, C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows", [128, 4096 + 64, 300, 32768])
 def test_swin_mlp_one_launch(dtype, rows):
     """edtr_swin_mlp: x + fc2(GELU(fc1(LayerNorm(x)))) of a Swin layer in one launch (reference model/swinir.py:24-37, :281-283)
