@@ -833,6 +833,149 @@ __global__ void __launch_bounds__(SA_THREADS) swin_attn_kernel(const edtr_swin_a
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// edtr_conv64 — 3 x 3 / stride 1 / pad 1 convolution of a 64-channel image into <= 64 channels (SwinIR's reconstruction tail:
+// conv_up1..3 behind a nearest-2x upsample, conv_hr, conv_last; reference model/swinir.py:776-787, :878-886).  On edtr_igemm these
+// run on 128-column tiles that are half padding, one launch-sized workgroup per 128 pixels, at 310 - 330 TFLOP/s — 0.5 ms for
+// the 512 x 512 level of a batch of 8, whose traffic is a 110 us job.  Here the workgroups are PERSISTENT (one per CU): the nine
+// 64 x 64 tap matrices stay in LDS (72 KiB) for the kernel's life and the image streams through as 16 x 16-pixel patches with
+// their 1-pixel halo (18 x 18 pixels x 128 B, two buffers, LDS-DMA one patch ahead; the nearest-2x upsample is the DMA's
+// source address, zero padding a 16-byte block of zeros).  The product runs transposed, out^T[n][pixel] = W[n][k] x^T[k][pixel],
+// so that a lane owns a pixel and eight consecutive channels per register group (weight rows with bits 2,3 swapped): results
+// leave as 16-byte stores (or, for the network's last convolution, as fp32 NCHW planes).  Wave w owns patch rows 2 w, 2 w + 1
+// (32 pixels) x 64 channels: per tap and 16-channel k-step one patch fragment feeds two MFMAs.
+// Patch image: pixel (py, px) at (18 py + px) * 128 B, 16-byte chunk c in slot c ^ ((px >> 1) & 7): the 16 pixels of a
+// ds_read_b128 lane group are 16 different columns (mod 16) for every tap — conflict-free; weights as tile_off (common.h).
+constexpr int C64_THREADS = 512;
+constexpr int C64_W_BYTES = 9 * 64 * 128;                    // 73728
+constexpr int C64_PATCH_INSTRS = 41;                         // 18 * 18 * 128 B = 40.5 KiB: 41 DMA instructions, the last one half used
+constexpr int C64_PATCH_BYTES = C64_PATCH_INSTRS * 1024;
+constexpr int C64_LDS = C64_W_BYTES + 2 * C64_PATCH_BYTES + 64 * 4;
+__device__ __attribute__((aligned(16))) uint32_t g_c64_zero[4];
+
+template <typename T>
+__global__ void __launch_bounds__(C64_THREADS) conv64_kernel(const edtr_conv64_params p, int patches) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    char* wl = smem;
+    char* pb = smem + C64_W_BYTES;
+    float* bias_l = reinterpret_cast<float*>(smem + C64_W_BYTES + 2 * C64_PATCH_BYTES);
+    const uint32_t lds0 = lds_addr_of(smem);
+    const int tiles_x = p.W >> 4, tiles_y = p.H >> 4;
+    const int SH = p.upsample2x ? p.H >> 1 : p.H, SW = p.upsample2x ? p.W >> 1 : p.W;        // source size
+
+    if (tid < 64) bias_l[tid] = p.bias[tid];
+    // weights: 72 instructions of 1 KiB, nine per wave (the images are already in LDS layout)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dma16(static_cast<const char*>(p.w) + (wave * 9 + q) * 1024 + lane * 16, lds0 + (wave * 9 + q) * 1024);
+
+    // this lane's share of a patch fetch: instruction Q = wave + 8 q (< 41), 16 bytes at byte o = 1024 Q + 16 lane of the patch image
+    int f_py[6], f_px[6], f_c[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int o = (wave + 8 * q) * 1024 + lane * 16, P = o >> 7, cs = (o >> 4) & 7;
+        f_py[q] = P / 18;
+        f_px[q] = P - 18 * f_py[q];
+        f_c[q] = cs ^ ((f_px[q] >> 1) & 7);
+    }
+    const uint16_t* xg = static_cast<const uint16_t*>(p.x);
+    auto fetch = [&](int patch, int buf) {
+        const int tx = patch % tiles_x, r = patch / tiles_x, ty = r % tiles_y, b = r / tiles_y;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (wave + 8 * q < C64_PATCH_INSTRS) {           // (wave-uniform)
+                const int Y = ty * 16 - 1 + f_py[q], X = tx * 16 - 1 + f_px[q];      // output-resolution coordinates of the patch pixel
+                const bool in = f_py[q] < 18 && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+                const int sy = p.upsample2x ? Y >> 1 : Y, sx = p.upsample2x ? X >> 1 : X;
+                const void* src = in ? static_cast<const void*>(xg + (((int64_t)b * SH + sy) * SW + sx) * p.ldx + f_c[q] * 8)
+                                     : static_cast<const void*>(g_c64_zero);
+                dma16(src, lds0 + C64_W_BYTES + buf * C64_PATCH_BYTES + (wave + 8 * q) * 1024);
+            }
+        }
+    };
+    int patch = blockIdx.x;
+    if (patch < patches) fetch(patch, 0);
+
+    // fragment addressing: this lane's pixel (y, x) = (2 wave + (l31 >> 4), l31 & 15) of the patch; weight row rs of either 32-row tile
+    const int px_x = l31 & 15;
+    const int pix0 = (18 * (2 * wave + (l31 >> 4)) + px_x) * 128;
+    int xperm[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) xperm[kx] = (lh ^ (((px_x + kx) >> 1) & 7)) << 4;
+    const int rs = (l31 & 16) | swap23(l31 & 15);
+    const int w_off = rs * 128 + ((lh ^ ((rs >> 1) & 7)) << 4);
+    uint16_t* og = static_cast<uint16_t*>(p.out);
+    float* of32 = static_cast<float*>(p.out);
+
+    int it = 0;
+#pragma unroll 1
+    for (; patch < patches; patch += gridDim.x, ++it) {
+        // the fetch of this patch (and, the first time, the weights) has landed; the previous patch's stores may still be in flight
+        // (counted: the fetch was issued BEFORE that patch's 4 — fp32 planes: n_valid >= 1 — store instructions)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (p.out_nchw_f32) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        const int next = patch + gridDim.x;
+        if (next < patches) fetch(next, (it + 1) & 1);
+        const char* pbuf = pb + (it & 1) * C64_PATCH_BYTES + pix0;
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const U4 xb = *reinterpret_cast<const U4*>(pbuf + (18 * ky + kx) * 128 + (xperm[kx] ^ (32 * ks)));
+                const U4 w0 = *reinterpret_cast<const U4*>(wl + t * 8192 + (w_off ^ (32 * ks)));
+                const U4 w1 = *reinterpret_cast<const U4*>(wl + t * 8192 + 4096 + (w_off ^ (32 * ks)));
+                acc[0] = T::mfma(w0, xb, acc[0]);
+                acc[1] = T::mfma(w1, xb, acc[1]);
+            }
+        }
+
+        // ---- epilogue: registers 8 s .. 8 s + 7 of acc[nt] are channels 32 nt + 16 s + 8 lh + 0..7 of this lane's pixel
+        const int tx = patch % tiles_x, r0 = patch / tiles_x, ty = r0 % tiles_y, b = r0 / tiles_y;
+        const int Y = ty * 16 + 2 * wave + (l31 >> 4), X = tx * 16 + px_x;
+        if (!p.out_nchw_f32) {
+            uint16_t* orow = og + (((int64_t)b * p.H + Y) * p.W + X) * p.ldo + 8 * lh;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float* bp = bias_l + 32 * nt + 16 * s + 8 * lh;
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = __builtin_fmaf(p.alpha, acc[nt][8 * s + e], b0[e]);
+                        v[4 + e] = __builtin_fmaf(p.alpha, acc[nt][8 * s + 4 + e], b1[e]);
+                    }
+                    if (p.act == EDTR_ACT_LRELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * p.act_slope);
+                    }
+                    stg16(orow + 32 * nt + 16 * s, pack8<T>(v));
+                }
+        } else {
+            // fp32 planes [b][c][Y][X], c < n_valid <= 4: channels 0..3 are registers 0..3 of acc[0] in the lanes with lh == 0
+            const int64_t plane = (int64_t)p.H * p.W;
+            float* o0 = of32 + (int64_t)b * p.n_valid * plane + (int64_t)Y * p.W + X;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = __builtin_fmaf(p.alpha, acc[0][c], bias_l[c]);
+                if (p.act == EDTR_ACT_LRELU) v = fmaxf(v, v * p.act_slope);
+                if (lh == 0 && c < p.n_valid) o0[c * plane] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // pixel-unshuffle front end: one thread = one (token, channel, dy) run of r source pixels
 template <typename T>
 __global__ void __launch_bounds__(256) pixel_unshuffle_kernel(const float* src, int B, int C, int H, int W, int r, const float* sub,
@@ -956,6 +1099,47 @@ extern "C" int edtr_swin_attn(const edtr_swin_attn_params* pp, edtr_stream_t str
             attr_set[1] = true;
         }
         hipLaunchKernelGGL(swin_attn_kernel<F16>, grid, dim3(SA_THREADS), SA_LDS, s, p, (int)windows);
+    }
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_conv64(const edtr_conv64_params* pp, edtr_stream_t stream) {
+    if (!pp) return EDTR_E_NULL;
+    const edtr_conv64_params& p = *pp;
+    if (!p.x || !p.w || !p.bias || !p.out) return EDTR_E_NULL;
+    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (p.B <= 0 || p.H <= 0 || p.W <= 0 || (p.H & 15) || (p.W & 15)) return EDTR_E_SHAPE;
+    if (p.act != EDTR_ACT_NONE && p.act != EDTR_ACT_LRELU) return EDTR_E_UNSUPPORTED;
+    if (p.ldx < 64 || (p.ldx & 7)) return EDTR_E_ALIGN;
+    if (p.out_nchw_f32) {
+        if (p.n_valid < 1 || p.n_valid > 4) return EDTR_E_UNSUPPORTED;
+    } else if (p.ldo < 64 || (p.ldo & 7)) return EDTR_E_ALIGN;
+    if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.out) || !aligned16(p.bias)) return EDTR_E_ALIGN;
+    const int64_t patches = (int64_t)p.B * (p.H >> 4) * (p.W >> 4);
+    if (patches > 0x7fffffffLL || (int64_t)p.B * p.H * p.W > 0x7fffffffLL) return EDTR_E_UNSUPPORTED;
+    static bool attr_set[2] = {false, false};
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EDTR_E_UNSUPPORTED;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(patches < cus ? patches : cus));          // persistent: one 154-KiB workgroup per CU
+    if (p.dtype == EDTR_BF16) {
+        if (!attr_set[0]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL(conv64_kernel<BF16>, grid, dim3(C64_THREADS), C64_LDS, s, p, (int)patches);
+    } else {
+        if (!attr_set[1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL(conv64_kernel<F16>, grid, dim3(C64_THREADS), C64_LDS, s, p, (int)patches);
     }
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;

@@ -343,16 +343,43 @@ class _SwinEngine:
         # ---- reconstruction: conv + LeakyReLU(0.01), three (nearest x2 -> conv -> LeakyReLU(0.2)), conv_hr, conv_last (:776-787,878-886)
         u = conv3(f, "conv_before_upsample.0.", 64, act=L.ACT_LRELU, slope=0.01, name="swin.conv_before_upsample")
         em.free(f)
+        # The 64-channel convolutions of the pixel levels run on edtr_conv64 (persistent workgroups, the nine tap matrices resident in
+        # LDS, the upsample as the patch fetch's address; the last one writes the fp32 NCHW result itself); EDTR_CONV64=0: edtr_igemm.
+        def conv64(x: Act, prefix: str, *, ups=False, act=0, slope=0.0, alpha=1.0, extra_bias=None, nchw_out=None, name="swin.conv64") -> Act:
+            key = ("swin_conv64", prefix, alpha)
+            if key not in store.cache:
+                b = ops_mod.pad_bias(store._p(prefix + "bias") * alpha, 64)
+                if extra_bias is not None:
+                    b[: extra_bias.numel()] += extra_bias
+                store.cache[key] = (ops_mod.pack_conv64_weight(store._p(prefix + "weight"), dt), b)
+            w, b = store.cache[key]
+            LH, LW = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
+            out = nchw_out if nchw_out is not None else em.new(x.B * LH * LW, 64)
+            self.prog.add(ops_mod.make_conv64(dtype=dt, x=x.t, ldx=x.ld, w=w, bias=b, out=out, B=x.B, H=LH, W=LW, upsample2x=ups, act=act,
+                                              act_slope=slope, alpha=alpha, ldo=0 if nchw_out is not None else 64,
+                                              out_nchw_f32=nchw_out is not None, n_valid=cfg["in_chans"] if nchw_out is not None else 0, name=name))
+            return Act(out, x.B, LH, LW, 64)
+
         for name in ("conv_up1.", "conv_up2.", "conv_up3.")[: int(math.log2(sf))]:
-            u2 = conv3(u, name, 64, ups=True, act=L.ACT_LRELU, slope=0.2, name="swin.conv_up")
+            if ops_mod.conv64_ok(u.H * 2, u.W * 2, u.C, 64):
+                u2 = conv64(u, name, ups=True, act=L.ACT_LRELU, slope=0.2, name="swin.conv_up")
+            else:
+                u2 = conv3(u, name, 64, ups=True, act=L.ACT_LRELU, slope=0.2, name="swin.conv_up")
             em.free(u)
             u = u2
-        hr = conv3(u, "conv_hr.", 64, act=L.ACT_LRELU, slope=0.2, name="swin.conv_hr")
+        if ops_mod.conv64_ok(u.H, u.W, u.C, 64):
+            hr = conv64(u, "conv_hr.", act=L.ACT_LRELU, slope=0.2, name="swin.conv_hr")
+        else:
+            hr = conv3(u, "conv_hr.", 64, act=L.ACT_LRELU, slope=0.2, name="swin.conv_hr")
         em.free(u)
         # x / range + mean folded into the last convolution's epilogue: alpha = 1/range, bias' = bias/range + mean
-        last = conv3(hr, "conv_last.", 8, out_f32=True, alpha=1.0 / rng, extra_bias=mean, name="swin.conv_last")
-        em.free(hr)
-        em.to_nchw(last.t, B, 3, oh * ow, self.y)
+        if ops_mod.conv64_ok(hr.H, hr.W, hr.C, cfg["in_chans"]) and cfg["in_chans"] <= 4:
+            conv64(hr, "conv_last.", alpha=1.0 / rng, extra_bias=mean, nchw_out=self.y, name="swin.conv_last")
+            em.free(hr)
+        else:
+            last = conv3(hr, "conv_last.", 8, out_f32=True, alpha=1.0 / rng, extra_bias=mean, name="swin.conv_last")
+            em.free(hr)
+            em.to_nchw(last.t, B, 3, oh * ow, self.y)
         self.graphed = False
         if graph:
             self.prog.run()                      # warm-up outside capture

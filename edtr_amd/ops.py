@@ -271,6 +271,37 @@ def make_swin_mlp(*, dtype, x, ldx, rows, c_valid, eps, w1, w2, c1, c2b, b2, out
     return Rec(L.load().edtr_swin_mlp, (ct.byref(p),), (p, x, w1, w2, c1, c2b, b2, out, row_stats), name, flops, nbytes)
 
 
+def pack_conv64_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[Cout <= 64, 64 (or fewer, zero padded), 3, 3] fp32 -> the nine 8-KiB LDS images of edtr_conv64 (edtr_hip.h)."""
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and co <= 64 and ci <= 64
+    full = torch.zeros((9, 64, 8, 8), dtype=torch.float32, device=w.device)                   # [tap][n][chunk][j]
+    full.reshape(9, 64, 64)[:, :co, :ci] = w.permute(2, 3, 0, 1).reshape(9, co, ci)
+    n = torch.arange(64, device=w.device)[:, None]
+    c = torch.arange(8, device=w.device)[None, :]
+    img = torch.empty_like(full)
+    img[:, n, c ^ ((n >> 1) & 7)] = full[:, n, c]
+    return img.to(dtype).reshape(-1).contiguous()
+
+
+def conv64_ok(H: int, W: int, cin: int, cout: int) -> bool:
+    """Does edtr_conv64 take this 3x3 convolution (output H x W)?  EDTR_CONV64=0 keeps edtr_igemm (A/B runs)."""
+    return os.environ.get("EDTR_CONV64", "1") != "0" and cin == 64 and cout <= 64 and H % 16 == 0 and W % 16 == 0
+
+
+def make_conv64(*, dtype, x, ldx, w, bias, out, B, H, W, upsample2x=False, act=0, act_slope=0.0, alpha=1.0, ldo=0, out_nchw_f32=False,
+                n_valid=0, name="conv64") -> Rec:
+    p = L.Conv64Params()
+    p.dtype, p.B, p.H, p.W, p.upsample2x = dt_code(dtype), B, H, W, int(upsample2x)
+    p.x, p.ldx, p.w, p.bias = ptr(x), ldx, ptr(w), ptr(bias)
+    p.act, p.act_slope, p.alpha = act, act_slope, alpha
+    p.out, p.ldo, p.out_nchw_f32, p.n_valid = ptr(out), ldo, int(out_nchw_f32), n_valid
+    flops = 2.0 * B * H * W * 64 * 9 * (n_valid if out_nchw_f32 else 64)
+    src = B * H * W * 64 * 2 / (4 if upsample2x else 1)
+    nbytes = src + (B * H * W * n_valid * 4 if out_nchw_f32 else B * H * W * 64 * 2)
+    return Rec(L.load().edtr_conv64, (ct.byref(p),), (p, x, w, bias, out), name, flops, nbytes)
+
+
 # --------------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------------

@@ -373,6 +373,31 @@ typedef struct edtr_swin_attn_params {
 
 int edtr_swin_attn(const edtr_swin_attn_params* p, edtr_stream_t stream);
 
+/* 3 x 3 / stride 1 / pad 1 convolution of a 64-channel NHWC image into <= 64 channels, persistent workgroups with the nine tap
+ * matrices resident in LDS (ABI 8) — SwinIR's reconstruction tail at the pixel levels, where edtr_igemm's 128-column tiles are
+ * half padding.  replaces: conv_up1 / conv_up2 / conv_up3 (behind `F.interpolate(scale_factor=2, mode="nearest")`), conv_hr and
+ * conv_last with their LeakyReLUs and the `x / img_range + mean` of the output, reference model/swinir.py:878-886.
+ *   x      : [B][SH][SW][ldx] 16-bit, 64 channels read; source size (SH, SW) = (H, W), or (H / 2, W / 2) when upsample2x != 0
+ *            (output pixel (Y, X) then reads source pixel (Y >> 1, X >> 1) — the nearest-neighbour upsample is never stored)
+ *   w      : 9 LDS images of 8192 bytes, tap t = 3 ky + kx: byte n*128 + ((c ^ ((n >> 1) & 7)) << 4) + 2 j = weight[n][8 c + j][ky][kx]
+ *            (n < 64 output channels, zero rows above the real count; 64 input channels)
+ *   bias   : fp32 [64];   out = act(alpha * conv + bias), act = EDTR_ACT_NONE or EDTR_ACT_LRELU (act_slope)
+ *   out    : 16-bit [B][H][W][ldo] (64 channels written), or — out_nchw_f32 != 0 — fp32 [B][n_valid][H][W] (n_valid <= 4)
+ * H % 16 == 0, W % 16 == 0; ldx % 8 == 0, ldo % 8 == 0; pointers 16-byte aligned. */
+typedef struct edtr_conv64_params {
+    int32_t dtype;
+    int32_t B, H, W;
+    int32_t upsample2x;
+    const void* x; int32_t ldx;
+    const void* w;
+    const float* bias;
+    int32_t act; float act_slope; float alpha;
+    void* out; int32_t ldo;
+    int32_t out_nchw_f32, n_valid;
+} edtr_conv64_params;
+
+int edtr_conv64(const edtr_conv64_params* p, edtr_stream_t stream);
+
 /* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p); columns cols..cols_pad-1
  * of every output row are written as zeros (so the row can feed a GEMM whose K is padded to a multiple of 8).
  * replaces: the softmax inside F.scaled_dot_product_attention of the d=512 single-head VAE

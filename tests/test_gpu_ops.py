@@ -899,6 +899,46 @@ def test_window_attention(dtype, B, H, W, heads, d, cp, shift):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,ups,cout,nchw", [(2, 32, 48, False, 64, False), (1, 64, 32, True, 64, False), (3, 16, 16, False, 64, False),
+                                                  (2, 48, 32, False, 3, True), (1, 256, 320, True, 64, False), (1, 512, 512, False, 64, False)])
+def test_conv64_persistent(dtype, B, H, W, ups, cout, nchw):
+    """edtr_conv64 (SwinIR's 64-channel reconstruction convolutions, reference model/swinir.py:878-886) vs torch fp32 conv2d on the
+    same 16-bit inputs: plain and behind a nearest-2x upsample, LeakyReLU, bias, the alpha scaling; 16-bit NHWC output and the
+    fp32 NCHW planes of the network's last convolution; one-patch images, more patches than workgroups (the persistent loop)."""
+    ops = _ops()
+    from edtr_amd import lib as L
+    d = dev()
+    SH, SW = (H // 2, W // 2) if ups else (H, W)
+    x = rnd((B, SH, SW, 64), 210, 1.2).to(dtype)
+    w = rnd((cout, 64, 3, 3), 211, 1 / math.sqrt(576))
+    bias = torch.zeros(64)
+    bias[:cout] = 0.3 * rnd((cout,), 212)
+    img = ops.pack_conv64_weight(w, dtype)
+    alpha, slope = (0.7, 0.0) if nchw else (1.0, 0.2)
+    if nchw:
+        out = torch.full((B, cout, H, W), float("nan"), dtype=torch.float32, device=d)
+    else:
+        out = torch.full((B * H * W, 64), float("nan"), dtype=dtype, device=d)
+    ops.launch(ops.make_conv64(dtype=dtype, x=x.reshape(-1, 64).to(d), ldx=64, w=img.to(d), bias=bias.to(d), out=out, B=B, H=H, W=W, upsample2x=ups,
+                               act=L.ACT_NONE if nchw else L.ACT_LRELU, act_slope=slope, alpha=alpha, ldo=0 if nchw else 64, out_nchw_f32=nchw,
+                               n_valid=cout if nchw else 0))
+    torch.cuda.synchronize()
+    xin = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = alpha * F.conv2d(xin, w.to(dtype).float(), None, padding=1) + bias[:cout, None, None]
+    if nchw:
+        got = out.cpu()
+    else:
+        ref = F.leaky_relu(ref, slope)
+        got = out.float().cpu().reshape(B, H, W, 64).permute(0, 3, 1, 2)
+        assert float(got[:, cout:].abs().max()) == 0.0 if cout < 64 else True
+        got = got[:, :cout]
+    assert torch.isfinite(got).all()
+    assert rel(got, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,shift", [(2, 16, 24, 0), (2, 16, 24, 4), (1, 8, 8, 4), (3, 24, 8, 3), (1, 64, 64, 4), (1, 8, 24, 0)])
 def test_swin_attention_half_one_launch(dtype, B, H, W, shift):
     """edtr_swin_attn: x + proj(WindowAttention(LayerNorm(x))) of a Swin layer in one launch (reference model/swinir.py:254-279,
