@@ -2032,6 +2032,17 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
     constexpr int BTAP = 128 * BK * 2;         // 16 KiB
     constexpr int B_BASE = 2 * PATCHB;
     constexpr int SCRATCH = B_BASE + 3 * BTAP; // IMG8 only
+    // GEO 0, a_gn != NULL (round 4): GroupNorm apply + SiLU of the INPUT fused into the patch staging.  The producing launch leaves
+    // the raw tensor in memory; edtr_gn_table turns its statistics into (scale, shift) per image and channel; here every wave
+    // normalises the patch pieces IT staged, in place in LDS, once they have landed and before the chunk that multiplies them
+    // starts: y = silu(x * scale[c] + shift[c]) exactly as edtr_gn_apply computes it, pixels outside the image keep the zeros the
+    // padding needs.  One piece (64 lanes x 8 elements) per phase in phases 6..11 of the previous chunk, behind that phase's MFMA
+    // issue (the fragment registers are dead there and the matrix pipe runs under the arithmetic); the 64 x 2 table entries of
+    // the next chunk arrive by one extra DMA per wave in phase 0 (every wave fetches the same 512 bytes: equal DMA counts keep
+    // the counted waits simple) into one of two 1-KiB slots behind the weight ring.  The normalised tensor never exists in
+    // memory: one read + one write of the activation per GroupNorm less.  Every 128-column tile of a patch repeats the arithmetic,
+    // so the callers use it where N == 128 (ops.gn_in_conv_ok: measured +1.4 % on the headline there, a loss at N >= 256).
+    constexpr int TBL = B_BASE + 3 * BTAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2070,6 +2081,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 
     // ---- staging geometry.  Patch piece q = wave + 8 j: LDS bytes [q KiB, +1 KiB) = pixels 8 q .. 8 q + 7, lane -> (pixel, slot)
     uint32_t voff_p[NPP], voff_w[2];
+    uint32_t gn_bits = 0;                      // per patch piece j: bits 4 j .. 4 j + 2 = the 8-channel group of this lane's 16 bytes, bit 4 j + 3 = inside the image
     uint32_t lds_p[NPP];                       // LDS byte offset of patch piece j inside a patch buffer (IMG8: or the scratch KiB)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -2100,6 +2112,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
             const int c = slot ^ (px & 7);
             voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOobOffset;
             lds_p[j] = (uint32_t)((wave + 8 * j) * 1024);
+            if (ok) gn_bits |= (uint32_t)(8 | c) << (4 * j);
         }
     }
     auto stage_w = [&](int chunk, int tap, int j, int buf) {
@@ -2110,6 +2123,48 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
         const uint32_t vo = chunk < cend ? voff_p[j] : kOobOffset;
         const uint32_t dst = (IMG8 && lds_p[j] == 0xFFFFFFFFu) ? (uint32_t)SCRATCH : (uint32_t)(par * PATCHB) + lds_p[j];
         dma16_buf(vo, srd_a, (uint32_t)(chunk * BK * 2), smem_base + dst);
+    };
+    const bool gnf = GEO == 0 && p.a_gn != nullptr;
+    const u32x4 srd_t = make_srd(gnf ? p.a_gn + (int64_t)img * Cin * 2 : reinterpret_cast<const float*>(a1));
+    auto stage_t = [&](int chunk, int par) {                 // (scale, shift) of the chunk's 64 channels: 512 bytes, lanes 0..31
+        const uint32_t vo = (chunk < cend && lane < 32) ? (uint32_t)(lane * 16) : kOobOffset;
+        dma16_buf(vo, srd_t, (uint32_t)(chunk * BK * 8), smem_base + TBL + par * 1024);
+    };
+    auto gn_piece = [&](int j, int par) {
+        const uint32_t bits = gn_bits >> (4 * j);
+        if (bits & 8) {
+            char* q = smem + par * PATCHB + (wave + 8 * j) * 1024 + lane * 16;
+            const float* tb = reinterpret_cast<const float*>(smem + TBL + par * 1024) + (bits & 7) * 16;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(tb + 8), t3 = *reinterpret_cast<const f32x4*>(tb + 12);
+            float f[8];
+            unpack8<T>(*reinterpret_cast<const U4*>(q), f);
+            f[0] = f[0] * t0[0] + t0[1]; f[1] = f[1] * t0[2] + t0[3];
+            f[2] = f[2] * t1[0] + t1[1]; f[3] = f[3] * t1[2] + t1[3];
+            f[4] = f[4] * t2[0] + t2[1]; f[5] = f[5] * t2[2] + t2[3];
+            f[6] = f[6] * t3[0] + t3[1]; f[7] = f[7] * t3[2] + t3[3];
+            if (p.a_gn_silu) {
+                // silu_f for the eight values in lockstep (common.h, gelu_erf_lockstep: left alone, hipcc runs each value's exp -> add ->
+                // rcp -> mul chain to its end before the next, at the VALU latency)
+                float e[8];
+                pin8(f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = f[i] * -1.4426950408889634f;
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = 1.0f + e[i];
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = f[i] * e[i];
+            }
+            *reinterpret_cast<U4*>(q) = pack8<T>(f);
+        }
     };
 
     // ---- fragment read geometry: A block mb of tap (ky, kx) = patch row 8 wr + mb + ky, pixels l15 + kx, K chunk 4 g + lq
@@ -2139,9 +2194,19 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
 
     // ---- prologue: patch of chunk 0, weight slices of taps 0 and 1
     EDTR_STAMP(1);
+    if constexpr (GEO == 0) {
+        if (gnf) stage_t(cbeg, 0);
+    }
 #pragma unroll
     for (int j = 0; j < NPP; ++j) stage_p(cbeg, j, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (GEO == 0) {
+        if (gnf) {           // the first chunk's patch: every wave normalises its own pieces (its own table copy has landed too)
+#pragma unroll
+            for (int j = 0; j < NPP; ++j) gn_piece(j, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run half a phase behind their SIMD partners
     asm volatile("" ::: "memory");
@@ -2172,10 +2237,15 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
             }
             stage_w(c2, TAP2, SUB, BUF2);
             if constexpr (PH >= PP0 && PH < PP0 + NPP) stage_p(c + 1, PH - PP0, par ^ 1);
+            if constexpr (GEO == 0 && PH == 0) {
+                if (gnf) stage_t(c + 1, par ^ 1);
+            }
             if constexpr (SUB == 1) {
                 // issued in this and the previous phase: 1 weight piece each, + 1 patch piece each in phases PP0 .. PP0 + NPP - 1
+                // (+ the table piece of phase 0 when the GroupNorm is fused)
                 constexpr int INFLIGHT = 2 + (PH >= PP0 && PH < PP0 + NPP ? 1 : 0) + (PH - 1 >= PP0 && PH - 1 < PP0 + NPP ? 1 : 0);
-                if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (GEO == 0 && PH == 1 && gnf) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // (GEO 0: INFLIGHT is 2 at phase 1)
+                else if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else if constexpr (INFLIGHT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             }
@@ -2189,6 +2259,10 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
                 for (int nb = 0; nb < 4; ++nb) acc[SUB * 4 + mb][nb] = T::mfma16(bfr[nb], afr[mb], acc[SUB * 4 + mb][nb]);    // transposed: D[channel][pixel]
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GEO == 0 && PH >= 6 && PH < 6 + NPP) {
+                // the piece this wave staged in phase PH - 4 landed before the wait of phase PH - 1 at the latest
+                if (gnf && c + 1 < cend) gn_piece(PH - 6, par ^ 1);
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
@@ -2276,7 +2350,7 @@ template <typename T, int GEO>
 int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr bool UP2 = GEO == 1;
     // 144 KiB (also SUBPIX); UP2: main loop 80 KiB, the epilogue's staging tile 132 KiB; IMG8: 2 x 50 KiB patches + 48 KiB weights + 1 KiB scratch
-    constexpr int lds = UP2 ? 256 * 132 * 4 : (GEO == 2 ? 2 * 50 * 1024 + 3 * 128 * BK * 2 + 1024 : 2 * 48 * 1024 + 3 * 128 * BK * 2);
+    constexpr int lds = UP2 ? 256 * 132 * 4 : (GEO == 2 ? 2 * 50 * 1024 + 3 * 128 * BK * 2 + 1024 : 2 * 48 * 1024 + 3 * 128 * BK * 2 + (GEO == 0 ? 2048 : 0));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T, GEO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -2395,6 +2469,61 @@ extern "C" int edtr_gn_finalize(const float* partial, int tiles_per_image, int B
     if (tiles_per_image <= 0 || B <= 0 || C <= 0 || groups <= 0 || C % groups) return EDTR_E_SHAPE;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
                        tiles_per_image, C, groups, sums);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+namespace {
+// (scale, shift) per image and channel of a GroupNorm whose statistics exist as tile partials of the producing edtr_igemm or as
+// the fp64 sums of edtr_gn_stats: table[b][c] = (gamma[c] rstd, beta[c] - mean gamma[c] rstd), the two numbers edtr_gn_apply
+// forms per channel — for consumers that normalise the tensor themselves (edtr_igemm's a_gn).
+__global__ void __launch_bounds__(256) gn_table_kernel(const float* partial, int tiles_per_image, const double* sums, int C, int groups,
+                                                      int HW, const float* gamma, const float* beta, float eps, float* table) {
+    __shared__ double red_s[256], red_q[256];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups;
+    double s = 0.0, q = 0.0;
+    if (partial) {
+        const int total = tiles_per_image * cpg;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int t = i / cpg, c = g * cpg + (i - t * cpg);
+            const float* src = partial + (((int64_t)b * tiles_per_image + t) * C + c) * 2;
+            s += (double)src[0];
+            q += (double)src[1];
+        }
+        red_s[threadIdx.x] = s;
+        red_q[threadIdx.x] = q;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) { red_s[threadIdx.x] += red_s[threadIdx.x + o]; red_q[threadIdx.x] += red_q[threadIdx.x + o]; }
+            __syncthreads();
+        }
+        s = red_s[0];
+        q = red_q[0];
+    } else {
+        s = sums[((int64_t)b * groups + g) * 2];
+        q = sums[((int64_t)b * groups + g) * 2 + 1];
+    }
+    const double inv_cnt = 1.0 / ((double)HW * cpg);
+    const double mean = s * inv_cnt;
+    double var = q * inv_cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = __builtin_amdgcn_rsqf((float)var + eps);
+    for (int i = threadIdx.x; i < cpg; i += 256) {
+        const int c = g * cpg + i;
+        const float sc = gamma[c] * rstd;
+        float* dst = table + ((int64_t)b * C + c) * 2;
+        dst[0] = sc;
+        dst[1] = beta[c] - (float)mean * sc;
+    }
+}
+}  // namespace
+
+extern "C" int edtr_gn_table(const float* partial, int tiles_per_image, const double* sums, int B, int C, int groups, int HW,
+                             const float* gamma, const float* beta, float eps, float* table, edtr_stream_t stream) {
+    if ((!partial && !sums) || !gamma || !beta || !table) return EDTR_E_NULL;
+    if ((partial && tiles_per_image <= 0) || B <= 0 || C <= 0 || groups <= 0 || C % groups || HW <= 0) return EDTR_E_SHAPE;
+    hipLaunchKernelGGL(gn_table_kernel, dim3(groups, B), dim3(256), 0, static_cast<hipStream_t>(stream), partial, tiles_per_image, sums,
+                       C, groups, HW, gamma, beta, eps, table);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }
@@ -2531,6 +2660,13 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (skinny && tile == 3 && p.N <= 32 && p.M >= 65536 && p.splitk <= 1 && !p.gn_partial && p.act != EDTR_ACT_GEGLU &&
             (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
             tile = 14;
+    }
+    if (p.a_gn) {           // GroupNorm (+ SiLU) of the input fused into the halo tile's patch staging: 16 x 16-patch geometry only
+        if ((p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) || !spatial || p.upsample2x || !dma_ok || !igemm_halo_ok(p, spatial) ||
+            igemm_halo_img8(p) || !igemm_fast_addressable(p, spatial) || (p.tile != 0 && p.tile != 16))
+            return EDTR_E_UNSUPPORTED;
+        if (!aligned16(p.a_gn)) return EDTR_E_ALIGN;
+        tile = 16;
     }
     if (p.out16) {
         if (!p.out_f32 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.vt_out) return EDTR_E_UNSUPPORTED;

@@ -482,6 +482,12 @@ class Act:
     W: int
     C: int
     gnp: Optional[torch.Tensor] = None    # fused GroupNorm partials written by the producing igemm ([rows/128][C][2] fp32)
+    # a GroupNorm (+ SiLU) that has NOT been applied: ``t`` is the raw tensor and ``gn_in`` the (scale, shift) table [B][C][2] the
+    # consuming 3x3 convolution applies while it stages its operand (edtr_hip.h: a_gn).  ``owns``: False = ``t`` still belongs to
+    # the Act it was derived from (Emitter.free releases the table only)
+    gn_in: Optional[torch.Tensor] = None
+    gn_silu: bool = True
+    owns: bool = True
 
     @property
     def ld(self) -> int:
@@ -569,6 +575,10 @@ class Emitter:
     def free(self, *ts) -> None:
         for t in ts:
             if isinstance(t, Act):
+                if t.gn_in is not None:
+                    self.arena.free(t.gn_in)
+                    if not t.owns:
+                        continue
                 self.arena.free(t.gnp)
                 t = t.t
             if isinstance(t, OpN):
@@ -810,6 +820,10 @@ class Emitter:
             tile, splitk = ops.invariant_tile(Ce, 0), 1
         if subpix:
             tile, splitk = 16, 1
+        if x.gn_in is not None:          # the input's GroupNorm rides in this convolution's patch staging (group_norm(..., conv_n=N))
+            if taps != 9 or stride != 1 or pad_tl != 1 or ups or self.hp or not ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, N, splitk):
+                raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")
+            tile = 16
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
         if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk, invariant=self.invariant):
@@ -821,7 +835,7 @@ class Emitter:
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
             ldr=residual.stride(0) if residual is not None else 0, residual_f32=res32, out_f32=out_f32, alpha=alpha, tile=tile,
             splitk=splitk, workspace=ws, gn_partial=gnp, name=name, w_phase_stride=(N * wt.stride(0)) if subpix else 0,
-            out16=m16, a_wrap=x.C if parts == ops.PARTS_2W else 0))
+            out16=m16, a_wrap=x.C if parts == ops.PARTS_2W else 0, a_gn=x.gn_in, a_gn_silu=x.gn_silu))
         self.arena.free(ws)
         self.arena.free(tmp)
         return Act(out, x.B, OH, OW, N, gnp)
@@ -846,9 +860,40 @@ class Emitter:
         y = self.new(rows, C)
         return y, y
 
-    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None, feeds=None) -> Act:
+    def gn_deferrable(self, x: Act, conv_n: int) -> bool:
+        """Can the 3x3 / stride 1 / pad 1 convolution with ``conv_n`` output channels that consumes this GroupNorm apply it itself
+        (fast modes, halo tile in its 16 x 16-patch geometry)?"""
+        if not conv_n or self.hp or self.invariant or x.t.dtype == torch.float32:
+            return False
+        _, splitk = ops.choose_splitk(x.rows, conv_n, 9 * x.C)
+        return ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, conv_n, splitk)
+
+    def _deferred(self, x: Act, table: torch.Tensor, silu: bool, take: bool) -> Act:
+        y = Act(x.t, x.B, x.H, x.W, x.C, x.gnp if take else None, gn_in=table, gn_silu=silu, owns=take)
+        if take:                 # the raw tensor now belongs to the deferred activation: the caller's em.free(x) is a no-op
+            x.t, x.gnp = None, None
+        return y
+
+    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None, feeds=None, conv_n: int = 0, take: bool = False) -> Act:
         """``feeds``: the GEMM classes that consume the result (their precision policy decides how many operand parts the
-        apply launch writes in the fp32-stream modes)."""
+        apply launch writes in the fp32-stream modes).  ``conv_n``: the result's ONLY consumer is a 3x3 / stride 1 / pad 1
+        convolution with that many output channels — where the halo tile takes it, no apply launch is emitted: one small launch
+        turns the statistics into a (scale, shift) table and the convolution normalises its operand while staging it (the returned
+        Act carries the RAW tensor; ``take``: it takes over x's storage, i.e. the caller is done with x)."""
+        if out is None and self.gn_deferrable(x, conv_n):
+            gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
+            table = self.arena.alloc((x.B, x.C, 2), torch.float32)
+            hw = x.H * x.W
+            if x.gnp is not None:
+                self.prog.add(ops.make_gn_table(partial=x.gnp, tiles_per_image=hw // 128, sums=None, B=x.B, C=x.C, HW=hw, gamma=gamma,
+                                                beta=beta, eps=eps, table=table))
+            else:
+                sums = self.prog.sums_slot(self.arena, x.B)
+                st, _ = self._gn_recs(x, prefix, eps, silu, sums, x.t, sums_zeroed=True)
+                self.prog.add(st)
+                self.prog.add(ops.make_gn_table(partial=None, tiles_per_image=0, sums=sums, B=x.B, C=x.C, HW=hw, gamma=gamma, beta=beta,
+                                                eps=eps, table=table))
+            return self._deferred(x, table, silu, take)
         parts = self.feeds_parts(feeds, x.rows)
         if self.hp and x.t.dtype != torch.float32:
             parts = 1            # (a branch-internal fp16 tensor: its low parts are exactly zero)
@@ -877,9 +922,24 @@ class Emitter:
         return Act(carried, x.B, x.H, x.W, x.C)
 
     def gn_stats_into(self, x: Act, prefix: str, eps: float, silu: bool, sums: torch.Tensor, sums_zeroed: bool = False,
-                      feeds=None):
+                      feeds=None, conv_n: int = 0, take: bool = False):
         """Statistics half only (tiled VAE: the caller pools `sums` across tiles before the apply half).
-        Returns a closure that emits the apply half and yields the normalised activation."""
+        Returns a closure that emits the apply half and yields the normalised activation.  ``conv_n`` / ``take``: as group_norm —
+        the apply half is then the (scale, shift) table launch and the activation stays raw."""
+        if self.gn_deferrable(x, conv_n):
+            if x.gnp is not None:
+                self.prog.add(ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums))
+            else:
+                st, _ = self._gn_recs(x, prefix, eps, silu, sums, x.t, sums_zeroed=sums_zeroed)
+                self.prog.add(st)
+
+            def table_apply() -> Act:
+                gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
+                table = self.arena.alloc((x.B, x.C, 2), torch.float32)
+                self.prog.add(ops.make_gn_table(partial=None, tiles_per_image=0, sums=sums, B=x.B, C=x.C, HW=x.H * x.W, gamma=gamma,
+                                                beta=beta, eps=eps, table=table))
+                return self._deferred(x, table, silu, take)
+            return table_apply
         parts = self.feeds_parts(feeds, x.rows)
         if self.hp and x.t.dtype != torch.float32:
             parts = 1

@@ -14,7 +14,7 @@ ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3, 4
 
 DECLARED_SYMBOLS = [
     "edtr_abi_version", "edtr_error_string", "edtr_device_info", "edtr_igemm", "edtr_flash_attn64",
-    "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
+    "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_gn_table", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample", "edtr_split3", "edtr_cast16",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp", "edtr_swin_attn", "edtr_conv64",
@@ -53,6 +53,7 @@ class IgemmParams(C.Structure):
         ("w_phase_stride", C.c_int64),
         ("out16", C.c_void_p), ("ld16", C.c_int32),
         ("a_wrap", C.c_int32),
+        ("a_gn", C.c_void_p), ("a_gn_silu", C.c_int32),
     ]
 
 
@@ -159,6 +160,7 @@ def load() -> C.CDLL:
     lib.edtr_gn_stats.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_apply.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_finalize.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.edtr_gn_table.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp]
     lib.edtr_layernorm.argtypes = [i32, vp, i64, i32, i32, i32, vp, vp, f32, vp, i32, vp]
     lib.edtr_softmax_rows.argtypes = [i32, vp, i64, i32, i64, vp, i64, i32, vp]
     lib.edtr_nchw_to_nhwc.argtypes = [i32, vp, i32, i32, i64, vp, i32, i32, i32, f32, f32, vp]

@@ -101,10 +101,11 @@ def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: in
 def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, offs: Dict[str, int], out=None, mirror=False) -> Act:
     """model/unet.py:203-223: GN-SiLU-conv (+bias +emb row) ; GN-SiLU-conv (+bias) + skip(x)."""
     p = P + l.prefix
-    n1 = em.group_norm(x, p + "in_layers.0.", 1e-5, True, feeds=("res.conv1",))
+    # (conv_n: where the halo tile takes the convolution, the GroupNorm is applied inside its operand staging — no apply launch)
+    n1 = em.group_norm(x, p + "in_layers.0.", 1e-5, True, feeds=("res.conv1",), conv_n=l.cout)
     h = em.conv(n1, p + "in_layers.2.", rowvec=table[:, offs[l.prefix]:], name="res.conv1", stats=True, feeds=("res.conv2",))
     em.free(n1)
-    n2 = em.group_norm(h, p + "out_layers.0.", 1e-5, True, feeds=("res.conv2",))
+    n2 = em.group_norm(h, p + "out_layers.0.", 1e-5, True, feeds=("res.conv2",), conv_n=l.cout, take=True)
     em.free(h)
     if l.cin != l.cout:
         skip = em.conv(x, p + "skip_connection.", taps=1, name="res.skip1x1").t
@@ -333,22 +334,22 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
 # ----------------------------------------------------------------------------------------------
 # VAE
 # ----------------------------------------------------------------------------------------------
-def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool, feeds=None):
+def _g_norm(em: Emitter, x: Act, prefix: str, silu: bool, feeds=None, conv_n: int = 0, take: bool = False):
     """GroupNorm as a suspension point of a VAE emission generator: yields the activation (the driver answers with the
     fp64 sums slice to fill), emits the statistics launch, yields again (the driver may pool the sums across tiles),
     then emits the apply launch.  Plain and tiled VAE share every other line of emission code."""
     sums = yield x
-    apply = em.gn_stats_into(x, prefix, 1e-6, silu, sums, sums_zeroed=True, feeds=feeds)     # slots of the program's pre-zeroed pool
+    apply = em.gn_stats_into(x, prefix, 1e-6, silu, sums, sums_zeroed=True, feeds=feeds, conv_n=conv_n, take=take)     # slots of the program's pre-zeroed pool
     yield None
     return apply()
 
 
 def _g_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act):
     """model/vae.py:103-124 (tiled form: resblock2task, utils/tilevae/tilevae.py:86-106)."""
-    n1 = yield from _g_norm(em, x, p + "norm1.", True, ("vae.conv1",))
+    n1 = yield from _g_norm(em, x, p + "norm1.", True, ("vae.conv1",), conv_n=l.cout)
     h = em.conv(n1, p + "conv1.", name="vae.conv1", stats=True, feeds=("vae.conv2",))
     em.free(n1)
-    n2 = yield from _g_norm(em, h, p + "norm2.", True, ("vae.conv2",))
+    n2 = yield from _g_norm(em, h, p + "norm2.", True, ("vae.conv2",), conv_n=l.cout, take=True)
     em.free(h)
     if l.cin != l.cout:
         skip = em.conv(x, p + "nin_shortcut.", taps=1, name="vae.nin_shortcut").t

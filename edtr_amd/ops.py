@@ -71,7 +71,8 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                vt_out: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_ld: int = 0, vt_alpha: float = 1.0,
                row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0, ln_valid: int = 0,
                ln_eps: float = 1e-5, ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None,
-               w_phase_stride: int = 0, out16: Optional[torch.Tensor] = None, a_wrap: int = 0, name: str = "igemm") -> Rec:
+               w_phase_stride: int = 0, out16: Optional[torch.Tensor] = None, a_wrap: int = 0, a_gn: Optional[torch.Tensor] = None,
+               a_gn_silu: bool = True, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -84,6 +85,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     if out16 is not None:                 # fp16 mirror of an fp32 stream output (mixed mode)
         p.out16, p.ld16 = ptr(out16), out16.stride(0)
     p.a_wrap = a_wrap                     # weights-exact two-part product: A columns read twice against [Wh | Wl]
+    p.a_gn, p.a_gn_silu = ptr(a_gn), int(a_gn_silu)     # GroupNorm apply (+ SiLU) of the input fused into the halo tile's staging
     p.w_zs_outer, p.w_zs_inner = w_zs
     p.alpha = alpha
     p.bias_n, p.bias_m, p.rowvec = ptr(bias_n), ptr(bias_m), ptr(rowvec)
@@ -110,12 +112,12 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
     nbytes = Z * (2.0 * a_rows * (C1 + C2) + 2.0 * N * p.K + (4.0 if out_f32 else 2.0) * M * n_out
                   + ((4.0 if residual_f32 else 2.0) * M * n_out if residual is not None else 0.0))
     rec = Rec(L.load().edtr_igemm, (ct.byref(p),), (p, a1, a2, w, out, bias_n, bias_m, rowvec, residual, workspace,
-                                                    gn_partial, vt_out, row_stats, ln_stats, ln_c1, ln_c2, out16), name, flops, nbytes)
+                                                    gn_partial, vt_out, row_stats, ln_stats, ln_c1, ln_c2, out16, a_gn), name, flops, nbytes)
     rec.tag = (f"taps{taps} M{M} N{N} K{p.K} Z{Z}" + (f" C2={C2}" if C2 else "") + (f" s{p.stride}" if spatial and p.stride != 1 else "")
                + ((" up2" if p.upsample2x == 1 else " up2sp") if spatial and p.upsample2x else "") + (f" sk{splitk}" if splitk > 1 else "") + (f" act{act}" if act else "")
                + (" f32" if out_f32 else "") + (" gnp" if gn_partial is not None else "") + (" vT" if vt_out is not None else "")
                + (" ln" if ln_stats is not None else "") + (" rs" if row_stats is not None else "")
-               + (" m16" if out16 is not None else "") + (" 2w" if a_wrap else ""))
+               + (" m16" if out16 is not None else "") + (" 2w" if a_wrap else "") + (" gnin" if a_gn is not None else ""))
     return rec
 
 
@@ -348,6 +350,26 @@ def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, gr
 
 def make_gn_finalize(*, partial, tiles_per_image, B, C, sums, groups: int = 32, name="gn.finalize") -> Rec:
     return Rec(L.load().edtr_gn_finalize, (ptr(partial), tiles_per_image, B, C, groups, ptr(sums)), (partial, sums), name)
+
+
+def make_gn_table(*, partial, tiles_per_image, sums, B, C, HW, gamma, beta, eps, table, groups: int = 32, name="gn.table") -> Rec:
+    """(scale, shift) per image and channel for a consumer that normalises the tensor itself (edtr_hip.h: edtr_gn_table, a_gn)."""
+    return Rec(L.load().edtr_gn_table, (ptr(partial), tiles_per_image, ptr(sums), B, C, groups, HW, ptr(gamma), ptr(beta), eps, ptr(table)),
+               (partial, sums, gamma, beta, table), name)
+
+
+def gn_in_conv_ok(B: int, H: int, W: int, C: int, N: int, splitk: int = 1) -> bool:
+    """Does the halo tile take this 3x3 / stride 1 / pad 1 convolution in its 16 x 16-patch geometry with the GroupNorm of its input
+    fused into the patch staging (edtr_hip.h: a_gn)?  The shape rules of edtr_igemm's automatic halo choice: 128-column tiles
+    without padding and >= 48 units — and N <= EDTR_GN_IN_CONV_MAXN (default 128): measured on the MI355X (profiles/r04/gn_in_conv_ab.log),
+    the fused form wins where ONE 128-column tile covers the output channels (the VAE's 512 x 512 level: headline +1.4 %) and loses
+    beyond (N = 256: -0.5 % against that, N = 512 / 640 / 1280: the whole path -1 .. -2 %), because every column tile of a patch
+    normalises the patch again.  EDTR_GN_IN_CONV=0 keeps the edtr_gn_apply launch everywhere (A/B runs)."""
+    if os.environ.get("EDTR_GN_IN_CONV", "1") == "0" or os.environ.get("EDTR_IGEMM_HALO", "1") == "0":
+        return False
+    if H % 16 or W % 16 or C % 64 or N % 128 or (H, W) == (8, 8) or N > int(os.environ.get("EDTR_GN_IN_CONV_MAXN", "128")):
+        return False         # (every 128-column tile of the convolution normalises the whole patch again: N / 128 times the arithmetic of edtr_gn_apply)
+    return (B * H * W // 256) * (N // 128) * max(splitk, 1) >= 48
 
 
 def gn_fusable(M: int, N: int, C1: int, hw: int, taps: int = 1, C2: int = 0, splitk: int = 1, invariant: bool = False) -> bool:

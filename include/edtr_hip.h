@@ -194,6 +194,15 @@ typedef struct edtr_igemm_params {
      * disappears at twice the MFMA work, with no low part of the activation to form.  Plain GEMMs (taps 1, non-spatial, no concat),
      * a_wrap % 64 == 0, tiles 0 / 1 / 2 / 3 / 8. */
     int32_t a_wrap;
+    /* GroupNorm apply (+ SiLU) of the INPUT fused into the operand staging (ABI 8; fast 16-bit modes): a_gn = fp32 [B][C1][2], the
+     * (scale, shift) edtr_gn_table derives from the tensor's statistics; the convolution then multiplies
+     *   act(a1 * scale[image][c] + shift[image][c]),  act = SiLU when a_gn_silu != 0, zero outside the image (the padding),
+     * rounded to `dtype` exactly as edtr_gn_apply stores it — the normalised tensor is never written or read.  Halo tile only, in
+     * its 16 x 16-patch geometry (taps 9, stride 1, pad 1, OH % 16 == OW % 16 == 0, C1 % 64 == 0, no upsample, not the 8 x 8 image
+     * form; split-K allowed); anything else is EDTR_E_UNSUPPORTED and the caller issues edtr_gn_apply.
+     * replaces: `F.silu(self.norm1(x))` / `in_layers[:2]` in front of the 3 x 3 convolutions of the ResBlocks, reference
+     * model/vae.py:103-114, model/unet.py:203-218 (GroupNorm32 + SiLU, model/util.py:146-163). */
+    const float* a_gn; int32_t a_gn_silu;
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -266,6 +275,11 @@ int edtr_gn_stats(const edtr_gn_params* p, edtr_stream_t stream);
 int edtr_gn_finalize(const float* partial, int tiles_per_image, int B, int C, int groups, double* sums,
                      edtr_stream_t stream);
 int edtr_gn_apply(const edtr_gn_params* p, edtr_stream_t stream);
+/* (scale, shift) = (gamma[c] rstd, beta[c] - mean gamma[c] rstd) per image and channel, table[B][C][2] fp32, from the tile partials
+ * of the producing edtr_igemm (partial != NULL) or from the fp64 sums of edtr_gn_stats / edtr_gn_finalize: what edtr_gn_apply forms
+ * per channel before it touches the tensor — for edtr_igemm's a_gn, which applies it while staging its operand (ABI 8). */
+int edtr_gn_table(const float* partial, int tiles_per_image, const double* sums, int B, int C, int groups, int HW,
+                  const float* gamma, const float* beta, float eps, float* table, edtr_stream_t stream);
 
 /* LayerNorm over the last dimension, rows x C (C <= 2048, multiple of 8), fp32 math, 16-bit in/out.
  * c_valid (0 = C): only the first c_valid columns are real — the statistics run over them, and columns c_valid..C-1 of y are

@@ -1086,6 +1086,55 @@ def test_halo_conv_tile16_upsample2x(dtype, case):
     _halo_case(dtype, case, ups=True)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,cin,cout,splitk,from_partial", [(1, 32, 48, 128, 128, 1, False), (2, 16, 16, 192, 256, 1, True), (1, 64, 64, 64, 128, 1, False),
+                                                               (2, 16, 32, 320, 128, 1, True), (1, 16, 16, 1280, 256, 3, False), (8, 32, 32, 640, 640, 1, True)])
+def test_halo_conv_with_groupnorm_of_its_input(dtype, B, H, W, cin, cout, splitk, from_partial):
+    """edtr_igemm with a_gn: GroupNorm apply + SiLU of the INPUT inside the halo tile's patch staging (reference model/vae.py:103-114,
+    model/unet.py:203-218: `conv(silu(norm(x)))`) — against the two-launch form (edtr_gn_apply, then the same convolution) and against
+    torch fp32.  One / three / five / twenty 64-channel chunks (the prologue-only path, the in-loop normalisation, odd chunk counts),
+    split-K, statistics from tile partials and from fp64 sums, image borders on every side of a patch (the padding must stay zero
+    AFTER the normalisation)."""
+    from edtr_amd import lib as L
+    ops = _ops()
+    d = dev()
+    M, HW = B * H * W, H * W
+    x = (rnd((M, cin), 401, 1.3) + 0.4).to(dtype)
+    w = rnd((cout, 9 * cin), 402, 1 / math.sqrt(9 * cin)).to(dtype)
+    bias = rnd((cout,), 403).to(d)
+    gamma, beta = (1 + 0.2 * rnd((cin,), 404)).to(d), (0.2 * rnd((cin,), 405)).to(d)
+    xd, wd = x.to(d), w.to(d)
+    sums = torch.zeros((B, 32, 2), dtype=torch.float64, device=d)
+    y = torch.empty((M, cin), dtype=dtype, device=d)
+    st, ap = ops.make_gn(dtype=dtype, x=xd, ldx=cin, B=B, HW=HW, C=cin, sums=sums, gamma=gamma, beta=beta, eps=1e-6, silu=True, y=y, ldy=cin,
+                         sums_zeroed=True)
+    ops.launch(st)
+    ops.launch(ap)
+    table = torch.full((B, cin, 2), float("nan"), dtype=torch.float32, device=d)
+    partial = None
+    if from_partial:            # the statistics as a producing igemm's epilogue leaves them: per 128-row tile and channel
+        xf = xd.float().reshape(B * HW // 128, 128, cin)
+        partial = torch.stack([xf.sum(1), (xf * xf).sum(1)], dim=-1).contiguous()
+    ops.launch(ops.make_gn_table(partial=partial, tiles_per_image=HW // 128, sums=None if from_partial else sums, B=B, C=cin, HW=HW, gamma=gamma,
+                                 beta=beta, eps=1e-6, table=table))
+    outs = {}
+    for fused in (False, True):
+        out = torch.full((M, cout), float("nan"), dtype=dtype, device=d)
+        ws = torch.empty((splitk * M * cout,), dtype=torch.float32, device=d) if splitk > 1 else None
+        ops.launch(ops.make_igemm(dtype=dtype, a1=xd if fused else y, w=wd, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, rows_per_image=HW, tile=16, splitk=splitk, workspace=ws,
+                                  a_gn=table if fused else None, a_gn_silu=True))
+        outs[fused] = out
+    torch.cuda.synchronize()
+    xr = F.silu(F.group_norm(x.float().reshape(B, H, W, cin).permute(0, 3, 1, 2), 32, gamma.cpu(), beta.cpu(), 1e-6))
+    ref = F.conv2d(xr, w.float().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2), bias.cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+    assert torch.isfinite(outs[True].float()).all()
+    assert rel(outs[True].float(), ref) < TOL[dtype]
+    # the fused form rounds the normalised activation exactly as edtr_gn_apply stores it: the two forms agree to the order of the
+    # statistics' summation (fp32 tile partials against fp64 sums) — an order of magnitude below the kernels' own rounding error
+    assert rel(outs[True].float(), outs[False].float()) < 0.1 * TOL[dtype]
+
+
 def _halo_case(dtype, case, ups):
     import torch.nn.functional as F
     from edtr_amd import lib as L
