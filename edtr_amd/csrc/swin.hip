@@ -225,10 +225,13 @@ constexpr int MLP_XT = MLP_TOKENS * 32 * MLP_CT * 2;         // token tile, rows
 constexpr int MLP_CONST_FLOATS = 2 * 32 * MLP_HT + 32 * MLP_CT;   // c1 | c2b | b2
 constexpr int MLP_LDS = MLP_WBUF + MLP_XT + MLP_CONST_FLOATS * 4;
 
-template <typename T>
-__global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_mlp_params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// IN_LDS (edtr_swin_layer): the token tile is already in LDS (the attention half of the layer left it there) and stays there — no
+// fetch, no store, no row statistics; the caller scatters it.
+template <typename T, bool IN_LDS>
+__device__ __forceinline__ void swin_mlp_body(const edtr_swin_mlp_params& p, char* smem) {
+    int tid = threadIdx.x;
+    if constexpr (IN_LDS) asm volatile("" : "+v"(tid));       // (re-derive the lane geometry here: nothing of it is carried through the attention half)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int t4 = wave & 3, hg = wave >> 2;
     char* xt = smem + MLP_WBUF;
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
         r = 8 * (2 * wave + q / 3) + rl;
         c = (e - 24 * rl) ^ ((r >> 1) & 7);
     };
-    {
+    if constexpr (!IN_LDS) {
         const uint16_t* xg = static_cast<const uint16_t*>(p.x);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -273,7 +276,7 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
     stage_unit(1);
 
     const int tok = tok_base + t4 * 32 + l31;
-    const bool live = tok < p.rows;
+    const bool live = IN_LDS || tok < p.rows;
     const int xrow = t4 * 32 + l31;
     const int x_off = xrow * (C * 2), xkey = (xrow >> 1) & 7;
     const int rs = (l31 & 16) | swap23(l31 & 15);              // the weight row this lane feeds to MFMA row l31
@@ -437,7 +440,7 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s += f[e]; q = __builtin_fmaf(f[e], f[e], q); }
             }
-        if (p.row_stats) {           // this wave's 96 columns: slot 3 hg carries the sums, the two after it are zero
+        if (!IN_LDS && p.row_stats) {           // this wave's 96 columns: slot 3 hg carries the sums, the two after it are zero
             s += __shfl_xor(s, 32, 64);
             q += __shfl_xor(q, 32, 64);
             if (live && lh == 0) {
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
     __syncthreads();
 
     // ---- the finished tile leaves as whole rows: lane-linear LDS reads, 16-byte stores, 128-byte runs per 8 lanes
-    {
+    if constexpr (!IN_LDS) {
         uint16_t* og = static_cast<uint16_t*>(p.out);
         int ln = lane;
         asm volatile("" : "+v"(ln));        // (recompute the slot arithmetic here instead of carrying the prologue's through the loop)
@@ -463,6 +466,12 @@ __global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_m
             if (tok_base + r < p.rows) stg16(og + (int64_t)(tok_base + r) * p.ldo + c * 8, v);
         }
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(MLP_THREADS) swin_mlp_kernel(const edtr_swin_mlp_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    swin_mlp_body<T, false>(p, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -496,10 +505,12 @@ constexpr int SA_XCH = 48 * 1024;                            // loop: K / V frag
 constexpr int SA_CONST_FLOATS = 2 * 3 * SA_HEADS * 32 + 32 * SA_CT + 2 * SA_TOKENS;      // c1 | c2b | bproj | per-token (rstd, -rstd mean)
 constexpr int SA_LDS = SA_WBUF + SA_XCH + SA_XT + SA_CONST_FLOATS * 4 + SA_TOKENS;       // + one region label per token
 
-template <typename T>
-__global__ void __launch_bounds__(SA_THREADS) swin_attn_kernel(const edtr_swin_attn_params p, int total_windows) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// KEEP (edtr_swin_layer): the finished tile stays in LDS for the MLP half; SCATTER_ONLY: nothing but the final scatter of the tile.
+template <typename T, bool KEEP, bool SCATTER_ONLY = false>
+__device__ __forceinline__ void swin_attn_body(const edtr_swin_attn_params& p, int total_windows, char* smem) {
+    int tid = threadIdx.x;
+    if constexpr (SCATTER_ONLY) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int t4 = wave & 3, g = wave >> 2, ww = t4 >> 1, tt = t4 & 1;
     char* xch = smem + SA_WBUF;
@@ -529,6 +540,7 @@ __global__ void __launch_bounds__(SA_THREADS) swin_attn_kernel(const edtr_swin_a
         c = (e - 24 * rl) ^ ((r >> 1) & 7);
     };
 
+    if constexpr (!SCATTER_ONLY) {
     for (int i = tid; i < NQKV; i += SA_THREADS) { cst[i] = p.c1[i]; cst[NQKV + i] = p.c2b[i]; }
     if (tid < C) cst[2 * NQKV + tid] = p.bproj[tid];
     if (tid < SA_TOKENS) {
@@ -815,9 +827,10 @@ __global__ void __launch_bounds__(SA_THREADS) swin_attn_kernel(const edtr_swin_a
     };
     if (g == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 1>{});
     __syncthreads();
+    }       // !SCATTER_ONLY
 
     // ---- the finished tile leaves as whole rows, scattered back through the row map
-    {
+    if constexpr (!KEEP) {
         uint16_t* og = static_cast<uint16_t*>(p.out);
         int ln = lane;
         asm volatile("" : "+v"(ln));        // (recompute the slot arithmetic here instead of carrying the prologue's through the loop)
@@ -830,6 +843,27 @@ __global__ void __launch_bounds__(SA_THREADS) swin_attn_kernel(const edtr_swin_a
             if (win < total_windows) stg16(og + token_row(win, tile_token(r) & 63) * p.ldo + c * 8, v);
         }
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SA_THREADS) swin_attn_kernel(const edtr_swin_attn_params p, int total_windows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    swin_attn_body<T, false>(p, total_windows, smem);
+}
+
+// edtr_swin_layer — a whole Swin layer in one launch: the attention half leaves its finished token tile in LDS, the MLP half runs on
+// it in place (same tile address, same row swizzle; it is a per-token operation, so the tile's window order does not matter), and
+// the result is scattered back through the attention half's row map: one launch, one store and one fetch of the token tensor less
+// per layer than edtr_swin_attn + edtr_swin_mlp.
+static_assert(SA_WBUF + SA_XCH == MLP_WBUF && SA_XT == MLP_XT, "the two halves keep the token tile at the same LDS address");
+constexpr int SL_LDS = SA_LDS > MLP_LDS ? SA_LDS : MLP_LDS;
+
+template <typename T>
+__global__ void __launch_bounds__(SA_THREADS) swin_layer_kernel(const edtr_swin_attn_params pa, const edtr_swin_mlp_params pm, int total_windows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    swin_attn_body<T, true>(pa, total_windows, smem);
+    swin_mlp_body<T, true>(pm, smem);
+    swin_attn_body<T, false, true>(pa, total_windows, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1099,6 +1133,46 @@ extern "C" int edtr_swin_attn(const edtr_swin_attn_params* pp, edtr_stream_t str
             attr_set[1] = true;
         }
         hipLaunchKernelGGL(swin_attn_kernel<F16>, grid, dim3(SA_THREADS), SA_LDS, s, p, (int)windows);
+    }
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_swin_layer(const edtr_swin_attn_params* pa, const edtr_swin_mlp_params* pm, edtr_stream_t stream) {
+    if (!pa || !pm) return EDTR_E_NULL;
+    const edtr_swin_attn_params& a = *pa;
+    const edtr_swin_mlp_params& m = *pm;
+    if (!a.x || !a.wqkv || !a.wproj || !a.c1 || !a.c2b || !a.bproj || !a.bias || !a.out) return EDTR_E_NULL;
+    if (!m.w1 || !m.w2 || !m.c1 || !m.c2b || !m.b2) return EDTR_E_NULL;
+    if ((a.dtype != EDTR_BF16 && a.dtype != EDTR_F16) || m.dtype != a.dtype) return EDTR_E_DTYPE;
+    if (a.B <= 0 || a.H <= 0 || a.W <= 0 || (a.H % WS) || (a.W % WS) || a.c_valid <= 0 || a.c_valid > a.C || m.c_valid != a.c_valid) return EDTR_E_SHAPE;
+    if (a.C != 32 * SA_CT || a.heads != SA_HEADS || a.head_dim > HP || a.head_dim <= 0 || m.C != a.C || m.hidden != 32 * MLP_HT) return EDTR_E_UNSUPPORTED;
+    if (a.shift < 0 || a.shift >= WS) return EDTR_E_SHAPE;
+    if (a.shift > 0 && !a.labels) return EDTR_E_NULL;
+    if (a.x == a.out) return EDTR_E_UNSUPPORTED;
+    if (a.ldx < a.C || a.ldo < a.C) return EDTR_E_SHAPE;
+    if ((a.ldx & 7) || (a.ldo & 7) || (a.W & 3)) return EDTR_E_ALIGN;
+    if (!aligned16(a.x) || !aligned16(a.wqkv) || !aligned16(a.wproj) || !aligned16(a.out) || !aligned16(a.c1) || !aligned16(a.c2b) ||
+        !aligned16(a.bproj) || !aligned16(a.bias) || (a.labels && (reinterpret_cast<uintptr_t>(a.labels) & 3u)) || !aligned16(m.w1) ||
+        !aligned16(m.w2) || !aligned16(m.c1) || !aligned16(m.c2b) || !aligned16(m.b2))
+        return EDTR_E_ALIGN;
+    const int64_t windows = (int64_t)a.B * (a.H / WS) * (a.W / WS);
+    if (windows > 0x3fffffffLL) return EDTR_E_UNSUPPORTED;
+    static bool attr_set[2] = {false, false};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((windows + 1) / 2));
+    if (a.dtype == EDTR_BF16) {
+        if (!attr_set[0]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_layer_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL(swin_layer_kernel<BF16>, grid, dim3(SA_THREADS), SL_LDS, s, a, m, (int)windows);
+    } else {
+        if (!attr_set[1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_layer_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL(swin_layer_kernel<F16>, grid, dim3(SA_THREADS), SL_LDS, s, a, m, (int)windows);
     }
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;

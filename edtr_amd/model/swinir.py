@@ -225,6 +225,9 @@ class _SwinEngine:
         fuse_attn = (os.environ.get("EDTR_SWIN_ATTN_FUSE", "1") != "0" and CP == ops_mod.SWIN_MLP_C and ws == 8 and tw % 4 == 0
                      and all(h == ops_mod.SWIN_ATTN_HEADS and C // h <= HEAD_PAD for h in cfg["num_heads"]))
 
+        # ... and the two halves as ONE launch (edtr_swin_layer); EDTR_SWIN_LAYER_FUSE=0 keeps them apart.
+        fuse_layer = os.environ.get("EDTR_SWIN_LAYER_FUSE", "1") != "0"
+
         def attn_images(p: str, heads: int):
             key = ("swin_attn", p)
             if key not in store.cache:
@@ -269,13 +272,22 @@ class _SwinEngine:
                     if shift and shift not in labels:
                         labels[shift] = torch.from_numpy(region_labels(th, tw, ws, shift)).to(dev).contiguous()
                     img_qkv, img_proj, ac1, ac2b, abp, abias = attn_images(p, heads)
+                    img1, img2, c1, c2b, b2 = mlp_images(p)
                     x1 = em.new(rows, CP)
-                    self.prog.add(ops_mod.make_swin_attn(dtype=dt, x=r, ldx=r.stride(0), out=x1, ldo=CP, B=B, H=th, W=tw, head_dim=d, shift=shift,
-                                                         c_valid=C, eps=1e-5, wqkv=img_qkv, wproj=img_proj, c1=ac1, c2b=ac2b, bproj=abp, bias=abias,
-                                                         labels=labels[shift] if shift else None))
+                    attn_rec = ops_mod.make_swin_attn(dtype=dt, x=r, ldx=r.stride(0), out=x1, ldo=CP, B=B, H=th, W=tw, head_dim=d, shift=shift,
+                                                      c_valid=C, eps=1e-5, wqkv=img_qkv, wproj=img_proj, c1=ac1, c2b=ac2b, bproj=abp, bias=abias,
+                                                      labels=labels[shift] if shift else None)
+                    if fuse_layer:       # both halves in ONE launch: the token tile stays in LDS between them (x1 is the layer's output)
+                        mlp_rec = ops_mod.make_swin_mlp(dtype=dt, x=x1, ldx=CP, rows=rows, c_valid=C, eps=1e-5, w1=img1, w2=img2, c1=c1, c2b=c2b,
+                                                        b2=b2, out=x1, ldo=CP, row_stats=None)
+                        self.prog.add(ops_mod.make_swin_layer(attn_rec, mlp_rec))
+                        if r is not t:
+                            em.free(r)
+                        r = x1
+                        continue
+                    self.prog.add(attn_rec)
                     if r is not t:
                         em.free(r)
-                    img1, img2, c1, c2b, b2 = mlp_images(p)
                     r = em.new(rows, CP)
                     self.prog.add(ops_mod.make_swin_mlp(dtype=dt, x=x1, ldx=x1.stride(0), rows=rows, c_valid=C, eps=1e-5, w1=img1, w2=img2,
                                                         c1=c1, c2b=c2b, b2=b2, out=r, ldo=CP, row_stats=None))

@@ -273,6 +273,14 @@ def make_swin_mlp(*, dtype, x, ldx, rows, c_valid, eps, w1, w2, c1, c2b, b2, out
     return Rec(L.load().edtr_swin_mlp, (ct.byref(p),), (p, x, w1, w2, c1, c2b, b2, out, row_stats), name, flops, nbytes)
 
 
+def make_swin_layer(attn: Rec, mlp: Rec, name="swin.layer") -> Rec:
+    """A whole Swin layer in one launch from the two half-layer records (edtr_hip.h: edtr_swin_layer): the attention record's x / out
+    are the layer's input / output, the MLP record contributes its weights and constants."""
+    pa, pm = attn.keep[0], mlp.keep[0]
+    return Rec(L.load().edtr_swin_layer, (ct.byref(pa), ct.byref(pm)), (attn.keep, mlp.keep), name, attn.flops + mlp.flops,
+               attn.bytes + mlp.bytes - 4.0 * pa.B * pa.H * pa.W * SWIN_MLP_C)
+
+
 def pack_conv64_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """[Cout <= 64, 64 (or fewer, zero padded), 3, 3] fp32 -> the nine 8-KiB LDS images of edtr_conv64 (edtr_hip.h)."""
     co, ci, kh, kw = w.shape

@@ -387,6 +387,12 @@ typedef struct edtr_swin_attn_params {
 
 int edtr_swin_attn(const edtr_swin_attn_params* p, edtr_stream_t stream);
 
+/* A whole Swin layer in one launch (ABI 8): edtr_swin_attn followed by edtr_swin_mlp on the token tile the attention half leaves in
+ * LDS — `attn->out` receives x + attention half + MLP half; `mlp->x`, `->out`, `->rows`, `->row_stats` and the ld fields are ignored
+ * (the tile never leaves the workgroup between the halves), its weight / constant operands are those of edtr_swin_mlp.  Same
+ * shape and alignment rules as the two entry points.  replaces: SwinTransformerBlock.forward, reference model/swinir.py:254-283. */
+int edtr_swin_layer(const edtr_swin_attn_params* attn, const edtr_swin_mlp_params* mlp, edtr_stream_t stream);
+
 /* 3 x 3 / stride 1 / pad 1 convolution of a 64-channel NHWC image into <= 64 channels, persistent workgroups with the nine tap
  * matrices resident in LDS (ABI 8) — SwinIR's reconstruction tail at the pixel levels, where edtr_igemm's 128-column tiles are
  * half padding.  replaces: conv_up1 / conv_up2 / conv_up3 (behind `F.interpolate(scale_factor=2, mode="nearest")`), conv_hr and

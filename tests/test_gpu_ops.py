@@ -989,6 +989,58 @@ def test_swin_attention_half_one_launch(dtype, B, H, W, shift):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,shift", [(2, 16, 24, 4), (1, 8, 24, 0), (1, 64, 64, 4)])
+def test_swin_layer_one_launch(dtype, B, H, W, shift):
+    """edtr_swin_layer (both halves of a Swin layer on one LDS tile) == edtr_swin_attn followed by edtr_swin_mlp, bit for bit: the
+    two forms run the same arithmetic on the same 16-bit tile."""
+    from edtr_amd.model import swinir as S
+    ops = _ops()
+    dv = dev()
+    heads, d, C, HID, CP, HP = 6, 30, 180, 360, ops.SWIN_MLP_C, ops.SWIN_MLP_HIDDEN
+    rows = B * H * W
+    x = torch.zeros((rows, CP))
+    x[:, :C] = rnd((rows, C), 220, 1.5) + 0.3
+    x = x.to(dtype).to(dv)
+    wq32, bq32 = S.pack_qkv(rnd((3 * C, C), 221, 1.5 / math.sqrt(C)), 0.2 * rnd((3 * C,), 222), heads, CP)
+    g1, b1 = torch.zeros(CP), torch.zeros(CP)
+    g1[:C], b1[:C] = 1 + 0.2 * rnd((C,), 223), 0.3 * rnd((C,), 224)
+    scale = torch.ones(3 * heads * 32)
+    scale[: heads * 32] = d ** -0.5
+    wg = wq32 * g1[None, :] * scale[:, None]
+    wpp = torch.zeros((CP, heads, 32))
+    wpp[:C, :, :d] = rnd((C, C), 225, 1 / math.sqrt(C)).reshape(C, heads, d)
+    img_qkv, img_proj = ops.pack_swin_attn_weights(wg, wpp.reshape(CP, heads * 32), dtype)
+    bpp = torch.zeros(CP)
+    bpp[:C] = 0.2 * rnd((C,), 226)
+    bias = ops.swin_attn_bias(S.expand_bias(rnd((225, heads), 227, 0.7), 8))
+    lab = torch.from_numpy(S.region_labels(H, W, 8, shift)).to(dv) if shift else None
+    w1g, w2p, c2b, b2p = torch.zeros((HP, CP)), torch.zeros((CP, HP)), torch.zeros(HP), torch.zeros(CP)
+    w1g[:HID, :C] = rnd((HID, C), 228, 1 / math.sqrt(C))
+    w2p[:C, :HID] = rnd((C, HID), 229, 1 / math.sqrt(HID))
+    c2b[:HID], b2p[:C] = 0.2 * rnd((HID,), 230), 0.2 * rnd((C,), 231)
+    img1, img2 = ops.pack_swin_mlp_weights(w1g, w2p, dtype)
+
+    def recs(x1, y):
+        a = ops.make_swin_attn(dtype=dtype, x=x, ldx=CP, out=x1, ldo=CP, B=B, H=H, W=W, head_dim=d, shift=shift, c_valid=C, eps=1e-5,
+                               wqkv=img_qkv.to(dv), wproj=img_proj.to(dv), c1=wg.to(dtype).float().sum(1).contiguous().to(dv),
+                               c2b=((wq32 @ b1 + bq32) * scale).contiguous().to(dv), bproj=bpp.to(dv), bias=bias.to(dv), labels=lab)
+        m = ops.make_swin_mlp(dtype=dtype, x=x1, ldx=CP, rows=rows, c_valid=C, eps=1e-5, w1=img1.to(dv), w2=img2.to(dv),
+                              c1=w1g.to(dtype).float().sum(1).contiguous().to(dv), c2b=c2b.to(dv), b2=b2p.to(dv), out=y, ldo=CP)
+        return a, m
+    x1 = torch.empty((rows, CP), dtype=dtype, device=dv)
+    two = torch.full((rows, CP), float("nan"), dtype=dtype, device=dv)
+    a, m = recs(x1, two)
+    ops.launch(a)
+    ops.launch(m)
+    one = torch.full((rows, CP), float("nan"), dtype=dtype, device=dv)
+    a2, m2 = recs(one, one)
+    ops.launch(ops.make_swin_layer(a2, m2))
+    torch.cuda.synchronize()
+    assert torch.isfinite(one.float()).all()
+    assert torch.equal(one, two)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows", [128, 4096 + 64, 300, 32768])
 def test_swin_mlp_one_launch(dtype, rows):
     """edtr_swin_mlp: x + fc2(GELU(fc1(LayerNorm(x)))) of a Swin layer in one launch (reference model/swinir.py:24-37, :281-283)
