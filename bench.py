@@ -640,6 +640,13 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
                                   "inside the timed region two lanes and two batches overlap, so the family's share of the wall is "
                                   "smaller than ms_per_pass_isolated",
                            "ms_per_pass_isolated": round(ig["ms"], 3)}
+        n_gnin = sum(v[2] for tag, v in shapes.items() if " gnin" in tag)
+        if n_gnin:
+            out["roofline"]["fused_groupnorm_inputs"] = {
+                "launches_per_pass": n_gnin,
+                "note": "these convolutions apply the GroupNorm + SiLU of their input while staging it (edtr_igemm a_gn): their duration "
+                        "includes that arithmetic (the edtr_gn_apply launch in front of each is gone), their FLOP count does not, so "
+                        "`frac` reads ~0.02 lower than with EDTR_GN_IN_CONV=0 while the path is 1.4 % faster (profiles/r04/gn_in_conv_ab.log)"}
         if ms_per_step:
             # self-consistent in-situ bound: the family's FLOP of one pass over the WALL time of one pass of the timed region
             # (as if nothing else ran): what the timed region certainly sustained, <= the isolated figure by construction
