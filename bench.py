@@ -77,7 +77,7 @@ def main() -> None:
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-name time table to stderr")
     ap.add_argument("--swinir", action="store_true",
                     help="also time the SwinIR pre-restoration in front of the path (excluded from the metric, SURVEY.md §8d) and "
-                         "report it separately as \"pre_restoration\"")
+                         "report it separately as \"pre_restoration\" (the default run does: --also none skips it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -304,7 +304,9 @@ def main() -> None:
     if args.dup:
         result["INVALID_measurement_aid"] = f"--dup {args.dup}"
 
-    if rank == 0 and args.swinir:
+    default_legs = (world == 1 and args.also != "none" and args.precision == "fast" and args.workload == "det512" and args.config == "sd21"
+                    and std_shape and not args.dup and not args.no_graph)
+    if rank == 0 and (args.swinir or default_legs):      # (on the default run too: the step in front of the path, on the driver's record)
         try:
             result["pre_restoration"] = swinir_leg(dev, dtype, B, S, args.steps)
         except Exception as e:       # reported separately: must never take the headline line down with it

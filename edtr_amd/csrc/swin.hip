@@ -1010,6 +1010,141 @@ __global__ void __launch_bounds__(C64_THREADS) conv64_kernel(const edtr_conv64_p
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// edtr_conv128_out — the VAE decoder's last step: GroupNorm + SiLU, 3 x 3 convolution of the 128-channel image into <= 4 channels,
+// fp32 NCHW result (reference model/vae.py:553-560: norm_out, nonlinearity, conv_out; the caller's NHWC -> NCHW).  As launches:
+// edtr_gn_apply (213 us for a batch of 8 at 512 x 512: one more round trip of the 537 MB tensor), edtr_igemm's 256 x 32 tile (366 us
+// at 105 TFLOP/s: 29 of its 32 columns are padding) and the layout kernel.  Here, edtr_conv64's structure with a 256-byte pixel:
+// persistent workgroups, the nine tap matrices (32 rows x 128 k) resident in LDS, 16 x 16-pixel patches with halo streamed through
+// ONE 81-KiB buffer (two do not fit), every lane normalising the 16 bytes it fetched — silu(x scale[c] + shift[c]) from the
+// image's (scale, shift) table (edtr_gn_table), pixels outside the image stay zero — before the patch is multiplied.
+// Pixel (py, px) at (18 py + px) * 256 B, chunk c in slot c ^ (px & 15); weight row n at n * 256 B, chunk c in slot c ^ (n & 15).
+constexpr int CO_THREADS = 512;
+constexpr int CO_W_BYTES = 9 * 32 * 256;                     // 73728
+constexpr int CO_PATCH_INSTRS = 81;                          // 18 * 18 * 256 B = 81 KiB
+constexpr int CO_PATCH_BYTES = CO_PATCH_INSTRS * 1024;
+constexpr int CO_TBL = CO_W_BYTES + CO_PATCH_BYTES;          // (scale, shift) of the patch's image: 128 x 2 floats
+constexpr int CO_LDS = CO_TBL + 1024 + 32 * 4;
+
+template <typename T>
+__global__ void __launch_bounds__(CO_THREADS) conv128_out_kernel(const edtr_conv128_out_params p, int patches) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    char* wl = smem;
+    char* pb = smem + CO_W_BYTES;
+    float* bias_l = reinterpret_cast<float*>(smem + CO_TBL + 1024);
+    const uint32_t lds0 = lds_addr_of(smem);
+    const int tiles_x = p.W >> 4, tiles_y = p.H >> 4;
+
+    if (tid < 32) bias_l[tid] = p.bias[tid];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dma16(static_cast<const char*>(p.w) + (wave * 9 + q) * 1024 + lane * 16, lds0 + (wave * 9 + q) * 1024);
+
+    // this lane's share of a patch fetch: instruction Q = wave + 8 q (< 81), 16 bytes at byte o = 1024 Q + 16 lane of the patch image;
+    // packed (py << 9 | px << 4 | source chunk)
+    int f_geo[11];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+        const int o = (wave + 8 * q) * 1024 + lane * 16, P = o >> 8, cs = (o >> 4) & 15;
+        const int py = P / 18, px = P - 18 * py;
+        f_geo[q] = (py << 9) | (px << 4) | (cs ^ (px & 15));
+    }
+    const uint16_t* xg = static_cast<const uint16_t*>(p.x);
+
+    const int px_x = l31 & 15;
+    const int pix0 = (18 * (2 * wave + (l31 >> 4)) + px_x) * 256;
+    int xperm[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) xperm[kx] = (lh ^ ((px_x + kx) & 15)) << 4;
+    const int rs = (l31 & 16) | swap23(l31 & 15);
+    const int w_off = rs * 256 + ((lh ^ (rs & 15)) << 4);
+    float* of32 = static_cast<float*>(p.out);
+
+#pragma unroll 1
+    for (int patch = blockIdx.x; patch < patches; patch += gridDim.x) {
+        const int tx = patch % tiles_x, r0 = patch / tiles_x, ty = r0 % tiles_y, b = r0 / tiles_y;
+        __syncthreads();                                        // everyone is done with the previous patch (and its table)
+        if (p.gn_table) dma16(reinterpret_cast<const char*>(p.gn_table + (int64_t)b * 256) + lane * 16, lds0 + CO_TBL);   // (every wave: the same KiB)
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            if (wave + 8 * q < CO_PATCH_INSTRS) {               // (wave-uniform)
+                const int py = f_geo[q] >> 9, px = (f_geo[q] >> 4) & 31, c = f_geo[q] & 15;
+                const int Y = ty * 16 - 1 + py, X = tx * 16 - 1 + px;
+                const bool in = Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+                const void* src = in ? static_cast<const void*>(xg + (((int64_t)b * p.H + Y) * p.W + X) * p.ldx + c * 8)
+                                     : static_cast<const void*>(g_c64_zero);
+                dma16(src, lds0 + CO_W_BYTES + (wave + 8 * q) * 1024);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (also the previous patch's stores, issued before these fetches)
+        if (p.gn_table) {
+            // GroupNorm apply + SiLU of this lane's own 16 bytes of every piece, in place (edtr_gn_apply's arithmetic and rounding)
+            const float* tbl = reinterpret_cast<const float*>(smem + CO_TBL);
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                if (wave + 8 * q < CO_PATCH_INSTRS) {
+                    const int py = f_geo[q] >> 9, px = (f_geo[q] >> 4) & 31, c = f_geo[q] & 15;
+                    const int Y = ty * 16 - 1 + py, X = tx * 16 - 1 + px;
+                    if (Y >= 0 && Y < p.H && X >= 0 && X < p.W) {
+                        char* q16 = smem + CO_W_BYTES + (wave + 8 * q) * 1024 + lane * 16;
+                        const float* tb = tbl + c * 16;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
+                        const f32x4 t2 = *reinterpret_cast<const f32x4*>(tb + 8), t3 = *reinterpret_cast<const f32x4*>(tb + 12);
+                        float f[8], e[8];
+                        unpack8<T>(*reinterpret_cast<const U4*>(q16), f);
+                        f[0] = f[0] * t0[0] + t0[1]; f[1] = f[1] * t0[2] + t0[3];
+                        f[2] = f[2] * t1[0] + t1[1]; f[3] = f[3] * t1[2] + t1[3];
+                        f[4] = f[4] * t2[0] + t2[1]; f[5] = f[5] * t2[2] + t2[3];
+                        f[6] = f[6] * t3[0] + t3[1]; f[7] = f[7] * t3[2] + t3[3];
+                        pin8(f);                                 // silu_f in lockstep (common.h: gelu_erf_lockstep)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) e[i] = f[i] * -1.4426950408889634f;
+                        pin8(e);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+                        pin8(e);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) e[i] = 1.0f + e[i];
+                        pin8(e);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+                        pin8(e);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = f[i] * e[i];
+                        *reinterpret_cast<U4*>(q16) = pack8<T>(f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const char* pbuf = pb + pix0;
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const U4 xb = *reinterpret_cast<const U4*>(pbuf + (18 * ky + kx) * 256 + (xperm[kx] ^ (32 * ks)));
+                const U4 w0 = *reinterpret_cast<const U4*>(wl + t * 8192 + (w_off ^ (32 * ks)));
+                acc = T::mfma(w0, xb, acc);
+            }
+        }
+        // fp32 planes [b][c][Y][X], c < n_valid <= 4: channels 0..3 are registers 0..3 in the lanes with lh == 0
+        const int Y = ty * 16 + 2 * wave + (l31 >> 4), X = tx * 16 + px_x;
+        const int64_t plane = (int64_t)p.H * p.W;
+        float* o0 = of32 + (int64_t)b * p.n_valid * plane + (int64_t)Y * p.W + X;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float v = __builtin_fmaf(p.alpha, acc[c], bias_l[c]);
+            if (lh == 0 && c < p.n_valid) o0[c * plane] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // pixel-unshuffle front end: one thread = one (token, channel, dy) run of r source pixels
 template <typename T>
 __global__ void __launch_bounds__(256) pixel_unshuffle_kernel(const float* src, int B, int C, int H, int W, int r, const float* sub,
@@ -1214,6 +1349,44 @@ extern "C" int edtr_conv64(const edtr_conv64_params* pp, edtr_stream_t stream) {
             attr_set[1] = true;
         }
         hipLaunchKernelGGL(conv64_kernel<F16>, grid, dim3(C64_THREADS), C64_LDS, s, p, (int)patches);
+    }
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_conv128_out(const edtr_conv128_out_params* pp, edtr_stream_t stream) {
+    if (!pp) return EDTR_E_NULL;
+    const edtr_conv128_out_params& p = *pp;
+    if (!p.x || !p.w || !p.bias || !p.out) return EDTR_E_NULL;
+    if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (p.B <= 0 || p.H <= 0 || p.W <= 0 || (p.H & 15) || (p.W & 15)) return EDTR_E_SHAPE;
+    if (p.n_valid < 1 || p.n_valid > 4) return EDTR_E_UNSUPPORTED;
+    if (p.ldx < 128 || (p.ldx & 7)) return EDTR_E_ALIGN;
+    if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.out) || !aligned16(p.bias) || (p.gn_table && !aligned16(p.gn_table))) return EDTR_E_ALIGN;
+    const int64_t patches = (int64_t)p.B * (p.H >> 4) * (p.W >> 4);
+    if (patches > 0x7fffffffLL || (int64_t)p.B * p.H * p.W > 0x7fffffffLL) return EDTR_E_UNSUPPORTED;
+    static bool attr_set[2] = {false, false};
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EDTR_E_UNSUPPORTED;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(patches < cus ? patches : cus));
+    if (p.dtype == EDTR_BF16) {
+        if (!attr_set[0]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv128_out_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS);
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL(conv128_out_kernel<BF16>, grid, dim3(CO_THREADS), CO_LDS, s, p, (int)patches);
+    } else {
+        if (!attr_set[1]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv128_out_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS);
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL(conv128_out_kernel<F16>, grid, dim3(CO_THREADS), CO_LDS, s, p, (int)patches);
     }
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;

@@ -840,6 +840,17 @@ class Emitter:
         self.arena.free(tmp)
         return Act(out, x.B, OH, OW, N, gnp)
 
+    def conv128_out(self, x: Act, prefix: str, out_nchw: torch.Tensor, n_valid: int, alpha: float = 1.0, name="vae.conv_out") -> None:
+        """The VAE decoder's conv_out on edtr_conv128_out: ``x`` carries its deferred GroupNorm (group_norm / gn_stats_into with
+        conv_n = -n_valid), the result goes straight into the fp32 NCHW tensor."""
+        key = ("conv128_out", prefix, alpha)
+        if key not in self.store.cache:
+            w = self.store._p(prefix + "weight")
+            self.store.cache[key] = (ops.pack_conv128_out_weight(w, self.dtype), ops.pad_bias(self.store._p(prefix + "bias") * alpha, 32))
+        w, b = self.store.cache[key]
+        self.prog.add(ops.make_conv128_out(dtype=self.dtype, x=x.t, ldx=x.ld, w=w, bias=b, out=out_nchw, B=x.B, H=x.H, W=x.W, n_valid=n_valid,
+                                           gn_table=x.gn_in, alpha=alpha, name=name))
+
     # -- norms --------------------------------------------------------------------------------
     def _gn_recs(self, x: Act, prefix: str, eps: float, silu: bool, sums: Optional[torch.Tensor], y: torch.Tensor,
                  sums_zeroed: bool = False, parts: int = 1, partial=None):
@@ -862,9 +873,11 @@ class Emitter:
 
     def gn_deferrable(self, x: Act, conv_n: int) -> bool:
         """Can the 3x3 / stride 1 / pad 1 convolution with ``conv_n`` output channels that consumes this GroupNorm apply it itself
-        (fast modes, halo tile in its 16 x 16-patch geometry)?"""
+        (fast modes, halo tile in its 16 x 16-patch geometry)?  conv_n < 0: the consumer is edtr_conv128_out with -conv_n channels."""
         if not conv_n or self.hp or self.invariant or x.t.dtype == torch.float32:
             return False
+        if conv_n < 0:
+            return ops.conv128_out_ok(x.H, x.W, x.C, -conv_n)
         _, splitk = ops.choose_splitk(x.rows, conv_n, 9 * x.C)
         return ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, conv_n, splitk)
 

@@ -17,7 +17,7 @@ DECLARED_SYMBOLS = [
     "edtr_gn_stats", "edtr_gn_apply", "edtr_gn_finalize", "edtr_gn_table", "edtr_layernorm", "edtr_softmax_rows", "edtr_nchw_to_nhwc",
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample", "edtr_split3", "edtr_cast16",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
-    "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp", "edtr_swin_attn", "edtr_swin_layer", "edtr_conv64",
+    "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp", "edtr_swin_attn", "edtr_swin_layer", "edtr_conv64", "edtr_conv128_out",
     "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror",
 ]
 
@@ -121,6 +121,16 @@ class Conv64Params(C.Structure):
     ]
 
 
+class Conv128OutParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("gn_table", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("alpha", C.c_float),
+        ("out", C.c_void_p), ("n_valid", C.c_int32),
+    ]
+
+
 class GnParams(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("groups", C.c_int32),
@@ -196,6 +206,7 @@ def load() -> C.CDLL:
     lib.edtr_swin_mlp.argtypes = [C.POINTER(SwinMlpParams), vp]
     lib.edtr_swin_attn.argtypes = [C.POINTER(SwinAttnParams), vp]
     lib.edtr_conv64.argtypes = [C.POINTER(Conv64Params), vp]
+    lib.edtr_conv128_out.argtypes = [C.POINTER(Conv128OutParams), vp]
     lib.edtr_swin_layer.argtypes = [C.POINTER(SwinAttnParams), C.POINTER(SwinMlpParams), vp]
     if lib.edtr_abi_version() != 8:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")

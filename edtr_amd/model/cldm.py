@@ -394,11 +394,13 @@ class VaeEngine:
             z2 = em.conv(Act(z, B, H, W, cp), "vae.post_quant_conv.", taps=1, name="vae.post_quant_conv")
             layers = arch.vae_decoder_arch(dd)
             if not tiled:
-                y = nets.emit_vae_net(em, "vae.decoder.", layers, z2, final_f32=True)
+                # (final_nchw: norm_out + SiLU + conv_out + the layout change as ONE launch where edtr_conv128_out takes them)
+                y = nets.emit_vae_net(em, "vae.decoder.", layers, z2, final_f32=True, final_nchw=self.out if dd["out_ch"] <= 4 else None)
             else:
                 y = self._tiled(em, "vae.decoder.", layers, z2.t, B, H, W, z2.C, tile_size, True, H * up, W * up)
                 self.nan_probe = self._probe_index(nets.split_tiles(H, W, tile_size, True)[1], dev)
-            em.to_nchw(y.t, B, dd["out_ch"], y.H * y.W, self.out)
+            if y is not None:
+                em.to_nchw(y.t, B, dd["out_ch"], y.H * y.W, self.out)
 
     @staticmethod
     def _tiled(em: Emitter, P: str, layers, full: torch.Tensor, B: int, H: int, W: int, C: int, tile_size: int,

@@ -403,15 +403,20 @@ def _g_vae_attn(em: Emitter, p: str, x: Act):
     return Act(y, x.B, x.H, x.W, C, em.last_gnp)
 
 
-def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool):
+def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool, final_nchw: Optional[torch.Tensor] = None):
     """Encoder.forward (model/vae.py:421-446) / Decoder.forward (:527-560) over the flat layer list, as a generator
-    suspended at every GroupNorm (see _g_norm)."""
+    suspended at every GroupNorm (see _g_norm).  ``final_nchw`` (decoder): the fp32 NCHW tensor of the result — where
+    edtr_conv128_out takes norm_out + SiLU + conv_out it writes that tensor itself and the generator returns None."""
     h = x
     first = True
+    out_ch = final_nchw.shape[1] if final_nchw is not None else 0
     for l in layers:
         p = P + l.prefix
         last = l is layers[-1]
-        if l.kind == "conv":
+        if l.kind == "conv" and last and h.gn_in is not None and h.C == 128:
+            em.conv128_out(h, p, final_nchw, out_ch)
+            y = None
+        elif l.kind == "conv":
             y = em.conv(h, p, out_f32=(final_f32 and last), name="vae.conv_in" if first else "vae.conv_out", stats=first)
         elif l.kind == "res":
             y = yield from _g_vae_resblock(em, p, l, h)
@@ -422,7 +427,7 @@ def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: 
         elif l.kind == "up":
             y = em.conv(h, p, ups=True, name="vae.upsample.conv", stats=True)           # nearest x2 + conv: vae.py:35-39
         elif l.kind == "norm_out":
-            y = yield from _g_norm(em, h, p, True, ("vae.conv_out",))
+            y = yield from _g_norm(em, h, p, True, ("vae.conv_out",), conv_n=-out_ch if out_ch else 0, take=True)
         else:
             raise ValueError(l.kind)
         if not first:
@@ -432,9 +437,9 @@ def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: 
     return h
 
 
-def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool) -> Act:
-    """Untiled network: every GroupNorm uses its own statistics."""
-    gen = gen_vae_net(em, P, layers, x, final_f32)
+def emit_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool, final_nchw: Optional[torch.Tensor] = None) -> Optional[Act]:
+    """Untiled network: every GroupNorm uses its own statistics.  Returns None when the last convolution wrote ``final_nchw`` itself."""
+    gen = gen_vae_net(em, P, layers, x, final_f32, final_nchw)
     sums = None
     try:
         req = next(gen)

@@ -294,6 +294,34 @@ def pack_conv64_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return img.to(dtype).reshape(-1).contiguous()
 
 
+def pack_conv128_out_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[Cout <= 32, 128, 3, 3] fp32 -> the nine 8-KiB LDS images of edtr_conv128_out (edtr_hip.h)."""
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and co <= 32 and ci == 128
+    full = torch.zeros((9, 32, 16, 8), dtype=torch.float32, device=w.device)                  # [tap][n][chunk][j]
+    full.reshape(9, 32, 128)[:, :co] = w.permute(2, 3, 0, 1).reshape(9, co, ci)
+    n = torch.arange(32, device=w.device)[:, None]
+    c = torch.arange(16, device=w.device)[None, :]
+    img = torch.empty_like(full)
+    img[:, n, c ^ (n & 15)] = full[:, n, c]
+    return img.to(dtype).reshape(-1).contiguous()
+
+
+def conv128_out_ok(H: int, W: int, cin: int, cout: int) -> bool:
+    """Does edtr_conv128_out take this convolution (the VAE decoder's conv_out)?  EDTR_CONV128_OUT=0 keeps the three launches."""
+    return os.environ.get("EDTR_CONV128_OUT", "1") != "0" and cin == 128 and cout <= 4 and H % 16 == 0 and W % 16 == 0
+
+
+def make_conv128_out(*, dtype, x, ldx, w, bias, out, B, H, W, n_valid, gn_table=None, alpha=1.0, name="vae.conv_out") -> Rec:
+    p = L.Conv128OutParams()
+    p.dtype, p.B, p.H, p.W = dt_code(dtype), B, H, W
+    p.x, p.ldx, p.gn_table, p.w, p.bias = ptr(x), ldx, ptr(gn_table), ptr(w), ptr(bias)
+    p.alpha, p.out, p.n_valid = alpha, ptr(out), n_valid
+    flops = 2.0 * B * H * W * 128 * 9 * n_valid
+    nbytes = 2.0 * B * H * W * 128 + 4.0 * B * H * W * n_valid
+    return Rec(L.load().edtr_conv128_out, (ct.byref(p),), (p, x, w, bias, out, gn_table), name, flops, nbytes)
+
+
 def conv64_ok(H: int, W: int, cin: int, cout: int) -> bool:
     """Does edtr_conv64 take this 3x3 convolution (output H x W)?  EDTR_CONV64=0 keeps edtr_igemm (A/B runs)."""
     return os.environ.get("EDTR_CONV64", "1") != "0" and cin == 64 and cout <= 64 and H % 16 == 0 and W % 16 == 0

@@ -418,6 +418,28 @@ typedef struct edtr_conv64_params {
 
 int edtr_conv64(const edtr_conv64_params* p, edtr_stream_t stream);
 
+/* The VAE decoder's last step in one launch (ABI 8): GroupNorm + SiLU + 3 x 3 / stride 1 / pad 1 convolution of a 128-channel NHWC
+ * image into <= 4 channels, written as fp32 NCHW planes.  replaces: `self.conv_out(nonlinearity(self.norm_out(h)))`, reference
+ * model/vae.py:553-560, and the NHWC -> NCHW of the result (model/cldm.py:136-156 returns NCHW).
+ *   x        : [B][H][W][ldx] 16-bit, 128 channels read
+ *   gn_table : fp32 [B][128][2] from edtr_gn_table (NULL: no normalisation, a plain convolution)
+ *   w        : 9 LDS images of 8192 bytes, tap t = 3 ky + kx: byte n*256 + ((c ^ (n & 15)) << 4) + 2 j = weight[n][8 c + j][ky][kx]
+ *              (n < 32 rows, zero above the real output channels; 128 input channels)
+ *   bias     : fp32 [32];   out = alpha * conv + bias -> fp32 [B][n_valid][H][W]
+ * H % 16 == 0, W % 16 == 0, ldx % 8 == 0, n_valid <= 4; pointers 16-byte aligned. */
+typedef struct edtr_conv128_out_params {
+    int32_t dtype;
+    int32_t B, H, W;
+    const void* x; int32_t ldx;
+    const float* gn_table;
+    const void* w;
+    const float* bias;
+    float alpha;
+    void* out; int32_t n_valid;
+} edtr_conv128_out_params;
+
+int edtr_conv128_out(const edtr_conv128_out_params* p, edtr_stream_t stream);
+
 /* Row softmax: fp32 scores [rows][cols] (ld_s) -> 16-bit probabilities [rows][cols] (ld_p); columns cols..cols_pad-1
  * of every output row are written as zeros (so the row can feed a GEMM whose K is padded to a multiple of 8).
  * replaces: the softmax inside F.scaled_dot_product_attention of the d=512 single-head VAE

@@ -38,11 +38,11 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_ctypes_structs_match_the_c_layout(tmp_path):
     from edtr_amd import lib
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "edtr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "edtr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(edtr_igemm_params),sizeof(edtr_attn_params),sizeof(edtr_gn_params),'
                    'offsetof(edtr_igemm_params,workspace),offsetof(edtr_igemm_params,out),'
                    'sizeof(edtr_window_attn_params),offsetof(edtr_window_attn_params,labels),offsetof(edtr_window_attn_params,scale),'
-                   'offsetof(edtr_igemm_params,act_slope),sizeof(edtr_swin_mlp_params),offsetof(edtr_swin_mlp_params,b2),offsetof(edtr_swin_mlp_params,row_stats),sizeof(edtr_swin_attn_params),offsetof(edtr_swin_attn_params,bias),offsetof(edtr_swin_attn_params,ldo),sizeof(edtr_conv64_params),offsetof(edtr_conv64_params,out));return 0;}\n')
+                   'offsetof(edtr_igemm_params,act_slope),sizeof(edtr_swin_mlp_params),offsetof(edtr_swin_mlp_params,b2),offsetof(edtr_swin_mlp_params,row_stats),sizeof(edtr_swin_attn_params),offsetof(edtr_swin_attn_params,bias),offsetof(edtr_swin_attn_params,ldo),sizeof(edtr_conv64_params),offsetof(edtr_conv64_params,out),sizeof(edtr_conv128_out_params),offsetof(edtr_conv128_out_params,out),offsetof(edtr_igemm_params,a_gn));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
@@ -63,6 +63,9 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     assert int(out[14]) == lib.SwinAttnParams.ldo.offset
     assert int(out[15]) == ctypes.sizeof(lib.Conv64Params)
     assert int(out[16]) == lib.Conv64Params.out.offset
+    assert int(out[17]) == ctypes.sizeof(lib.Conv128OutParams)
+    assert int(out[18]) == lib.Conv128OutParams.out.offset
+    assert int(out[19]) == lib.IgemmParams.a_gn.offset
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from edtr_amd import lib

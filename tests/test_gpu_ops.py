@@ -939,6 +939,40 @@ def test_conv64_persistent(dtype, B, H, W, ups, cout, nchw):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,gn", [(2, 32, 48, True), (1, 16, 16, True), (3, 64, 32, False), (1, 512, 512, True)])
+def test_conv128_out_one_launch(dtype, B, H, W, gn):
+    """edtr_conv128_out: the VAE decoder's norm_out -> SiLU -> conv_out -> NCHW (reference model/vae.py:553-560) in one launch vs
+    torch fp32 on the same 16-bit input; with and without the normalisation, one-patch images, more patches than workgroups."""
+    ops = _ops()
+    d = dev()
+    HW = H * W
+    x = (rnd((B * HW, 128), 240, 1.3) + 0.3).to(dtype)
+    w = rnd((3, 128, 3, 3), 241, 1 / math.sqrt(1152))
+    bias = torch.zeros(32)
+    bias[:3] = 0.3 * rnd((3,), 242)
+    gamma, beta = (1 + 0.2 * rnd((128,), 243)).to(d), (0.2 * rnd((128,), 244)).to(d)
+    xd = x.to(d)
+    table = None
+    if gn:
+        sums = torch.zeros((B, 32, 2), dtype=torch.float64, device=d)
+        st, _ = ops.make_gn(dtype=dtype, x=xd, ldx=128, B=B, HW=HW, C=128, sums=sums, gamma=gamma, beta=beta, eps=1e-6, silu=True, y=xd, ldy=128,
+                            sums_zeroed=True)
+        ops.launch(st)
+        table = torch.empty((B, 128, 2), dtype=torch.float32, device=d)
+        ops.launch(ops.make_gn_table(partial=None, tiles_per_image=0, sums=sums, B=B, C=128, HW=HW, gamma=gamma, beta=beta, eps=1e-6, table=table))
+    out = torch.full((B, 3, H, W), float("nan"), dtype=torch.float32, device=d)
+    ops.launch(ops.make_conv128_out(dtype=dtype, x=xd, ldx=128, w=ops.pack_conv128_out_weight(w, dtype).to(d), bias=bias.to(d), out=out, B=B, H=H, W=W,
+                                    n_valid=3, gn_table=table, alpha=0.9))
+    torch.cuda.synchronize()
+    xin = x.float().reshape(B, H, W, 128).permute(0, 3, 1, 2)
+    if gn:
+        xin = F.silu(F.group_norm(xin, 32, gamma.cpu(), beta.cpu(), 1e-6)).to(dtype).float()      # (the kernel rounds the normalised operand to 16 bits)
+    ref = 0.9 * F.conv2d(xin, w.to(dtype).float(), None, padding=1) + bias[:3, None, None]
+    assert torch.isfinite(out).all()
+    assert rel(out.cpu(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,shift", [(2, 16, 24, 0), (2, 16, 24, 4), (1, 8, 8, 4), (3, 24, 8, 3), (1, 64, 64, 4), (1, 8, 24, 0)])
 def test_swin_attention_half_one_launch(dtype, B, H, W, shift):
     """edtr_swin_attn: x + proj(WindowAttention(LayerNorm(x))) of a Swin layer in one launch (reference model/swinir.py:254-279,
