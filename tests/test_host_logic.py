@@ -314,6 +314,68 @@ def test_swin_mlp_weight_images():
             assert len({((r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) >> 4) & 15 for r in range(r0, r0 + 16)}) == 16
 
 
+def test_round4_weight_images_and_tables():
+    """The LDS images and tables of the round-4 kernels, element for element against the layouts include/edtr_hip.h documents:
+    edtr_swin_attn (per-head q / k / v tiles, proj slices, the key-group-major bias table), edtr_conv64 and edtr_conv128_out (nine tap
+    matrices); and every ds_read_b128 lane group of the kernels' operand reads lands on 16 different 16-byte bank slots."""
+    from edtr_amd import ops
+    from edtr_amd.model import swinir as S
+    rng = np.random.default_rng(1)
+    H, CP = ops.SWIN_ATTN_HEADS, ops.SWIN_MLP_C
+    wq = (torch.arange(3 * H * 32 * CP, dtype=torch.float32).reshape(3 * H * 32, CP) % 2027) / 8.0
+    wp = (torch.arange(CP * H * 32, dtype=torch.float32).reshape(CP, H * 32) % 2017) / 8.0
+    iq, ip = ops.pack_swin_attn_weights(wq, wp, torch.float16)
+    bq, bp = iq.view(torch.uint8).numpy(), ip.view(torch.uint8).numpy()
+    hq, hp = wq.to(torch.float16).numpy(), wp.to(torch.float16).numpy()
+    for _ in range(300):
+        h, s_, r, c, j = rng.integers(H), rng.integers(3), rng.integers(32), rng.integers(CP // 8), rng.integers(8)
+        off = (3 * h + s_) * 12288 + r * 384 + ((c ^ ((r >> 1) & 7)) << 4) + 2 * j
+        assert bq[off:off + 2].view(np.float16)[0] == hq[s_ * H * 32 + h * 32 + r, 8 * c + j]        # pack_qkv's row order is (s, h, e)
+        r2, c2 = rng.integers(CP), rng.integers(4)
+        off = h * 12288 + r2 * 64 + ((c2 ^ ((r2 >> 2) & 3)) << 4) + 2 * j
+        assert bp[off:off + 2].view(np.float16)[0] == hp[r2, 32 * h + 8 * c2 + j]
+    bias = torch.arange(H * 64 * 64, dtype=torch.float32).reshape(H, 64, 64)
+    bt = ops.swin_attn_bias(bias)
+    assert bt.shape == (H, 16, 64, 4) and float(bt[3, 5, 17, 2]) == float(bias[3, 17, 4 * 5 + 2])
+    # edtr_conv64: [64 n][64 k] per tap, chunk c of row n in slot c ^ ((n >> 1) & 7)
+    w64 = (torch.arange(48 * 64 * 9, dtype=torch.float32).reshape(48, 64, 3, 3) % 2003) / 8.0
+    b64 = ops.pack_conv64_weight(w64, torch.float16).view(torch.uint8).numpy()
+    h64 = w64.to(torch.float16).numpy()
+    for _ in range(300):
+        t, n, c, j = rng.integers(9), rng.integers(64), rng.integers(8), rng.integers(8)
+        off = t * 8192 + n * 128 + ((c ^ ((n >> 1) & 7)) << 4) + 2 * j
+        want = h64[n, 8 * c + j, t // 3, t % 3] if n < 48 else 0.0
+        assert b64[off:off + 2].view(np.float16)[0] == want
+    # edtr_conv128_out: [32 n][128 k] per tap, chunk c of row n in slot c ^ (n & 15)
+    w128 = (torch.arange(3 * 128 * 9, dtype=torch.float32).reshape(3, 128, 3, 3) % 1999) / 8.0
+    b128 = ops.pack_conv128_out_weight(w128, torch.float16).view(torch.uint8).numpy()
+    h128 = w128.to(torch.float16).numpy()
+    for _ in range(300):
+        t, n, c, j = rng.integers(9), rng.integers(32), rng.integers(16), rng.integers(8)
+        off = t * 8192 + n * 256 + ((c ^ (n & 15)) << 4) + 2 * j
+        want = h128[n, 8 * c + j, t // 3, t % 3] if n < 3 else 0.0
+        assert b128[off:off + 2].view(np.float16)[0] == want
+    # bank slots (64 banks x 4 B = 16 slots of 16 B per bank row) of the lane groups of a ds_read_b128: {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+    swap = lambda v: (v & ~12) | ((v & 4) << 1) | ((v & 8) >> 1)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for grp in groups:
+        rows = [(l & 16) | swap(l & 15) for l in grp]                     # the weight row lane l feeds (bits 2, 3 swapped)
+        for c in range(24):               # 384-byte rows (swin weight tiles, token tiles): key (r >> 1) & 7
+            assert len({((r * 384 + ((c ^ ((r >> 1) & 7)) << 4)) >> 4) & 15 for r in rows}) == 16
+        for c in range(4):                # 64-byte rows (swin weight slices): key (r >> 2) & 3
+            assert len({((r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) >> 4) & 15 for r in rows}) == 16
+        for c in range(8):                # conv64 weights: 128-byte rows, key (n >> 1) & 7
+            assert len({((r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) >> 4) & 15 for r in rows}) == 16
+        for c in range(16):               # conv128_out weights: 256-byte rows, key n & 15
+            assert len({((r * 256 + ((c ^ (r & 15)) << 4)) >> 4) & 15 for r in rows}) == 16
+        for kx in range(3):               # patch reads: lane l -> pixel (y + (l >> 4), (l & 15) + kx) of an 18-pixel-wide patch
+            px = [((l >> 4) * 18 + (l & 15) + kx, (l & 15) + kx) for l in grp]
+            for c in range(8):            # conv64: 128-byte pixels, key (x >> 1) & 7
+                assert len({((p_ * 128 + ((c ^ ((x >> 1) & 7)) << 4)) >> 4) & 15 for p_, x in px}) == 16
+            for c in range(16):           # conv128_out: 256-byte pixels, key x & 15
+                assert len({((p_ * 256 + ((c ^ (x & 15)) << 4)) >> 4) & 15 for p_, x in px}) == 16
+
+
 def test_engine_cache_lru():
     """Shape-keyed engine cache: hits refresh recency, the least recently used entry is evicted and released past capacity."""
     from edtr_amd.engine import EngineCache
