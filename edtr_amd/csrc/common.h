@@ -191,4 +191,8 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// tile 17 of edtr_igemm lives in its own translation unit (halo512.hip)
+bool edtr_halo512_ok(const edtr_igemm_params& p);
+int edtr_launch_halo512(const edtr_igemm_params& p, hipStream_t stream);
+
 #define EDTR_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

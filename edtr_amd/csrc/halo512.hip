@@ -1,0 +1,610 @@
+// Halo tile, 512-pixel unit (tile 17 of edtr_igemm, round 5): 3x3 / stride 1 / pad 1 convolutions whose output image is a
+// multiple of 32 x 16 pixels and whose N is a multiple of 128 — the VAE ResnetBlock convolutions (reference model/vae.py:74-124,
+// 479-525) at the 512^2 ... 64^2 levels.
+//
+// Why a second geometry.  The 256-pixel halo tile (igemm.hip, tile 16) gives each of its 8 waves 128 pixels x 64 channels x ONE
+// HALF of K, so the two halves must meet in an fp32 staging tile in LDS: in-kernel stamps of a K = 1152 unit read 2.3k cycles of
+// address set-up + 3.1k of first-load flight + 22.7k of multiply loop + 10.9k of epilogue (accumulators -> LDS, second half added
+// in LDS, row loop out of LDS): 42 % of a unit's life is not the loop, and with one 144-KiB workgroup per CU nothing else runs
+// under it.  Here the unit is 32 x 16 = 512 output pixels x 128 channels and a wave owns 128 pixels x 64 channels over ALL of K
+// (the same 128 accumulator registers), so
+//   * a weight slice is multiplied against twice the pixels (L2 -> LDS weight traffic per FLOP halves),
+//   * the fixed costs (set-up, first-load flight) are paid once per 512 pixels,
+//   * the accumulators are FINAL in registers: the epilogue needs no LDS at all.  The weight rows are fed to the MFMA in a
+//     permuted order (the permutation is the DMA's source address: free) such that a lane ends up with two runs of 8 CONSECUTIVE
+//     output channels of its pixel: bias / time-embedding row / residual / 16-byte stores straight from registers, four lanes
+//     writing 64 contiguous bytes of a pixel row.
+// LDS: the input patch is staged per 32-CHANNEL chunk (34 x 18 pixels x 64 B = 38.25 KiB, double buffered) — the 16x16x32 MFMA
+// takes exactly one chunk per instruction — plus a ring of three 8-KiB weight slices (one per tap): 106 KiB.  Pixel (py, px) sits
+// at (34 py + px) * 64 B with its four 16-byte channel groups XOR-ed by kKey[px & 7]; that table was found by exhaustive search
+// against the actual lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ... MI355X_MICROARCH.md, LDS) so that the A fragments
+// of all three dx and the B fragments are conflict-free with 64-byte pixels (no (px & 3)-style closed form is).
+// Same eight-wave ping-pong as tile 16: waves w / w + 4 share a SIMD and run half a phase (16 MFMAs) apart, counted vmcnt waits,
+// raw s_barriers, one weight piece per wave and tap, five patch pieces per wave and chunk.
+// a_gn (GroupNorm + SiLU of the input applied in the patch staging) as in tile 16; per output pixel it normalises 1.20 patch
+// pixels instead of 1.27.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+// Diagnostic build only (tools/exp/halo512_stamps.py compiles with -DEDTR_STAMPS): thread 0 of every workgroup stores s_memtime at
+// phase boundaries into p.workspace (unused by this tile otherwise).  The product library contains no stamp code.
+#ifdef EDTR_STAMPS
+#define H5_STAMP(i)                                                                                     \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && p.workspace) {                                                          \
+            uint64_t* sb__ = static_cast<uint64_t*>(p.workspace) + (size_t)blockIdx.x * 16;             \
+            if ((i) == 14) sb__[7] = (uint64_t)__builtin_amdgcn_s_getreg(63492) | ((uint64_t)__builtin_amdgcn_s_getreg(63508) << 32); \
+            sb__[i] = ((i) >= 14) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();    \
+        }                                                                                               \
+    } while (0)
+#else
+#define H5_STAMP(i)
+#endif
+
+namespace {
+
+constexpr uint32_t kOob = 0xFFFFFF00u;     // >= num_records - 15: the buffer range check turns the lane's 16 bytes into zeros
+
+__device__ __forceinline__ u32x4 srd_of(const void* base) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    u32x4 srd;
+    srd.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    srd.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);   // stride 0 (raw buffer)
+    srd.z = 0xFFFFFF00u;
+    srd.w = 0x00020000u;
+    return srd;
+}
+
+// buffer-addressed LDS-DMA: lane i's 16 bytes (SRD base + voff + soff) land at LDS byte lds_addr + 16 i
+__device__ __forceinline__ void dma(uint32_t voff, const u32x4& srd, uint32_t soff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :
+                 : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
+                 : "memory");
+}
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+constexpr int CK = 32;                          // channels per chunk = K of one 16x16x32 MFMA
+constexpr int WTAP = 128 * CK * 2;              // 8 KiB: one tap's [128][32] weight slice
+namespace h1 {                                  // tile 17
+constexpr int PW = 34, PROWS = 18, PPIX = PW * PROWS, PROWB = PW * 64;
+constexpr int NPP = 5;                          // patch pieces (1 KiB = 16 pixels) per wave and chunk: 40 >= 38.25
+constexpr int PATCHB = 40 * 1024;
+constexpr int W_BASE = 2 * PATCHB;
+constexpr int TBL = W_BASE + 3 * WTAP;          // two 1-KiB slots for the (scale, shift) rows of a chunk (a_gn)
+constexpr int RED = 128 * 1024;                 // epilogue: [0, 128 KiB) = the unit's 16-bit residual (16 KiB per wave), then the GroupNorm partial sums
+constexpr int LDS_BYTES = RED + 4096;
+}
+
+// 2-bit XOR key of a 64-byte LDS row (a patch pixel or a weight row), by row index mod 8: {3, 3, 0, 1, 0, 1, 3, 2}
+__device__ __forceinline__ int key8(int x) {
+    constexpr uint32_t kKey = 3u | (3u << 2) | (0u << 4) | (1u << 6) | (0u << 8) | (1u << 10) | (3u << 12) | (2u << 14);
+    return (int)((kKey >> (2 * (x & 7))) & 3u);
+}
+
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane: four v_add_f32 with DPP operands
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else static_assert(N >= 1 && N <= 4, "wait_vm");
+}
+
+// ---- epilogue of the halo kernels of this file, straight from the accumulators (no LDS staging).  NW = waves per workgroup
+// (8: tile 17, wave = 4 rows x 32 pixels; 4: tile 19, wave = 8 rows x 16 pixels), mu0 = the wave's first pixel, RED_OFF = LDS offset of
+// the GroupNorm scratch (below it: 16 KiB per wave for the residual)
+template <typename T, int NW, int RED_OFF>
+__device__ __forceinline__ void direct_epilogue(const edtr_igemm_params& p, f32x4 (&acc)[8][4], char* smem, uint32_t smem_base, int lane, int wave,
+                                                int wc, int64_t mu0, int n0, int img, int tm) {
+    auto blk_off = [&](int mb) { return NW == 8 ? (mb & 3) * p.OW + 16 * (mb >> 2) : mb * p.OW; };     // pixel block mb of the wave, from mu0
+    //   acc[mb][nb][i] = pixel (row 4 q + (mb & 3), column 16 (mb >> 2) + l15),
+    // channel n0 + wc 64 + 32 (nb >> 1) + 8 lq + 4 (nb & 1) + i: per half hp = nb >> 1 a lane holds EIGHT consecutive channels of its
+    // pixel.  One pass per hp (the pass's 64 accumulator registers die as it goes; per-channel addends and GroupNorm sums are
+    // 8 + 16 registers instead of twice that), four pixel blocks at a time with their residual vectors requested together.
+    // (lane-derived epilogue values come from an OPAQUE copy of the lane index: otherwise the compiler computes them at kernel entry
+    //  and carries them — spilled — through the main loop, whose register file is full)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int tid = (int)threadIdx.x;
+    const int l15e = lane_e & 15, lqe = lane_e >> 4;
+    const float alpha = p.alpha;
+    const bool gn_acc = p.gn_partial != nullptr;
+    // addresses = a wave-uniform 64-bit base per pixel block (scalar registers) + ONE 32-bit lane offset per tensor: with 64-bit
+    // per-lane addresses the compiler keeps the 8 blocks' pointers alive across the two passes and spills
+    const int nu = n0 + wc * 64;                         // + 32 hp
+    const uint32_t lo_out = (uint32_t)(l15e * p.ldc + 8 * lqe), lo_res = (uint32_t)(l15e * p.ldr + 8 * lqe), lo_16 = (uint32_t)(l15e * p.ld16 + 8 * lqe);
+    float* red = reinterpret_cast<float*>(smem + RED_OFF);   // [8 waves][64 channels][2]: the main loop's buffers are dead (every wave is
+                                                         // past its last fragment read and its last DMA has landed)
+
+    // 16-bit output: WHOLE 128-byte lines per store / load instruction.  A lane's two 16-byte runs (hp = 0 / 1) lie 64 bytes apart in
+    // its pixel's row, and the four lanes of a pixel cover 64 contiguous bytes per instruction: stored as they sit, an instruction
+    // touches 16 pixel rows with half a line each, and the vector-memory path runs at its LINE rate, not its byte rate (stamps:
+    // ~64 cycles per wave-instruction whatever it moves: 16 B/clk/CU, a 16.5k-cycle epilogue with a residual).  So lanes (pixel P,
+    // lq) and (pixel P + 8, lq) — eight lanes apart in their DPP row — swap one run each (row_ror:8): instruction 1 then writes
+    // both runs of pixels 0..7 (lanes < 8: own run 0; lanes >= 8: the partner's run 1), instruction 2 those of pixels 8..15: eight
+    // whole lines per instruction.  The residual is fetched in the same shape and swapped back before the add, so the
+    // arithmetic and its single rounding are unchanged.
+    auto ror8 = [&](const U4& v) {
+        U4 r;
+        r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x128, 0xF, 0xF, false);
+        r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x128, 0xF, 0xF, false);
+        r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x128, 0xF, 0xF, false);
+        r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x128, 0xF, 0xF, false);
+        return r;
+    };
+    auto sel = [&](bool c, const U4& a, const U4& b) {
+        U4 r;
+        r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; r.z = c ? a.z : b.z; r.w = c ? a.w : b.w;
+        return r;
+    };
+    auto finish16 = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+        const bool lo8 = l15e < 8;
+        const int pa = l15e & 7, co = (lo8 ? 0 : 32) + 8 * lqe;       // instruction 1: pixel pa, instruction 2: pixel pa + 8; channel offset of this lane's 16 bytes
+        const uint32_t lo_o1 = (uint32_t)(pa * p.ldc + co), lo_o2 = lo_o1 + 8u * (uint32_t)p.ldc;
+        const uint32_t lo_r1 = (uint32_t)(pa * p.ldr + co), lo_r2 = lo_r1 + 8u * (uint32_t)p.ldr;
+        float cb[2][8], gs[2][8], gq[2][8];
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int nl = nu + 32 * hp + 8 * lqe;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cb[hp][j] = 0.0f; gs[hp][j] = 0.0f; gq[hp][j] = 0.0f; }
+            if (p.bias_n) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias_n + nl), b1 = *reinterpret_cast<const f32x4*>(p.bias_n + nl + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cb[hp][j] = b0[j]; cb[hp][j + 4] = b1[j]; }
+            }
+            if (p.rowvec) {
+                const float* rv = p.rowvec + (int64_t)img * p.rowvec_ld + nl;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv), b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cb[hp][j] += b0[j]; cb[hp][j + 4] += b1[j]; }
+            }
+        }
+        // The residual goes global -> LDS by DMA, all 16 KiB of the wave at once (the main loop's LDS is dead; registers could hold
+        // two blocks ahead at most, and eight dependent round trips to HBM cost 10k cycles), in the whole-line shape above: piece
+        // 2 mb = instruction 1's lanes, piece 2 mb + 1 = instruction 2's; a lane then reads both of ITS runs from one piece
+        // (lanes < 8 of a row: piece 2 mb at lane and lane + 8; lanes >= 8: piece 2 mb + 1 at lane - 8 and lane).  vmcnt is in-order
+        // and two stores follow every block: 14 operations may stay in flight behind the block's two pieces, always.
+        char* const rl = smem + wave * 16384;
+        if constexpr (RES) {
+            pin8(cb[0]); pin8(cb[1]);                   // (the bias loads are consumed BEFORE the DMAs: a compiler-placed wait on them would drain the DMAs too)
+            const u32x4 srd_r = srd_of(p.residual);
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                const int64_t mu = mu0 + blk_off(mb);
+                const uint32_t so = (uint32_t)((mu * p.ldr + nu) * 2);
+                dma(lo_r1 * 2, srd_r, so, smem_base + wave * 16384 + (2 * mb) * 1024);
+                dma(lo_r2 * 2, srd_r, so, smem_base + wave * 16384 + (2 * mb + 1) * 1024);
+            }
+        }
+        const int rd0 = (lo8 ? 0 : 1024) + (lane_e & ~8) * 16, rd1 = (lo8 ? 0 : 1024) + (lane_e | 8) * 16;
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const int64_t mu = mu0 + blk_off(mb);
+            float f[2][8];
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f[hp][i] = __builtin_fmaf(acc[mb][2 * hp][i], alpha, cb[hp][i]);
+                    f[hp][i + 4] = __builtin_fmaf(acc[mb][2 * hp + 1][i], alpha, cb[hp][i + 4]);
+                }
+            if constexpr (RES) {
+                asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                const U4 q0 = *reinterpret_cast<const U4*>(rl + mb * 2048 + rd0), q1 = *reinterpret_cast<const U4*>(rl + mb * 2048 + rd1);
+                float rf[8];
+                unpack8<T>(q0, rf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[0][i] += rf[i];
+                unpack8<T>(q1, rf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[1][i] += rf[i];
+            }
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { gs[hp][i] += f[hp][i]; gq[hp][i] += f[hp][i] * f[hp][i]; }
+                pin8(gs[hp]);        // (keeps the sums HERE: the optimizer otherwise sinks them into the `if (gn_acc)` below and carries
+                pin8(gq[hp]);        //  every finished value there — through scratch)
+            }
+            const U4 h0 = pack8<T>(f[0]), h1 = pack8<T>(f[1]);
+            const U4 got = ror8(sel(lo8, h1, h0));
+            uint16_t* op = static_cast<uint16_t*>(p.out) + (mu * p.ldc + nu);
+#ifdef H5_NOSTORE      // (diagnostic builds of tools/exp/halo512_stamps.py only)
+            if (p.alpha == 12345.0f)
+#endif
+            {
+            stg16(op + lo_o1, sel(lo8, h0, got));
+            stg16(op + lo_o2, sel(lo8, got, h1));
+            }
+        }
+        if (gn_acc) {
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gs[hp][j] = row16_sum(gs[hp][j]); gq[hp][j] = row16_sum(gq[hp][j]); }
+                if (l15e == 0) {
+                    float* dst = red + (wave * 64 + 32 * hp + 8 * lqe) * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[hp][j]; dst[2 * j + 1] = gq[hp][j]; }
+                }
+            }
+        }
+    };
+    // (every launch-uniform option is a template parameter: tested inside the unrolled block loop, each one cuts the loop into
+    // basic blocks that run at instruction latency with one wave per SIMD — DESIGN.md §4, shared epilogue)
+    auto finish = [&](auto out32_c, auto res_c, auto mir_c) {
+        constexpr bool OUT32 = decltype(out32_c)::value, MIR = decltype(mir_c)::value && OUT32;
+        constexpr int RES = decltype(res_c)::value;      // 0 none, 1 16-bit, 2 fp32
+        constexpr int GJ = 4;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int nl = n0 + wc * 64 + 32 * hp + 8 * lqe;      // first of this lane's eight channels
+            float cb[8], gs[8], gq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cb[j] = 0.0f; gs[j] = 0.0f; gq[j] = 0.0f; }
+            if (p.bias_n) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias_n + nl), b1 = *reinterpret_cast<const f32x4*>(p.bias_n + nl + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cb[j] = b0[j]; cb[j + 4] = b1[j]; }
+            }
+            if (p.rowvec) {                              // the time-embedding row of the unit's image (a unit never leaves its image)
+                const float* rv = p.rowvec + (int64_t)img * p.rowvec_ld + nl;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv), b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cb[j] += b0[j]; cb[j + 4] += b1[j]; }
+            }
+#pragma unroll
+            for (int grp = 0; grp < 8 / GJ; ++grp) {
+                U4 r16[GJ];
+                f32x4 r32[GJ][2];
+                if constexpr (RES != 0) {
+#pragma unroll
+                    for (int j = 0; j < GJ; ++j) {
+                        const int mb = grp * GJ + j;
+                        const int64_t mu = mu0 + blk_off(mb);
+                        if constexpr (RES == 1) {
+                            r16[j] = ldg16(static_cast<const uint16_t*>(p.residual) + (mu * p.ldr + nu + 32 * hp) + lo_res);
+                        } else {
+                            const float* rp = static_cast<const float*>(p.residual) + (mu * p.ldr + nu + 32 * hp) + lo_res;
+                            r32[j][0] = *reinterpret_cast<const f32x4*>(rp);
+                            r32[j][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    const int mb = grp * GJ + j;
+                    const int64_t mu = mu0 + blk_off(mb);
+                    float f[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f[i] = __builtin_fmaf(acc[mb][2 * hp][i], alpha, cb[i]);
+                        f[i + 4] = __builtin_fmaf(acc[mb][2 * hp + 1][i], alpha, cb[i + 4]);
+                    }
+                    if constexpr (RES == 1) {
+                        float rf[8];
+                        unpack8<T>(r16[j], rf);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] += rf[i];
+                    } else if constexpr (RES == 2) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { f[i] += r32[j][0][i]; f[i + 4] += r32[j][1][i]; }
+                    }
+                    const int64_t oidx = mu * p.ldc + nu + 32 * hp;          // wave-uniform
+                    if constexpr (OUT32) {
+                        float* o = static_cast<float*>(p.out) + oidx + lo_out;
+                        f32x4 o0, o1;
+                        o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2]; o0[3] = f[3];
+                        o1[0] = f[4]; o1[1] = f[5]; o1[2] = f[6]; o1[3] = f[7];
+                        *reinterpret_cast<f32x4*>(o) = o0;
+                        *reinterpret_cast<f32x4*>(o + 4) = o1;
+                        if constexpr (MIR) stg16(static_cast<uint16_t*>(p.out16) + (mu * p.ld16 + nu + 32 * hp) + lo_16, pack8<T>(f));
+                    } else {
+                        stg16(static_cast<uint16_t*>(p.out) + oidx + lo_out, pack8<T>(f));
+                    }
+                    // (unconditional: nearly every launch of this tile wants the statistics, and a launch-uniform test here would cut
+                    //  the unrolled loop into basic blocks)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { gs[i] += f[i]; gq[i] += f[i] * f[i]; }
+                    pin8(gs);        // (keeps the sums HERE: the optimizer otherwise sinks them into the `if (gn_acc)` below and carries
+                    pin8(gq);        //  all 64 finished values of the pass there — through scratch)
+                }
+            }
+            if (gn_acc) {        // fold the 16 pixel lanes that share this channel run; lane l15 == 0 publishes the wave's 128-pixel sums
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gs[j] = row16_sum(gs[j]); gq[j] = row16_sum(gq[j]); }
+                if (l15e == 0) {
+                    float* dst = red + (wave * 64 + 32 * hp + 8 * lqe) * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+                }
+            }
+        }
+    };
+    {
+        using std::true_type;
+        using std::false_type;
+        const bool res32 = p.residual && p.residual_f32, res16 = p.residual && !p.residual_f32, mir = p.out16 != nullptr;
+        if (!p.out_f32) {
+            if (res16) finish16(true_type{});
+            else if (res32) finish(false_type{}, IC<2>{}, false_type{});
+            else finish16(false_type{});
+        } else if (mir) {
+            if (res32) finish(true_type{}, IC<2>{}, true_type{});
+            else if (res16) finish(true_type{}, IC<1>{}, true_type{});
+            else finish(true_type{}, IC<0>{}, true_type{});
+        } else {
+            if (res32) finish(true_type{}, IC<2>{}, false_type{});
+            else if (res16) finish(true_type{}, IC<1>{}, false_type{});
+            else finish(true_type{}, IC<0>{}, false_type{});
+        }
+    }
+    H5_STAMP(4);
+    if (gn_acc) {
+        // the four pixel quarters of a channel half meet in LDS: per-channel sum / sum of squares of the unit's 512 pixels
+        __syncthreads();
+        if (tid < 128) {
+            const int wcc = tid >> 6, cl = tid & 63;
+            float a = 0.0f, s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NW / 2; ++k) { a += red[((2 * k + wcc) * 64 + cl) * 2]; s += red[((2 * k + wcc) * 64 + cl) * 2 + 1]; }
+            float* dst = p.gn_partial + ((int64_t)(NW / 2 * tm) * p.N + n0 + tid) * 2;  // NW / 2 slots of 128 rows per unit: the first takes the sums
+            dst[0] = a;
+            dst[1] = s;
+#pragma unroll
+            for (int k = 1; k < NW / 2; ++k) { dst[2 * k * (int64_t)p.N] = 0.0f; dst[2 * k * (int64_t)p.N + 1] = 0.0f; }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512, 1) igemm_halo512_kernel(const edtr_igemm_params p) {
+    using namespace h1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    H5_STAMP(0); H5_STAMP(14);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, q = wave >> 1, wc = wave & 1;     // ping-pong group, pixel quarter (patch rows 4 q .. 4 q + 3), channel half
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int tw = p.OW >> 5, tpi = tw * (p.OH >> 4);
+    const int nbm = (p.M / (p.OH * p.OW)) * tpi, nbn = p.N >> 7;
+    int bid = blockIdx.x;
+    {       // an XCD (blockIdx mod 8) owns a contiguous range of units: the column tiles of a patch share its L2
+        const int nblk = nbm * nbn, qq = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int img = tm / tpi, tr = tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;
+    const int oy0 = ty * 16, ox0 = tx * 32, n0 = tn * 128;
+    const int sy0 = oy0 - 1, sx0 = ox0 - 1;
+    const int m0 = (img * p.OH + oy0) * p.OW + ox0;
+
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const u32x4 srd_a = srd_of(a1);
+    const u32x4 srd_w = srd_of(p.w);
+    const int Cin = p.C1, nchunk = Cin / CK;
+
+    // ---- staging geometry
+    // weight piece = wave: LDS rows R = 16 wave .. + 15 of the slice, lane -> (R, slot).  LDS row R = wcR 64 + nb 16 + r holds the
+    // weights of output channel wcR 64 + 32 (nb >> 1) + 8 (r >> 2) + 4 (nb & 1) + (r & 3): the MFMA's row block nb then leaves
+    // lane (pixel, lq) with channels 32 (nb >> 1) + 8 lq + 4 (nb & 1) + (0..3) — two runs of eight consecutive channels
+    uint32_t voff_w;
+    {
+        const int R = wave * 16 + (lane >> 2), slot = lane & 3;
+        const int r = R & 15, nb = (R >> 4) & 3;
+        const int n = n0 + (R & 64) + 32 * (nb >> 1) + 8 * (r >> 2) + 4 * (nb & 1) + (r & 3);
+        const int c = slot ^ key8(R);
+        voff_w = (uint32_t)(((int64_t)n * p.ldw + c * 8) * 2);
+    }
+    auto stage_w = [&](int chunk, int tap, int buf) {
+        const uint32_t vo = chunk < nchunk ? voff_w : kOob;
+        dma(vo, srd_w, (uint32_t)((tap * Cin + chunk * CK) * 2), smem_base + W_BASE + buf * WTAP + wave * 1024);
+    };
+    // the weight slices of taps 0 and 1 start their flight before the patch addresses are worked out
+    stage_w(0, 0, 0);
+    stage_w(0, 1, 1);
+    uint32_t voff_p[NPP];
+    uint32_t gn_bits = 0;          // per patch piece j: bits 4 j, 4 j + 1 = the 8-channel group of this lane's 16 bytes, bit 4 j + 3 = inside the image
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) {
+        const int u = (wave + 8 * j) * 64 + lane, pp = u >> 2, slot = u & 3;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = sy0 + py, ix = sx0 + px;
+        const bool ok = pp < PPIX && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const int c = slot ^ key8(px);
+        voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOob;
+        if (ok) gn_bits |= (uint32_t)(8 | c) << (4 * j);
+    }
+    auto stage_p = [&](int chunk, int j, int par) {
+        const uint32_t vo = chunk < nchunk ? voff_p[j] : kOob;
+        dma(vo, srd_a, (uint32_t)(chunk * CK * 2), smem_base + par * PATCHB + (wave + 8 * j) * 1024);
+    };
+    const bool gnf = p.a_gn != nullptr;
+    const u32x4 srd_t = srd_of(gnf ? p.a_gn + (int64_t)img * Cin * 2 : reinterpret_cast<const float*>(a1));
+    auto stage_t = [&](int chunk, int par) {                 // (scale, shift) of the chunk's 32 channels: 256 bytes, lanes 0..15
+        const uint32_t vo = (chunk < nchunk && lane < 16) ? (uint32_t)(lane * 16) : kOob;
+        dma(vo, srd_t, (uint32_t)(chunk * CK * 8), smem_base + TBL + par * 1024);
+    };
+    auto gn_piece = [&](int j, int par) {
+        const uint32_t bits = gn_bits >> (4 * j);
+        if (bits & 8) {
+            char* qp = smem + par * PATCHB + (wave + 8 * j) * 1024 + lane * 16;
+            const float* tb = reinterpret_cast<const float*>(smem + TBL + par * 1024) + (bits & 3) * 16;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(tb + 8), t3 = *reinterpret_cast<const f32x4*>(tb + 12);
+            float f[8];
+            unpack8<T>(*reinterpret_cast<const U4*>(qp), f);
+            f[0] = f[0] * t0[0] + t0[1]; f[1] = f[1] * t0[2] + t0[3];
+            f[2] = f[2] * t1[0] + t1[1]; f[3] = f[3] * t1[2] + t1[3];
+            f[4] = f[4] * t2[0] + t2[1]; f[5] = f[5] * t2[2] + t2[3];
+            f[6] = f[6] * t3[0] + t3[1]; f[7] = f[7] * t3[2] + t3[3];
+            if (p.a_gn_silu) {       // eight values in lockstep (common.h, gelu_erf_lockstep)
+                float e[8];
+                pin8(f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = f[i] * -1.4426950408889634f;
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = 1.0f + e[i];
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = f[i] * e[i];
+            }
+            *reinterpret_cast<U4*>(qp) = pack8<T>(f);
+        }
+    };
+
+    // ---- fragment read geometry.  Pixel block (j, h) of this wave: patch row 4 q + j (+ ky), pixels 16 h + l15 (+ kx); the key has
+    // period 8, so the right half is the left half + 1 KiB
+    int a_rd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = l15 + kx;
+        a_rd[kx] = (4 * q * PW + px) * 64 + ((lq ^ key8(px)) << 4);
+    }
+    const int b_rd = (wc * 64 + l15) * 64 + ((lq ^ key8(l15)) << 4);      // + nb KiB
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    U4 afr[4], bfr[4];
+
+    // ---- prologue: patch of chunk 0 (+ its table)
+    H5_STAMP(1);
+    if (gnf) stage_t(0, 0);
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) stage_p(0, j, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (gnf) {               // the first chunk's patch: every wave normalises its own pieces (its own table copy has landed too)
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) gn_piece(j, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run half a phase behind their SIMD partners
+    asm volatile("" ::: "memory");
+
+    H5_STAMP(2);
+    constexpr int PP0 = 2;                               // phases PP0 .. PP0 + NPP - 1 of a chunk stage a piece of the next patch
+    // (the last chunk is a peeled copy of the loop body: no next patch to normalise, so its registers can hold the early residual)
+    auto chunk_body = [&](int c, auto LASTc) {
+        constexpr bool LAST = decltype(LASTc)::value;
+        const int par = c & 1;
+        const char* pa = smem + par * PATCHB;
+        auto phase = [&](auto TAPc, auto SUBc) {
+            constexpr int TAP = decltype(TAPc)::value, SUB = decltype(SUBc)::value, KY = TAP / 3, KX = TAP % 3;
+            constexpr int TAP2 = (TAP + 2) % 9, PH = 2 * TAP + SUB, BUF = TAP % 3, BUF2 = TAP2 % 3;
+            const int c2 = TAP + 2 >= 9 ? c + 1 : c;
+            if constexpr (SUB == 0) {
+                const char* pb = smem + W_BASE + BUF * WTAP + b_rd;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(pb + nb * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) afr[j] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (j + KY) * PROWB + SUB * 1024);
+            if constexpr (SUB == 0) stage_w(c2, TAP2, BUF2);
+            if constexpr (PH >= PP0 && PH < PP0 + NPP) stage_p(c + 1, PH - PP0, par ^ 1);
+            if constexpr (PH == 0) {
+                if (gnf) stage_t(c + 1, par ^ 1);
+            }
+            if constexpr (SUB == 1) {
+                // in flight by design: what this and the previous phase issued (one weight piece, up to two patch pieces, the table)
+                constexpr int INFLIGHT = 1 + (PH >= PP0 && PH < PP0 + NPP ? 1 : 0) + (PH - 1 >= PP0 && PH - 1 < PP0 + NPP ? 1 : 0);
+                if (PH == 1 && gnf) wait_vm<INFLIGHT + 1>();
+                else wait_vm<INFLIGHT>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[SUB * 4 + j][nb] = T::mfma16(bfr[nb], afr[j], acc[SUB * 4 + j][nb]);    // D[channel][pixel]
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PH >= 6 && PH < 6 + NPP) {
+                // the piece this wave staged in phase PH - 4 landed before the wait of phase PH - 1 at the latest
+                if constexpr (!LAST) {
+                    if (gnf) gn_piece(PH - 6, par ^ 1);
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto tap_body = [&](auto TAPc) { phase(TAPc, IC<0>{}); phase(TAPc, IC<1>{}); };
+        tap_body(IC<0>{}); tap_body(IC<1>{}); tap_body(IC<2>{}); tap_body(IC<3>{}); tap_body(IC<4>{});
+        tap_body(IC<5>{}); tap_body(IC<6>{}); tap_body(IC<7>{}); tap_body(IC<8>{});
+#ifdef EDTR_STAMPS
+        if (c == 0) H5_STAMP(6);
+#endif
+    };
+    for (int c = 0; c < nchunk - 1; ++c) chunk_body(c, std::false_type{});
+    chunk_body(nchunk - 1, std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave groups
+    H5_STAMP(3);
+
+    direct_epilogue<T, 8, RED>(p, acc, smem, smem_base, lane, wave, wc, (int64_t)m0 + 4 * q * p.OW, n0, img, tm);
+    H5_STAMP(5); H5_STAMP(15);
+}
+
+template <typename T>
+int launch_halo512(const edtr_igemm_params& p, hipStream_t stream) {
+    using namespace h1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo512_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return EDTR_E_UNSUPPORTED;
+        attr_set = true;
+    }
+    const int nbm = (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 5), nbn = p.N >> 7;
+    hipLaunchKernelGGL((igemm_halo512_kernel<T>), dim3(nbm * nbn), dim3(512), LDS_BYTES, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+}  // namespace
+
+// shape / option requirements of tile 17 (the caller has validated the generic edtr_igemm rules and buffer addressability)
+bool edtr_halo512_ok(const edtr_igemm_params& p) {
+    return p.OH > 0 && p.taps == 9 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.C2 == 0 && (p.C1 % CK) == 0 && !p.upsample2x &&
+           p.OH == p.IH && p.OW == p.IW && (p.OH & 15) == 0 && (p.OW & 31) == 0 && p.Z == 1 && p.splitk <= 1 && p.act == EDTR_ACT_NONE &&
+           !p.bias_m && (p.N & 127) == 0 && (p.n_valid == 0 || p.n_valid == p.N) && !p.vt_out && !p.row_stats && !p.ln_stats && !p.a_wrap &&
+           p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW && (!p.rowvec || p.rows_per_image == p.OH * p.OW) &&
+           (!p.residual || p.residual_f32 || (int64_t)p.M * p.ldr * 2 < 0xF0000000LL);      // (a 16-bit residual is fetched by buffer-addressed DMA)
+}
+
+int edtr_launch_halo512(const edtr_igemm_params& p, hipStream_t stream) {
+    return p.dtype == EDTR_BF16 ? launch_halo512<BF16>(p, stream) : launch_halo512<F16>(p, stream);
+}
+
+#ifdef EDTR_STAMPS
+extern "C" int edtr_halo512_stamped(const edtr_igemm_params* p, void* stream) {      // stand-alone diagnostic build: no edtr_igemm in front
+    if (!edtr_halo512_ok(*p)) return EDTR_E_UNSUPPORTED;
+    return edtr_launch_halo512(*p, static_cast<hipStream_t>(stream));
+}
+#endif

@@ -2402,10 +2402,17 @@ static int dbg_flags() {
     return dbg;
 }
 
+// dry: edtr_igemm_plan — every check of the chosen kernel, no launch; the answer is the tile number
 template <typename T>
-int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) {
+int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s, bool dry) {
+    if (tile == 17) {      // halo tile, 512-pixel units (halo512.hip)
+        if (!spatial || !edtr_halo512_ok(p) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
+        if (dry) return tile;
+        return edtr_launch_halo512(p, s);
+    }
     if (tile == 16) {      // halo tile for 3x3 / stride 1 convolutions
         if (!igemm_halo_ok(p, spatial) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
+        if (dry) return tile;
         if (igemm_halo_img8(p)) return launch_halo<T, 2>(p, s);
         if (p.upsample2x == 2) return launch_halo<T, 3>(p, s);
         return p.upsample2x ? launch_halo<T, 1>(p, s) : launch_halo<T, 0>(p, s);
@@ -2416,19 +2423,24 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s) 
         if (tile == 14) {  // 256 x 32 tile for skinny-N convolutions (N <= 32: the decoder's 3-channel output conv wastes 94 % of a
                            // 128-wide tile); an instantiation of the 16x16x32 template, experiment, same status
             if (!fast || p.act == EDTR_ACT_GEGLU || p.gn_partial) return EDTR_E_UNSUPPORTED;
+            if (dry) return tile;
             return spatial ? launch_n160<T, true, 8, 1>(p, s) : launch_n160<T, false, 8, 1>(p, s);
         }
         if (tile == 8) {
             if (!fast || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+            if (dry) return tile;
             return spatial ? launch_n160<T, true, 4, 5>(p, s) : launch_n160<T, false, 4, 5>(p, s);
         }
         if (tile == 6) {
             if (!fast || p.splitk > 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+            if (dry) return tile;
             return spatial ? launch_256<T, true>(p, s) : launch_256<T, false>(p, s);
         }
+        if (dry) return tile;
         if (!spatial) return fast ? launch_dma<T, false, true>(p, s) : launch_dma<T, false, false>(p, s);
         return fast ? launch_dma<T, true, true>(p, s) : launch_dma<T, true, false>(p, s);
     }
+    if (dry) return tile;
     if (tile == 1) return spatial ? launch<T, 2, 2, true>(p, s) : launch<T, 2, 2, false>(p, s);
     return spatial ? launch<T, 1, 1, true>(p, s) : launch<T, 1, 1, false>(p, s);
 }
@@ -2528,7 +2540,7 @@ extern "C" int edtr_gn_table(const float* partial, int tiles_per_image, const do
     return EDTR_OK;
 }
 
-extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
+static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry) {
     if (!pp) return EDTR_E_NULL;
     edtr_igemm_params p = *pp;
     if (!p.a1 || !p.w || !p.out) return EDTR_E_NULL;
@@ -2661,12 +2673,27 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
             (!p.upsample2x || p.stride == 1) && igemm_fast_addressable(p, spatial))
             tile = 14;
     }
-    if (p.a_gn) {           // GroupNorm (+ SiLU) of the input fused into the halo tile's patch staging: 16 x 16-patch geometry only
-        if ((p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) || !spatial || p.upsample2x || !dma_ok || !igemm_halo_ok(p, spatial) ||
-            igemm_halo_img8(p) || !igemm_fast_addressable(p, spatial) || (p.tile != 0 && p.tile != 16))
-            return EDTR_E_UNSUPPORTED;
+    // Halo tile with 512-pixel units (tile 17, halo512.hip): the plain 3x3 / stride-1 convolutions whose image is a multiple of
+    // 32 x 16 pixels, N a multiple of 128, no split-K / activation — wherever the 256-pixel halo tile was chosen and there are at
+    // least two rounds of 512-pixel units.  EDTR_IGEMM_HALO512=0 switches the automatic choice off (A/B on one device).
+    static int halo512 = -1;
+    if (halo512 < 0) {
+        const char* e5 = getenv("EDTR_IGEMM_HALO512");
+        halo512 = e5 ? atoi(e5) : 1;
+    }
+    const bool h512_ok = spatial && (p.C1 & 31) == 0 && edtr_halo512_ok(p) && igemm_fast_addressable(p, spatial);
+    if (p.tile == 0 && tile == 16 && halo512 > 0 && h512_ok && (int64_t)(p.M >> 9) * (p.N >> 7) >= 256 * halo512) tile = 17;
+    if (p.a_gn) {           // GroupNorm (+ SiLU) of the input fused into the halo tiles' patch staging: 16 x 16 / 32 x 16-patch geometries only
+        if (p.tile == 17 || (p.tile == 0 && tile == 17)) {
+            if (!h512_ok) return EDTR_E_UNSUPPORTED;
+            tile = 17;
+        } else {
+            if ((p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) || !spatial || p.upsample2x || !dma_ok || !igemm_halo_ok(p, spatial) ||
+                igemm_halo_img8(p) || !igemm_fast_addressable(p, spatial) || (p.tile != 0 && p.tile != 16))
+                return EDTR_E_UNSUPPORTED;
+            tile = 16;
+        }
         if (!aligned16(p.a_gn)) return EDTR_E_ALIGN;
-        tile = 16;
     }
     if (p.out16) {
         if (!p.out_f32 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.vt_out) return EDTR_E_UNSUPPORTED;
@@ -2698,15 +2725,15 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         if (p.tile != 0) return EDTR_E_UNSUPPORTED;
         tile = dma_ok ? 3 : 1;
     }
-    if ((p.row_stats || p.vt_out) && tile == 16) return EDTR_E_UNSUPPORTED;
+    if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 17)) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
-    if (tile >= 3 && !dma_ok) return EDTR_E_UNSUPPORTED;
+    if (tile >= 3 && !dma_ok && !(tile == 17 && p.C2 == 0 && (p.C1 & 31) == 0)) return EDTR_E_UNSUPPORTED;      // (tile 17 walks 32-channel chunks)
     if (p.gn_partial && (tile == 2 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
         return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
-    // live tiles: 1, 2 (register-staged), 3 (LDS-DMA 128x128), 6 (256x256 ping-pong), 8 (128x160), 14 (256x32), 16 (halo).
-    // 4, 5, 7, 9 - 13, 15, 17, 18 were experiments, measured (profiles/r01 - r03) and removed (15 = the 8-wave ping-pong 128x128 tile
+    // live tiles: 1, 2 (register-staged), 3 (LDS-DMA 128x128), 6 (256x256 ping-pong), 8 (128x160), 14 (256x32), 16 (halo), 17 (halo, 512-pixel units).
+    // 4, 5, 7, 9 - 13, 15, 18 (and a round-2 "17") were experiments, measured (profiles/r01 - r03) and removed (15 = the 8-wave ping-pong 128x128 tile
     // for small grids and 18 = the persistent halo tile were faster in isolation and neutral on the whole path: round 4 took them out)
-    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || tile == 14 || tile == 16)) return EDTR_E_DTYPE;
+    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || tile == 14 || tile == 16 || tile == 17)) return EDTR_E_DTYPE;
     // lockstep breaker of the two-workgroups-per-CU kernels (stagger_second_slot): only when the grid has more than one round
     // (>= 768 workgroups: below that the second slot's blocks are the tail anyway) and the tile is short enough for the epilogue
     // to matter.  EDTR_IGEMM_STAGGER = percent of the estimated half life (default 100; 0 = off).
@@ -2727,5 +2754,11 @@ extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) {
         }
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s) : dispatch<F16>(p, tile, spatial, s);
+    return p.dtype == EDTR_BF16 ? dispatch<BF16>(p, tile, spatial, s, dry) : dispatch<F16>(p, tile, spatial, s, dry);
 }
+
+extern "C" int edtr_igemm(const edtr_igemm_params* pp, edtr_stream_t stream) { return igemm_run(pp, stream, false); }
+
+// Which kernel would edtr_igemm run for these parameters?  Every validation and every shape rule of the launch, no launch (no HIP
+// call: usable without a GPU): > 0 = the tile number (edtr_igemm_params.tile), < 0 = the error edtr_igemm would return.
+extern "C" int edtr_igemm_plan(const edtr_igemm_params* pp) { return igemm_run(pp, nullptr, true); }

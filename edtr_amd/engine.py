@@ -802,7 +802,7 @@ class Emitter:
         # nearest-2x upsample convolutions run in their sub-pixel form (four 2x2 convolutions of the source image with pre-summed
         # weights: 4 instead of 9 multiply-adds per output element) wherever the halo kernel's geometry takes them
         subpix = (ups and taps == 9 and stride == 1 and pad_tl == 1 and not self.invariant
-                  and ops.subpixel_ok(x.H, x.W, Ce, N, x.B))
+                  and ops.subpixel_ok(x.H, x.W, Ce, N, x.B, a.stride(0)))
         if subpix:
             w, bias = self.store.conv_subpixel(prefix, cin_pad=x.C, bias_scale=alpha)
             spatial = spatial[:7] + (2,)
@@ -821,9 +821,9 @@ class Emitter:
         if subpix:
             tile, splitk = 16, 1
         if x.gn_in is not None:          # the input's GroupNorm rides in this convolution's patch staging (group_norm(..., conv_n=N))
-            if taps != 9 or stride != 1 or pad_tl != 1 or ups or self.hp or not ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, N, splitk):
+            if taps != 9 or stride != 1 or pad_tl != 1 or ups or self.hp or not ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, N, splitk, x.ld):
                 raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")
-            tile = 16
+            tile = 0             # (edtr_igemm picks the halo geometry itself: tile 17 from 256 units of 512 pixels, tile 16 below)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
         if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk, invariant=self.invariant):
@@ -879,7 +879,7 @@ class Emitter:
         if conv_n < 0:
             return ops.conv128_out_ok(x.H, x.W, x.C, -conv_n)
         _, splitk = ops.choose_splitk(x.rows, conv_n, 9 * x.C)
-        return ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, conv_n, splitk)
+        return ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, conv_n, splitk, x.ld)
 
     def _deferred(self, x: Act, table: torch.Tensor, silu: bool, take: bool) -> Act:
         y = Act(x.t, x.B, x.H, x.W, x.C, x.gnp if take else None, gn_in=table, gn_silu=silu, owns=take)

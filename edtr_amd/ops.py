@@ -394,7 +394,17 @@ def make_gn_table(*, partial, tiles_per_image, sums, B, C, HW, gamma, beta, eps,
                (partial, sums, gamma, beta, table), name)
 
 
-def gn_in_conv_ok(B: int, H: int, W: int, C: int, N: int, splitk: int = 1) -> bool:
+def igemm_fast_addressable(rows_in: int, ld: int, IW: int, K: int, N: int, ldw: int) -> bool:
+    """Mirror of igemm.hip: igemm_fast_addressable — the buffer-addressed kernels (every LDS-DMA tile, the halo tiles) reach their
+    operands through 32-bit byte offsets; edtr_igemm answers EDTR_E_UNSUPPORTED for an explicit halo request beyond that, so the
+    predicates below must not promise the halo tile there (the untiled 1024 x 1024 decode at batch 8 has a 4.29-GB
+    operand).  tests/test_host_logic.py checks the predicates against edtr_igemm_plan."""
+    a_bytes = (rows_in + 3 * IW + 3) * ld * 2 + K * 2
+    w_bytes = N * ldw * 2 + K * 2
+    return a_bytes < 0xF0000000 and w_bytes < 0xF0000000
+
+
+def gn_in_conv_ok(B: int, H: int, W: int, C: int, N: int, splitk: int = 1, ld: int = 0) -> bool:
     """Does the halo tile take this 3x3 / stride 1 / pad 1 convolution in its 16 x 16-patch geometry with the GroupNorm of its input
     fused into the patch staging (edtr_hip.h: a_gn)?  The shape rules of edtr_igemm's automatic halo choice: 128-column tiles
     without padding and >= 48 units — and N <= EDTR_GN_IN_CONV_MAXN (default 128): measured on the MI355X (profiles/r04/gn_in_conv_ab.log),
@@ -405,6 +415,8 @@ def gn_in_conv_ok(B: int, H: int, W: int, C: int, N: int, splitk: int = 1) -> bo
         return False
     if H % 16 or W % 16 or C % 64 or N % 128 or (H, W) == (8, 8) or N > int(os.environ.get("EDTR_GN_IN_CONV_MAXN", "128")):
         return False         # (every 128-column tile of the convolution normalises the whole patch again: N / 128 times the arithmetic of edtr_gn_apply)
+    if max(splitk, 1) > C // 64 or not igemm_fast_addressable(B * H * W, ld or C, W, 9 * C, N, 9 * C):
+        return False         # (edtr_igemm's own preconditions for the halo tile: split-K over whole chunks, 32-bit operand offsets)
     return (B * H * W // 256) * (N // 128) * max(splitk, 1) >= 48
 
 
@@ -621,13 +633,15 @@ def pack_conv_weight_subpixel(w: torch.Tensor, dtype, cin_pad: Optional[int] = N
     return split3_weight(out, dt16, parts).reshape(4 * cop, -1)
 
 
-def subpixel_ok(H: int, W: int, Ce: int, N: int, B: int) -> bool:
+def subpixel_ok(H: int, W: int, Ce: int, N: int, B: int, ld: int = 0) -> bool:
     """Does the halo kernel's sub-pixel geometry take this nearest-2x upsample convolution (source H x W, Ce operand channels incl.
     parts, N output channels)?  16 x 16 source blocks, 64-channel chunks, 128-column tiles, and enough units to be worth a
     146-KiB workgroup (the halo tile's own threshold).  EDTR_SUBPIXEL=0 keeps the 9-tap gather (A/B runs)."""
     if os.environ.get("EDTR_SUBPIXEL", "1") == "0":
         return False
     units = B * (H // 16) * (W // 16) * 4 * ((N + 127) // 128)
+    if not igemm_fast_addressable(B * H * W, ld or Ce, W, 9 * Ce, 4 * N, 4 * Ce):     # (four phase matrices of [N][4 Ce])
+        return False
     return H % 16 == 0 and W % 16 == 0 and Ce % 64 == 0 and N % 128 == 0 and units >= 48
 
 

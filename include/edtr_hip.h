@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EDTR_ABI_VERSION 8
+#define EDTR_ABI_VERSION 9
 
 enum edtr_dtype {
     EDTR_BF16 = 0, EDTR_F16 = 1,
@@ -125,7 +125,11 @@ typedef struct edtr_igemm_params {
                                upsampled as a gather or in the sub-pixel form, or four whole 8x8 images per workgroup — on outputs whose
                                height and width are multiples of 16: the 18x18 input patch of a 16x16 output patch stays in LDS for
                                all taps; automatic for N % 128 == 0 and >= 48 units incl. split-K; EDTR_E_UNSUPPORTED for any other
-                               shape).  4, 5, 7, 9 - 13, 15, 17 and 18 were experiments (3-stage BK32, 256x128 tiles, 64x128,
+                               shape); 17 = the halo tile on 32 x 16-pixel units (ABI 9, halo512.hip: 32-channel chunks, a wave owns 128
+                               pixels x 64 channels over ALL of K, epilogue straight from the accumulators with whole-line stores; plain
+                               3x3 / stride 1 / pad 1 convolutions with OW % 32 == 0, OH % 16 == 0, N % 128 == 0, C1 % 32 == 0, no split-K /
+                               activation / bias_m; a_gn allowed; automatic where tile 16 would run and >= 256 such units exist:
+                               1.10 - 1.13 x over tile 16 on the VAE's convolutions).  4, 5, 7, 9 - 13, 15, 18, 19 were experiments (3-stage BK32, 256x128 tiles, 64x128,
                                16x16x32 at 128x128, deeper LDS rings, bank-swizzled epilogue staging, an 8-wave ping-pong 128x128 tile
                                for small grids, two-workgroup and persistent halo variants), measured without a whole-path gain
                                (profiles/r01 - r03) and removed: EDTR_E_DTYPE */
@@ -206,6 +210,10 @@ typedef struct edtr_igemm_params {
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
+/* Which kernel would edtr_igemm run for these parameters (ABI 9)?  All of edtr_igemm's validation and shape rules, no launch and no
+ * HIP call (works without a GPU): > 0 = the tile number (see `tile` above), < 0 = the error edtr_igemm would return.  The host side
+ * uses it to keep its own launch-shape predicates (edtr_amd/ops.py: gn_in_conv_ok, subpixel_ok) provably inside the library's. */
+int edtr_igemm_plan(const edtr_igemm_params* p);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head attention, head width 64: out = softmax(q k^T * scale) v per (batch, head),

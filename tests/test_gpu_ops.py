@@ -1138,7 +1138,7 @@ def test_skinny_n_conv_tile14_matches_tile3(dtype):
     torch.cuda.synchronize()
     assert rel(outs[1], outs[0]) < 1e-5                     # other MFMA shape, same products: fp32 summation order only
     assert torch.equal(outs[2], outs[1])                    # tile 0 (auto) picked tile 14
-    for gone in (4, 5, 7, 9, 10, 11, 15, 17, 18):                   # the removed experiments are rejected, not silently remapped
+    for gone in (4, 5, 7, 9, 10, 11, 15, 18, 19):                   # the removed experiments are rejected, not silently remapped
         with pytest.raises(RuntimeError):
             ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=outs[0], taps=9, M=B * H * W, N=cout, C1=cin, ld1=cin, ldw=9 * cin,
                                       ldc=cout, spatial=(H, W, H, W, 1, 1, 1, 0), out_f32=True, tile=gone))
@@ -1170,6 +1170,134 @@ def test_halo_conv_tile16(dtype, case):
 ])
 def test_halo_conv_tile16_upsample2x(dtype, case):
     _halo_case(dtype, case, ups=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tile 17 (halo512.hip, round 5): the halo tile on 32 x 16-pixel units with 32-channel chunks and an epilogue that works
+# straight from the accumulators (weight rows permuted so that a lane holds runs of eight consecutive channels; whole-line
+# stores through a row_ror:8 exchange; a 16-bit residual fetched by LDS-DMA).  Same products as tiles 3 / 16 in another
+# summation order.  One / three / five chunks, every image border inside a unit and between units, several column tiles,
+# every epilogue path the VAE convolutions use in the three precision modes.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # B, H, W, cin, cout, bias, rowvec, SiLU, residual, gn_partial, out_f32
+    (2, 16, 32, 32, 128, True, False, 0, False, True, False),      # ONE unit per image, ONE chunk: every border, the next chunk's staging is out-of-range loads
+    (1, 32, 64, 96, 128, True, False, 0, True, True, False),       # 2 x 2 units, 3 chunks, 16-bit residual (LDS-DMA) + statistics: VAE conv2
+    (3, 16, 64, 160, 256, True, True, 0, False, True, False),      # 5 chunks, two column tiles, time-embedding row per image
+    (1, 48, 32, 64, 384, False, False, 0, True, False, False),     # three column tiles, no bias, residual without statistics
+    (2, 32, 32, 128, 128, True, False, 0, False, True, True),      # fp32 output (the parity modes) + statistics
+    (1, 16, 32, 64, 128, True, False, 0, True, False, True),       # fp32 output + 16-bit residual
+])
+def test_halo_conv_tile17(dtype, case):
+    _halo_case(dtype, case, ups=False, tile=17)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_halo_conv_tile17_fp32_residual_and_mirror(dtype):
+    """The mixed mode's conv2: fp32 output, fp32 residual, 16-bit mirror of the sum (edtr_igemm_params.out16), statistics."""
+    ops = _ops()
+    d = dev()
+    B, H, W, cin, cout = 2, 16, 64, 64, 128
+    M = B * H * W
+    x = rnd((M, cin), 501).to(dtype)
+    w = rnd((cout, 9 * cin), 502, 1 / math.sqrt(9 * cin)).to(dtype)
+    bias = rnd((cout,), 503).to(d)
+    res = rnd((M, cout), 504).to(d)
+    outs = {}
+    for t in (3, 17):
+        out = torch.full((M, cout), float("nan"), dtype=torch.float32, device=d)
+        mir = torch.full((M, cout), float("nan"), dtype=dtype, device=d)
+        gn = torch.full((M // 128, cout, 2), float("nan"), dtype=torch.float32, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x.to(d), w=w.to(d), out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, residual=res, ldr=cout, residual_f32=True, out_f32=True,
+                                  out16=mir, gn_partial=gn, tile=t))
+        outs[t] = (out, mir, gn)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().reshape(B, H, W, cin).permute(0, 3, 1, 2), w.float().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2), bias.cpu(),
+                   padding=1).permute(0, 2, 3, 1).reshape(M, cout) + res.cpu()
+    assert rel(outs[17][0], ref) < 2e-5 and rel(outs[17][0], outs[3][0]) < 2e-6
+    assert torch.equal(outs[17][1], outs[17][0].to(dtype))                                  # the mirror is the stored sum, rounded once
+    s17, s3 = (g.double().reshape(B, -1, cout, 2).sum(1) for g in (outs[17][2], outs[3][2]))
+    assert float((s17 - s3).abs().max() / s3.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,cin,cout,from_partial", [(1, 16, 32, 32, 128, False), (2, 32, 32, 96, 128, True), (1, 32, 64, 160, 256, False), (2, 16, 64, 128, 128, True)])
+def test_halo_conv_tile17_with_groupnorm_of_its_input(dtype, B, H, W, cin, cout, from_partial):
+    """a_gn on tile 17 (prologue-only path with one chunk, the in-loop normalisation with 3 / 5 / 4 chunks; image borders on every side
+    of a unit: the padding must stay zero AFTER the normalisation) — against edtr_gn_apply + the same convolution, and torch fp32."""
+    ops = _ops()
+    d = dev()
+    M, HW = B * H * W, H * W
+    x = (rnd((M, cin), 401, 1.3) + 0.4).to(dtype)
+    w = rnd((cout, 9 * cin), 402, 1 / math.sqrt(9 * cin)).to(dtype)
+    bias = rnd((cout,), 403).to(d)
+    gamma, beta = (1 + 0.2 * rnd((cin,), 404)).to(d), (0.2 * rnd((cin,), 405)).to(d)
+    xd, wd = x.to(d), w.to(d)
+    sums = torch.zeros((B, 32, 2), dtype=torch.float64, device=d)
+    y = torch.empty((M, cin), dtype=dtype, device=d)
+    st, ap = ops.make_gn(dtype=dtype, x=xd, ldx=cin, B=B, HW=HW, C=cin, sums=sums, gamma=gamma, beta=beta, eps=1e-6, silu=True, y=y, ldy=cin,
+                         sums_zeroed=True)
+    ops.launch(st)
+    ops.launch(ap)
+    table = torch.full((B, cin, 2), float("nan"), dtype=torch.float32, device=d)
+    partial = None
+    if from_partial:
+        xf = xd.float().reshape(B * HW // 128, 128, cin)
+        partial = torch.stack([xf.sum(1), (xf * xf).sum(1)], dim=-1).contiguous()
+    ops.launch(ops.make_gn_table(partial=partial, tiles_per_image=HW // 128, sums=None if from_partial else sums, B=B, C=cin, HW=HW, gamma=gamma,
+                                 beta=beta, eps=1e-6, table=table))
+    outs = {}
+    for fused in (False, True):
+        out = torch.full((M, cout), float("nan"), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=xd if fused else y, w=wd, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, rows_per_image=HW, tile=17,
+                                  a_gn=table if fused else None, a_gn_silu=True))
+        outs[fused] = out
+    torch.cuda.synchronize()
+    xr = F.silu(F.group_norm(x.float().reshape(B, H, W, cin).permute(0, 3, 1, 2), 32, gamma.cpu(), beta.cpu(), 1e-6))
+    ref = F.conv2d(xr, w.float().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2), bias.cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+    assert torch.isfinite(outs[True].float()).all()
+    assert rel(outs[True].float(), ref) < TOL[dtype]
+    assert rel(outs[True].float(), outs[False].float()) < 0.1 * TOL[dtype]
+
+
+def test_halo512_is_the_automatic_choice_from_256_units_and_rejects_other_shapes():
+    """tile 0 picks tile 17 where tile 16 would run and there are >= 256 units of 512 pixels x 128 channels; below that tile 16; an
+    explicit tile 17 on a shape it cannot run (width not a multiple of 32, split-K, an activation) is an error."""
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    B, H, W, cin, cout = 1, 256, 512, 64, 128                    # 256 units
+    M = B * H * W
+    x = rnd((M, cin), 511).to(dtype).to(d)
+    w = rnd((cout, 9 * cin), 512, 1 / math.sqrt(9 * cin)).to(dtype).to(d)
+    outs = []
+    for t in (17, 0, 16):
+        out = torch.empty((M, cout), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), tile=t))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])                         # tile 0 (auto) ran tile 17 ...
+    assert rel(outs[0], outs[2]) < TOL[dtype] and not torch.equal(outs[0], outs[2])      # ... not tile 16 (another summation order)
+    Ms = 128 * 512
+    outs = []
+    for t in (16, 0):                                            # 128 units: the 256-pixel halo tile stays
+        out = torch.empty((Ms, cout), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=out, taps=9, M=Ms, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(128, 512, 128, 512, 1, 1, 1, 0), tile=t))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    for kw in (dict(spatial=(64, 48, 64, 48, 1, 1, 1, 0), M=64 * 48), dict(spatial=(64, 64, 64, 64, 1, 1, 1, 0), M=4096, act=1)):
+        m = kw.pop("M")
+        from edtr_amd import lib as L
+        act = L.ACT_SILU if kw.pop("act", 0) else L.ACT_NONE
+        with pytest.raises(RuntimeError):
+            ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=torch.empty((m, cout), dtype=dtype, device=d), taps=9, M=m, N=cout,
+                                      C1=cin, ld1=cin, ldw=9 * cin, ldc=cout, act=act, tile=17, **kw))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1221,7 +1349,7 @@ def test_halo_conv_with_groupnorm_of_its_input(dtype, B, H, W, cin, cout, splitk
     assert rel(outs[True].float(), outs[False].float()) < 0.1 * TOL[dtype]
 
 
-def _halo_case(dtype, case, ups):
+def _halo_case(dtype, case, ups, tile=16):
     import torch.nn.functional as F
     from edtr_amd import lib as L
     ops = _ops()
@@ -1236,7 +1364,8 @@ def _halo_case(dtype, case, ups):
     res = rnd((M, cout), 305).to(dtype).to(d) if use_res else None
     xd, wd = x.to(d), w.to(d)
     outs, gns = {}, {}
-    for t in (3, 16):
+    ref_tile = 3 if cin % 64 == 0 else 1                     # (the LDS-DMA 128x128 loop needs whole 64-channel K-tiles)
+    for t in (ref_tile, tile):
         out = torch.full((M, cout), float("nan"), dtype=torch.float32 if out_f32 else dtype, device=d)
         gn = torch.full((M // 128, cout, 2), float("nan"), dtype=torch.float32, device=d) if use_gn else None
         ops.launch(ops.make_igemm(dtype=dtype, a1=xd, w=wd, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
@@ -1257,12 +1386,12 @@ def _halo_case(dtype, case, ups):
     ref = ref.permute(0, 2, 3, 1).reshape(M, cout)
     if use_res:
         ref = ref + res.float().cpu()
-    assert torch.isfinite(outs[16].float()).all()
-    assert rel(outs[16], ref) < (2e-5 if out_f32 else TOL[dtype])
-    assert rel(outs[16], outs[3]) < (2e-6 if out_f32 else TOL[dtype])           # same products, other summation order
+    assert torch.isfinite(outs[tile].float()).all()
+    assert rel(outs[tile], ref) < (2e-5 if out_f32 else TOL[dtype])
+    assert rel(outs[tile], outs[ref_tile]) < (2e-6 if out_f32 else TOL[dtype])           # same products, other summation order
     if use_gn:
-        # the per-tile partials sit in other slots (one 256-pixel patch = two 128-row slots): compare the per-image sums
-        s16, s3 = (g.double().reshape(B, -1, cout, 2).sum(1) for g in (gns[16], gns[3]))
+        # the per-tile partials sit in other slots (one 256-pixel patch = two 128-row slots, one 512-pixel unit = four): compare the per-image sums
+        s16, s3 = (g.double().reshape(B, -1, cout, 2).sum(1) for g in (gns[tile], gns[ref_tile]))
         assert torch.isfinite(s16).all()
         assert float((s16 - s3).abs().max() / s3.abs().max()) < 1e-5
         want = torch.stack([ref.double().reshape(B, H * W, cout).sum(1), (ref.double() ** 2).reshape(B, H * W, cout).sum(1)], -1)

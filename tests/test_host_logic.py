@@ -527,3 +527,54 @@ def test_max_norm_gate_catches_a_localised_defect(golden_dir):
     st = err_stats(bad[sel], g["z"])
     assert st["max"] > 20 * st["l2"] and st["p9999"] > 10 * st["l2"]
     assert err_stats(torch.ones(10), torch.ones(10)) == {"l2": 0.0, "max": 0.0, "p9999": 0.0}
+
+
+def test_host_launch_predicates_imply_the_librarys_own(monkeypatch):
+    """ops.gn_in_conv_ok / ops.subpixel_ok decide in Python that the halo tile WILL take a convolution (the
+    emitter then has no edtr_gn_apply launch to fall back to).  They must therefore sit inside edtr_igemm's own rules, including the
+    two they used to omit: 32-bit addressability of the operand and split-K over whole 64-channel chunks.  edtr_igemm_plan answers
+    with the tile the library would run (no launch, no GPU)."""
+    import ctypes as C
+    from edtr_amd import lib as L
+    lib = L.load()
+    for k in ("EDTR_GN_IN_CONV", "EDTR_IGEMM_HALO", "EDTR_SUBPIXEL", "EDTR_GN_IN_CONV_MAXN", "EDTR_IGEMM_HALO512"):
+        monkeypatch.delenv(k, raising=False)
+    dummy = C.create_string_buffer(64)
+    base = C.addressof(dummy) & ~15
+
+    def plan(B, H, W, cin, N, *, ld=None, splitk=1, a_gn=False, ups=0, ldw=None, K=None, phase=0):
+        p = L.IgemmParams()
+        OH, OW = (2 * H, 2 * W) if ups else (H, W)
+        p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = 0, 9, B * OH * OW, N, K or 9 * cin, 1, 1
+        p.a1, p.C1, p.ld1, p.w, p.ldw = base, cin, ld or cin, base, ldw or 9 * cin
+        p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l, p.upsample2x = H, W, OH, OW, 1, 1, 1, ups
+        p.alpha, p.out, p.ldc, p.tile, p.splitk = 1.0, base, N, 0, splitk
+        if splitk > 1:
+            p.workspace, p.workspace_bytes = base, splitk * p.M * N * 4
+        if a_gn:
+            p.a_gn, p.a_gn_silu = base, 1
+        p.w_phase_stride = phase
+        return lib.edtr_igemm_plan(C.byref(p))
+
+    seen = {16: 0, 17: 0}
+    shapes = [(8, 512, 512, 128, 128), (8, 1024, 1024, 128, 128), (8, 1024, 1024, 256, 128), (1, 64, 64, 64, 128), (4, 32, 32, 128, 128), (8, 16, 16, 1280, 128),
+              (8, 256, 256, 256, 256), (2, 16, 16, 192, 128), (3, 64, 64, 64, 128), (8, 64, 48, 128, 128), (8, 2048, 1024, 128, 128)]
+    for (B, H, W, cin, N) in shapes:
+        for splitk in (1, 2, 3, 6):
+            for ld in (cin, 2 * cin):
+                if ops.gn_in_conv_ok(B, H, W, cin, N, splitk, ld):
+                    t = plan(B, H, W, cin, N, ld=ld, splitk=splitk, a_gn=True)
+                    assert t in (16, 17), (B, H, W, cin, N, splitk, ld, t)
+                    seen[t] += 1
+    assert seen[16] and seen[17]
+    # the cases the old predicates got wrong are now refused by the predicate (and by the library, which is why they must be)
+    assert not ops.gn_in_conv_ok(8, 1024, 1024, 256, 128, 1, 256) and plan(8, 1024, 1024, 256, 128, a_gn=True) < 0       # 4.29-GB operand
+    assert not ops.gn_in_conv_ok(8, 16, 16, 128, 128, 6, 128)                                                           # 6 splits of 2 chunks
+    n_sub = 0
+    for (B, H, W, Ce, N) in [(8, 256, 256, 256, 256), (8, 128, 128, 512, 512), (8, 32, 32, 640, 640), (2, 16, 16, 64, 128), (8, 512, 512, 768, 128),
+                             (8, 1024, 1024, 384, 128)]:
+        for ld in (Ce, 3 * Ce):
+            if ops.subpixel_ok(H, W, Ce, N, B, ld):
+                assert plan(B, H, W, Ce, N, ld=ld, ups=2, ldw=4 * Ce, phase=N * 4 * Ce) == 16, (B, H, W, Ce, N, ld)
+                n_sub += 1
+    assert n_sub >= 4 and not ops.subpixel_ok(1024, 1024, 384, 128, 8, 384)
