@@ -570,21 +570,26 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
         prog.graph = g
         for name, ms, flops, nbytes, tag in rows:
             kind = kernel_of(name)
+            # EXECUTED multiply-adds: the sub-pixel form of the upsample convolutions runs 4 of the 9 algorithmic taps (edtr_hip.h,
+            # upsample2x == 2); everything else executes what it is credited with (per-shape lines above the peak)
+            fx = flops * (4.0 / 9.0) if " up2sp" in tag else flops
             if tag:
-                sh = shapes.setdefault(tag, [0.0, 0.0, 0])
+                sh = shapes.setdefault(tag, [0.0, 0.0, 0, 0.0])
                 sh[0] += ms * mult
                 sh[1] += flops * mult
                 sh[2] += mult
-            a = agg.setdefault(kind, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "by_name": {}})
+                sh[3] += fx * mult
+            a = agg.setdefault(kind, {"ms": 0.0, "flops": 0.0, "flops_exec": 0.0, "bytes": 0.0, "n": 0, "by_name": {}})
             a["ms"] += ms * mult
             a["flops"] += flops * mult
+            a["flops_exec"] += fx * mult
             a["bytes"] += nbytes * mult
             a["n"] += mult
             if " sk" in tag:
                 a["n_splitk"] = a.get("n_splitk", 0) + mult
             bn = a["by_name"].setdefault(name, [0.0, 0.0, 0])
             bn[0] += ms * mult
-            bn[1] += flops * mult
+            bn[1] += fx * mult            # (executed)
             bn[2] += mult
     total_ms = sum(a["ms"] for a in agg.values())
     if args.breakdown:
@@ -597,13 +602,31 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
                 log(f"    {name:28s} {ms:9.3f} ms  n={n:5d}  {tfn:8.1f} TFLOP/s")
     if args.breakdown:
         log("--- igemm launches by shape (top 45 by time) ---")
-        for tag, (ms, fl, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:45]:
-            log(f"    {tag:58s} {ms:8.3f} ms  n={n:4d}  {ms / n * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s")
+        for tag, (ms, fl, n, fx) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:45]:
+            log(f"    {tag:58s} {ms:8.3f} ms  n={n:4d}  {ms / n * 1e3:8.1f} us  {fx / (ms * 1e-3) / 1e12:7.1f} TFLOP/s executed"
+                + (f"  ({fl / (ms * 1e-3) / 1e12:7.1f} algorithmic: 9 taps credited, 4 run)" if fx != fl else ""))
     ig = agg.get("igemm_kernel")
     at = agg.get("flash_attn64_kernel")
     out = {}
+
+    def pmc_family(names):
+        """(bytes per pass, note) of kernel families in the committed PMC passes, None when stale or absent"""
+        try:
+            from edtr_amd.build import source_hash
+            with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
+                pm = json.load(f)
+            if pm.get("kernel_source_hash") != source_hash():
+                return None, f"{PMC_TRAFFIC_FILE} was measured on kernel sources {pm.get('kernel_source_hash')}, this build is {source_hash()}: stale, not reported"
+            fams = [pm["families"][n] for n in names if n in pm["families"]]
+            if not fams:
+                return None, None
+            return (sum(f["hbm_side_bytes_per_pass"] for f in fams), sum(f["launches_per_pass"] for f in fams)), PMC_TRAFFIC_FILE
+        except (OSError, KeyError, ValueError):
+            return None, None
+
     if ig:
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+        ach_x = ig["flops_exec"] / (ig["ms"] * 1e-3) / 1e12
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read live); the
         # entry is used only if it was measured on a launch list of the same length as the one just timed
         traffic, traffic_src = None, None
@@ -632,7 +655,11 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
             traffic_src = str(e)
         out["roofline"] = {"kernel": "edtr_igemm family (implicit-GEMM conv / linear, MFMA 32x32x16 and 16x16x32 tiles)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
+                           "frac": round(ach / PEAK_TFLOPS, 4),
+                           "achieved_executed": round(ach_x, 2), "frac_executed": round(ach_x / PEAK_TFLOPS, 4),
+                           "frac_note": "frac = ALGORITHMIC FLOP (2 M N K of the reference's operation) / time; frac_executed = the multiply-adds "
+                                        "the kernels actually run / time: the sub-pixel upsample convolutions run 4 of their 9 algorithmic taps",
+                           "traffic": traffic,
                            "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["n"]),
                            "traffic_source": traffic_src,
                            "launches_per_pass": ig["n"], "avg_launch_ms": round(ig["ms"] / ig["n"], 4),
@@ -657,8 +684,14 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
                                                   "wall_ms_per_pass": round(ms_per_step, 3)}
     if at:
         ach = at["flops"] / (at["ms"] * 1e-3) / 1e12
+        tr, tr_src = pmc_family(["flash_attn_smallk", "flash_attn_v1", "flash_attn_v3", "flash_attn_d512"])
+        at_traffic = round(tr[0] / at["n"]) if tr and abs(tr[1] - at["n"]) <= 0.02 * at["n"] else None
         out["roofline_attention"] = {"kernel": "flash_attn64_kernel", "bound": "mfma", "achieved": round(ach, 2),
                                      "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
+                                     "achieved_executed": round(ach, 2), "frac_executed": round(ach / PEAK_TFLOPS, 4),
+                                     "frac_note": "algorithmic = executed for attention up to key padding (the 77-key cross-attention multiplies 80 - 128 keys); "
+                                                  "4 B H Nq Nk d FLOP per call",
+                                     "traffic": at_traffic, "algorithmic_bytes_per_launch": round(at["bytes"] / at["n"]), "traffic_source": tr_src,
                                      "launches_per_pass": at["n"], "share_of_pass": round(at["ms"] / total_ms, 3)}
     out["kernel_time_ms_per_pass"] = {k: round(a["ms"], 3) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     out["launches_per_pass"] = int(sum(a["n"] for a in agg.values()))
@@ -669,7 +702,7 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
                 table[name] = {"kernel": kind, "ms": round(ms, 4), "flops": fl, "n": n}
         os.makedirs(os.path.dirname(os.path.abspath(args.breakdown_json)), exist_ok=True)
         with open(args.breakdown_json, "w") as f:
-            json.dump({"by_name": table, "by_shape": {t: {"ms": round(v[0], 4), "flops": v[1], "n": v[2]} for t, v in shapes.items()},
+            json.dump({"by_name": table, "by_shape": {t: {"ms": round(v[0], 4), "flops": v[1], "n": v[2], "flops_executed": v[3]} for t, v in shapes.items()},
                        "total_ms": total_ms, "precision": args.precision, "workload": args.workload}, f, indent=1)
     return out
 

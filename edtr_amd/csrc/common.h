@@ -195,4 +195,28 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 bool edtr_halo512_ok(const edtr_igemm_params& p);
 int edtr_launch_halo512(const edtr_igemm_params& p, hipStream_t stream);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: one flag per (launch site, device), not one per process (ADVICE r04:
+// a process that drives a second GPU launched the large-LDS kernels without the attribute there).  A failure is an error, not a
+// launch that fails later.
+struct EdtrLdsOnce { bool done[32] = {}; };
+static inline int edtr_lds_attr(const void* fn, int bytes, EdtrLdsOnce& once) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = -1;
+    if (dev >= 0 && once.done[dev]) return EDTR_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return EDTR_E_UNSUPPORTED;
+    if (dev >= 0) once.done[dev] = true;
+    return EDTR_OK;
+}
+// CU count of the CURRENT device (persistent kernels size their grids with it)
+static inline int edtr_cu_count() {
+    static int cus[32] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
 #define EDTR_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -575,12 +575,8 @@ __global__ void __launch_bounds__(512, 1) igemm_halo512_kernel(const edtr_igemm_
 template <typename T>
 int launch_halo512(const edtr_igemm_params& p, hipStream_t stream) {
     using namespace h1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo512_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return EDTR_E_UNSUPPORTED;
-        attr_set = true;
-    }
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_halo512_kernel<T>), LDS_BYTES, attr_set)) return rc_;
     const int nbm = (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 5), nbn = p.N >> 7;
     hipLaunchKernelGGL((igemm_halo512_kernel<T>), dim3(nbm * nbn), dim3(512), LDS_BYTES, stream, p);
     EDTR_LAUNCH_CHECK();

@@ -1298,12 +1298,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_dma_kernel(const edtr_igemm
 template <typename T, bool SPATIAL, bool FAST>
 int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int lds = 2 * (128 + 128) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_dma_kernel<T, SPATIAL, FAST>), lds, attr_set)) return rc_;
     const int nbm = (p.M + 127) / 128, nbn = (p.N + 127) / 128;
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
     hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST>), grid, dim3(kThreads), lds, stream, p);
@@ -1624,12 +1620,8 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
 template <typename T, bool SPATIAL>
 int launch_256(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int lds = 2 * 4 * 128 * BK * 2;     // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_256_kernel<T, SPATIAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_256_kernel<T, SPATIAL>), lds, attr_set)) return rc_;
     const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
     dim3 grid(nbm * nbn, 1, p.Z);
     hipLaunchKernelGGL((igemm_256_kernel<T, SPATIAL>), grid, dim3(512), lds, stream, p);
@@ -1919,12 +1911,8 @@ int launch_n160(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int loop_lds = 2 * (BM + BN) * BK * 2, stage_lds = BM * BN * 4;     // 72 KiB main loop / 80 KiB fp32 staging for 128 x 160
     constexpr int lds = loop_lds > stage_lds ? loop_lds : stage_lds;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_n160_kernel<T, SPATIAL, MB, NB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_n160_kernel<T, SPATIAL, MB, NB>), lds, attr_set)) return rc_;
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
     hipLaunchKernelGGL((igemm_n160_kernel<T, SPATIAL, MB, NB>), grid, dim3(kThreads), lds, stream, p);
@@ -1944,12 +1932,8 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     constexpr int lds = 2 * (BM + BN) * BK * 2;
     static_assert(lds >= BM * BN * 4, "epilogue staging must fit the main-loop LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, MI, NI, SPATIAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_kernel<T, MI, NI, SPATIAL>), lds, attr_set)) return rc_;
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
     hipLaunchKernelGGL((igemm_kernel<T, MI, NI, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
@@ -2351,11 +2335,8 @@ int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
     constexpr bool UP2 = GEO == 1;
     // 144 KiB (also SUBPIX); UP2: main loop 80 KiB, the epilogue's staging tile 132 KiB; IMG8: 2 x 50 KiB patches + 48 KiB weights + 1 KiB scratch
     constexpr int lds = UP2 ? 256 * 132 * 4 : (GEO == 2 ? 2 * 50 * 1024 + 3 * 128 * BK * 2 + 1024 : 2 * 48 * 1024 + 3 * 128 * BK * 2 + (GEO == 0 ? 2048 : 0));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T, GEO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_halo_kernel<T, GEO>), lds, attr_set)) return rc_;
     const int nbm = GEO == 2 ? p.M >> 8 : (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4), nbn = (p.N + 127) / 128;
     hipLaunchKernelGGL((igemm_halo_kernel<T, GEO>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
     EDTR_LAUNCH_CHECK();

@@ -1216,20 +1216,14 @@ extern "C" int edtr_swin_mlp(const edtr_swin_mlp_params* pp, edtr_stream_t strea
     if (!aligned16(p.x) || !aligned16(p.w1) || !aligned16(p.w2) || !aligned16(p.out) || !aligned16(p.c1) || !aligned16(p.c2b) ||
         !aligned16(p.b2) || (p.row_stats && !aligned16(p.row_stats)))
         return EDTR_E_ALIGN;
-    static bool attr_set[2] = {false, false};
+    static EdtrLdsOnce attr_set[2];
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((p.rows + MLP_TOKENS - 1) / MLP_TOKENS));
     if (p.dtype == EDTR_BF16) {
-        if (!attr_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_mlp_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
-            attr_set[0] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&swin_mlp_kernel<BF16>), MLP_LDS, attr_set[0])) return rc_;
         hipLaunchKernelGGL(swin_mlp_kernel<BF16>, grid, dim3(MLP_THREADS), MLP_LDS, s, p);
     } else {
-        if (!attr_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_mlp_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
-            attr_set[1] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&swin_mlp_kernel<F16>), MLP_LDS, attr_set[1])) return rc_;
         hipLaunchKernelGGL(swin_mlp_kernel<F16>, grid, dim3(MLP_THREADS), MLP_LDS, s, p);
     }
     EDTR_LAUNCH_CHECK();
@@ -1253,20 +1247,14 @@ extern "C" int edtr_swin_attn(const edtr_swin_attn_params* pp, edtr_stream_t str
         return EDTR_E_ALIGN;
     const int64_t windows = (int64_t)p.B * (p.H / WS) * (p.W / WS);
     if (windows > 0x3fffffffLL) return EDTR_E_UNSUPPORTED;
-    static bool attr_set[2] = {false, false};
+    static EdtrLdsOnce attr_set[2];
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((windows + 1) / 2));
     if (p.dtype == EDTR_BF16) {
-        if (!attr_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS);
-            attr_set[0] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&swin_attn_kernel<BF16>), SA_LDS, attr_set[0])) return rc_;
         hipLaunchKernelGGL(swin_attn_kernel<BF16>, grid, dim3(SA_THREADS), SA_LDS, s, p, (int)windows);
     } else {
-        if (!attr_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, SA_LDS);
-            attr_set[1] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&swin_attn_kernel<F16>), SA_LDS, attr_set[1])) return rc_;
         hipLaunchKernelGGL(swin_attn_kernel<F16>, grid, dim3(SA_THREADS), SA_LDS, s, p, (int)windows);
     }
     EDTR_LAUNCH_CHECK();
@@ -1293,20 +1281,14 @@ extern "C" int edtr_swin_layer(const edtr_swin_attn_params* pa, const edtr_swin_
         return EDTR_E_ALIGN;
     const int64_t windows = (int64_t)a.B * (a.H / WS) * (a.W / WS);
     if (windows > 0x3fffffffLL) return EDTR_E_UNSUPPORTED;
-    static bool attr_set[2] = {false, false};
+    static EdtrLdsOnce attr_set[2];
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((windows + 1) / 2));
     if (a.dtype == EDTR_BF16) {
-        if (!attr_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_layer_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
-            attr_set[0] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&swin_layer_kernel<BF16>), SL_LDS, attr_set[0])) return rc_;
         hipLaunchKernelGGL(swin_layer_kernel<BF16>, grid, dim3(SA_THREADS), SL_LDS, s, a, m, (int)windows);
     } else {
-        if (!attr_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_layer_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
-            attr_set[1] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&swin_layer_kernel<F16>), SL_LDS, attr_set[1])) return rc_;
         hipLaunchKernelGGL(swin_layer_kernel<F16>, grid, dim3(SA_THREADS), SL_LDS, s, a, m, (int)windows);
     }
     EDTR_LAUNCH_CHECK();
@@ -1327,27 +1309,15 @@ extern "C" int edtr_conv64(const edtr_conv64_params* pp, edtr_stream_t stream) {
     if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.out) || !aligned16(p.bias)) return EDTR_E_ALIGN;
     const int64_t patches = (int64_t)p.B * (p.H >> 4) * (p.W >> 4);
     if (patches > 0x7fffffffLL || (int64_t)p.B * p.H * p.W > 0x7fffffffLL) return EDTR_E_UNSUPPORTED;
-    static bool attr_set[2] = {false, false};
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EDTR_E_UNSUPPORTED;
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static EdtrLdsOnce attr_set[2];
+    const int cus = edtr_cu_count();
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(patches < cus ? patches : cus));          // persistent: one 154-KiB workgroup per CU
     if (p.dtype == EDTR_BF16) {
-        if (!attr_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
-            attr_set[0] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&conv64_kernel<BF16>), C64_LDS, attr_set[0])) return rc_;
         hipLaunchKernelGGL(conv64_kernel<BF16>, grid, dim3(C64_THREADS), C64_LDS, s, p, (int)patches);
     } else {
-        if (!attr_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
-            attr_set[1] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&conv64_kernel<F16>), C64_LDS, attr_set[1])) return rc_;
         hipLaunchKernelGGL(conv64_kernel<F16>, grid, dim3(C64_THREADS), C64_LDS, s, p, (int)patches);
     }
     EDTR_LAUNCH_CHECK();
@@ -1365,27 +1335,15 @@ extern "C" int edtr_conv128_out(const edtr_conv128_out_params* pp, edtr_stream_t
     if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.out) || !aligned16(p.bias) || (p.gn_table && !aligned16(p.gn_table))) return EDTR_E_ALIGN;
     const int64_t patches = (int64_t)p.B * (p.H >> 4) * (p.W >> 4);
     if (patches > 0x7fffffffLL || (int64_t)p.B * p.H * p.W > 0x7fffffffLL) return EDTR_E_UNSUPPORTED;
-    static bool attr_set[2] = {false, false};
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EDTR_E_UNSUPPORTED;
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static EdtrLdsOnce attr_set[2];
+    const int cus = edtr_cu_count();
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(patches < cus ? patches : cus));
     if (p.dtype == EDTR_BF16) {
-        if (!attr_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv128_out_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS);
-            attr_set[0] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&conv128_out_kernel<BF16>), CO_LDS, attr_set[0])) return rc_;
         hipLaunchKernelGGL(conv128_out_kernel<BF16>, grid, dim3(CO_THREADS), CO_LDS, s, p, (int)patches);
     } else {
-        if (!attr_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv128_out_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS);
-            attr_set[1] = true;
-        }
+        if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&conv128_out_kernel<F16>), CO_LDS, attr_set[1])) return rc_;
         hipLaunchKernelGGL(conv128_out_kernel<F16>, grid, dim3(CO_THREADS), CO_LDS, s, p, (int)patches);
     }
     EDTR_LAUNCH_CHECK();

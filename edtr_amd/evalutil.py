@@ -25,6 +25,21 @@ def batch_to_list(img_batch: torch.Tensor, img_list: Sequence[torch.Tensor]) -> 
     return [img_batch[i][:, :img.size(1), :img.size(2)] for i, img in enumerate(img_list)]
 
 
+def pad_if_smaller(imgs: torch.Tensor, size: int) -> torch.Tensor:
+    """Zero-pad (n, c, h, w) at the bottom / right up to ``size`` in each dimension that is smaller (utils/common.py:337-340)."""
+    _, _, h, w = imgs.size()
+    return torch.nn.functional.pad(imgs, pad=(0, max(size - w, 0), 0, max(size - h, 0)), mode="constant", value=0)
+
+
+def pad_to_multiples_of(imgs: torch.Tensor, multiple: int) -> torch.Tensor:
+    """Zero-pad (n, c, h, w) at the bottom / right to the next multiples of ``multiple`` (utils/common.py:343-348)."""
+    _, _, h, w = imgs.size()
+    if h % multiple == 0 and w % multiple == 0:
+        return imgs.clone()
+    ph, pw = ((x + multiple - 1) // multiple * multiple - x for x in (h, w))
+    return torch.nn.functional.pad(imgs, pad=(0, pw, 0, ph), mode="constant", value=0)
+
+
 def rgb2ycbcr_pt(img: torch.Tensor, y_only: bool = False) -> torch.Tensor:
     """ITU-R BT.601 RGB -> YCbCr on (n, 3, h, w) in [0, 1] (common.py:194-216)."""
     if y_only:
@@ -53,13 +68,16 @@ def calculate_psnr_pt(img: torch.Tensor, img2: torch.Tensor, crop_border: int, t
 @torch.no_grad()
 def restore_dataset(cldm, diffusion, sampler, pre_restored: Sequence[torch.Tensor], gts: Optional[Sequence[torch.Tensor]] = None,
                     img_size: int = 512, batch_size: int = 8, used_timesteps=(50, 100, 150, 200), start_timestep: int = 200,
-                    colour_fix: bool = True, swinir=None) -> Tuple[List[torch.Tensor], Optional[torch.Tensor]]:
+                    colour_fix: bool = True, swinir=None, pad_mode: str = "batch", multiple: int = 64,
+                    clamp: bool = True) -> Tuple[List[torch.Tensor], Optional[torch.Tensor]]:
     """The restoration loop of main/det/test_edtr.py:121-135 without accelerate: this rank's shard of the
     (C, h, w <= img_size) pre-restored images is padded, pushed through vae_encode -> q_sample(t) -> spaced sampler ->
     vae_decode (-> wavelet colour fix), cropped back, and — when ground truth is given — scored with PSNR; the scalar
     PSNR sums are all-reduced, nothing else crosses ranks.  With ``swinir`` (an edtr_amd.model.SwinIR) the inputs are the
     low-quality images themselves and the pre-restoration runs on the padded batch first (`cfg.model.pre_restoration`,
-    main/det/test_edtr.py:118).  Returns (restored images of this shard, mean PSNR or None)."""
+    main/det/test_edtr.py:118).  ``pad_mode="demo"`` is the single-image flow of demo.py:84-131,165 instead: every image on its own,
+    `pad_if_smaller(img_size)` -> `pad_to_multiples_of(multiple)` -> (SwinIR) -> the same path -> crop back to the input's size
+    (``clamp=False`` keeps the values the reference hands to `save_image`).  Returns (restored images of this shard, mean PSNR or None)."""
     import torch.distributed as dist
     from .wavelet import wavelet_reconstruction
     dev = next(cldm.unet.parameters()).device
@@ -68,9 +86,15 @@ def restore_dataset(cldm, diffusion, sampler, pre_restored: Sequence[torch.Tenso
     sl = shard_slice(rank, world, len(pre_restored))
     mine = list(pre_restored[sl])
     outs: List[torch.Tensor] = []
-    for i in range(0, len(mine), batch_size):
-        chunk = mine[i:i + batch_size]
-        pre = list_to_batch(chunk, img_size, dev).float()
+    if pad_mode not in ("batch", "demo"):
+        raise ValueError(f"pad_mode must be 'batch' or 'demo', got {pad_mode!r}")
+    step = 1 if pad_mode == "demo" else batch_size
+    for i in range(0, len(mine), step):
+        chunk = mine[i:i + step]
+        if pad_mode == "demo":
+            pre = pad_to_multiples_of(pad_if_smaller(chunk[0][None].to(dev).float(), img_size), multiple)
+        else:
+            pre = list_to_batch(chunk, img_size, dev).float()
         if swinir is not None:
             pre = swinir(pre)
         cond = cldm.prepare_condition(pre, [""] * pre.size(0))
@@ -82,7 +106,7 @@ def restore_dataset(cldm, diffusion, sampler, pre_restored: Sequence[torch.Tenso
         res = (cldm.vae_decode(z) + 1) / 2
         if colour_fix:
             res = wavelet_reconstruction(res, pre)
-        outs.extend(batch_to_list(res.clamp(0, 1), chunk))
+        outs.extend(batch_to_list(res.clamp(0, 1) if clamp else res, chunk))
     psnr = None
     if gts is not None:
         mine_gt = list(gts[sl])

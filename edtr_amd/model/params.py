@@ -83,6 +83,23 @@ def params_fingerprint(module: nn.Module) -> Tuple:
     counter), so the per-forward cost stays one pass over a cached list (~1300 integer reads), not a walk of the module tree.
     (`module.to(device)` replaces ``.data`` in place, not the objects; the device of the first parameter is part of the result.)"""
     hit = module.__dict__.get("_fp_params")
+    if hit is not None and hit[0] == _STRUCT_EPOCH[0]:
+        # replacements that bypass register_parameter — `module._parameters[name] = p` (accelerate's set_module_tensor_to_device),
+        # torch.__future__.set_overwrite_module_params_on_conversion — do not bump the epoch (ADVICE r04): a cheap spot check of the
+        # first, the last and one middle parameter's identity catches whole-model conversions; a single `_parameters[...]` write
+        # elsewhere still needs release_engines()
+        plist = hit[1]
+        it = iter(module.parameters())
+        first = next(it, None)
+        if (first is None) != (not plist) or (plist and first is not plist[0]):
+            hit = None
+        elif len(plist) > 2:
+            sub = list(module._modules.values())[-1] if module._modules else module
+            last = None
+            for last in sub.parameters():
+                pass
+            if last is not None and last is not plist[-1]:
+                hit = None
     if hit is None or hit[0] != _STRUCT_EPOCH[0]:
         plist = list(module.parameters())
         hit = (_STRUCT_EPOCH[0], plist, hash(tuple(id(p) for p in plist)))     # (the objects' identities: a replaced parameter may

@@ -165,10 +165,16 @@ class SpacedSampler(nn.Module):
                 x_tile, t, {"c_txt": cond["c_txt"], "c_img": cond["c_img"][..., hi:hi_end, wi:wi_end]}),
             tile_size, tile_stride, batched_fn=batched)
 
-    def _loop(self, model, device, img, batch_size, cond, uncond, cfg_scale, return_intermediates):
+    def _loop(self, model, device, img, batch_size, cond, uncond, cfg_scale, return_intermediates, progress=False, progress_leave=True):
         timesteps = np.flip(self.timesteps)
         total = len(self.timesteps)
         intermediates = []
+        if progress:             # the reference's bar (utils/sampler.py:232,308: tqdm(..., leave=progress_leave, disable=not progress))
+            try:
+                from tqdm import tqdm
+                timesteps = tqdm(timesteps, total=total, leave=progress_leave, desc="Spaced Sampler")
+            except ImportError:  # tqdm is the reference's dependency, not this package's: without it the loop runs silently
+                pass
         for i, step in enumerate(timesteps):
             ts = torch.full((batch_size,), int(step), device=device, dtype=torch.long)
             img, pred_x0 = self.p_sample(model, img, ts, total - i - 1, cond, uncond, cfg_scale)
@@ -184,7 +190,7 @@ class SpacedSampler(nn.Module):
         if tiled:
             self._install_tiling(model, tile_size, tile_stride)
         img = torch.randn((batch_size, *x_size), device=device) if x_T is None else x_T
-        return self._loop(model, device, img, batch_size, cond, uncond, cfg_scale, return_intermediates)
+        return self._loop(model, device, img, batch_size, cond, uncond, cfg_scale, return_intermediates, progress, progress_leave)
 
     @torch.no_grad()
     def manual_sample_with_timesteps(self, model, device, x_T, steps, used_timesteps, batch_size, cond, uncond, cfg_scale,
@@ -194,4 +200,4 @@ class SpacedSampler(nn.Module):
         self.to(device)
         if tiled:
             self._install_tiling(model, tile_size, tile_stride)
-        return self._loop(model, device, x_T, batch_size, cond, uncond, cfg_scale, return_intermediates)
+        return self._loop(model, device, x_T, batch_size, cond, uncond, cfg_scale, return_intermediates, progress, progress_leave)

@@ -57,6 +57,10 @@ def smoke(verbose: bool = True) -> dict:
             print(f"smoke[{tag}]: rel err latent {e_z:.2e}, image {e_img:.2e} (tolerance {tol:.2e})")
         if not (e_img < tol and e_z < tol):
             raise AssertionError(f"smoke parity failed for {tag}: latent {e_z:.3e}, image {e_img:.3e}")
+        # the parity modes also keep a MARGIN to the north star itself (a gate at 0.95e-3 passes on synthetic weights
+        # while the default may miss 1e-3 on heavier-tailed ones)
+        if mode != "fast" and not (e_img < 0.8e-3 and e_z < 0.8e-3):
+            raise AssertionError(f"smoke: {tag} is within its own tolerance but closer than 20 % to the 1e-3 north star: latent {e_z:.3e}, image {e_img:.3e}")
     return out
 
 

@@ -290,6 +290,50 @@ def test_restore_dataset_driver_shapes_and_psnr():
     assert torch.isfinite(psnr) and 0.0 < float(psnr) < 60.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_demo_flow_through_the_harness_vs_reference_golden(golden_dir, dtype):
+    """SURVEY §8 row f4 with VALUES: the demo flow of demo.py:84-131,165 — a 150 x 100 image,
+    pad_if_smaller -> pad_to_multiples_of(64) -> SwinIR -> vae_encode -> q_sample(200) -> 4 steps -> vae_decode ->
+    wavelet_reconstruction -> crop — through evalutil.restore_dataset(pad_mode="demo") on the GPU against what the REFERENCE's own
+    functions produced on the same weights, input and noise (tools/make_goldens.py gen_demo -> tests/golden/demo_flow.npz).
+    Stated tolerance on the restored image (relative L2): fp16 4e-3, bf16 3e-2 (<= 1.5 x measured)."""
+    from edtr_amd import evalutil, synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.model.swinir import SwinIR
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise, rel_err
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "demo_flow.npz"))
+    cfg = synth.tiny_config()
+    cldm = build_synthetic_cldm(cfg, dev, dtype)
+    cldm.clip.set_embedding(synth.synth_input("demo:c_txt", (1, 77, cfg["unet_cfg"]["context_dim"]), -1.0, 1.0).to(dev))
+    sw = SwinIR(**synth.swinir_small_config())
+    sw.load_state_dict({k: (synth.synth_param("swinirsmall." + k, tuple(v.shape)) if v.dtype.is_floating_point and not k.endswith("attn_mask") else v)
+                        for k, v in sw.state_dict().items()}, strict=True)
+    sw = sw.eval().to(dev)
+    sw.compute_dtype = dtype
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(dev)
+    sampler = SpacedSampler(diffusion.betas)
+    img = synth.synth_input("demo:lq", (3, 150, 100), 0.0, 1.0)
+    noises = [synth.synth_normal(f"demo:noise{i}", tuple(g["z_pre"].shape)) for i in range(5)]
+    with injected_noise(noises):
+        outs, psnr = evalutil.restore_dataset(cldm, diffusion, sampler, [img], gts=[img], img_size=128, swinir=sw, pad_mode="demo",
+                                              multiple=64, clamp=False)
+    torch.cuda.synchronize()
+    assert len(outs) == 1 and tuple(outs[0].shape) == (3, 150, 100) == tuple(g["res"].shape)
+    err = rel_err(outs[0], g["res"])
+    print(f"\n[demo flow {dtype}] restored image rel err {err:.2e}, PSNR vs the input {float(psnr):.2f} dB")
+    assert err < (4e-3 if dtype == torch.float16 else 3e-2)
+    # the clamped form is what the harness returns by default; its PSNR against the input is the reference's own number
+    want = evalutil.calculate_psnr_pt(torch.from_numpy(g["res"])[None].clamp(0, 1), img[None], crop_border=0)[0]
+    with injected_noise(noises):
+        outs_c, psnr_c = evalutil.restore_dataset(cldm, diffusion, sampler, [img], gts=[img], img_size=128, swinir=sw, pad_mode="demo")
+    assert float(outs_c[0].min()) >= 0.0 and float(outs_c[0].max()) <= 1.0
+    assert abs(float(psnr_c) - float(want)) < (0.05 if dtype == torch.float16 else 0.3)
+
+
 def test_full_size_batch_invariance_and_determinism():
     """Size-independent properties at the BASELINE workload's full size (SD-2.1 widths, 512x512 images, 4 steps): the
     restoration of an image does not depend on the batch it travels in (batch 3 vs batch 1: different tile choices and

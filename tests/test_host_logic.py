@@ -578,3 +578,17 @@ def test_host_launch_predicates_imply_the_librarys_own(monkeypatch):
                 assert plan(B, H, W, Ce, N, ld=ld, ups=2, ldw=4 * Ce, phase=N * 4 * Ce) == 16, (B, H, W, Ce, N, ld)
                 n_sub += 1
     assert n_sub >= 4 and not ops.subpixel_ok(1024, 1024, 384, 128, 8, 384)
+
+
+def test_demo_padding_helpers_vs_reference_golden(golden_dir):
+    """evalutil.pad_if_smaller / pad_to_multiples_of (utils/common.py:337-348): the padded size the REFERENCE produced for the demo
+    golden's 150 x 100 input, zeros at the bottom / right only, and a no-op (clone) on aligned sizes."""
+    from edtr_amd import evalutil
+    g = np.load(os.path.join(golden_dir, "demo_flow.npz"))
+    img = synth.synth_input("demo:lq", (1, 3, 150, 100), 0.0, 1.0)
+    x = evalutil.pad_to_multiples_of(evalutil.pad_if_smaller(img, size=128), multiple=64)
+    assert tuple(x.shape) == tuple(g["padded_shape"]) == (1, 3, 192, 128)
+    assert torch.equal(x[:, :, :150, :100], img) and float(x[:, :, 150:].abs().max()) == 0.0 and float(x[:, :, :, 100:].abs().max()) == 0.0
+    y = evalutil.pad_to_multiples_of(x, 64)
+    assert torch.equal(y, x) and y.data_ptr() != x.data_ptr()
+    assert tuple(evalutil.pad_if_smaller(torch.zeros(1, 3, 600, 40), 512).shape) == (1, 3, 600, 512)

@@ -411,6 +411,38 @@ def gen_swinir():
     print("swinir.npz written")
 
 
+def gen_demo():
+    """The demo flow, demo.py:84-131 + the crop of :165, in miniature through the REFERENCE's own functions: a 150 x 100 low-quality
+    image -> pad_if_smaller(128) (512 in the demo) -> pad_to_multiples_of(64) -> SwinIR (2 x 2-layer) -> vae_encode(pre * 2 - 1) ->
+    q_sample(t = 200) -> 4 spaced steps -> vae_decode -> (x + 1) / 2 -> wavelet_reconstruction(res, pre) -> [:, :h0, :w0].
+    The golden of edtr_amd.evalutil.restore_dataset(pad_mode="demo") (VERDICT r04 item 9 / SURVEY §8 row f4)."""
+    ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
+    cldm, cfg = build_reference_cldm("tiny")
+    swinir = build_reference_swinir("small", synth.swinir_small_config())
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    sampler = SpacedSampler(diffusion.betas)
+    img = synth.synth_input("demo:lq", (1, 3, 150, 100), 0.0, 1.0)
+    h0, w0 = img.shape[2:]
+    x = ref_common.pad_to_multiples_of(ref_common.pad_if_smaller(img, size=128), multiple=64)
+    c_txt = synth.synth_input("demo:c_txt", (1, 77, cfg["unet_cfg"]["context_dim"]), -1.0, 1.0)
+    out = {"padded_shape": np.array(x.shape)}
+    with torch.no_grad():
+        pre = swinir(x)
+        z_pre = cldm.vae_encode(pre * 2 - 1, sample=False)
+        noises = [synth.synth_normal(f"demo:noise{i}", tuple(z_pre.shape)) for i in range(5)]
+        with injected_noise(noises):
+            noise = torch.randn_like(z_pre)                      # demo.py:109
+            z_partial = diffusion.q_sample(x_start=z_pre, t=torch.tensor([200], dtype=torch.int64), noise=noise)
+            z = sampler.manual_sample_with_timesteps(model=cldm, device="cpu", x_T=z_partial, steps=4, used_timesteps=USED_TIMESTEPS,
+                                                     batch_size=1, cond=dict(c_txt=c_txt, c_img=z_pre), uncond=None, cfg_scale=1.0,
+                                                     progress=False)
+        res = (cldm.vae_decode(z) + 1) / 2
+        res = ref_common.wavelet_reconstruction(res, pre)[0]
+    out.update(pre=pre.numpy().astype(np.float16), z_pre=z_pre.numpy(), z=z.numpy(), res=res[:, :h0, :w0].numpy())
+    np.savez_compressed(os.path.join(GOLD, "demo_flow.npz"), **out)
+    print("demo_flow.npz written: padded", tuple(x.shape), "restored", tuple(out["res"].shape), "range", float(res.min()), float(res.max()))
+
+
 TOKEN_PROMPTS = [
     "", "a cat", "A photo of a DOG, running fast!", "remove dense noise", "high quality, 8k, ultra-detailed",
     "it's the artist's best work; they've said so", "  multiple   spaces\tand\nnewlines  ", "naïve café — déjà vu",
@@ -545,7 +577,7 @@ def main():
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "vaesample": gen_vaesample, "heavy": gen_heavy, "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens}[name]()
+         "vaesample": gen_vaesample, "heavy": gen_heavy, "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens, "demo": gen_demo}[name]()
 
 
 if __name__ == "__main__":
