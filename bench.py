@@ -708,7 +708,7 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
 
 
 def kernel_of(name: str) -> str:
-    if name.startswith("flash"):
+    if name.startswith("flash") or name.endswith(".flash"):        # (the d = 64 kernels and the VAE's d = 512 kernel: one attention family)
         return "flash_attn64_kernel"
     if name.endswith(".stats"):
         return "gn_stats_kernel"

@@ -18,7 +18,7 @@ DECLARED_SYMBOLS = [
     "edtr_nhwc_to_nchw", "edtr_add", "edtr_timestep_embedding", "edtr_sampler_update", "edtr_axpby", "edtr_q_sample", "edtr_split3", "edtr_cast16",
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp", "edtr_swin_attn", "edtr_swin_layer", "edtr_conv64", "edtr_conv128_out",
-    "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror", "edtr_igemm_plan",
+    "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror", "edtr_igemm_plan", "edtr_flash_attn512",
 ]
 
 
@@ -168,6 +168,7 @@ def load() -> C.CDLL:
     lib.edtr_igemm.argtypes = [C.POINTER(IgemmParams), vp]
     lib.edtr_igemm_plan.argtypes = [C.POINTER(IgemmParams)]
     lib.edtr_flash_attn64.argtypes = [C.POINTER(AttnParams), vp]
+    lib.edtr_flash_attn512.argtypes = [C.POINTER(AttnParams), vp]
     lib.edtr_gn_stats.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_apply.argtypes = [C.POINTER(GnParams), vp]
     lib.edtr_gn_finalize.argtypes = [vp, i32, i32, i32, i32, vp, vp]

@@ -382,21 +382,28 @@ def _g_vae_attn(em: Emitter, p: str, x: Act):
         qk = em.to16(qk32, rows, 2 * C)
         vt = em.to16(vt32, B * C, ldv)
         em.free(qk32, vt32)
-    lds = round_up(N, 8)
-    s = em.new(rows, lds, torch.float32)
-    em.prog.add(ops.make_igemm(dtype=adt, a1=qk[:, :C], w=qk[:, C:], out=s, M=N, N=lds, n_valid=N, C1=C,
-                               ld1=qk.stride(0), ldw=qk.stride(0), ldc=lds, Z=B, a_zs=(N * qk.stride(0), 0),
-                               w_zs=(N * qk.stride(0), 0), o_zs=(N * lds, 0), alpha=1.0 / math.sqrt(C), out_f32=True,
-                               name="vae.attn.scores"))
-    em.free(qk)
-    pr = em.arena.alloc((rows, lds), adt)
-    em.prog.add(ops.make_softmax_rows(dtype=adt, s=s, rows=rows, cols=N, ld_s=lds, p=pr, ld_p=lds, cols_pad=lds))
-    em.free(s)
     o = em.new(rows, C)      # fp32 in the high-precision mode
-    # K is padded to a multiple of 8: the pad columns of P are exact zeros, those of V^T hold the (finite) bias
-    em.prog.add(ops.make_igemm(dtype=adt, a1=pr, w=vt, out=o, M=N, N=C, C1=lds, ld1=lds, ldw=ldv, ldc=C, Z=B,
-                               a_zs=(N * lds, 0), w_zs=(C * ldv, 0), o_zs=(N * C, 0), out_f32=em.hp, name="vae.attn.pv"))
-    em.free(pr, vt)
+    if ops.flash_attn512_ok(N, C):
+        # one launch, the scores never leave the CU (round 5; before: QK^T GEMM -> fp32 score matrix -> edtr_softmax_rows -> PV GEMM)
+        em.prog.add(ops.make_flash_attn512(dtype=adt, q=qk[:, :C], k=qk[:, C:], vt=vt, out=o, B=B, N=N, q_bs=N * qk.stride(0), q_ld=qk.stride(0),
+                                           k_bs=N * qk.stride(0), k_ld=qk.stride(0), vt_bs=C * ldv, vt_ld=ldv, o_bs=N * o.stride(0),
+                                           o_ld=o.stride(0), scale=1.0 / math.sqrt(C), out_f32=em.hp, name="vae.attn.flash"))
+        em.free(qk, vt)
+    else:
+        lds = round_up(N, 8)
+        s = em.new(rows, lds, torch.float32)
+        em.prog.add(ops.make_igemm(dtype=adt, a1=qk[:, :C], w=qk[:, C:], out=s, M=N, N=lds, n_valid=N, C1=C,
+                                   ld1=qk.stride(0), ldw=qk.stride(0), ldc=lds, Z=B, a_zs=(N * qk.stride(0), 0),
+                                   w_zs=(N * qk.stride(0), 0), o_zs=(N * lds, 0), alpha=1.0 / math.sqrt(C), out_f32=True,
+                                   name="vae.attn.scores"))
+        em.free(qk)
+        pr = em.arena.alloc((rows, lds), adt)
+        em.prog.add(ops.make_softmax_rows(dtype=adt, s=s, rows=rows, cols=N, ld_s=lds, p=pr, ld_p=lds, cols_pad=lds))
+        em.free(s)
+        # K is padded to a multiple of 8: the pad columns of P are exact zeros, those of V^T hold the (finite) bias
+        em.prog.add(ops.make_igemm(dtype=adt, a1=pr, w=vt, out=o, M=N, N=C, C1=lds, ld1=lds, ldw=ldv, ldc=C, Z=B,
+                                   a_zs=(N * lds, 0), w_zs=(C * ldv, 0), o_zs=(N * C, 0), out_f32=em.hp, name="vae.attn.pv"))
+        em.free(pr, vt)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
     y = em.gemm(o, wo, rows, C, C, bias=bo, residual=x.t, name="vae.attn.proj_out", stats_hw=N)
     em.free(o)

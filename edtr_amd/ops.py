@@ -184,6 +184,29 @@ def make_flash_attn(*, dtype, q, k, vt, out, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_l
     return rec
 
 
+def flash_attn512_ok(N: int, C: int) -> bool:
+    """Does edtr_flash_attn512 take the VAE's single-head attention over N positions of C channels?  (head width 512, whole 32-key
+    tiles; EDTR_ATTN512=0 keeps the GEMM -> softmax -> GEMM form for A/B runs)"""
+    return os.environ.get("EDTR_ATTN512", "1") != "0" and C == 512 and N % 32 == 0
+
+
+def make_flash_attn512(*, dtype, q, k, vt, out, B, N, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld, scale: float, out_f32: bool = False,
+                       name: str = "flash_attn512") -> Rec:
+    """The VAE AttnBlock's softmax(q k^T scale) v in one launch (edtr_hip.h: edtr_flash_attn512): q / k rows of 512 channels, vt = V^T."""
+    p = L.AttnParams()
+    p.dtype, p.B, p.H, p.Nq, p.Nk = dt_code(dtype), B, 1, N, N
+    p.q, p.q_bs, p.q_ld = ptr(q), q_bs, q_ld
+    p.k, p.k_bs, p.k_ld = ptr(k), k_bs, k_ld
+    p.vt, p.vt_bs, p.vt_ld = ptr(vt), vt_bs, vt_ld
+    p.out, p.o_bs, p.o_ld = ptr(out), o_bs, o_ld
+    p.scale, p.out_f32 = scale, int(out_f32)
+    flops = 4.0 * B * N * N * 512
+    nbytes = 2.0 * B * 512 * (3 * N) + (4.0 if out_f32 else 2.0) * B * N * 512
+    rec = Rec(L.load().edtr_flash_attn512, (ct.byref(p),), (p, q, k, vt, out), name, flops, nbytes)
+    rec.tag = f"attn512 B{B} N{N}" + (" f32" if out_f32 else "")
+    return rec
+
+
 def make_window_attn(*, dtype, qkv, ld_qkv, out, ld_out, B, H, W, heads, head_dim, c_pad, shift, bias, labels, scale,
                      name: str = "window_attn") -> Rec:
     """SwinIR shifted-window attention (edtr_hip.h: edtr_window_attn): qkv [B*H*W, 3*heads*32] -> out [B*H*W, c_pad]."""

@@ -251,6 +251,15 @@ typedef struct edtr_attn_params {
 
 int edtr_flash_attn64(const edtr_attn_params* p, edtr_stream_t stream);
 
+/* Fused single-head attention with head width 512 (ABI 9): the VAE's AttnBlock, softmax(q k^T * scale) v over the latent positions.
+ * Same parameter block as edtr_flash_attn64 with H == 1 and rows of 512 channels: q [B][Nq][q_ld], k [B][Nk][k_ld],
+ * vt = V^T [B][512][vt_ld] (vt_ld >= Nk), out [B][Nq][o_ld] (16-bit, or fp32 with out_f32); `scale` is applied inside.
+ * Nk must be a multiple of 32 (EDTR_E_UNSUPPORTED otherwise: the caller keeps GEMM -> edtr_softmax_rows -> GEMM); any Nq;
+ * no causal mask / pre-scaled q / split operands.  The score matrix never exists in memory (4096^2 fp32 per image before).
+ * replaces: F.scaled_dot_product_attention in AttnBlock.forward, reference model/vae.py:279-308 (and the tile-local attention of
+ * utils/tilevae/attn.py:85-115). */
+int edtr_flash_attn512(const edtr_attn_params* p, edtr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (32 groups in the reference; `groups` here) over NHWC 16-bit activations, fp32 math.
  * replaces: GroupNorm32 (model/util.py:146-163, eps 1e-5), Normalize (model/attention.py:50-51,

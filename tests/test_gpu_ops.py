@@ -1614,3 +1614,54 @@ def test_zz_measured_error_envelope():
     if path:
         with open(path, "w") as f:
             json.dump({"worst": worst, "all": MEASURED}, f, indent=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# edtr_flash_attn512 (attn512.hip, round 5): the VAE AttnBlock's single-head attention with head width 512 in one launch
+# (reference model/vae.py:279-308) against fp32 softmax attention of the same 16-bit operands.  The bench shape (B, 4096, 512), the
+# untiled 1024^2 shape (1, 16384, 512), the tiled VAE's 40 x 40 tile (N = 1600: a ragged last query block), one tile only, odd
+# tile counts, sharp rows (the deferred-rescale path), fp32 output.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,sharp,out_f32", [(2, 4096, 1.0, False), (1, 16384, 1.0, False), (3, 1600, 1.0, False), (2, 32, 1.0, False), (1, 96, 1.0, True),
+                                               (2, 1024, 12.0, False), (1, 2080, 40.0, True)])
+def test_flash_attn512_vs_fp32_softmax(dtype, B, N, sharp, out_f32):
+    ops = _ops()
+    d = dev()
+    C = 512
+    ld = 2 * C                                              # q | k side by side in one projection buffer, as the emitter lays them out
+    ldv = N + 8                                             # V^T rows with a pad
+    qk = rnd((B * N, ld), 601).to(dtype)
+    qk[:, :C] *= sharp                                      # sharper rows: scores of +-50 and more, the running maximum moves late
+    vt = rnd((B * C, ldv), 602).to(dtype)
+    out = torch.full((B * N, C), float("nan"), dtype=torch.float32 if out_f32 else dtype, device=d)
+    qd, vd = qk.to(d), vt.to(d)
+    ops.launch(ops.make_flash_attn512(dtype=dtype, q=qd[:, :C], k=qd[:, C:], vt=vd, out=out, B=B, N=N, q_bs=N * ld, q_ld=ld, k_bs=N * ld, k_ld=ld,
+                                      vt_bs=C * ldv, vt_ld=ldv, o_bs=N * C, o_ld=C, scale=1.0 / math.sqrt(C), out_f32=out_f32))
+    torch.cuda.synchronize()
+    q = qd[:, :C].float().reshape(B, N, C)
+    k = qd[:, C:].float().reshape(B, N, C)
+    v = vd.float().reshape(B, C, ldv)[:, :, :N].transpose(1, 2)
+    worst = 0.0
+    for b in range(B):                                       # (row blocks: the 16384^2 score matrix is the thing this kernel avoids)
+        for r0 in range(0, N, 4096):
+            w = torch.softmax((q[b, r0:r0 + 4096].double() @ k[b].double().t()) / math.sqrt(C), dim=-1)
+            ref = (w @ v[b].double()).float()
+            got = out[b * N + r0:b * N + min(r0 + 4096, N)].float()
+            assert torch.isfinite(got).all()
+            worst = max(worst, rel(got, ref))
+    MEASURED[f"flash_attn512[{dtype}-{B}-{N}-{sharp}]"] = worst
+    assert worst < (4e-3 if dtype == torch.float16 else 2.5e-2) * (1.0 if sharp < 20 else 2.0), worst
+
+
+def test_flash_attn512_rejects_what_it_cannot_run():
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    x = torch.zeros((40, 1024), dtype=dtype, device=d)
+    vt = torch.zeros((512, 48), dtype=dtype, device=d)
+    out = torch.zeros((40, 512), dtype=dtype, device=d)
+    with pytest.raises(RuntimeError):                        # 40 keys: not whole 32-key tiles
+        ops.launch(ops.make_flash_attn512(dtype=dtype, q=x[:, :512], k=x[:, 512:], vt=vt, out=out, B=1, N=40, q_bs=40 * 1024, q_ld=1024, k_bs=40 * 1024,
+                                          k_ld=1024, vt_bs=512 * 48, vt_ld=48, o_bs=40 * 512, o_ld=512, scale=1.0))
+    assert not ops.flash_attn512_ok(40, 512) and not ops.flash_attn512_ok(4096, 256) and ops.flash_attn512_ok(1600, 512)

@@ -21,6 +21,8 @@ import sys
 
 def family(name: str) -> str:
     n = name.lower()
+    if "flash_attn512" in n:
+        return "flash_attn_d512"
     if "flash_attn" in n:
         if "smallk" in n:
             return "flash_attn_smallk"
