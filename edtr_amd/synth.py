@@ -102,7 +102,35 @@ def synth_param_heavy(key: str, shape: Tuple[int, ...], device=None) -> torch.Te
     return base * scale.reshape((n0,) + (1,) * (len(shape) - 1))
 
 
-WEIGHT_SETS = {"smooth": synth_param, "heavy": synth_param_heavy}
+MODERATE_ROW, MODERATE_GAIN, MODERATE_QK = 8.0, 3.0, 1.3
+
+
+def synth_param_moderate(key: str, shape: Tuple[int, ...], device=None) -> torch.Tensor:
+    """The "moderate-outlier" weight set: the heavy set's STRUCTURE — one outlier output channel in
+    ~128, one large norm gain in ~64, sharper attention, larger biases — at factors (x8 rows, +-3 gains, x1.3 q / k, x3 biases)
+    calibrated so that the residual stream stays below ~6e3, i.e. inside what the reference's own fp16-autocast GPU path runs with
+    headroom, and the network's amplification of a rounding stays within a small factor of the smooth set's (the heavy set's 10 -
+    30 x makes its 4-step pipeline a poor gate: two builds of the same arithmetic moved its fp16 error 2 x).  This is the set on
+    which the FAST parity mode (precision="mixed") has a pinned claim off the smooth set: tests/test_gpu_heavy.py holds it to the
+    north-star 1e-3 against the reference's outputs (tests/golden/moderate.npz)."""
+    base = synth_param(key, shape, device=device)
+    shape = tuple(int(s) for s in shape)
+    n0 = shape[0] if len(shape) else 1
+    seed = zlib.crc32(("moderate:" + key).encode("utf-8")) & _M32
+    ch = _hash_u32(torch.arange(n0, dtype=torch.int64, device=device), seed)
+    if len(shape) <= 1:
+        if key.endswith("bias"):
+            return 3.0 * base
+        big = (ch % 64) == 0
+        sign = torch.where((ch >> 7) % 2 == 0, 1.0, -1.0)
+        return torch.where(big, MODERATE_GAIN * sign, base)
+    scale = torch.where((ch % 128) == 0, MODERATE_ROW, 1.0).to(torch.float32)
+    if any(key.endswith(sfx) for sfx in ("to_q.weight", "to_k.weight", ".q.weight", ".k.weight")):
+        scale = scale * MODERATE_QK
+    return base * scale.reshape((n0,) + (1,) * (len(shape) - 1))
+
+
+WEIGHT_SETS = {"smooth": synth_param, "heavy": synth_param_heavy, "moderate": synth_param_moderate}
 
 
 def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], prefix: str = "") -> Dict[str, torch.Tensor]:

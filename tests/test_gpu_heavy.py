@@ -156,3 +156,70 @@ def test_layernorm_fold_on_heavy_weights(golden_dir, dtype, monkeypatch):
         cldm.release_engines()
     print(f"\n[heavy sd21 widths, {dtype}] eps error with the LayerNorm launched {errs['0']:.2e}, folded {errs['1']:.2e}")
     assert errs["1"] < 1.3 * errs["0"], errs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The MODERATE-outlier weight set (edtr_amd.synth.synth_param_moderate; tests/golden/moderate.npz from the reference, round 5):
+# the parity modes' pinned claims OFF the smooth set on everything the reference produced: the tiny
+# 4-step pipeline (encoded latent, final latent, decoded image), one ControlNet + UNet evaluation at the SD-2.1 widths, VAE encode and
+# decode at the SD-2.1 widths.
+# ---------------------------------------------------------------------------------------------------------------------
+NORTH_STAR = 1e-3
+# Measured (round 5; z_pre z img | eps vae_z vae_dec):
+#   mixed 6.4e-4 1.88e-3 1.63e-3 | 1.69e-3 6.5e-4 2.9e-4      high 1.3e-4 8.3e-5 1.1e-4 | 2.8e-5 6.3e-5 1.0e-4
+#   fp16  1.24e-3 3.4e-3 2.8e-3 | 2.4e-3 1.5e-3 1.3e-3         bf16 1.0e-2 2.8e-2 2.4e-2 | 2.0e-2 1.1e-2 9.9e-3
+# What this pins: with outlier channels in the weights the FAST parity mode (one fp16 product on the FLOP-heavy classes) does NOT
+# hold the north-star 1e-3 — 1.6 - 1.9e-3 on the denoiser's output — and no cheap re-allocation does (tools/exp/r05_moderate_policies*.sh,
+# profiles/r05/moderate_policies.log: every UNet GEMM at three parts still leaves 1.2e-3, because the weight AND the activation
+# rounding of every class contribute); three fp16 parts everywhere (5.4e-4 / 4.5e-4 / 6.4e-4) or the robust mode (`high`) do.  So the
+# 1e-3 claim of `mixed` stays scoped to well-conditioned weights, and `high` is asserted here against the north star WITH a 4 x margin.
+# Every figure is held to <= 1.5 x its measurement.
+MODERATE = {"mixed": (None, "mixed", dict(z_pre=9.6e-4, z=2.8e-3, img=2.45e-3, eps=2.55e-3, vae=9.7e-4)),
+            "high": (None, "high", dict(z_pre=1.9e-4, z=1.25e-4, img=1.6e-4, eps=4.3e-5, vae=1.5e-4)),
+            "fp16": (torch.float16, "fast", dict(z_pre=1.9e-3, z=5.1e-3, img=4.2e-3, eps=3.7e-3, vae=2.2e-3)),
+            "bf16": (torch.bfloat16, "fast", dict(z_pre=1.55e-2, z=4.2e-2, img=3.6e-2, eps=2.95e-2, vae=1.7e-2))}
+
+
+@pytest.mark.parametrize("mode", list(MODERATE))
+def test_moderate_outlier_weights_pipeline_and_sd21_widths(golden_dir, mode):
+    from edtr_amd import synth
+    from edtr_amd.diffusion import Diffusion
+    from edtr_amd.sampler import SpacedSampler
+    from edtr_amd.testing import build_synthetic_cldm, injected_noise
+    d = dev()
+    dtype, precision, tol = MODERATE[mode]
+    g = np.load(os.path.join(golden_dir, "moderate.npz"))
+    cldm = build_synthetic_cldm(synth.tiny_config(), d, dtype, precision=precision, weights="moderate")
+    diffusion = Diffusion(linear_start=0.00085, linear_end=0.0120, timesteps=1000).to(d)
+    sampler = SpacedSampler(diffusion.betas)
+    B, H, W = 2, 128, 128
+    pre_res = synth.synth_input("moderate:pre_res", (B, 3, H, W), 0.0, 1.0).to(d)
+    c_txt = synth.synth_input("moderate:c_txt", (B, 77, 64), -1.0, 1.0).to(d)
+    noises = [synth.synth_normal(f"moderate:noise{i}", (B, 4, H // 8, W // 8)).to(d) for i in range(5)]
+    z_pre = cldm.vae_encode(pre_res * 2 - 1, sample=False)
+    x_T = diffusion.q_sample(z_pre, torch.full((B,), 200, dtype=torch.int64, device=d), noises[0])
+    with injected_noise(noises[1:]):
+        z = sampler.manual_sample_with_timesteps(model=cldm, device=d, x_T=x_T, steps=4, used_timesteps=USED, batch_size=B,
+                                                 cond={"c_txt": c_txt, "c_img": z_pre}, uncond=None, cfg_scale=1.0, progress=False)
+    img = cldm.vae_decode(z)
+    torch.cuda.synchronize()
+    assert finite(z_pre, z, img)
+    errs = {"z_pre": rel(z_pre, g["z_pre"]), "z": rel(z, g["z"]), "img": rel(img, g["img"])}
+    cldm.release_engines()
+    del cldm
+    big = build_synthetic_cldm(synth.sd21_config(), d, dtype, precision=precision, weights="moderate")
+    x = synth.synth_normal("moderate:x", (1, 4, 32, 32)).to(d)
+    c_img = synth.synth_normal("moderate:c_img", (1, 4, 32, 32)).to(d)
+    c_txt = synth.synth_input("moderate:c_txt", (1, 77, 1024), -1.0, 1.0).to(d)
+    eps = big.forward(x, torch.tensor([200], device=d), {"c_txt": c_txt, "c_img": c_img})
+    vz = big.vae_encode(synth.synth_input("moderate:img", (1, 3, 128, 128), -1.0, 1.0).to(d), sample=False)
+    dec = big.vae_decode(synth.synth_normal("moderate:zdec", (1, 4, 16, 16)).to(d))
+    torch.cuda.synchronize()
+    assert finite(eps, vz, dec)
+    errs.update(eps=rel(eps, g["sd21_eps"]), vae_z=rel(vz, g["sd21_vae_z"]), vae_dec=rel(dec, g["sd21_vae_dec"]))
+    print(f"\n[moderate, {mode}; reference stream peak {float(g['sd21_mid_absmax'][0]):.0f} at the SD-2.1 middle block] "
+          + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    lim = dict(tol, vae_z=tol["vae"], vae_dec=tol["vae"])
+    assert all(v < lim[k] for k, v in errs.items()), errs
+    if mode == "high":          # the robust parity mode meets the north star on outlier-bearing weights with a 4 x margin
+        assert max(errs.values()) < 0.25 * NORTH_STAR, errs

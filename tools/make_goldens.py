@@ -210,20 +210,26 @@ def gen_sd21():
     print("sd21_blocks.npz written")
 
 
-def gen_heavy():
+def gen_moderate():
+    """The same fixtures on the MODERATE-outlier weight set (edtr_amd.synth.synth_param_moderate: x4 rows, +-2 gains, x1.2 q / k): the
+    set on which the mixed parity mode is pinned to the north-star 1e-3 off the smooth set (tests/golden/moderate.npz)."""
+    gen_heavy(weights="moderate", tag="moderate", fname="moderate.npz")
+
+
+def gen_heavy(weights="heavy", tag="heavy", fname="heavy.npz"):
     """Range-robustness fixtures: the reference on the HEAVY-TAILED weight set (edtr_amd.synth.synth_param_heavy: outlier
     channels x50, norm gains +-10, sharp attention) — the tiny end-to-end pipeline, and one denoise step + VAE at SD-2.1
     widths on small grids (latent 32x32; 128x128 image; 16x16 latent)."""
     ControlLDM, Diffusion, SpacedSampler, ref_common = ref_import.import_reference()
-    cldm, cfg = build_reference_cldm("tiny", "heavy")
-    out = run_pipeline(cldm, cfg, 2, 128, 128, "heavy", Diffusion, SpacedSampler, ref_common, store_controls=False)
+    cldm, cfg = build_reference_cldm("tiny", weights)
+    out = run_pipeline(cldm, cfg, 2, 128, 128, tag, Diffusion, SpacedSampler, ref_common, store_controls=False)
     out = {k: v for k, v in out.items() if k in ("z_pre", "eps0", "eps3", "z", "img", "ctrl_stats")}
     del cldm
-    cldm, cfg = build_reference_cldm("sd21", "heavy")
+    cldm, cfg = build_reference_cldm("sd21", weights)
     with torch.no_grad():
-        x = synth.synth_normal("heavy:x", (1, 4, 32, 32))
-        c_img = synth.synth_normal("heavy:c_img", (1, 4, 32, 32))
-        c_txt = synth.synth_input("heavy:c_txt", (1, 77, 1024), -1.0, 1.0)
+        x = synth.synth_normal(f"{tag}:x", (1, 4, 32, 32))
+        c_img = synth.synth_normal(f"{tag}:c_img", (1, 4, 32, 32))
+        c_txt = synth.synth_input(f"{tag}:c_txt", (1, 77, 1024), -1.0, 1.0)
         t = torch.tensor([200], dtype=torch.int64)
         acts = {}
         # activation magnitudes the fixture exercises (max |x| of the residual stream at the ends of the UNet encoder)
@@ -231,10 +237,10 @@ def gen_heavy():
         out["sd21_eps"] = cldm(x, t, {"c_txt": c_txt, "c_img": c_img}).numpy()
         h.remove()
         out["sd21_mid_absmax"] = np.array([acts["mid_absmax"]])
-        out["sd21_vae_z"] = cldm.vae_encode(synth.synth_input("heavy:img", (1, 3, 128, 128), -1.0, 1.0), sample=False).numpy()
-        out["sd21_vae_dec"] = cldm.vae_decode(synth.synth_normal("heavy:zdec", (1, 4, 16, 16))).numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(GOLD, "heavy.npz"), **out)
-    print("heavy.npz written; |eps| max", float(np.abs(out["sd21_eps"]).max()), "mid absmax", acts["mid_absmax"],
+        out["sd21_vae_z"] = cldm.vae_encode(synth.synth_input(f"{tag}:img", (1, 3, 128, 128), -1.0, 1.0), sample=False).numpy()
+        out["sd21_vae_dec"] = cldm.vae_decode(synth.synth_normal(f"{tag}:zdec", (1, 4, 16, 16))).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+    print(fname, "written; |eps| max", float(np.abs(out["sd21_eps"]).max()), "mid absmax", acts["mid_absmax"],
           "tiny img absmax", float(np.abs(out["img"]).max()))
 
 
@@ -577,7 +583,7 @@ def main():
     todo = args.only.split(",")
     for name in todo:
         {"schedule": gen_schedule, "tiny": gen_tiny, "sd21": gen_sd21, "tiled": gen_tiled, "tiledvae": gen_tiledvae,
-         "vaesample": gen_vaesample, "heavy": gen_heavy, "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens, "demo": gen_demo}[name]()
+         "vaesample": gen_vaesample, "heavy": gen_heavy, "wavelet": gen_wavelet, "clip": gen_clip, "psnr": gen_psnr, "swinir": gen_swinir, "full": gen_full, "tokens": gen_tokens, "demo": gen_demo, "moderate": gen_moderate}[name]()
 
 
 if __name__ == "__main__":
