@@ -15,7 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "tools", "exp", "_build")
-SO = os.path.join(OUT, "libhalo512_stamps.so")
+SO = os.environ.get("H5_SO") or os.path.join(OUT, "libhalo512_stamps.so")
 
 
 def build():
