@@ -194,6 +194,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // tile 17 of edtr_igemm lives in its own translation unit (halo512.hip)
 bool edtr_halo512_ok(const edtr_igemm_params& p);
 int edtr_launch_halo512(const edtr_igemm_params& p, hipStream_t stream);
+bool edtr_halo160_ok(const edtr_igemm_params& p);            // tile 20
+int edtr_launch_halo160(const edtr_igemm_params& p, hipStream_t stream);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: one flag per (launch site, device), not one per process (ADVICE r04:
 // a process that drives a second GPU launched the large-LDS kernels without the attribute there).  A failure is an error, not a

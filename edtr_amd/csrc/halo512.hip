@@ -572,6 +572,281 @@ __global__ void __launch_bounds__(512, 1) igemm_halo512_kernel(const edtr_igemm_
     H5_STAMP(5); H5_STAMP(15);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Tile 20 (round 5): the halo tile for N % 160 == 0 — the UNet / ControlNet ResBlock convolutions of the 64 x 64 latent level
+// (N = 320, M = 32768 at batch 8; reference model/unet.py:152,178).  The 128-column halo tiles pad N = 320 to three column tiles and
+// 1.5 rounds of units, which is why these convolutions stayed on the 128 x 160 implicit-GEMM tile (tile 8: every input element staged
+// nine times, 847 TFLOP/s).  Here the unit is 16 x 16 pixels x 160 channels: 128 x 2 = 256 units at batch 8, exactly one per CU.
+// Wave w owns patch rows 2 w, 2 w + 1 (two 16-pixel blocks) x ALL 160 channels (ten 16-channel blocks: 80 accumulator registers);
+// per 32-channel chunk and tap one phase of 20 MFMAs, 10 weight + 2 pixel fragment reads; waves w / w + 4 share a SIMD and run half
+// a phase apart (the ping-pong of tiles 16 / 17).  Weight slices are 10 KiB (160 rows x 64 B; every wave issues two pieces per tap,
+// pieces 10..15 are out-of-range and land in a dump KiB), ring of FOUR: the slice of tap t + 3 is requested behind the first barrier
+// of phase t (every wave is then past its reads of tap t - 1, whose slot it takes), the wait in front of phase t's first barrier
+// leaves only phase t - 1's requests in flight, i.e. retires tap t + 1's slice two phases after its request.
+// LDS row R = 16 nb + r of a slice holds channel 40 (r >> 2) + 4 nb + (r & 3): a lane ends with FORTY consecutive channels of its pixel
+// (five 16-byte runs), epilogue straight from the accumulators as in tile 17.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace h3 {
+constexpr int PW = 18, PPIX = PW * PW, PROWB = PW * 64;
+constexpr int NPP = 3;                          // patch pieces per wave and chunk: 8 x 3 = 24 one-KiB pieces, 21 real
+constexpr int PATCHB = 21 * 1024;
+constexpr int WSL = 10 * 1024;                  // one tap's [160][32] weight slice
+constexpr int NRING = 4;
+constexpr int W_BASE = 0, P_BASE = NRING * WSL, DUMP = P_BASE + 2 * PATCHB, RED = DUMP + 1024;
+constexpr int LDS_BYTES = RED + 8 * 160 * 8;    // 94 KiB (GroupNorm scratch: [8 waves][160 channels][2] floats)
+static_assert(PATCHB + 3 * PROWB < 65536 && NRING * WSL + 10 * 1024 < 65536, "ds_read immediates (the patch base sits in the lane register)");
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512, 1) igemm_halo160_kernel(const edtr_igemm_params p) {
+    using namespace h3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int tw = p.OW >> 4, tpi = tw * (p.OH >> 4);
+    const int nbm = (p.M / (p.OH * p.OW)) * tpi, nbn = p.N / 160;
+    int bid = blockIdx.x;
+    {
+        const int nblk = nbm * nbn, qq = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + j;
+    }
+    const int tm = bid / nbn, tn = bid - tm * nbn;
+    const int img = tm / tpi, tr = tm - img * tpi, ty = tr / tw, tx = tr - ty * tw;
+    const int oy0 = ty * 16, ox0 = tx * 16, n0 = tn * 160;
+    const int sy0 = oy0 - 1, sx0 = ox0 - 1;
+    const int m0 = (img * p.OH + oy0) * p.OW + ox0;
+
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const u32x4 srd_a = srd_of(a1);
+    const u32x4 srd_w = srd_of(p.w);
+    const int Cin = p.C1, nchunk = Cin / CK;
+
+    // ten weight pieces per tap (LDS rows 16 piece ..): wave w requests piece w, waves 0 and 1 also pieces 8 and 9 — NOT two requests
+    // from every wave with six of them empty: a DMA issue costs ~65 cycles whether or not it moves anything, and the part of a
+    // phase that is not MFMAs (12 fragment reads, the requests, wait + barriers) must fit under the partner wave's 320 cycles of
+    // MFMAs.  The counted waits therefore differ between waves 0 - 1 and 2 - 7 (a scalar branch per phase).
+    const int nwp = wave < 2 ? 2 : 1;
+    uint32_t voff_w[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int R = (wave + 8 * jj) * 16 + (lane >> 2), slot = lane & 3;
+        const int r = R & 15, nb = R >> 4;
+        const int n = n0 + 40 * (r >> 2) + 4 * nb + (r & 3);
+        voff_w[jj] = R < 160 ? (uint32_t)(((int64_t)n * p.ldw + (slot ^ key8(R)) * 8) * 2) : kOob;
+    }
+    auto stage_w = [&](int chunk, int tap, int buf) {
+        dma(chunk < nchunk ? voff_w[0] : kOob, srd_w, (uint32_t)((tap * Cin + chunk * CK) * 2), smem_base + W_BASE + buf * WSL + wave * 1024);
+        if (nwp == 2) dma(chunk < nchunk ? voff_w[1] : kOob, srd_w, (uint32_t)((tap * Cin + chunk * CK) * 2), smem_base + W_BASE + buf * WSL + (wave + 8) * 1024);
+    };
+    stage_w(0, 0, 0);
+    stage_w(0, 1, 1);
+    stage_w(0, 2, 2);
+    uint32_t voff_p[NPP];
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) {
+        const int u = (wave + 8 * j) * 64 + lane, pp = u >> 2, slot = u & 3;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = sy0 + py, ix = sx0 + px;
+        const bool ok = pp < PPIX && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        voff_p[j] = ok ? (uint32_t)(((((int64_t)img * p.IH + iy) * p.IW + ix) * p.ld1 + (slot ^ key8(px)) * 8) * 2) : kOob;
+    }
+    auto stage_p = [&](int chunk, int j, int par) {
+        const int piece = wave + 8 * j;
+        dma(chunk < nchunk ? voff_p[j] : kOob, srd_a, (uint32_t)(chunk * CK * 2), smem_base + (piece < 21 ? P_BASE + par * PATCHB + piece * 1024 : DUMP));
+    };
+
+    // fragment reads: pixel block mb = patch row 2 wave + mb (+ ky), pixels l15 (+ kx); weight block nb = slice rows 16 nb + l15
+    int a_rd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = l15 + kx;
+        a_rd[kx] = P_BASE + (2 * wave * PW + px) * 64 + ((lq ^ key8(px)) << 4);
+    }
+    const int b_rd = W_BASE + l15 * 64 + ((lq ^ key8(l15)) << 4);       // + slot WSL + nb KiB
+
+    f32x4 acc[2][10];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) stage_p(0, j, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run half a phase behind their SIMD partners
+    asm volatile("" ::: "memory");
+
+    // (chunk loop unrolled by four: patch parity and ring position (9 c) & 3 = c & 3 are compile-time)
+    auto chunk_body = [&](int c, auto POSc) {
+        constexpr int POS = decltype(POSc)::value, par = POS & 1, rb = POS;
+        auto phase = [&](auto TAPc) {
+            constexpr int TAP = decltype(TAPc)::value, KY = TAP / 3, KX = TAP % 3, TAP3 = (TAP + 3) % 9, PREV = (TAP + 8) % 9;
+            const int c3 = TAP + 3 >= 9 ? c + 1 : c;
+            U4 bfr[10], afr[2];
+            const char* pb = smem + ((rb + TAP) & 3) * WSL + b_rd;
+#pragma unroll
+            for (int nb = 0; nb < 10; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(pb + nb * 1024);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) afr[mb] = *reinterpret_cast<const U4*>(smem + par * PATCHB + a_rd[KX] + (mb + KY) * PROWB);
+            // in flight by design: what the PREVIOUS phase requested behind its barrier (two weight pieces, a patch piece in phases 1..3)
+            constexpr int INFL = 1 + (PREV >= 1 && PREV <= NPP ? 1 : 0);
+            if (nwp == 2) wait_vm<INFL + 1>();
+            else wait_vm<INFL>();
+            __builtin_amdgcn_s_barrier();
+            stage_w(c3, TAP3, (rb + TAP + 3) & 3);
+            if constexpr (TAP >= 1 && TAP <= NPP) stage_p(c + 1, TAP - 1, par ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 10; ++nb) acc[mb][nb] = T::mfma16(bfr[nb], afr[mb], acc[mb][nb]);    // D[channel][pixel]
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        phase(IC<0>{}); phase(IC<1>{}); phase(IC<2>{}); phase(IC<3>{}); phase(IC<4>{}); phase(IC<5>{}); phase(IC<6>{}); phase(IC<7>{}); phase(IC<8>{});
+    };
+    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+        chunk_body(c0, IC<0>{});
+        if (c0 + 1 < nchunk) chunk_body(c0 + 1, IC<1>{});
+        if (c0 + 2 < nchunk) chunk_body(c0 + 2, IC<2>{});
+        if (c0 + 3 < nchunk) chunk_body(c0 + 3, IC<3>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave groups
+
+    // ---- epilogue straight from the accumulators: acc[mb][nb][i] = pixel (row 2 wave + mb, column l15), channel n0 + 40 lq + 4 nb + i
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int l15e = lane_e & 15, lqe = lane_e >> 4;
+    const float alpha = p.alpha;
+    const bool gn_acc = p.gn_partial != nullptr;
+    const int64_t mu0 = (int64_t)m0 + 2 * wave * p.OW;   // + mb OW: first pixel of block mb (wave-uniform)
+    const int nl = n0 + 40 * lqe;                        // first of this lane's 40 channels
+    const uint32_t lo_out = (uint32_t)(l15e * p.ldc + 40 * lqe), lo_res = (uint32_t)(l15e * p.ldr + 40 * lqe), lo_16 = (uint32_t)(l15e * p.ld16 + 40 * lqe);
+    float* red = reinterpret_cast<float*>(smem + RED);
+    auto finish = [&](auto out32_c, auto res_c, auto mir_c) {
+        constexpr bool OUT32 = decltype(out32_c)::value, MIR = decltype(mir_c)::value && OUT32;
+        constexpr int RES = decltype(res_c)::value;      // 0 none, 1 16-bit, 2 fp32
+        U4 r16[2][5];
+        if constexpr (RES == 1) {                        // all ten residual vectors of the lane at once: one exposure of the memory latency
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    r16[mb][k] = ldg16(static_cast<const uint16_t*>(p.residual) + ((mu0 + mb * p.OW) * p.ldr + n0 + 8 * k) + lo_res);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {                    // channel run k: channels nl + 8 k .. + 7 = MFMA blocks 2 k, 2 k + 1
+            float cb[8], gs[8], gq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cb[j] = 0.0f; gs[j] = 0.0f; gq[j] = 0.0f; }
+            if (p.bias_n) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias_n + nl + 8 * k), b1 = *reinterpret_cast<const f32x4*>(p.bias_n + nl + 8 * k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cb[j] = b0[j]; cb[j + 4] = b1[j]; }
+            }
+            if (p.rowvec) {                              // the time-embedding row of the unit's image
+                const float* rv = p.rowvec + (int64_t)img * p.rowvec_ld + nl + 8 * k;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv), b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cb[j] += b0[j]; cb[j + 4] += b1[j]; }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int64_t mu = mu0 + mb * p.OW;
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f[i] = __builtin_fmaf(acc[mb][2 * k][i], alpha, cb[i]);
+                    f[i + 4] = __builtin_fmaf(acc[mb][2 * k + 1][i], alpha, cb[i + 4]);
+                }
+                if constexpr (RES == 1) {
+                    float rf[8];
+                    unpack8<T>(r16[mb][k], rf);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] += rf[i];
+                } else if constexpr (RES == 2) {
+                    const float* rp = static_cast<const float*>(p.residual) + (mu * p.ldr + n0 + 8 * k) + lo_res;
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(rp), q1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { f[i] += q0[i]; f[i + 4] += q1[i]; }
+                }
+                const int64_t oidx = mu * p.ldc + n0 + 8 * k;          // wave-uniform
+                if constexpr (OUT32) {
+                    float* o = static_cast<float*>(p.out) + oidx + lo_out;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
+                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
+                    if constexpr (MIR) stg16(static_cast<uint16_t*>(p.out16) + (mu * p.ld16 + n0 + 8 * k) + lo_16, pack8<T>(f));
+                } else {
+                    stg16(static_cast<uint16_t*>(p.out) + oidx + lo_out, pack8<T>(f));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { gs[i] += f[i]; gq[i] += f[i] * f[i]; }
+                pin8(gs);
+                pin8(gq);
+            }
+            if (gn_acc) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gs[j] = row16_sum(gs[j]); gq[j] = row16_sum(gq[j]); }
+                if (l15e == 0) {
+                    float* dst = red + (wave * 160 + 40 * lqe + 8 * k) * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[j]; dst[2 * j + 1] = gq[j]; }
+                }
+            }
+        }
+    };
+    {
+        using std::true_type;
+        using std::false_type;
+        const bool res32 = p.residual && p.residual_f32, res16 = p.residual && !p.residual_f32, mir = p.out16 != nullptr;
+        if (!p.out_f32) {
+            if (res16) finish(false_type{}, IC<1>{}, false_type{});
+            else if (res32) finish(false_type{}, IC<2>{}, false_type{});
+            else finish(false_type{}, IC<0>{}, false_type{});
+        } else if (mir) {
+            if (res32) finish(true_type{}, IC<2>{}, true_type{});
+            else if (res16) finish(true_type{}, IC<1>{}, true_type{});
+            else finish(true_type{}, IC<0>{}, true_type{});
+        } else {
+            if (res32) finish(true_type{}, IC<2>{}, false_type{});
+            else if (res16) finish(true_type{}, IC<1>{}, false_type{});
+            else finish(true_type{}, IC<0>{}, false_type{});
+        }
+    }
+    if (gn_acc) {
+        __syncthreads();
+        if (tid < 160) {
+            float a = 0.0f, sq = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { a += red[(w * 160 + tid) * 2]; sq += red[(w * 160 + tid) * 2 + 1]; }
+            float* dst = p.gn_partial + ((int64_t)(2 * tm) * p.N + n0 + tid) * 2;      // two 128-row slots per 256-pixel unit
+            dst[0] = a;
+            dst[1] = sq;
+            dst[2 * (int64_t)p.N] = 0.0f;
+            dst[2 * (int64_t)p.N + 1] = 0.0f;
+        }
+    }
+}
+
+template <typename T>
+int launch_halo160(const edtr_igemm_params& p, hipStream_t stream) {
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_halo160_kernel<T>), h3::LDS_BYTES, attr_set)) return rc_;
+    const int nbm = (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4), nbn = p.N / 160;
+    hipLaunchKernelGGL((igemm_halo160_kernel<T>), dim3(nbm * nbn), dim3(512), h3::LDS_BYTES, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 template <typename T>
 int launch_halo512(const edtr_igemm_params& p, hipStream_t stream) {
     using namespace h1;
@@ -598,8 +873,21 @@ int edtr_launch_halo512(const edtr_igemm_params& p, hipStream_t stream) {
     return p.dtype == EDTR_BF16 ? launch_halo512<BF16>(p, stream) : launch_halo512<F16>(p, stream);
 }
 
+// tile 20: 16 x 16-pixel units x 160 channels (no a_gn: the emitters fuse a GroupNorm input only into N <= 128 convolutions)
+bool edtr_halo160_ok(const edtr_igemm_params& p) {
+    return p.OH > 0 && p.taps == 9 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.C2 == 0 && (p.C1 % CK) == 0 && !p.upsample2x &&
+           p.OH == p.IH && p.OW == p.IW && (p.OH & 15) == 0 && (p.OW & 15) == 0 && p.Z == 1 && p.splitk <= 1 && p.act == EDTR_ACT_NONE &&
+           !p.bias_m && p.N % 160 == 0 && (p.n_valid == 0 || p.n_valid == p.N) && !p.vt_out && !p.row_stats && !p.ln_stats && !p.a_wrap && !p.a_gn &&
+           p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW && (!p.rowvec || p.rows_per_image == p.OH * p.OW);
+}
+
+int edtr_launch_halo160(const edtr_igemm_params& p, hipStream_t stream) {
+    return p.dtype == EDTR_BF16 ? launch_halo160<BF16>(p, stream) : launch_halo160<F16>(p, stream);
+}
+
 #ifdef EDTR_STAMPS
 extern "C" int edtr_halo512_stamped(const edtr_igemm_params* p, void* stream) {      // stand-alone diagnostic build: no edtr_igemm in front
+    if (p->tile == 20) return edtr_halo160_ok(*p) ? edtr_launch_halo160(*p, static_cast<hipStream_t>(stream)) : EDTR_E_UNSUPPORTED;
     if (!edtr_halo512_ok(*p)) return EDTR_E_UNSUPPORTED;
     return edtr_launch_halo512(*p, static_cast<hipStream_t>(stream));
 }

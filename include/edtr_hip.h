@@ -129,7 +129,10 @@ typedef struct edtr_igemm_params {
                                pixels x 64 channels over ALL of K, epilogue straight from the accumulators with whole-line stores; plain
                                3x3 / stride 1 / pad 1 convolutions with OW % 32 == 0, OH % 16 == 0, N % 128 == 0, C1 % 32 == 0, no split-K /
                                activation / bias_m; a_gn allowed; automatic where tile 16 would run and >= 256 such units exist:
-                               1.10 - 1.13 x over tile 16 on the VAE's convolutions).  4, 5, 7, 9 - 13, 15, 18, 19 were experiments (3-stage BK32, 256x128 tiles, 64x128,
+                               1.10 - 1.13 x over tile 16 on the VAE's convolutions); 20 = the halo tile on 16 x 16 pixels x 160 channels
+                               (ABI 9, halo512.hip: N % 160 == 0, otherwise tile 17's rules with OW % 16 == 0 and no a_gn; automatic
+                               where the 128x160 tile would run and the units fill one round of the chip, 192 .. 256: the 64 x 64-latent
+                               ResBlock convolutions at batch 8).  4, 5, 7, 9 - 13, 15, 18, 19 were experiments (3-stage BK32, 256x128 tiles, 64x128,
                                16x16x32 at 128x128, deeper LDS rings, bank-swizzled epilogue staging, an 8-wave ping-pong 128x128 tile
                                for small grids, two-workgroup and persistent halo variants), measured without a whole-path gain
                                (profiles/r01 - r03) and removed: EDTR_E_DTYPE */

@@ -1138,7 +1138,7 @@ def test_skinny_n_conv_tile14_matches_tile3(dtype):
     torch.cuda.synchronize()
     assert rel(outs[1], outs[0]) < 1e-5                     # other MFMA shape, same products: fp32 summation order only
     assert torch.equal(outs[2], outs[1])                    # tile 0 (auto) picked tile 14
-    for gone in (4, 5, 7, 9, 10, 11, 15, 18, 19):                   # the removed experiments are rejected, not silently remapped
+    for gone in (4, 5, 7, 9, 10, 11, 15, 18, 19, 21):                   # the removed experiments are rejected, not silently remapped
         with pytest.raises(RuntimeError):
             ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=outs[0], taps=9, M=B * H * W, N=cout, C1=cin, ld1=cin, ldw=9 * cin,
                                       ldc=cout, spatial=(H, W, H, W, 1, 1, 1, 0), out_f32=True, tile=gone))
@@ -1261,6 +1261,60 @@ def test_halo_conv_tile17_with_groupnorm_of_its_input(dtype, B, H, W, cin, cout,
     assert torch.isfinite(outs[True].float()).all()
     assert rel(outs[True].float(), ref) < TOL[dtype]
     assert rel(outs[True].float(), outs[False].float()) < 0.1 * TOL[dtype]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tile 20 (halo512.hip, round 5): the halo tile on 16 x 16 pixels x 160 channels for N % 160 == 0 (the 64 x 64-latent ResBlock
+# convolutions of the UNet / ControlNet: N = 320).  One / three / ten chunks, one / two / four column tiles, time-embedding row,
+# residual (16-bit and fp32), statistics, fp32 output + mirror.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # B, H, W, cin, cout, bias, rowvec, SiLU, residual, gn_partial, out_f32
+    (2, 16, 16, 32, 160, True, False, 0, False, True, False),      # ONE unit per image, ONE chunk, one column tile: every border
+    (1, 32, 48, 96, 320, True, True, 0, False, True, False),       # 2 x 3 units, 3 chunks, two column tiles, time-embedding row: UNet conv1
+    (3, 16, 32, 320, 320, True, False, 0, True, True, False),      # 10 chunks (the unrolled-by-four chunk loop wraps), 16-bit residual: UNet conv2
+    (2, 32, 16, 64, 640, False, False, 0, True, False, False),     # four column tiles, no bias
+    (1, 16, 32, 128, 160, True, True, 0, False, True, True),       # fp32 output + statistics (parity modes)
+])
+def test_halo_conv_tile20(dtype, case):
+    _halo_case(dtype, case, ups=False, tile=20)
+
+
+def test_halo160_fp32_residual_mirror_and_automatic_choice():
+    ops = _ops()
+    d = dev()
+    dtype = torch.float16
+    B, H, W, cin, cout = 2, 32, 32, 64, 320
+    M = B * H * W
+    x = rnd((M, cin), 521).to(dtype).to(d)
+    w = rnd((cout, 9 * cin), 522, 1 / math.sqrt(9 * cin)).to(dtype).to(d)
+    bias = rnd((cout,), 523).to(d)
+    res = rnd((M, cout), 524).to(d)
+    outs = {}
+    for t in (3, 20):
+        out = torch.full((M, cout), float("nan"), dtype=torch.float32, device=d)
+        mir = torch.full((M, cout), float("nan"), dtype=dtype, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias, residual=res, ldr=cout, residual_f32=True, out_f32=True,
+                                  out16=mir, tile=t))
+        outs[t] = (out, mir)
+    torch.cuda.synchronize()
+    assert rel(outs[20][0], outs[3][0]) < 2e-6 and torch.equal(outs[20][1], outs[20][0].to(dtype))
+    # automatic: 256 units (8 images of 64 x 64, N = 320) -> tile 20; 128 units -> not
+    from edtr_amd import lib as L
+    import ctypes as C
+    def plan(Bn, Hn, N):
+        p = L.IgemmParams()
+        p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = 0, 9, Bn * Hn * Hn, N, 9 * 320, 1, 1
+        p.a1, p.C1, p.ld1, p.w, p.ldw = x.data_ptr(), 320, 320, w.data_ptr(), 9 * 320
+        p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l = Hn, Hn, Hn, Hn, 1, 1, 1
+        p.alpha, p.out, p.ldc = 1.0, outs[3][0].data_ptr(), N
+        return L.load().edtr_igemm_plan(C.byref(p))
+    assert plan(8, 64, 320) == 20 and plan(4, 64, 320) != 20 and plan(8, 64, 640) != 20
+    with pytest.raises(RuntimeError):                        # N = 128 is not a multiple of 160
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w[:128], out=torch.empty((M, 128), dtype=dtype, device=d), taps=9, M=M, N=128, C1=cin, ld1=cin,
+                                  ldw=9 * cin, ldc=128, spatial=(H, W, H, W, 1, 1, 1, 0), tile=20))
 
 
 def test_halo512_is_the_automatic_choice_from_256_units_and_rejects_other_shapes():

@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--tol", type=float, default=0.0, help="0 = bit-exact; else max |a-b| / max|a|")
     ap.add_argument("--dt", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4", "up2", "smallgemm", "halo512", "halo512big"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
+    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4", "up2", "smallgemm", "halo512", "halo512big", "halo160b"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
     args = ap.parse_args()
     dt = 0 if args.dt == "bf16" else 1
     rng = np.random.default_rng(0)
@@ -87,6 +87,9 @@ def main():
     if args.cases == "halo512":     # tile 17 (32 x 16-pixel units, 32-channel chunks): borders, 1 / 3 / 5 chunks, several column tiles
         cases = [("conv", c, 1) for c in [(2, 16, 32, 32, 128, 0), (1, 32, 64, 96, 128, 0), (3, 16, 64, 160, 256, 0), (2, 48, 32, 64, 384, 0), (1, 64, 64, 128, 128, 0),
                                            (8, 64, 64, 512, 512, 0), (2, 128, 128, 256, 256, 0)]]
+    if args.cases == "halo160b":    # tile 20 (16 x 16 pixels x 160 channels): borders, 1 / 3 / 10 chunks, one / two / four column tiles, the bench shapes
+        cases = [("conv", c, 1) for c in [(2, 16, 16, 32, 160, 0), (1, 32, 48, 96, 320, 0), (3, 16, 32, 64, 640, 0), (8, 64, 64, 320, 320, 0), (8, 64, 64, 640, 320, 0),
+                                           (8, 64, 64, 960, 320, 0), (4, 64, 64, 320, 320, 0), (8, 32, 32, 640, 640, 0)]]
     if args.cases == "halo512big":  # the VAE's ResnetBlock convolutions at batch 8
         cases = [("conv", c, 1) for c in [(8, 512, 512, 128, 128, 0), (8, 512, 512, 256, 128, 0), (8, 256, 256, 256, 256, 0), (8, 256, 256, 512, 256, 0),
                                            (8, 128, 128, 512, 512, 0), (8, 64, 64, 512, 512, 0)]]

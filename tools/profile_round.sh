@@ -6,7 +6,7 @@
 #      stamped with the kernel source hash bench.py checks before it quotes roofline.traffic
 #   3. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -> pmc_mfma_busy_bench.json
 # (counters are never combined with a trace domain: gpurun refuses that; the program itself follows `--`.)
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$R/prof
 mkdir -p $OUT
@@ -25,6 +25,7 @@ python3 $ROOT/tools/prof_summary.py pmc $OUT/pmc_fetch $OUT/pmc_fetch.json --pas
 python3 $ROOT/tools/prof_summary.py pmc $OUT/pmc_write $OUT/pmc_write.json --passes 4 > /dev/null
 python3 $ROOT/tools/prof_summary.py pmc $OUT/pmc_mfma $OUT/pmc_mfma_busy_bench.json --passes 4 > /dev/null
 python3 $ROOT/tools/exp/pmc_by_kernel.py $OUT/pmc_fetch FETCH_SIZE > $OUT/pmc_fetch_by_kernel.txt
+python3 $ROOT/tools/exp/pmc_mfma_by_kernel.py $OUT/pmc_mfma > $OUT/pmc_mfma_busy_by_kernel.txt
 python3 - $OUT $ROOT <<'PY'
 import json, sys, os
 out, root = sys.argv[1], sys.argv[2]
