@@ -331,6 +331,17 @@ def main() -> None:
         # ---- the mode that meets the north-star tolerance, timed in the SAME run (the headline above is the fast bf16 mode)
         try:
             result["parity_mode"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err)
+            pm = result["parity_mode"]
+            # how to read `value` against BASELINE.json's north star: `value` is the bf16-storage mode that
+            # configs[1] names — its own image error is 1.2e-2 — and the throughput at which "parity within 1e-3" HOLDS is the figure below
+            result["north_star"] = {
+                "parity_tolerance": NORTH_STAR,
+                "images_per_s_at_parity": pm.get("images_per_s") if pm.get("meets_north_star") else None,
+                "ratio_to_value": round(pm["images_per_s"] / value, 3) if pm.get("meets_north_star") and value else None,
+                "mode": "precision=\"mixed\" (fp32 activation stream, 1 - 3 fp16 products per layer class), same model / inputs / run",
+                "value_mode_image_error": result.get("parity_vs_reference_golden", {}).get("rel_err_image_samples"),
+                "scope": "well-conditioned weights (synthetic smooth set, tests/golden/full_det512.npz); with outlier channels in the weights "
+                         "the mode that holds 1e-3 is precision=\"high\" (~0.36 x): tests/test_gpu_heavy.py, profiles/r05/moderate_policies.log"}
         except Exception as e:       # never take the headline down
             result["parity_mode"] = {"error": repr(e)}
     if dist is not None:

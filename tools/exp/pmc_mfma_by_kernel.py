@@ -1,6 +1,7 @@
 """Per-kernel matrix-pipe occupancy from one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass over bench.py:
     python3 tools/exp/pmc_mfma_by_kernel.py <rocprof dir>
-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs) per kernel name (and grid, for the igemm kernels) —
+busy fraction = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8: the counter is summed over
+the 8 XCDs) per kernel name (and grid, for the igemm kernels) —
 the same definition tools/prof_summary.py uses per family (the halo kernels on their own, not the family figure)."""
 import collections
 import csv
@@ -30,7 +31,7 @@ for key, c in agg.items():
     act = c.get("GRBM_GUI_ACTIVE", 0.0)
     if act <= 0:
         continue
-    rows.append((c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (act * 4 * 256), act, key))
+    rows.append((c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * act / 8.0), act, key))
 print(f"{'kernel':56s} {'grid':>10s} {'launches':>8s} {'GUI-active cycles/launch':>24s}  MFMA pipe busy")
 for frac, act, (k, g) in sorted(rows, key=lambda r: -r[1])[:40]:
     n = max(1, cnt[(k, g)])
