@@ -821,7 +821,8 @@ class Emitter:
         if subpix:
             tile, splitk = 16, 1
         if x.gn_in is not None:          # the input's GroupNorm rides in this convolution's patch staging (group_norm(..., conv_n=N))
-            if taps != 9 or stride != 1 or pad_tl != 1 or ups or self.hp or not ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, N, splitk, x.ld):
+            if (taps != 9 or stride != 1 or pad_tl != 1 or ups or (self.hp and (a.dtype != self.dtype or parts != 1 or a is not x.t))
+                    or not ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, N, splitk, x.ld)):
                 raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")
             tile = 0             # (edtr_igemm picks the halo geometry itself: tile 17 from 256 units of 512 pixels, tile 16 below)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
@@ -871,10 +872,15 @@ class Emitter:
         y = self.new(rows, C)
         return y, y
 
-    def gn_deferrable(self, x: Act, conv_n: int) -> bool:
+    def gn_deferrable(self, x: Act, conv_n: int, feeds=None) -> bool:
         """Can the 3x3 / stride 1 / pad 1 convolution with ``conv_n`` output channels that consumes this GroupNorm apply it itself
-        (fast modes, halo tile in its 16 x 16-patch geometry)?  conv_n < 0: the consumer is edtr_conv128_out with -conv_n channels."""
-        if not conv_n or self.hp or self.invariant or x.t.dtype == torch.float32:
+        (halo tiles)?  conv_n < 0: the consumer is edtr_conv128_out with -conv_n channels.  Fast modes: any 16-bit tensor.  fp32-stream
+        modes (round 5): only a BRANCH-INTERNAL tensor that is already stored in the operand format (conv1 -> norm2 -> conv2 of a
+        ResBlock under `branch16`) whose consumer runs the one-part product — the same arithmetic and rounding as the apply launch."""
+        if not conv_n or self.invariant or x.t.dtype == torch.float32:
+            return False
+        if self.hp and (conv_n < 0 or x.t.dtype != self.dtype or feeds is None or self.feeds_parts(feeds, x.rows) != 1
+                        or os.environ.get("EDTR_GN_IN_CONV_HP", "1") == "0"):
             return False
         if conv_n < 0:
             return ops.conv128_out_ok(x.H, x.W, x.C, -conv_n)
@@ -893,7 +899,7 @@ class Emitter:
         convolution with that many output channels — where the halo tile takes it, no apply launch is emitted: one small launch
         turns the statistics into a (scale, shift) table and the convolution normalises its operand while staging it (the returned
         Act carries the RAW tensor; ``take``: it takes over x's storage, i.e. the caller is done with x)."""
-        if out is None and self.gn_deferrable(x, conv_n):
+        if out is None and self.gn_deferrable(x, conv_n, feeds):
             gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
             table = self.arena.alloc((x.B, x.C, 2), torch.float32)
             hw = x.H * x.W
@@ -939,7 +945,7 @@ class Emitter:
         """Statistics half only (tiled VAE: the caller pools `sums` across tiles before the apply half).
         Returns a closure that emits the apply half and yields the normalised activation.  ``conv_n`` / ``take``: as group_norm —
         the apply half is then the (scale, shift) table launch and the activation stays raw."""
-        if self.gn_deferrable(x, conv_n):
+        if self.gn_deferrable(x, conv_n, feeds):
             if x.gnp is not None:
                 self.prog.add(ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums))
             else:
