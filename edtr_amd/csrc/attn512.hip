@@ -92,14 +92,16 @@ __global__ void __launch_bounds__(512, 1) flash_attn512_kernel(const edtr_attn_p
         const int chan = (Lr & ~63) + 16 * (rr >> 2) + 4 * cb + (rr & 3);
         voff_v = (uint32_t)((chan * p.vt_ld + ((slot ^ key8(Lr)) * 8)) * 2);
     }
-    auto stage = [&](int t, int buf) {
+    // piece j of a wave and tile (0..3 K, 4..7 V^T): K piece j = LDS row (wave + 8 (j & 1)) + 16 (j >> 1)
+    auto stage_piece = [&](int t, int buf, int j8) {
         const uint32_t sk = (uint32_t)(t * TK) * (uint32_t)p.k_ld * 2u, sv = (uint32_t)(t * TK * 2);
+        const int j = j8 & 3;
+        if (j8 < 4) dma(voff_k[j & 1], srd_k, sk + (uint32_t)((j >> 1) * 4 * p.k_ld * 2), smem_base + K_BASE + buf * KTILE + (wave + 8 * (j & 1) + 16 * (j >> 1)) * 1024);
+        else dma(voff_v, srd_v, sv + (uint32_t)(128 * j) * (uint32_t)p.vt_ld * 2u, smem_base + V_BASE + buf * VTILE + (wave + 8 * j) * 1024);
+    };
+    auto stage = [&](int t, int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // K piece j: LDS row (wave + 8 (j & 1)) + 16 (j >> 1)
-            dma(voff_k[j & 1], srd_k, sk + (uint32_t)((j >> 1) * 4 * p.k_ld * 2), smem_base + K_BASE + buf * KTILE + (wave + 8 * (j & 1) + 16 * (j >> 1)) * 1024);
-            dma(voff_v, srd_v, sv + (uint32_t)(128 * j) * (uint32_t)p.vt_ld * 2u, smem_base + V_BASE + buf * VTILE + (wave + 8 * j) * 1024);
-        }
+        for (int j8 = 0; j8 < 8; ++j8) stage_piece(t, buf, j8);
     };
     stage(0, 0);
 
@@ -133,9 +135,10 @@ __global__ void __launch_bounds__(512, 1) flash_attn512_kernel(const edtr_attn_p
         constexpr int BUF = decltype(BUFc)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // tile t landed for every wave; every wave is past tile t - 1
-        if (t + 1 < NT) stage(t + 1, BUF ^ 1);
+        const bool more = t + 1 < NT;                       // tile t + 1's eight pieces are requested one per MFMA group of the S phase below: up
+                                                            // front they cost ~500 cycles of DMA issue with no MFMA of any wave beside them
         // ---- S^T block of this wave: 32 keys x 16 queries over d = 512
-        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f}, s2 = {0.0f, 0.0f, 0.0f, 0.0f}, s3 = {0.0f, 0.0f, 0.0f, 0.0f};      // two chains per key block
 #pragma unroll
         for (int sh = 0; sh < 8; ++sh) {                    // two steps at a time: 4 fragment reads in flight (8 would spill)
             U4 kf[2][2];
@@ -144,12 +147,14 @@ __global__ void __launch_bounds__(512, 1) flash_attn512_kernel(const edtr_attn_p
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
                     kf[m][kb] = *reinterpret_cast<const U4*>(smem + koff[2 * (sh & 1) + m] + BUF * KTILE + kb * 16384 + (sh >> 1) * 256);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                s0 = T::mfma16(kf[m][0], qf[2 * sh + m], s0);
-                s1 = T::mfma16(kf[m][1], qf[2 * sh + m], s1);
-            }
+            if (more) stage_piece(t + 1, BUF ^ 1, sh);
+            s0 = T::mfma16(kf[0][0], qf[2 * sh], s0);
+            s1 = T::mfma16(kf[0][1], qf[2 * sh], s1);
+            s2 = T::mfma16(kf[1][0], qf[2 * sh + 1], s2);
+            s3 = T::mfma16(kf[1][1], qf[2 * sh + 1], s3);
         }
+        s0 += s2;
+        s1 += s3;
         // ---- online softmax of this lane's query over its 8 keys (8 lq .. 8 lq + 7), exp2 domain
         float sv[8] = {s0[0] * sc, s0[1] * sc, s0[2] * sc, s0[3] * sc, s1[0] * sc, s1[1] * sc, s1[2] * sc, s1[3] * sc};
         float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));

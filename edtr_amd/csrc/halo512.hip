@@ -23,6 +23,7 @@
 // raw s_barriers, one weight piece per wave and tap, five patch pieces per wave and chunk.
 // a_gn (GroupNorm + SiLU of the input applied in the patch staging) as in tile 16; per output pixel it normalises 1.20 patch
 // pixels instead of 1.27.
+// The file also holds tile 20 (igemm_halo160_kernel, below): the same ideas on 16 x 16 pixels x 160 channels for N % 160 == 0.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -103,7 +104,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 }
 
 // ---- epilogue of the halo kernels of this file, straight from the accumulators (no LDS staging).  NW = waves per workgroup
-// (8: tile 17, wave = 4 rows x 32 pixels; 4: tile 19, wave = 8 rows x 16 pixels), mu0 = the wave's first pixel, RED_OFF = LDS offset of
+// (8: tile 17, wave = 4 rows x 32 pixels; 4 would be 8 rows x 16 pixels: the removed two-workgroups-per-CU experiment), mu0 = the wave's first pixel, RED_OFF = LDS offset of
 // the GroupNorm scratch (below it: 16 KiB per wave for the residual)
 template <typename T, int NW, int RED_OFF>
 __device__ __forceinline__ void direct_epilogue(const edtr_igemm_params& p, f32x4 (&acc)[8][4], char* smem, uint32_t smem_base, int lane, int wave,
