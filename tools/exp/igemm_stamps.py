@@ -24,7 +24,7 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "edtr_amd", "csrc", "igemm.hip")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DEDTR_STAMPS",
-                    src, "-o", SO], check=True)
+                    src, os.path.join(ROOT, "edtr_amd", "csrc", "halo512.hip"), "-o", SO], check=True)
     print(SO)
 
 
@@ -124,6 +124,17 @@ def run():
             case(f"t{t} ff.out 64^2 K1280 N320 +res", B * 4096, 320, 1280, residual=True, tile=t)
             case(f"t{t} proj 32^2 K640 N640 +res", B * 1024, 640, 640, residual=True, tile=t)
             case(f"t{t} conv 64^2 320->320", B * 4096, 320, 320, taps=9, H=64, tile=t)
+        return
+    if len(sys.argv) > 2 and sys.argv[2] == "short":          # the transformer blocks' square linears: one round of <= 512 workgroups
+        for t in (3, 8):
+            case(f"t{t} M32768 K320 N320 +res", 32768, 320, 320, residual=True, tile=t)
+            case(f"t{t} M8192 K640 N640 +res", 8192, 640, 640, residual=True, tile=t)
+            case(f"t{t} M2048 K1280 N1280 +res", 2048, 1280, 1280, residual=True, tile=t)
+            case(f"t{t} M1024 K1280 N1280 +res", 1024, 1280, 1280, residual=True, tile=t)
+            case(f"t{t} M512 K1280 N1280 +res", 512, 1280, 1280, residual=True, tile=t)
+            case(f"t{t} M2048 K5120 N1280 +res", 2048, 1280, 5120, residual=True, tile=t)
+            case(f"t{t} M4096 K640 N640 +res", 4096, 640, 640, residual=True, tile=t)
+            case(f"t{t} M16384 K320 N320 +res", 16384, 320, 320, residual=True, tile=t)
         return
     if len(sys.argv) > 2 and sys.argv[2] == "spatial1":
         case("1x1 spatial 64^2 K320 N320", B * 4096, 320, 320, taps=1, H=64)
