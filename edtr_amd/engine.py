@@ -488,6 +488,9 @@ class Act:
     gn_in: Optional[torch.Tensor] = None
     gn_silu: bool = True
     owns: bool = True
+    # emits the ordinary apply launch of that GroupNorm and returns the normalised Act: what Emitter.conv falls back to when the
+    # convolution that receives the deferred Act turns out not to be one the halo tiles take (the decision is conv()'s)
+    gn_apply: Optional[object] = None
 
     @property
     def ld(self) -> int:
@@ -792,6 +795,21 @@ class Emitter:
         parts = self.parts_for(name, M, N, taps * x.C)
         if parts == ops.PARTS_2W and (taps != 1 or x.C % 64):
             parts = 3           # (the weights-exact form exists for 1x1 convolutions = plain GEMMs)
+        if x.gn_in is not None:          # a deferred GroupNorm: is this one of the convolutions that apply it while staging their operand?
+            img8_ = taps == 9 and stride == 1 and pad_tl == 1 and not ups and (x.H, x.W) == (8, 8) and x.C % 64 == 0
+            fusable = (taps == 9 and stride == 1 and pad_tl == 1 and not ups and not self.invariant
+                       and (not self.hp or (x.t.dtype == self.dtype and parts == 1))
+                       and ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, N, ops.choose_splitk(M, N, taps * x.C, img8=img8_)[1], x.ld))
+            if not fusable:
+                # the caller's conv_n promised another convolution than the one that arrived: the GroupNorm gets its
+                # own apply launch after all, on the same statistics, and the convolution runs on the normalised tensor
+                if x.gn_apply is None:
+                    raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")
+                xn = x.gn_apply()
+                y = self.conv(xn, prefix, taps=taps, stride=stride, pad_tl=pad_tl, ups=ups, rowvec=rowvec, residual=residual, out=out,
+                              out_f32=out_f32, alpha=alpha, name=name, stats=stats, feeds=feeds, mirror=mirror)
+                self.free(xn)
+                return y
         a, tmp = x.t, None
         if self.hp:
             a, tmp, parts = self._operand(x.t, x.rows, x.C, parts)
@@ -823,7 +841,7 @@ class Emitter:
         if x.gn_in is not None:          # the input's GroupNorm rides in this convolution's patch staging (group_norm(..., conv_n=N))
             if (taps != 9 or stride != 1 or pad_tl != 1 or ups or (self.hp and (a.dtype != self.dtype or parts != 1 or a is not x.t))
                     or not ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, N, splitk, x.ld)):
-                raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")
+                raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")      # (checked above)
             tile = 0             # (edtr_igemm picks the halo geometry itself: tile 17 from 256 units of 512 pixels, tile 16 below)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         gnp = None
@@ -887,8 +905,8 @@ class Emitter:
         _, splitk = ops.choose_splitk(x.rows, conv_n, 9 * x.C)
         return ops.gn_in_conv_ok(x.B, x.H, x.W, x.C, conv_n, splitk, x.ld)
 
-    def _deferred(self, x: Act, table: torch.Tensor, silu: bool, take: bool) -> Act:
-        y = Act(x.t, x.B, x.H, x.W, x.C, x.gnp if take else None, gn_in=table, gn_silu=silu, owns=take)
+    def _deferred(self, x: Act, table: torch.Tensor, silu: bool, take: bool, apply=None) -> Act:
+        y = Act(x.t, x.B, x.H, x.W, x.C, x.gnp if take else None, gn_in=table, gn_silu=silu, owns=take, gn_apply=apply)
         if take:                 # the raw tensor now belongs to the deferred activation: the caller's em.free(x) is a no-op
             x.t, x.gnp = None, None
         return y
@@ -912,7 +930,24 @@ class Emitter:
                 self.prog.add(st)
                 self.prog.add(ops.make_gn_table(partial=None, tiles_per_image=0, sums=sums, B=x.B, C=x.C, HW=hw, gamma=gamma, beta=beta,
                                                 eps=eps, table=table))
-            return self._deferred(x, table, silu, take)
+            raw, gnp, geo = x.t, x.gnp, (x.B, x.H, x.W, x.C)
+            stat_sums = None if x.gnp is not None else sums
+
+            def apply_now() -> Act:          # the launch(es) group_norm would have emitted without the deferral, on the same statistics
+                xr = Act(raw, *geo, gnp)
+                y, carried = self._norm_out(xr.rows, xr.C, 1)
+                if gnp is not None and ops.gn_foldable(xr.H * xr.W, xr.C):
+                    _, ap = self._gn_recs(xr, prefix, eps, silu, None, y, partial=gnp)
+                elif gnp is not None:
+                    fs = self.arena.alloc((xr.B, 32, 2), torch.float64)
+                    _, ap = self._gn_recs(xr, prefix, eps, silu, fs, y)
+                    self.prog.add(ops.make_gn_finalize(partial=gnp, tiles_per_image=(xr.H * xr.W) // 128, B=xr.B, C=xr.C, sums=fs))
+                    self.arena.free(fs)
+                else:
+                    _, ap = self._gn_recs(xr, prefix, eps, silu, stat_sums, y, sums_zeroed=True)
+                self.prog.add(ap)
+                return Act(carried, *geo)
+            return self._deferred(x, table, silu, take, apply_now)
         parts = self.feeds_parts(feeds, x.rows)
         if self.hp and x.t.dtype != torch.float32:
             parts = 1            # (a branch-internal fp16 tensor: its low parts are exactly zero)
@@ -957,7 +992,15 @@ class Emitter:
                 table = self.arena.alloc((x.B, x.C, 2), torch.float32)
                 self.prog.add(ops.make_gn_table(partial=None, tiles_per_image=0, sums=sums, B=x.B, C=x.C, HW=x.H * x.W, gamma=gamma,
                                                 beta=beta, eps=eps, table=table))
-                return self._deferred(x, table, silu, take)
+                raw, geo = x.t, (x.B, x.H, x.W, x.C)
+
+                def apply_now() -> Act:
+                    xr = Act(raw, *geo)
+                    y, carried = self._norm_out(xr.rows, xr.C, 1)
+                    _, ap = self._gn_recs(xr, prefix, eps, silu, sums, y, sums_zeroed=True)
+                    self.prog.add(ap)
+                    return Act(carried, *geo)
+                return self._deferred(x, table, silu, take, apply_now)
             return table_apply
         parts = self.feeds_parts(feeds, x.rows)
         if self.hp and x.t.dtype != torch.float32:

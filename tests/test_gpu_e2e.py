@@ -522,3 +522,45 @@ def test_tiled_pre_restoration():
         num[..., hi:he, wi:we] += swinir(x[..., hi:he, wi:we].contiguous()).cpu() * w
         den[..., hi:he, wi:we] += w
     assert y.shape == x.shape and rel_err(y, num / den) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["stride2", "splitk", "fusable"])
+def test_deferred_groupnorm_falls_back_to_its_apply_launch(case):
+    """`group_norm(..., conv_n=N)` defers the apply to the consuming convolution on the caller's promise of what that
+    convolution is; when another one arrives (stride 2; a shape whose split-K the halo tile does not take) `Emitter.conv` emits the apply
+    launch itself instead of raising — same numbers as the undeferred program (reference model/vae.py:103-114: norm -> swish -> conv)."""
+    from edtr_amd.engine import Act, Arena, Emitter, Program, WeightStore
+    dev = torch.device("cuda:0")
+    B, H, C, N = 2, 80, 128, 128          # 50 units of 16 x 16 pixels: a shape the halo tile's fused GroupNorm takes
+    g = torch.Generator().manual_seed(3)
+    params = {"n.weight": torch.rand(C, generator=g) + 0.5, "n.bias": torch.randn(C, generator=g) * 0.1,
+              "c.weight": torch.randn(N, C, 3, 3, generator=g) / (3 * C ** 0.5), "c.bias": torch.randn(N, generator=g) * 0.1}
+    x0 = torch.randn(B * H * H, C, generator=g).to(dev, torch.bfloat16)
+    outs = []
+    for defer in (False, True):
+        prog, arena = Program("t"), Arena(dev, 1 << 26)
+        em = Emitter(prog, arena, WeightStore(params, torch.bfloat16, dev), torch.bfloat16)
+        xa = Act(arena.alloc((B * H * H, C), torch.bfloat16), B, H, H, C)
+        xa.t.copy_(x0)
+        kw = dict(stride=2, pad_tl=0) if case == "stride2" else {}
+        h = em.group_norm(xa, "n.", 1e-6, True, conv_n=N if defer else 0)
+        if defer:
+            assert h.gn_in is not None and h.gn_apply is not None
+            if case == "splitk":         # the promise breaks after the fact: the tensor the convolution sees is not 32-bit addressable
+                h = Act(h.t, h.B, h.H, h.W, h.C, h.gnp, gn_in=h.gn_in, gn_silu=h.gn_silu, owns=h.owns, gn_apply=h.gn_apply)
+                import edtr_amd.ops as ops_mod
+                real = ops_mod.gn_in_conv_ok
+                ops_mod.gn_in_conv_ok = lambda *a, **k: False
+        try:
+            y = em.conv(h, "c.", name="res.conv1", **kw)
+        finally:
+            if defer and case == "splitk":
+                ops_mod.gn_in_conv_ok = real
+        n_apply = sum(1 for r in prog.recs if r.name == "gn.apply")
+        assert n_apply == (1 if (not defer or case != "fusable") else 0), (case, defer, [r.name for r in prog.recs])
+        prog.run()
+        torch.cuda.synchronize()
+        outs.append(y.t.float().cpu())
+    err = (outs[0] - outs[1]).norm() / outs[0].norm()
+    assert err < (2e-2 if case == "fusable" else 1e-6), (case, float(err))

@@ -33,7 +33,7 @@ def run(dt, tile, *, M, N, K, taps, spatial, C1, a, w, bias, res, splitk=1, gnp=
     p.a1, p.C1, p.ld1, p.w, p.ldw = a.p, C1, C1, w.p, K
     if spatial:
         p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l, p.upsample2x = spatial
-    p.alpha, p.bias_n, p.residual, p.ldr = 1.0, bias.p, res.p, N
+    p.alpha, p.bias_n, p.residual, p.ldr = 1.0, bias.p, (None if os.environ.get('AB_NORES') else res.p), N
     p.out, p.ldc, p.tile, p.splitk = out.p, N, tile, splitk
     keep = [out]
     if splitk > 1:
@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--tol", type=float, default=0.0, help="0 = bit-exact; else max |a-b| / max|a|")
     ap.add_argument("--dt", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4", "up2", "smallgemm", "halo512", "halo512big", "halo160b"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
+    ap.add_argument("--cases", default="all", choices=["all", "halo", "smallm", "halo160", "b4", "up2", "smallgemm", "halo512", "halo512big", "halo160b", "bign"], help="halo: stride-1 3x3 convs on 16-pixel-aligned images only")
     args = ap.parse_args()
     dt = 0 if args.dt == "bf16" else 1
     rng = np.random.default_rng(0)
@@ -74,6 +74,9 @@ def main():
                                            (2048, 1280, 5120), (4096, 640, 640), (4096, 640, 2560), (8192, 640, 640), (1000, 520, 1152), (130, 136, 128), (77, 640, 1024),
                                            (300, 72, 192), (2048, 1280, 320)]]
         cases += [("gemm", (2048, 1280, 5120), 2), ("gemm", (1024, 1280, 5120), 3), ("gemm", (512, 1280, 1280), 2)]
+    if args.cases == "bign":        # the wide-N linears (GEGLU projection, fused qkv) as plain GEMMs: which tile would they want?
+        cases = [("gemm", g, 1) for g in [(32768, 2560, 320), (8192, 5120, 640), (2048, 10240, 1280), (32768, 960, 320), (8192, 1920, 640), (2048, 3840, 1280),
+                                           (32768, 1280, 320), (8192, 2560, 640), (2048, 5120, 1280)]]
     if args.cases == "up2":         # nearest-2x upsample convolutions (VAE decoder / UNet Upsample)
         cases = [("conv", c, 1) for c in [(2, 16, 16, 64, 128, 1), (1, 24, 8, 128, 256, 1), (8, 256, 256, 256, 256, 1), (8, 128, 128, 512, 512, 1),
                                            (8, 64, 64, 512, 512, 1), (8, 32, 32, 640, 640, 1), (8, 16, 16, 1280, 1280, 1), (8, 8, 8, 1280, 1280, 1)]]
@@ -110,7 +113,7 @@ def main():
         w = H.Dev(H.rand16(rng, (N, K), dt, 1.0 / np.sqrt(K)))
         bias = H.Dev(rng.standard_normal(N, dtype=np.float32))
         res = H.Dev(H.rand16(rng, (M, N), dt))
-        gnp = splitk == 1 and M % 128 == 0 and N % 32 == 0
+        gnp = splitk == 1 and M % 128 == 0 and N % 32 == 0 and not os.environ.get('AB_NORES')
         kw = dict(M=M, N=N, K=K, taps=taps, spatial=spatial, C1=C1, a=a, w=w, bias=bias, res=res, splitk=splitk, gnp=gnp)
         ya, ga, ta, ca = run(dt, args.a, **kw)
         yb, gb, tb, cb = run(dt, args.b, **kw)
