@@ -97,7 +97,7 @@ def main() -> None:
         if not steps_given:
             args.steps = 16
     if s50:
-        args.batch, args.size = 4, 512
+        args.batch, args.size = int(os.environ.get("EDTR_S50_BATCH", "4")), 512       # (EDTR_S50_BATCH: experiments only — configs[4] is batch 4 per GPU)
         args.no_cpu_baseline = True
         if not steps_given:
             args.steps = 8
