@@ -22,7 +22,7 @@ VARIANTS = {  # name: (ahead, dma_spread, stamps, drop)
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    others = [os.path.join(CSRC, "build", f"{n}.o") for n in ("igemm", "norm", "elementwise", "swin")]
+    others = [os.path.join(CSRC, "build", f"{n}.o") for n in ("igemm", "halo512", "attn512", "norm", "elementwise", "swin")]
     for name, (ahead, spread, stamps, drop) in VARIANTS.items():
         inc = os.path.join(OUT, f"attn_v3_{name}.inc")
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_v2.py"), "--ahead", str(ahead), "--dma-spread", str(spread),
