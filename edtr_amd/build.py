@@ -42,23 +42,42 @@ def source_hash() -> str:
     return h.hexdigest()[:12]
 
 
+def _object_key(flags, deps) -> str:
+    """sha1 over the compile flags and the bytes of every dependency: an object is reused only when this matches the key
+    written next to it, so an object compiled elsewhere or with other -D flags can never be linked by accident (mtimes lie)."""
+    import hashlib
+    h = hashlib.sha1(" ".join(flags).encode())
+    for d in deps:
+        with open(d, "rb") as fh:
+            h.update(b"\0" + os.path.basename(d).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
+    relink = force
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS + EXTRA_DEPS.get(src, [])):
-            # -Werror=pass-failed: a `#pragma unroll` the optimizer could not honour is an ERROR — in round 4 such a loop around the
-            # shared epilogue silently stayed rolled and sent a kernel's accumulators through scratch memory
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Werror=pass-failed", "-c", s, "-o", o]
+        # -Werror=pass-failed: a `#pragma unroll` the optimizer could not honour is an ERROR — in round 4 such a loop around the
+        # shared epilogue silently stayed rolled and sent a kernel's accumulators through scratch memory
+        flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Werror=pass-failed"]
+        key = _object_key(flags, [s] + HEADERS + EXTRA_DEPS.get(src, []))
+        keyfile = o + ".key"
+        have = open(keyfile).read().strip() if os.path.exists(keyfile) and os.path.exists(o) else ""
+        if force or have != key:
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+            with open(keyfile, "w") as fh:
+                fh.write(key + "\n")
+            relink = True
         objs.append(o)
-    if force or _stale(LIB_PATH, objs):
+    if relink or _stale(LIB_PATH, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -89,21 +89,34 @@ def params_fingerprint(module: nn.Module) -> Tuple:
         # first, the last and one middle parameter's identity catches whole-model conversions; a single `_parameters[...]` write
         # elsewhere still needs release_engines()
         plist = hit[1]
-        it = iter(module.parameters())
-        first = next(it, None)
+        first = next(iter(module.parameters()), None)
         if (first is None) != (not plist) or (plist and first is not plist[0]):
             hit = None
         elif len(plist) > 2:
-            sub = list(module._modules.values())[-1] if module._modules else module
-            last = None
-            for last in sub.parameters():
-                pass
-            if last is not None and last is not plist[-1]:
+            # last and middle: the last parameter of the last non-None child that has any (a reversed walk, no full traversal), and
+            # the first parameter of the middle child; both compared by MEMBERSHIP in the cached identity set — a tied parameter is
+            # deduplicated by module.parameters() and need not sit at plist[-1]
+            ids = hit[3]
+            kids = [m for m in module._modules.values() if m is not None]
+            probes = []
+            for sub in reversed(kids):
+                last = None
+                for last in sub.parameters():
+                    pass
+                if last is not None:
+                    probes.append(last)
+                    break
+            if kids:
+                mid = next(iter(kids[len(kids) // 2].parameters()), None)
+                if mid is not None:
+                    probes.append(mid)
+            if any(id(p) not in ids for p in probes):
                 hit = None
     if hit is None or hit[0] != _STRUCT_EPOCH[0]:
         plist = list(module.parameters())
-        hit = (_STRUCT_EPOCH[0], plist, hash(tuple(id(p) for p in plist)))     # (the objects' identities: a replaced parameter may
-        module.__dict__["_fp_params"] = hit                                    #  carry the same version counter as the old one)
+        ids = frozenset(id(p) for p in plist)                                  # (the objects' identities: a replaced parameter may
+        hit = (_STRUCT_EPOCH[0], plist, hash(tuple(id(p) for p in plist)), ids)  #  carry the same version counter as the old one)
+        module.__dict__["_fp_params"] = hit
     ver, dev = 0, None
     for p in hit[1]:
         ver += p._version

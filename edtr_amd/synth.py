@@ -110,9 +110,10 @@ def synth_param_moderate(key: str, shape: Tuple[int, ...], device=None) -> torch
     ~128, one large norm gain in ~64, sharper attention, larger biases — at factors (x8 rows, +-3 gains, x1.3 q / k, x3 biases)
     calibrated so that the residual stream stays below ~6e3, i.e. inside what the reference's own fp16-autocast GPU path runs with
     headroom, and the network's amplification of a rounding stays within a small factor of the smooth set's (the heavy set's 10 -
-    30 x makes its 4-step pipeline a poor gate: two builds of the same arithmetic moved its fp16 error 2 x).  This is the set on
-    which the FAST parity mode (precision="mixed") has a pinned claim off the smooth set: tests/test_gpu_heavy.py holds it to the
-    north-star 1e-3 against the reference's outputs (tests/golden/moderate.npz)."""
+    30 x makes its 4-step pipeline a poor gate: two builds of the same arithmetic moved its fp16 error 2 x).  What the tests pin
+    on this set (tests/test_gpu_heavy.py against the reference's outputs in tests/golden/moderate.npz): precision="mixed" does NOT
+    meet the north-star 1e-3 here (it measures 1.6 - 1.9e-3 and is bounded at <= 1.5 x its measured value); the modes asserted
+    against 1e-3 itself are the ones named there (`high`, and any faster mode that test lists)."""
     base = synth_param(key, shape, device=device)
     shape = tuple(int(s) for s in shape)
     n0 = shape[0] if len(shape) else 1

@@ -211,8 +211,9 @@ def gen_sd21():
 
 
 def gen_moderate():
-    """The same fixtures on the MODERATE-outlier weight set (edtr_amd.synth.synth_param_moderate: x4 rows, +-2 gains, x1.2 q / k): the
-    set on which the mixed parity mode is pinned to the north-star 1e-3 off the smooth set (tests/golden/moderate.npz)."""
+    """The same fixtures on the MODERATE-outlier weight set (edtr_amd.synth.synth_param_moderate: x8 rows, +-3 gains, x1.3 q / k,
+    x3 biases — the constants MODERATE_ROW / MODERATE_GAIN / MODERATE_QK there are authoritative): the robustness set off the smooth
+    one; which precision modes hold the north-star 1e-3 on it is pinned by tests/test_gpu_heavy.py (tests/golden/moderate.npz)."""
     gen_heavy(weights="moderate", tag="moderate", fname="moderate.npz")
 
 
