@@ -59,6 +59,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     objs = []
     relink = force
+    jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -69,14 +70,25 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         keyfile = o + ".key"
         have = open(keyfile).read().strip() if os.path.exists(keyfile) and os.path.exists(o) else ""
         if force or have != key:
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-            with open(keyfile, "w") as fh:
-                fh.write(key + "\n")
-            relink = True
+            jobs.append(([hipcc] + flags + ["-c", s, "-o", o], keyfile, key))
         objs.append(o)
+
+    def _compile(job):
+        cmd, keyfile, key = job
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        if os.path.exists(keyfile):
+            os.remove(keyfile)                 # (a failed compile must not leave a key that vouches for the old object)
+        subprocess.run(cmd, check=True)
+        with open(keyfile, "w") as fh:
+            fh.write(key + "\n")
+
+    if jobs:
+        # translation units compile independently: a few at a time (the container has 8 cores; one hipcc peaks near 3 GB)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("EDTR_BUILD_JOBS", "4")))) as pool:
+            list(pool.map(_compile, jobs))
+        relink = True
     if relink or _stale(LIB_PATH, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:
