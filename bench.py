@@ -50,7 +50,7 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
-    ap.add_argument("--precision", default="fast", choices=["fast", "mixed", "high"],
+    ap.add_argument("--precision", default="fast", choices=["fast", "mixed", "high", "hybrid"],
                     help="fast = 16-bit activation storage in --dtype (headline); mixed = the fast parity mode (fp32 stream, fp16 "
                          "operands, 1-3 products per layer class: edtr_amd/precision.py); high = the robust parity mode (fp32 stream, "
                          "bf16 split-3 products everywhere).  Both parity modes meet the 1e-3 north-star tolerance")
@@ -281,7 +281,8 @@ def main() -> None:
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"high": "bf16 split-3 products over an fp32 stream (precision=high)",
-                  "mixed": "fp16 1-3-part products over an fp32 stream (precision=mixed)"}.get(args.precision, args.dtype),
+                  "mixed": "fp16 1-3-part products over an fp32 stream (precision=mixed)",
+                  "hybrid": "fp16 storage in the denoiser, fp16 1-3-part products over an fp32 stream in the VAE (precision=hybrid)"}.get(args.precision, args.dtype),
         "data": "synthetic",
         "config": {"workload": (f"EDTR-seg s4 ({args.config}), configs[3]: tiled vae_encode (256-px tiles) + q_sample(t=200) + 4 x latent-tiled "
                                 f"(64/32) ControlNet+UNet + untiled vae_decode, batch {B}/GPU of {S}x{S}") if tiled else
@@ -299,8 +300,11 @@ def main() -> None:
         "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE_BY_WORKLOAD[args.workload] / (world * PEAK_TFLOPS * 1e12), 4)
         if (args.config == "sd21" and std_shape) else None,
     }
-    if args.precision == "mixed":
+    if args.precision in ("mixed", "hybrid") and cldm._policy() is not None:
         result["config"]["precision_policy"] = cldm._policy().describe()
+    if args.precision == "hybrid":
+        from edtr_amd.model.cldm import hybrid_sections
+        result["config"]["hybrid_sections"] = hybrid_sections()
     if args.dup:
         result["INVALID_measurement_aid"] = f"--dup {args.dup}"
 
@@ -741,7 +745,7 @@ def kernel_of(name: str) -> str:
 # for z_pre / latent / image over the three workloads) so that a 2x regression of a mode's numerics fails the run; the north-star
 # 1e-3 is what the parity modes (mixed, high) must additionally meet
 TOLERANCE = {"bf16": {"z_pre": 1.75e-2, "latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"z_pre": 2.2e-3, "latent": 1.3e-3, "image": 2.3e-3},
-             "mixed": {"z_pre": 1e-3, "latent": 8.2e-4, "image": 9e-4}, "high": {"z_pre": 4.4e-5, "latent": 1.8e-5, "image": 3.6e-5}}
+             "mixed": {"z_pre": 1e-3, "latent": 8.2e-4, "image": 9e-4}, "hybrid": {"z_pre": 1e-3, "latent": 1e-3, "image": 1e-3}, "high": {"z_pre": 4.4e-5, "latent": 1.8e-5, "image": 3.6e-5}}
 NORTH_STAR = 1e-3
 # max-norm bound as a multiple of the L2 tolerance: measured max / L2 ratios of the shipped modes are 0.9 - 1.3 (the peak of a latent / image is a few times its RMS)
 # (profiles/r04/maxnorm_measured.log), a defect in one 16 x 16 tile of a 512 x 512 image with O(1) errors gives > 100

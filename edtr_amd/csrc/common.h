@@ -189,6 +189,28 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
     return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
 
+// Buffer-addressed LDS-DMA: address = SRD base + voff (per lane) + soff (wave uniform); lanes whose voff fails the
+// descriptor's range check write zeros.
+constexpr uint32_t kOobOffset = 0xFFFFFF00u;     // >= num_records - 15 -> always out of range
+constexpr uint32_t kNumRecords = 0xFFFFFF00u;
+
+__device__ __forceinline__ u32x4 make_srd(const void* base) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    u32x4 srd;
+    srd.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    srd.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);   // stride 0 (raw buffer)
+    srd.z = kNumRecords;
+    srd.w = 0x00020000u;
+    return srd;
+}
+
+__device__ __forceinline__ void dma16_buf(uint32_t voff, const u32x4& srd, uint32_t soff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :
+                 : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
+                 : "memory");   // M0 is free here: hipcc keeps no value in it across statements on gfx950
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // tile 17 of edtr_igemm lives in its own translation unit (halo512.hip)

@@ -1,0 +1,316 @@
+// edtr_ffn — the feed-forward half of a BasicTransformerBlock in ONE launch (see include/edtr_hip.h):
+//     out = x + W2 . ( GEGLU( W1 . LayerNorm(x) + b1 ) ) + b2            reference model/attention.py:20-47, 232-233
+// As two edtr_igemm launches (+ a LayerNorm launch at batch 8) the (rows, 4 d) hidden tensor makes a round trip through HBM —
+// 84 MB written and read back at the 64 x 64 latent level, 34 us of memory time on its own — and both GEMMs are short-K launches
+// whose prologue / GEGLU epilogue is as long as their loop (profiles/r05/stamps_short_linears.log).  Here a workgroup owns 128
+// tokens for the whole hidden dimension and nothing but its tokens and the weights ever moves.
+//
+// Everything is computed TRANSPOSED so that the accumulator layout of one product is the operand layout of the next (the trick of
+// attention.hip / swin.hip) and the token rows live in REGISTERS:
+//   H^T[hidden][token] = W1 . X^T      A = W1 rows from LDS, B = this wave's 32 token rows (20 fragments = 80 registers, loaded once)
+//   G = value * gelu(gate)              in the accumulators: lane = token, registers = hidden units; LayerNorm folded in per lane
+//   O^T[out][token] += W2 . G^T        A = W2 rows from LDS, B = G packed to 16 bits — the accumulator registers 8 u .. 8 u + 7 of a
+//                                       32 x 32 tile ARE the B fragment of k-step u once W2's columns are permuted inside every group
+//                                       of 16 ([0-3, 8-11, 4-7, 12-15], done on the host: edtr_hip.h)
+// Eight waves: wave (t, h) owns tokens 32 t .. 32 t + 31; in the first product it computes hidden half h of the chunk (32 gated
+// units = a 32-row value tile and its gate tile: one lane holds a value and its gate), in the second product output half h (160
+// columns = five 32 x 32 accumulators).  The two waves of a token tile swap their G fragments through 2 KiB of LDS per chunk.
+// LDS holds only weights: 15 granules of 8 KiB (64 rows x 64 k, the XOR-swizzled tile of common.h) per 64-unit chunk — ten of
+// W1 (k-tile kt, half h) and five of W2 (64 output rows each) — every granule type has a FIXED slot, refilled by LDS-DMA for the
+// next chunk as soon as the step that read it is over (one dma per wave and granule: the counted vmcnt waits are uniform).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int FD = 320;                    // model width d
+constexpr int FH = 1280;                   // gated hidden width 4 d
+constexpr int FBM = 128;                   // tokens per workgroup
+constexpr int FTHREADS = 512;
+constexpr int FCH = 64;                    // gated hidden units per chunk
+constexpr int FNCH = FH / FCH;             // 20 chunks
+constexpr int GRAN = 8192;                 // one granule: 64 rows x 128 bytes
+constexpr int NGRAN = 15;                  // per chunk: W1 (kt, h) at slot 2 kt + h, W2 rows 64 j .. at slot 10 + j
+constexpr int RING = NGRAN * GRAN;
+constexpr int XCH_OFF = RING;              // G fragments: [wave][k-step u] x 1 KiB (one buffer: a chunk's fragments are written behind the
+constexpr int XCH = 8 * 2048;              //  barrier of its last k-tile, which every wave reaches after reading the previous chunk's)
+constexpr int XFL = 2;                     // token fragments 20 - XFL .. 19 live in LDS, not in registers (the register file is full)
+constexpr int XF_OFF = XCH_OFF + XCH;      // [wave][XFL] x 1 KiB
+constexpr int CST_OFF = XF_OFF + 8 * XFL * 1024;     // folded-LayerNorm constants of a chunk: [chunk parity][half][128 floats]
+constexpr int CST = 2 * 2 * 512;
+constexpr int FLDS = CST_OFF + CST;        // 157696 bytes
+constexpr int OPITCH = 656;                // output tile row pitch in bytes (640 + 16: the 8-byte column writes of 32 rows spread over the banks)
+static_assert(FLDS <= 160 * 1024 && FBM * OPITCH <= RING, "LDS budget");
+
+// one buffer_load_dword ... lds: lane i's 4 bytes land at lds_addr + 4 i (buffer-addressed like dma16_buf: one 32-bit offset per lane,
+// the chunk moves the scalar offset — no 64-bit pointer to carry through the loop)
+__device__ __forceinline__ void dma4_buf(uint32_t voff, const u32x4& srd, uint32_t soff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %3 offen lds"
+                 :
+                 : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+#ifdef FFN_DRAIN        // diagnostic build (tools/exp/ffn_debug.py): every counted wait drains the queue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void block_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename T, int HALF>
+__device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int t = wave & 3;
+    constexpr int h = HALF;
+    const int m0 = blockIdx.x * FBM;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    // ---- this wave's share of every granule: rows 8 wave .. 8 wave + 7, LDS slot (lane & 7) holds logical chunk slot ^ key(row)
+    const int grow = 8 * wave + (lane >> 3);
+    const int gchunk = (lane & 7) ^ ((grow >> 1) & 7);
+    const uint32_t voff1 = (uint32_t)((grow * FD + 8 * gchunk) * 2);             // W1 [2 FH][FD]
+    const uint32_t voff2 = (uint32_t)((grow * FH + 8 * gchunk) * 2);             // W2 [FD][FH]
+    const u32x4 srd1 = make_srd(p.w1), srd2 = make_srd(p.w2);
+    const uint32_t my_slot = lds0 + wave * 1024;
+    auto issue_w1 = [&](int c, int kt) {          // both halves of k-tile kt of chunk c
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            dma16_buf(voff1, srd1, (uint32_t)(((128 * c + 64 * hh) * FD + 64 * kt) * 2), my_slot + (2 * kt + hh) * GRAN);
+    };
+    auto issue_w2 = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dma16_buf(voff2, srd2, (uint32_t)((64 * j * FH + 64 * c) * 2), my_slot + (10 + j) * GRAN);
+    };
+    // constants of chunk c: 2 halves x 128 floats; wave (t, hw) brings floats 64 (t & 1) .. of half hw (waves t and t + 2 bring the
+    // same 256 bytes: every wave issues ONE dma per chunk, which keeps the counted waits uniform)
+    const u32x4 srdc = make_srd(p.cst);
+    auto issue_cst = [&](int c) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));            // (re-derived per use: see the GEGLU section)
+        dma4_buf((uint32_t)(ln * 4 + c * 1024 + ((wave >> 2) * 128 + (t & 1) * 64) * 4), srdc, 0u,
+                 lds0 + CST_OFF + (c & 1) * 1024 + (wave >> 2) * 512 + (t & 1) * 256);
+    };
+
+    // ---- prologue: the token rows into registers (B fragments: lane = token l31, k = 16 s + 8 lh ..), first weights in flight
+    U4 xf[20 - XFL];
+    U4 xtail[XFL];
+    {
+        const uint16_t* xr = static_cast<const uint16_t*>(p.x) + (int64_t)(m0 + 32 * t + l31) * p.ldx + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 20 - XFL; ++s) xf[s] = ldg16(xr + 16 * s);
+#pragma unroll
+        for (int s = 0; s < XFL; ++s) xtail[s] = ldg16(xr + 16 * (20 - XFL + s));
+    }
+    issue_cst(0);
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) issue_w1(0, kt);
+
+    // LayerNorm statistics of this lane's token over the stored 16-bit values (model/attention.py:224 norm3, eps 1e-5)
+    float k0, k1, k0h;
+    {
+        float s = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            float f[8];
+            unpack8<T>(i < 20 - XFL ? xf[i < 20 - XFL ? i : 0] : xtail[i < 20 - XFL ? 0 : i - (20 - XFL)], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s += f[j]; q = __builtin_fmaf(f[j], f[j], q); }
+        }
+#pragma unroll
+        for (int i = 0; i < XFL; ++i) *reinterpret_cast<U4*>(smem + XF_OFF + (wave * XFL + i) * 1024 + lane * 16) = xtail[i];      // (own lanes only: no barrier needed)
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float mean = s * (1.0f / FD);
+        const float var = fmaxf(q * (1.0f / FD) - mean * mean, 0.0f);
+        k0 = __builtin_amdgcn_rsqf(var + p.eps);
+        k1 = -k0 * mean;
+        k0h = 0.5f * k0;
+    }
+
+    f32x16 oacc[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[b][r] = 0.0f;
+
+    const int arow = l31 * 128, akey = (l31 >> 1) & 7;        // fragment row l31 (and l31 + 32: same key) of a granule
+    auto frag = [&](const char* gran, int row32, int c) {     // 16-byte chunk c of row row32 + l31
+        return *reinterpret_cast<const U4*>(gran + row32 * 128 + arow + ((c ^ akey) << 4));
+    };
+
+#pragma unroll 1
+    for (int c = 0; c < FNCH; ++c) {
+        const bool more = c + 1 < FNCH;
+        f32x16 hv, hg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hv[r] = 0.0f; hg[r] = 0.0f; }
+
+        // ---- first product: five k-tiles of 64
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt) {
+            // this wave's pieces of k-tile kt have landed (counts: DMAs issued after them, see the schedule in the header comment)
+            if (kt == 0) wait_vm<8>();
+            else if (more) wait_vm<12>();
+            else if (kt == 1) wait_vm<11>();
+            else if (kt == 2) wait_vm<9>();
+            else if (kt == 3) wait_vm<7>();
+            else wait_vm<5>();
+            block_sync();                                       // ... everyone's; the step before is over: its slots are free
+            if (kt == 0) {
+                issue_w2(c);                                    // needed five steps from now
+                if (more) issue_cst(c + 1);
+            } else if (more) {
+                issue_w1(c + 1, kt - 1);
+            }
+            const char* gran = smem + (2 * kt + h) * GRAN;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const U4 av = frag(gran, 0, 2 * ks + lh), ag = frag(gran, 32, 2 * ks + lh);
+                constexpr int NR = 20 - XFL;
+                const int si = 4 * kt + ks;
+                U4 xb_;
+                if (si < NR) {
+                    xb_ = xf[si < NR ? si : 0];
+                } else {
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    xb_ = *reinterpret_cast<const U4*>(smem + XF_OFF + (wave * XFL + (si < NR ? 0 : si - NR)) * 1024 + ln * 16);
+                }
+                hv = T::mfma(av, xb_, hv);
+                hg = T::mfma(ag, xb_, hg);
+            }
+        }
+
+        // ---- GEGLU with the folded LayerNorm: register r = 4 q + e is hidden unit e + 8 q + 4 lh of this wave's 32
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));        // (addresses re-derived here: carried through the loop they spill, and a scratch reload drains the DMA queue)
+            const float* cst = reinterpret_cast<const float*>(smem + CST_OFF + (c & 1) * 1024 + h * 512) + 4 * (ln >> 5);
+            char* mine = smem + XCH_OFF + wave * 2048 + ln * 16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float val[8], gate[8];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * u + qq;
+                    const f32x4 c1v = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 0) * 2 + 0) * 8);
+                    const f32x4 c2v = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 0) * 2 + 1) * 8);
+                    const f32x4 c1g = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 1) * 2 + 0) * 8);
+                    const f32x4 c2g = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 1) * 2 + 1) * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        val[4 * qq + e] = __builtin_fmaf(k0, hv[4 * q + e], __builtin_fmaf(k1, c1v[e], c2v[e]));
+                        gate[4 * qq + e] = __builtin_fmaf(k0h, hg[4 * q + e], __builtin_fmaf(k1, c1g[e], c2g[e]));      // gate / 2 (constants halved on the host)
+                    }
+                }
+                gelu_erf_lockstep<true>(gate);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] *= gate[e];
+                *reinterpret_cast<U4*>(mine + u * 1024) = pack8<T>(val);
+            }
+        }
+
+        // ---- second product: K = this chunk's 64 gated units (k-step 2 h' + u: half h', u = 0 / 1), five output tiles
+        if (more) wait_vm<9>(); else wait_vm<0>();
+        block_sync();                                           // W2 of the chunk everyone's; both halves' G fragments published
+        if (more) issue_w1(c + 1, 4);
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const char* xb = smem + XCH_OFF + (wave & 3) * 2048 + ln * 16;      // wave t of half 0; + 8192: half 1
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const U4 g = *reinterpret_cast<const U4*>(xb + (ks >> 1) * 8192 + (ks & 1) * 1024);
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    const int gb = 5 * h + b;
+                    const U4 a = frag(smem + (10 + (gb >> 1)) * GRAN, 32 * (gb & 1), 2 * ks + lh);
+                    oacc[b] = T::mfma(a, g, oacc[b]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: + bias + residual (the raw rows) in fp32, one rounding, through an LDS tile so that whole rows leave coalesced
+    block_sync();                                               // every wave is done with the ring
+    {
+        const uint16_t* xr = static_cast<const uint16_t*>(p.x) + (int64_t)(m0 + 32 * t + l31) * p.ldx;
+        char* trow = smem + (32 * t + l31) * OPITCH;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            uint2 res[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const uint2*>(xr + 160 * h + 32 * b + 8 * q + 4 * lh);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 160 * h + 32 * b + 8 * q + 4 * lh;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b2 + n);
+                const float r0 = T::to_f32((uint16_t)(res[q].x & 0xffff)), r1 = T::to_f32((uint16_t)(res[q].x >> 16));
+                const float r2 = T::to_f32((uint16_t)(res[q].y & 0xffff)), r3 = T::to_f32((uint16_t)(res[q].y >> 16));
+                uint2 o;
+                o.x = pack2<T>(oacc[b][4 * q + 0] + bias[0] + r0, oacc[b][4 * q + 1] + bias[1] + r1);
+                o.y = pack2<T>(oacc[b][4 * q + 2] + bias[2] + r2, oacc[b][4 * q + 3] + bias[3] + r3);
+                *reinterpret_cast<uint2*>(trow + n * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        uint16_t* og = static_cast<uint16_t*>(p.out);
+#pragma unroll
+        for (int i = 0; i < (FBM * 40) / FTHREADS; ++i) {
+            const int idx = tid + FTHREADS * i, row = idx / 40, ch = idx - row * 40;
+            const U4 v = *reinterpret_cast<const U4*>(smem + row * OPITCH + ch * 16);
+            stg16(og + (int64_t)(m0 + row) * p.ldo + ch * 8, v);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(FTHREADS, 1) ffn320_kernel(const edtr_ffn_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (threadIdx.x < 256) ffn_body<T, 0>(p, smem);
+    else ffn_body<T, 1>(p, smem);
+}
+
+template <typename T>
+int launch_ffn(const edtr_ffn_params& p, hipStream_t stream) {
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&ffn320_kernel<T>), FLDS, attr_set)) return rc_;
+    hipLaunchKernelGGL((ffn320_kernel<T>), dim3(p.M / FBM), dim3(FTHREADS), FLDS, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+}  // namespace
+
+static int ffn_check(const edtr_ffn_params* p) {
+    if (!p) return EDTR_E_NULL;
+    if (!p->x || !p->w1 || !p->w2 || !p->cst || !p->b2 || !p->out) return EDTR_E_NULL;
+    if (p->dtype != EDTR_BF16 && p->dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (p->M <= 0 || p->D <= 0 || p->H <= 0) return EDTR_E_SHAPE;
+    if (p->D != FD || p->H != FH || p->M % FBM != 0) return EDTR_E_UNSUPPORTED;      // the caller issues the two edtr_igemm launches
+    if ((p->ldx & 7) || (p->ldo & 7) || p->ldx < FD || p->ldo < FD) return EDTR_E_ALIGN;
+    if (!aligned16(p->x) || !aligned16(p->w1) || !aligned16(p->w2) || !aligned16(p->cst) || !aligned16(p->b2) || !aligned16(p->out))
+        return EDTR_E_ALIGN;
+    if (p->x == p->out) return EDTR_E_UNSUPPORTED;              // (rows are re-read as the residual after other rows were stored)
+    return EDTR_OK;
+}
+
+extern "C" int edtr_ffn(const edtr_ffn_params* p, edtr_stream_t stream) {
+    if (int rc = ffn_check(p)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return p->dtype == EDTR_BF16 ? launch_ffn<BF16>(*p, s) : launch_ffn<F16>(*p, s);
+}
+
+// HIP-free: would edtr_ffn take these parameters?  (EDTR_OK or the error edtr_ffn would return)
+extern "C" int edtr_ffn_plan(const edtr_ffn_params* p) { return ffn_check(p); }

@@ -959,28 +959,6 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const edtr_igemm_par
 // 16 bytes of zeros in device memory: the LDS-DMA source of every out-of-range chunk (conv halo, M / N tails).
 __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4];
 
-// Buffer-addressed LDS-DMA: address = SRD base + voff (per lane) + soff (wave uniform); lanes whose voff fails the
-// descriptor's range check write zeros.
-constexpr uint32_t kOobOffset = 0xFFFFFF00u;     // >= num_records - 15 -> always out of range
-constexpr uint32_t kNumRecords = 0xFFFFFF00u;
-
-__device__ __forceinline__ u32x4 make_srd(const void* base) {
-    const uint64_t b = reinterpret_cast<uint64_t>(base);
-    u32x4 srd;
-    srd.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
-    srd.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);   // stride 0 (raw buffer)
-    srd.z = kNumRecords;
-    srd.w = 0x00020000u;
-    return srd;
-}
-
-__device__ __forceinline__ void dma16_buf(uint32_t voff, const u32x4& srd, uint32_t soff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                 :
-                 : "v"(voff), "s"(srd), "s"(lds_addr), "s"(soff)
-                 : "memory");   // M0 is free here: hipcc keeps no value in it across statements on gfx950
-}
-
 // ------------------------------------------------------------------------------------------------------
 // LDS-DMA main loop (128x128x64 tile): operands go global -> LDS directly (global_load_lds_dwordx4), no VGPR
 // staging and no ds_write traffic.  One wave instruction fills 1 KiB = 8 tile rows; the XOR swizzle is applied

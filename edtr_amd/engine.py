@@ -153,10 +153,39 @@ class WeightStore:
         (fp16 matrices with 1..3 parts per WRef.get)."""
         self.params, self.dtype, self.device = params, dtype, device
         self.cache: Dict[tuple, object] = {}
-        self.frozen: Optional[str] = None     # set on ranks whose fp32 parameters are placeholders (parallel.broadcast_packed)
+        self._frozen: Optional[str] = None    # set on ranks whose fp32 parameters are placeholders (parallel.broadcast_packed)
+        # the hybrid precision mode packs the SAME parameters in two storage formats (fp16 one-part matrices for the denoiser,
+        # the mixed mode's multi-part matrices for the VAE): the formats are sibling stores under one root, so that everything
+        # that walks "the" store — the packed broadcast, its checksum, the freeze — sees all of them
+        self._root: Optional["WeightStore"] = None
+        self._siblings: Dict[object, "WeightStore"] = {}
+
+    def for_dtype(self, dtype) -> "WeightStore":
+        """The store of the same parameters in another storage format (created on first use; ``self`` when it already is)."""
+        root = self._root or self
+        if dtype == self.dtype:
+            return self
+        if dtype == root.dtype:
+            return root
+        sib = root._siblings.get(dtype)
+        if sib is None:
+            sib = WeightStore(root.params, dtype, root.device)
+            sib._root = root
+            root._siblings[dtype] = sib
+        return sib
+
+    @property
+    def frozen(self) -> Optional[str]:
+        return (self._root or self)._frozen
+
+    @frozen.setter
+    def frozen(self, why: Optional[str]) -> None:
+        (self._root or self)._frozen = why
 
     def invalidate(self):
         self.cache.clear()
+        for sib in self._siblings.values():
+            sib.cache.clear()
 
     def _p(self, name: str) -> torch.Tensor:
         if self.frozen:
@@ -268,6 +297,17 @@ class WeightStore:
         packed, b, c1, c2 = self.cache[key]
         return packed, b, c1, c2
 
+    def ffn(self, w1name: str, b1name: str, w2name: str, b2name: str, ln_prefix: str):
+        """Operands of edtr_ffn (include/edtr_hip.h) for one FeedForward: (w1 packed with the LayerNorm gamma folded in and value / gate
+        rows interleaved, w2 with its columns permuted, the per-chunk constants, b2).  Fast modes only."""
+        key = ("ffn", w1name, w2name, ln_prefix)
+        if key not in self.cache:
+            w1p, b1p, c1, c2 = self.ln_fold("geglu", [w1name], [b1name], ln_prefix)
+            cst = ops.pack_ffn_constants(c1, c2 + b1p)
+            w2p = ops.pack_ffn_w2(self._p(w2name).reshape(self.params[w2name].shape[0], -1), self.dtype)
+            self.cache[key] = (w1p, w2p, cst, self._p(b2name).reshape(-1).contiguous())
+        return self.cache[key]
+
     def raw(self, name: str) -> torch.Tensor:
         """The fp32 parameter itself on the device (embedding tables)."""
         key = ("raw", name)
@@ -294,12 +334,14 @@ class WeightStore:
         """Every device tensor of the store in a deterministic order (same programs -> same keys on every rank)."""
         out: List[torch.Tensor] = []
         seen = set()
-        for key in sorted(self.cache, key=repr):
-            val = self.cache[key]
-            for t in (val if isinstance(val, (tuple, list)) else (val,)):
-                if isinstance(t, torch.Tensor) and t.data_ptr() not in seen:
-                    seen.add(t.data_ptr())
-                    out.append(t)
+        stores = [self] + [self._siblings[k] for k in sorted(self._siblings, key=str)]      # (a root lists its sibling formats too)
+        for st in stores:
+            for key in sorted(st.cache, key=repr):
+                val = st.cache[key]
+                for t in (val if isinstance(val, (tuple, list)) else (val,)):
+                    if isinstance(t, torch.Tensor) and t.data_ptr() not in seen:
+                        seen.add(t.data_ptr())
+                        out.append(t)
         return out
 
 
@@ -683,6 +725,21 @@ class Emitter:
         if a.C != K or ln_vec is None:
             raise ValueError("folded LayerNorm: the consumer needs K == C and the folded weight's (c1, c2)")
         return a.x, dict(ln_stats=a.stats, ln_C=a.C, ln_valid=a.c_valid, ln_eps=1e-5, ln_c1=ln_vec[0], ln_c2=ln_vec[1])
+
+    def ffn_ok(self, rows: int, C: int) -> bool:
+        """May x + ff(norm3(x)) of a transformer block run as ONE edtr_ffn launch?  (fast modes; the shapes edtr_ffn is built for)"""
+        return not self.hp and not self.invariant and ops.ffn_ok(rows, C, 4 * C)
+
+    def ffn(self, x: torch.Tensor, rows: int, C: int, tb: str, name: str = "ff.fused") -> torch.Tensor:
+        """out = x + W2 GEGLU(W1 LayerNorm(x) + b1) + b2 on the RAW rows x (model/attention.py:233) as one launch."""
+        w1, w2, cst, b2 = self.store.ffn(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias", tb + "ff.net.2.weight", tb + "ff.net.2.bias",
+                                         tb + "norm3.")
+        out = self.new(rows, C)
+        self.prog.add(ops.make_ffn(dtype=self.dtype, x=x, ldx=x.stride(0), M=rows, w1=w1, w2=w2, cst=cst, b2=b2, out=out, ldo=out.stride(0),
+                                   name=name))
+        self.last_gnp = None
+        self.last_row_stats = None
+        return out
 
     def gemm(self, a, w, M: int, N: int, K: int, *, bias=None, out=None, act=0,
              residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,

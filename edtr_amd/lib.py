@@ -19,6 +19,7 @@ DECLARED_SYMBOLS = [
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp", "edtr_swin_attn", "edtr_swin_layer", "edtr_conv64", "edtr_conv128_out",
     "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror", "edtr_igemm_plan", "edtr_flash_attn512",
+    "edtr_ffn", "edtr_ffn_plan",
 ]
 
 
@@ -92,6 +93,17 @@ class SwinMlpParams(C.Structure):
         ("c1", C.c_void_p), ("c2b", C.c_void_p), ("b2", C.c_void_p),
         ("out", C.c_void_p), ("ldo", C.c_int32),
         ("row_stats", C.c_void_p),
+    ]
+
+
+class FfnParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("M", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+        ("eps", C.c_float),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("w1", C.c_void_p), ("w2", C.c_void_p),
+        ("cst", C.c_void_p), ("b2", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
     ]
 
 
@@ -210,7 +222,9 @@ def load() -> C.CDLL:
     lib.edtr_conv64.argtypes = [C.POINTER(Conv64Params), vp]
     lib.edtr_conv128_out.argtypes = [C.POINTER(Conv128OutParams), vp]
     lib.edtr_swin_layer.argtypes = [C.POINTER(SwinAttnParams), C.POINTER(SwinMlpParams), vp]
-    if lib.edtr_abi_version() != 9:
+    lib.edtr_ffn.argtypes = [C.POINTER(FfnParams), vp]
+    lib.edtr_ffn_plan.argtypes = [C.POINTER(FfnParams)]
+    if lib.edtr_abi_version() != 10:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -25,7 +25,38 @@ def default_compute_dtype() -> torch.dtype:
     return _DTYPES[os.environ.get("EDTR_AMD_DTYPE", "bf16").lower()]
 
 
-PRECISIONS = ("fast", "mixed", "high")
+PRECISIONS = ("fast", "mixed", "high", "hybrid")
+
+# The hybrid parity mode (round 6): what each SECTION of the path runs.  Plain fp16 storage is already
+# inside the north-star 1e-3 on the LATENT (8.7e-4 at full size, 114.8 images/s against 118 for bf16); the excess on the image
+# (1.5e-3) is added by the decoder, whose few stream-carrying convolutions pass their operand roundings straight into the pixels.
+# So: the denoiser in the fast fp16 mode, the VAE in the mixed mode (fp32 stream, three-part products on its stream carriers:
+# edtr_amd/precision.py).  EDTR_AMD_HYBRID (JSON: {"cldm": "fast16" | "fastbf16" | "mixed" | "high", "vae.encode": ...,
+# "vae.decode": ...}) overrides the table for experiments (tools/exp/r06_hybrid_sweep.py).
+HYBRID_SECTIONS = {"cldm": "fast16", "vae.encode": "mixed", "vae.decode": "mixed"}
+_SECTION_MODES = {"fast16": ("fast", torch.float16), "fastbf16": ("fast", torch.bfloat16), "mixed": ("mixed", None), "high": ("high", None)}
+
+
+def hybrid_sections() -> Dict[str, str]:
+    table = dict(HYBRID_SECTIONS)
+    env = os.environ.get("EDTR_AMD_HYBRID")
+    if env:
+        import json
+        for k, v in json.loads(env).items():
+            if k not in table or v not in _SECTION_MODES:
+                raise ValueError(f"EDTR_AMD_HYBRID: {k!r} -> {v!r} (sections {sorted(table)}, modes {sorted(_SECTION_MODES)})")
+            table[k] = v
+    return table
+
+
+def section_mode(precision: str, compute_dtype, section: str):
+    """(precision mode, compute dtype) that ``section`` ("cldm" | "vae.encode" | "vae.decode") runs under ``precision``."""
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+    if precision != "hybrid":
+        return precision, compute_dtype
+    mode, dt = _SECTION_MODES[hybrid_sections()[section]]
+    return mode, (dt or compute_dtype)
 
 
 def default_precision() -> str:
@@ -40,10 +71,16 @@ def default_precision() -> str:
     return p
 
 
-def _store_dtype(precision: str, compute_dtype):
-    if precision not in PRECISIONS:
-        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
-    return {"high": ops_mod.F32S, "mixed": ops_mod.MIXED}.get(precision, compute_dtype)
+def _store_dtype(precision: str, compute_dtype, section: str = "cldm"):
+    mode, dt = section_mode(precision, compute_dtype, section)
+    return {"high": ops_mod.F32S, "mixed": ops_mod.MIXED}.get(mode, dt)
+
+
+def _policy_for(owner, section: str = "cldm"):
+    """The mixed-mode precision policy of ``section`` (None where the section does not run the mixed mode)."""
+    from ..precision import mixed_policy
+    mode, _ = section_mode(owner.precision, owner.compute_dtype, section)
+    return (owner.precision_policy or mixed_policy()) if mode == "mixed" else None
 
 
 def _require_gpu(t: torch.Tensor, what: str) -> None:
@@ -83,12 +120,15 @@ class _NetPart(ParamTree):
         return next(self.parameters()).device
 
     def _policy(self):
-        from ..precision import mixed_policy
-        return (self.precision_policy or mixed_policy()) if self.precision == "mixed" else None
+        return _policy_for(self, "cldm")
+
+    def _mode(self):
+        """(precision mode, compute dtype) of the programs of this net (the hybrid mode's denoiser section)."""
+        return section_mode(self.precision, self.compute_dtype, "cldm")
 
     def _store(self) -> WeightStore:
         pol = self._policy()
-        fp = (params_fingerprint(self), self.compute_dtype, self.precision, pol.key() if pol else None)
+        fp = (params_fingerprint(self), self._mode(), pol.key() if pol else None)
         if fp != self._part_fp:
             self._part_engines.drop_all()
             self._part_store, self._part_fp = None, fp
@@ -175,10 +215,11 @@ class CldmEngine:
 
     def __init__(self, owner: "ControlLDM", B: int, h: int, w: int, nctx: int):
         dev = owner._device()
-        dt = owner.compute_dtype
+        mode, dt = section_mode(owner.precision, owner.compute_dtype, "cldm")
+        pol = _policy_for(owner, "cldm")
         self.B, self.h, self.w, self.nctx = B, h, w, nctx
         self.arena = Arena(dev)
-        store = owner._store()
+        store = owner._store("cldm")
         ua, ca = owner.unet.arch, owner.controlnet.arch
         f32 = torch.float32
         self.x_in = torch.zeros((B, ua.in_channels, h, w), dtype=f32, device=dev)
@@ -190,14 +231,14 @@ class CldmEngine:
 
         # ---- context program
         self.ctx_prog = Program("cldm.context")
-        em = Emitter(self.ctx_prog, self.arena, store, dt, owner.precision, owner._policy())
+        em = Emitter(self.ctx_prog, self.arena, store, dt, mode, pol)
         ctx16 = em.cast_flat(self.ctx_in, B * nctx * ua.context_dim).view(B * nctx, ua.context_dim)
         self.kv_c = nets.emit_context_kv(em, "controlnet.", ca, ctx16, B, nctx)
         self.kv_u = nets.emit_context_kv(em, "unet.", ua, ctx16, B, nctx)
 
         # ---- step program
         self.step_prog = Program("cldm.step")
-        em = Emitter(self.step_prog, self.arena, store, dt, owner.precision, owner._policy())
+        em = Emitter(self.step_prog, self.arena, store, dt, mode, pol)
         hw = h * w
         cin_c = ca.in_channels + ca.hint_channels
         x8c = em.new(B * hw, arch_round8(cin_c))
@@ -210,7 +251,7 @@ class CldmEngine:
         tab_u, offs_u = nets.emit_time_rows(em, "unet.", ua, self.t_in, B)
         # ControlNet (lane 1, own arena) is independent of the UNet encoder + middle block (lane 0): two graph branches
         self.arena_cn = Arena(dev)
-        em_cn = Emitter(self.step_prog, self.arena_cn, store, dt, owner.precision, owner._policy())
+        em_cn = Emitter(self.step_prog, self.arena_cn, store, dt, mode, pol)
         self.step_prog.fork()
         self.step_prog.set_lane(1)
         ctrl = nets.emit_controlnet(em_cn, "controlnet.", ca, Act(x8c, B, h, w, x8c.shape[1]), tab_c, offs_c, self.kv_c,
@@ -247,7 +288,8 @@ class _PartEngineBase:
         a = part.arch
         self.arena = Arena(dev)
         self.prog = Program(name)
-        em = Emitter(self.prog, self.arena, store, part.compute_dtype, part.precision, part._policy())
+        mode, dt = part._mode()
+        em = Emitter(self.prog, self.arena, store, dt, mode, part._policy())
         f32 = torch.float32
         self.x_in = torch.zeros((B, a.in_channels, h, w), dtype=f32, device=dev)
         self.t_in = torch.zeros((B,), dtype=torch.int64, device=dev)
@@ -340,15 +382,16 @@ class VaeEngine:
 
     def __init__(self, owner: "ControlLDM", kind: str, B: int, H: int, W: int, tile_size: int = 0, sample: bool = False):
         dev = owner._device()
-        dt = owner.compute_dtype
+        section = "vae." + kind
+        mode, dt = section_mode(owner.precision, owner.compute_dtype, section)
         self.arena = Arena(dev)
-        store = owner._store()
+        store = owner._store(section)
         dd = owner.vae.cfg["ddconfig"]
         f32 = torch.float32
         self.prog = Program(f"vae.{kind}" + (".tiled" if tile_size else ""))
         self.nan_probe = None      # tiled form: (rows, cols) index tensors of the first output pixel of every tile
         self.noise_in = None       # encoder with sample=True: the N(0, 1) draw of DiagonalGaussianDistribution.sample()
-        em = Emitter(self.prog, self.arena, store, dt, owner.precision, owner._policy())
+        em = Emitter(self.prog, self.arena, store, dt, mode, _policy_for(owner, section))
         if kind == "encode" and os.environ.get("EDTR_AMD_BRANCH16_ENC", "1") == "0":
             # mixed mode, A/B switch: the ENCODER with its branch-internal tensors in fp32.  z_pre (the conditioning of every denoise step
             # and the start of the trajectory) is 6.9e-4 from the reference instead of 8.0e-4 of its 1e-3 budget, the final latent /
@@ -488,13 +531,17 @@ class ControlLDM(nn.Module):
         return next(self.unet.parameters()).device
 
     def _policy(self):
-        from ..precision import mixed_policy
-        return (self.precision_policy or mixed_policy()) if self.precision == "mixed" else None
+        """The mixed-mode policy in force (the hybrid mode: of whichever sections run the mixed mode), else None."""
+        for section in ("cldm", "vae.encode", "vae.decode"):
+            pol = _policy_for(self, section)
+            if pol is not None:
+                return pol
+        return None
 
     def _check_fresh(self) -> None:
         pol = self._policy()
         wfp = (params_fingerprint(self.unet), params_fingerprint(self.controlnet), params_fingerprint(self.vae),
-               self.compute_dtype, self.precision)
+               self.compute_dtype, self.precision, tuple(sorted(hybrid_sections().items())) if self.precision == "hybrid" else None)
         fp = (wfp, tuple(self.control_scales), pol.key() if pol else None)
         if fp != self._fingerprint:
             # programs depend on everything; the packed store only on the parameters and the storage format, so a change of
@@ -524,14 +571,16 @@ class ControlLDM(nn.Module):
         for eng in self._cldm_engines.values():
             eng.ctx_key = None
 
-    def _store(self) -> WeightStore:
+    def _store(self, section: str = "cldm") -> WeightStore:
+        """The packed weights in the storage format ``section`` runs in.  One root store (the denoiser's format); the hybrid mode's
+        other formats are its siblings (WeightStore.for_dtype), so the packed broadcast and its checksum cover them."""
         if self._weights is None:
             params: Dict[str, torch.Tensor] = {}
             params.update(self.unet.flat_params("unet."))
             params.update(self.controlnet.flat_params("controlnet."))
             params.update(self.vae.flat_params("vae."))
             self._weights = WeightStore(params, _store_dtype(self.precision, self.compute_dtype), self._device())
-        return self._weights
+        return self._weights.for_dtype(_store_dtype(self.precision, self.compute_dtype, section))
 
     def cldm_engine(self, B: int, h: int, w: int, nctx: int = 77) -> CldmEngine:
         self._check_fresh()

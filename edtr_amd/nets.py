@@ -195,20 +195,26 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     vt_view = vt3[:, off:off + C, :kv.ldv]
     vt_lo = vt3[:, off:off + C, kv.ldv:] if kv.split >= 2 else None
     ctx = (k_view, vt_view, kv.Nctx * kv.k_all.stride(0), kv.sumC * ldv_all, ldv_all, kv.Nctx, k_lo, vt_lo)
-    t2 = emit_attention_core(em, tb + "attn2.", l2, B, N, C, l.heads, ctx, t1, row_stats=fold)
+    fused_ff = em.ffn_ok(rows, C)           # (edtr_ffn takes the row statistics from the rows it holds: no row_stats from attn.out)
+    t2 = emit_attention_core(em, tb + "attn2.", l2, B, N, C, l.heads, ctx, t1, row_stats=fold and not fused_ff)
     st = em.last_row_stats
     em.free(l2, t1)
-    l3 = em.layer_norm(t2, rows, C, tb + "norm3.", feeds=("ff.geglu",), stats=st)
-    if isinstance(l3, LNRef):
-        wg, bg, c1, c2 = em.store.ln_fold("geglu", [tb + "ff.net.0.proj.weight"], [tb + "ff.net.0.proj.bias"], l3.prefix)
-        g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out", ln_vec=(c1, c2))
+    if fused_ff:
+        # norm3 + ff.geglu + ff.out + residual as ONE launch on the raw rows (edtr_ffn: the (rows, 4 C) hidden tensor stays on chip)
+        t3 = em.ffn(t2, rows, C, tb)
+        em.free(t2)
     else:
-        wg, bg = em.store.geglu(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias")
-        g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out")
-    em.free(l3)
-    wf, bf = em.store.linear([tb + "ff.net.2.weight"], [tb + "ff.net.2.bias"])
-    t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out", feeds="st.proj_out" if em.branch16 else None)
-    em.free(g, t2)
+        l3 = em.layer_norm(t2, rows, C, tb + "norm3.", feeds=("ff.geglu",), stats=st)
+        if isinstance(l3, LNRef):
+            wg, bg, c1, c2 = em.store.ln_fold("geglu", [tb + "ff.net.0.proj.weight"], [tb + "ff.net.0.proj.bias"], l3.prefix)
+            g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out", ln_vec=(c1, c2))
+        else:
+            wg, bg = em.store.geglu(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias")
+            g = em.gemm(l3, wg, rows, 8 * C, C, bias=bg, act=L.ACT_GEGLU, name="ff.geglu", feeds="ff.out")
+        em.free(l3)
+        wf, bf = em.store.linear([tb + "ff.net.2.weight"], [tb + "ff.net.2.bias"])
+        t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out", feeds="st.proj_out" if em.branch16 else None)
+        em.free(g, t2)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
     y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out", stats_hw=0 if out is not None else N, mirror=mirror)
     em.free(t3)

@@ -296,6 +296,52 @@ def make_swin_mlp(*, dtype, x, ldx, rows, c_valid, eps, w1, w2, c1, c2b, b2, out
     return Rec(L.load().edtr_swin_mlp, (ct.byref(p),), (p, x, w1, w2, c1, c2b, b2, out, row_stats), name, flops, nbytes)
 
 
+FFN_D, FFN_H, FFN_ROWS = 320, 1280, 128       # what edtr_ffn is built for (include/edtr_hip.h)
+FFN_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def ffn_ok(M: int, D: int, H: int) -> bool:
+    """Does edtr_ffn (the feed-forward half of a transformer block in one launch) take this shape?  EDTR_FFN=0 keeps the two-GEMM
+    form for A/B runs."""
+    return os.environ.get("EDTR_FFN", "1") != "0" and D == FFN_D and H == FFN_H and M > 0 and M % FFN_ROWS == 0
+
+
+def pack_ffn_w2(w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[D, H] fp32 -> 16-bit with the columns permuted inside every aligned group of 16 (edtr_hip.h: edtr_ffn_params.w2)."""
+    d, hid = w2.shape
+    assert hid % 16 == 0
+    perm = (torch.arange(hid // 16, device=w2.device)[:, None] * 16 + torch.tensor(FFN_PERM16, device=w2.device)[None, :]).reshape(-1)
+    return w2[:, perm].to(dtype).contiguous()
+
+
+def pack_ffn_constants(c1: torch.Tensor, c2b: torch.Tensor) -> torch.Tensor:
+    """The folded-LayerNorm constants in edtr_ffn's per-chunk order (edtr_hip.h: edtr_ffn_params.cst).  ``c1`` / ``c2b`` are indexed
+    by the PACKED (value / gate interleaved) w1 row; gate entries are stored halved."""
+    n = c1.numel()
+    assert n % 128 == 0 and c2b.numel() == n
+    dev = c1.device
+    c, hh, q, vg, kind, lh, e = torch.meshgrid(torch.arange(n // 128, device=dev), torch.arange(2, device=dev), torch.arange(4, device=dev),
+                                               torch.arange(2, device=dev), torch.arange(2, device=dev), torch.arange(2, device=dev),
+                                               torch.arange(4, device=dev), indexing="ij")
+    R = 128 * c + 64 * hh + 32 * vg + e + 8 * q + 4 * lh
+    both = torch.stack([c1.float(), c2b.float()])            # [kind][R]
+    out = both[kind, R] * torch.where(vg == 1, 0.5, 1.0)
+    return out.reshape(-1).contiguous()                      # [chunk][half][q][vg][kind][lh][e]
+
+
+def make_ffn(*, dtype, x, ldx, M, w1, w2, cst, b2, out, ldo, eps=1e-5, name="ff.fused") -> Rec:
+    """x + ff(LayerNorm(x)) in one launch (edtr_hip.h: edtr_ffn)."""
+    p = L.FfnParams()
+    p.dtype, p.M, p.D, p.H, p.eps = dt_code(dtype), M, FFN_D, FFN_H, eps
+    p.x, p.ldx, p.w1, p.w2, p.cst, p.b2 = ptr(x), ldx, ptr(w1), ptr(w2), ptr(cst), ptr(b2)
+    p.out, p.ldo = ptr(out), ldo
+    flops = 2.0 * M * FFN_D * 3 * FFN_H
+    nbytes = 2.0 * M * 2 * FFN_D + 2.0 * 3 * FFN_D * FFN_H
+    rec = Rec(L.load().edtr_ffn, (ct.byref(p),), (p, x, w1, w2, cst, b2, out), name, flops, nbytes)
+    rec.tag = f"ffn M{M} D{FFN_D} H{FFN_H}"
+    return rec
+
+
 def make_swin_layer(attn: Rec, mlp: Rec, name="swin.layer") -> Rec:
     """A whole Swin layer in one launch from the two half-layer records (edtr_hip.h: edtr_swin_layer): the attention record's x / out
     are the layer's input / output, the MLP record contributes its weights and constants."""

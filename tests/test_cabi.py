@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in names:
         assert hasattr(handle, name), f"{name} declared in edtr_hip.h but not exported"
     assert sorted(lib.DECLARED_SYMBOLS) == names, "lib.DECLARED_SYMBOLS out of sync with the header"
-    assert handle.edtr_abi_version() == 9
+    assert handle.edtr_abi_version() == 10
     assert b"EDTR_E_ALIGN" in handle.edtr_error_string(-3)
     assert handle.edtr_igemm(None, None) == -1          # NULL params -> EDTR_E_NULL, nothing launched
 

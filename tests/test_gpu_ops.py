@@ -1653,23 +1653,6 @@ def test_gemm_tile_orders_cover_every_tile(M, N, K, tile):
     assert rel(out.float(), ref) < TOL[dtype]
 
 
-def test_zz_measured_error_envelope():
-    """Bookkeeping (runs last in this file): the largest error each dtype's kernels measured against their torch references —
-    TOL above is held to <= 1.5 x these (VERDICT r02 item 1c)."""
-    import json
-    import os
-    worst = {}
-    for key, v in MEASURED.items():
-        dt = "bf16" if "bfloat16" in key or "dtype0" in key else ("fp16" if "float16" in key or "dtype1" in key else "other")
-        if v > worst.get(dt, ("", 0.0))[1]:
-            worst[dt] = (key, v)
-    print("\n[per-kernel error envelope] " + "; ".join(f"{k}: {v[1]:.2e} ({v[0].split('::')[-1]})" for k, v in sorted(worst.items())))
-    path = os.environ.get("EDTR_TEST_ERRLOG")
-    if path:
-        with open(path, "w") as f:
-            json.dump({"worst": worst, "all": MEASURED}, f, indent=1)
-
-
 # ---------------------------------------------------------------------------------------------------------------------
 # edtr_flash_attn512 (attn512.hip, round 5): the VAE AttnBlock's single-head attention with head width 512 in one launch
 # (reference model/vae.py:279-308) against fp32 softmax attention of the same 16-bit operands.  The bench shape (B, 4096, 512), the
@@ -1719,3 +1702,117 @@ def test_flash_attn512_rejects_what_it_cannot_run():
         ops.launch(ops.make_flash_attn512(dtype=dtype, q=x[:, :512], k=x[:, 512:], vt=vt, out=out, B=1, N=40, q_bs=40 * 1024, q_ld=1024, k_bs=40 * 1024,
                                           k_ld=1024, vt_bs=512 * 48, vt_ld=48, o_bs=40 * 512, o_ld=512, scale=1.0))
     assert not ops.flash_attn512_ok(40, 512) and not ops.flash_attn512_ok(4096, 256) and ops.flash_attn512_ok(1600, 512)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# edtr_ffn (ffn.hip, round 6): x + W2 GEGLU(W1 LayerNorm(x) + b1) + b2 of a BasicTransformerBlock in one launch (reference
+# model/attention.py:20-47, 233) against torch LayerNorm -> linear -> chunk -> x * gelu(gate) -> linear -> + x in fp32 on the same
+# 16-bit rows.  Row counts: one workgroup, the bench level (32768 = 8 x 64 x 64), a non-power-of-two multiple of 128; rows with a
+# large mean (the folded mean term must cancel) and a padded row stride.
+# ---------------------------------------------------------------------------------------------------------------------
+def _ffn_operands(ops, dtype, seed=0):
+    D, H = ops.FFN_D, ops.FFN_H
+    gamma, beta = 1 + 0.2 * rnd((D,), 700 + seed), 0.3 * rnd((D,), 701 + seed)
+    w1 = rnd((2 * H, D), 702 + seed, 1 / math.sqrt(D))
+    b1 = 0.5 * rnd((2 * H,), 703 + seed)
+    w2 = rnd((D, H), 704 + seed, 1 / math.sqrt(H))
+    b2 = 0.5 * rnd((D,), 705 + seed)
+    perm = ops.geglu_perm(H)
+    w1p = ops.pack_linear_weight(w1[perm] * gamma[None, :], dtype)
+    c1 = w1p.float().sum(1)
+    c2b = w1[perm] @ beta + b1[perm]
+    return dict(gamma=gamma, beta=beta, w1=w1, b1=b1, w2=w2, b2=b2, w1p=w1p, w2p=ops.pack_ffn_w2(w2, dtype), cst=ops.pack_ffn_constants(c1, c2b))
+
+
+def _ffn_reference(x16, o):
+    xf = x16.float()
+    ln = F.layer_norm(xf, (xf.shape[1],), o["gamma"], o["beta"], 1e-5)
+    hcat = ln @ o["w1"].t() + o["b1"]
+    val, gate = hcat.chunk(2, dim=-1)
+    return xf + (val * F.gelu(gate)) @ o["w2"].t() + o["b2"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,ldx,shift", [(128, 320, 0.0), (32768, 320, 0.7), (640, 328, 3.0)])
+def test_ffn_fused_vs_fp32_reference(dtype, M, ldx, shift):
+    ops = _ops()
+    d = dev()
+    o = _ffn_operands(ops, dtype)
+    D = ops.FFN_D
+    xs = torch.zeros((M, ldx), dtype=dtype)
+    xs[:, :D] = (rnd((M, D), 710, 1.5) + shift).to(dtype)
+    xd = xs.to(d)
+    out = torch.full((M, ldx), float("nan"), dtype=dtype, device=d)
+    assert ops.ffn_ok(M, D, 4 * D)
+    ops.launch(ops.make_ffn(dtype=dtype, x=xd[:, :D], ldx=ldx, M=M, w1=o["w1p"].to(d), w2=o["w2p"].to(d), cst=o["cst"].to(d), b2=o["b2"].to(d),
+                            out=out[:, :D], ldo=ldx))
+    torch.cuda.synchronize()
+    got = out[:, :D].float().cpu()
+    assert torch.isfinite(got).all()
+    ref = _ffn_reference(xs[:, :D], o)
+    # the branch alone (residual removed): the sum is dominated by x, which would hide an error of the feed-forward part
+    e_all, e_branch = rel(got, ref), rel(got - xs[:, :D].float(), ref - xs[:, :D].float())
+    MEASURED[f"ffn_branch[{dtype}-{M}]"] = e_branch
+    assert e_all < TOL[dtype], (e_all, e_branch)
+    assert e_branch < (1.2e-2 if dtype == torch.bfloat16 else 1.6e-3), (e_all, e_branch)      # (the branch is a rounded 16-bit sum with x: its own error is ~ 2^-9 / 2^-12 of |x| / |branch|)
+    if ldx > D:
+        assert bool(torch.isnan(out[:, D:].float()).all())      # pad columns untouched
+
+
+def test_ffn_matches_the_two_gemm_form():
+    """The fused launch against the product path it replaces (LayerNorm launch -> GEGLU edtr_igemm -> edtr_igemm + residual) on the same
+    operands: the two differ by 16-bit roundings of the hidden tensor only."""
+    from edtr_amd import lib as L
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    o = _ffn_operands(ops, dtype, seed=20)
+    M, D, H = 1024, ops.FFN_D, ops.FFN_H
+    x = (rnd((M, D), 730, 1.5) + 0.4).to(dtype).to(d)
+    fused = torch.empty((M, D), dtype=dtype, device=d)
+    ops.launch(ops.make_ffn(dtype=dtype, x=x, ldx=D, M=M, w1=o["w1p"].to(d), w2=o["w2p"].to(d), cst=o["cst"].to(d), b2=o["b2"].to(d), out=fused, ldo=D))
+    xn = torch.empty_like(x)
+    ops.launch(ops.make_layernorm(dtype=dtype, x=x, rows=M, C=D, ldx=D, gamma=o["gamma"].to(d), beta=o["beta"].to(d), eps=1e-5, y=xn, ldy=D))
+    perm = ops.geglu_perm(H)
+    g = torch.empty((M, H), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=xn, w=ops.pack_linear_weight(o["w1"][perm], dtype).to(d), out=g, M=M, N=2 * H, C1=D, ld1=D, ldw=D, ldc=H,
+                              bias_n=o["b1"][perm].to(d), act=L.ACT_GEGLU))
+    two = torch.empty((M, D), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=g, w=ops.pack_linear_weight(o["w2"], dtype).to(d), out=two, M=M, N=D, C1=H, ld1=H, ldw=H, ldc=D,
+                              bias_n=o["b2"].to(d), residual=x, ldr=D))
+    torch.cuda.synchronize()
+    ref = _ffn_reference(x.cpu(), o)
+    e_f, e_t = rel(fused.float().cpu(), ref), rel(two.float().cpu(), ref)
+    assert e_f < TOL[dtype] and e_f < 1.3 * e_t + 1e-4, (e_f, e_t)
+
+
+def test_ffn_rejects_what_it_cannot_run():
+    from edtr_amd import lib as L
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    o = _ffn_operands(ops, dtype)
+    x = torch.zeros((192, 320), dtype=dtype, device=d)
+    out = torch.zeros_like(x)
+    with pytest.raises(RuntimeError):                        # 192 rows: not whole 128-row workgroups
+        ops.launch(ops.make_ffn(dtype=dtype, x=x, ldx=320, M=192, w1=o["w1p"].to(d), w2=o["w2p"].to(d), cst=o["cst"].to(d), b2=o["b2"].to(d), out=out, ldo=320))
+    with pytest.raises(RuntimeError):                        # in place: rows are re-read as the residual
+        ops.launch(ops.make_ffn(dtype=dtype, x=x[:128], ldx=320, M=128, w1=o["w1p"].to(d), w2=o["w2p"].to(d), cst=o["cst"].to(d), b2=o["b2"].to(d), out=x[:128], ldo=320))
+    assert not ops.ffn_ok(192, 320, 1280) and not ops.ffn_ok(8192, 640, 2560) and ops.ffn_ok(16384, 320, 1280)
+
+
+def test_zz_measured_error_envelope():
+    """Bookkeeping (runs last in this file): the largest error each dtype's kernels measured against their torch references —
+    TOL above is held to <= 1.5 x these (VERDICT r02 item 1c)."""
+    import json
+    import os
+    worst = {}
+    for key, v in MEASURED.items():
+        dt = "bf16" if "bfloat16" in key or "dtype0" in key else ("fp16" if "float16" in key or "dtype1" in key else "other")
+        if v > worst.get(dt, ("", 0.0))[1]:
+            worst[dt] = (key, v)
+    print("\n[per-kernel error envelope] " + "; ".join(f"{k}: {v[1]:.2e} ({v[0].split('::')[-1]})" for k, v in sorted(worst.items())))
+    path = os.environ.get("EDTR_TEST_ERRLOG")
+    if path:
+        with open(path, "w") as f:
+            json.dump({"worst": worst, "all": MEASURED}, f, indent=1)
