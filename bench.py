@@ -332,20 +332,32 @@ def main() -> None:
         result.update(golden_parity(args.workload, img, z, rel_err, tol_key))
     if (rank == 0 and world == 1 and args.parity_steps > 0 and args.precision == "fast" and args.workload == "det512"
             and args.config == "sd21" and std_shape and not args.dup):
-        # ---- the mode that meets the north-star tolerance, timed in the SAME run (the headline above is the fast bf16 mode)
+        # ---- the modes that meet the north-star tolerance, timed in the SAME run (the headline above is the fast bf16 mode):
+        #      "hybrid" = the fastest one on well-conditioned weights (round 6), "mixed" = the all-sections form of rounds 3-5 (kept on the
+        #      record for continuity), "high" = the one that holds 1e-3 on outlier-bearing weights too (a short leg: it is 3 x the MFMA work)
         try:
-            result["parity_mode"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err)
-            pm = result["parity_mode"]
+            result["parity_mode"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="hybrid")
+            result["parity_mode_mixed"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="mixed")
+            result["parity_mode_high"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="high",
+                                                         steps=max(4, args.parity_steps // 3))
+            pm = max((result[k] for k in ("parity_mode", "parity_mode_mixed") if result[k].get("meets_north_star")),
+                     key=lambda r: r["images_per_s"], default=result["parity_mode"])
+            ph = result["parity_mode_high"]
             # how to read `value` against BASELINE.json's north star: `value` is the bf16-storage mode that
             # configs[1] names — its own image error is 1.2e-2 — and the throughput at which "parity within 1e-3" HOLDS is the figure below
             result["north_star"] = {
                 "parity_tolerance": NORTH_STAR,
                 "images_per_s_at_parity": pm.get("images_per_s") if pm.get("meets_north_star") else None,
                 "ratio_to_value": round(pm["images_per_s"] / value, 3) if pm.get("meets_north_star") and value else None,
-                "mode": "precision=\"mixed\" (fp32 activation stream, 1 - 3 fp16 products per layer class), same model / inputs / run",
+                "mode": f"precision=\"{pm.get('precision')}\" (see parity_mode / parity_mode_mixed), same model / inputs / run",
                 "value_mode_image_error": result.get("parity_vs_reference_golden", {}).get("rel_err_image_samples"),
-                "scope": "well-conditioned weights (synthetic smooth set, tests/golden/full_det512.npz); with outlier channels in the weights "
-                         "the mode that holds 1e-3 is precision=\"high\" (~0.36 x): tests/test_gpu_heavy.py, profiles/r05/moderate_policies.log"}
+                "images_per_s_at_parity_outlier_weights": ph.get("images_per_s") if ph.get("meets_north_star") else None,
+                "ratio_to_value_outlier_weights": round(ph["images_per_s"] / value, 3) if ph.get("meets_north_star") and value else None,
+                "scope": "hybrid / mixed hold 1e-3 on well-conditioned weights (synthetic smooth set, tests/golden/full_det512.npz).  With outlier "
+                         "channels in the weights (moderate set: tests/golden/moderate.npz) NO mode faster than precision=\"high\" holds 1e-3: "
+                         "every part-count allocation short of three parts everywhere leaves 1.2 - 1.9e-3 on the denoiser's output "
+                         "(profiles/r05/moderate_policies.log, profiles/r06/moderate_policies.log, tests/test_gpu_heavy.py) — `high` "
+                         "(parity_mode_high, timed above) is the figure to quote for such weights"}
         except Exception as e:       # never take the headline down
             result["parity_mode"] = {"error": repr(e)}
     if dist is not None:
@@ -449,12 +461,14 @@ def dry_run_rank(rank: int, world: int) -> int:
     return 0
 
 
-def parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err) -> dict:
-    """Switch the SAME model to the mixed-precision parity mode (fp32 stream, fp16 operands, 1-3 products per layer class),
-    rebuild its programs, time `--parity-steps` passes the way the headline was timed, and check the result against the
-    reference golden.  The fast-mode engines are dropped (the roofline pass over them has already run)."""
+def parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="mixed", steps=None) -> dict:
+    """Switch the SAME model to a parity mode — "hybrid" (fp16 storage in the encoder and the denoiser, the decoder on the mixed mode's
+    fp32 stream), "mixed" (fp32 stream, fp16 operands, 1-3 products per layer class everywhere) or "high" (bf16 split-3 products
+    everywhere: the mode that holds 1e-3 on outlier-bearing weights) — rebuild its programs, time `--parity-steps` passes the way the
+    headline was timed, and check the result against the reference golden.  The previous mode's engines are dropped."""
     t0 = time.time()
-    cldm.precision = cldm.unet.precision = cldm.controlnet.precision = "mixed"
+    steps = steps or args.parity_steps
+    cldm.precision = cldm.unet.precision = cldm.controlnet.precision = mode
     for sl_ in range(args.inflight):
         cldm.engine_slot = sl_
         one_pass()
@@ -464,18 +478,22 @@ def parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err) ->
     torch.cuda.synchronize()
     build_s = time.time() - t0
     t0 = time.perf_counter()
-    run_steps(args.parity_steps)
+    run_steps(steps)
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / args.parity_steps * 1e3
+    ms = (time.perf_counter() - t0) / steps * 1e3
     cldm.engine_slot = 0
     img, z = one_pass(inject=True)         # untimed parity pass: the golden's noise tensors
     torch.cuda.synchronize()
-    out = {"precision": "mixed", "policy": cldm._policy().describe(), "images_per_s": round(B / ms * 1e3, 3), "ms_per_step": round(ms, 3),
-           "steps": args.parity_steps, "build_seconds": round(build_s, 1),
+    pol = cldm._policy()
+    out = {"precision": mode, "policy": pol.describe() if pol is not None else None, "images_per_s": round(B / ms * 1e3, 3), "ms_per_step": round(ms, 3),
+           "steps": steps, "build_seconds": round(build_s, 1),
            "mfma_frac_whole_path": round(B / ms * 1e3 * FLOP_PER_IMAGE / (PEAK_TFLOPS * 1e12), 4),
            "note": "same model, same inputs, same run as the headline; fp32 activation stream + multi-part fp16 products "
                    "(algorithmic FLOP unchanged: the extra products are precision overhead, not counted)"}
-    gp = golden_parity(args.workload, img, z, rel_err, "mixed").get("parity_vs_reference_golden")
+    if mode == "hybrid":
+        from edtr_amd.model.cldm import hybrid_sections
+        out["sections"] = hybrid_sections()
+    gp = golden_parity(args.workload, img, z, rel_err, mode).get("parity_vs_reference_golden")
     if gp:
         out.update(rel_err_latent=gp["rel_err_latent"], rel_err_image=gp["rel_err_image_samples"], fixture=gp["fixture"],
                    max_err_latent=gp["max_err_latent"], max_err_image=gp["max_err_image_samples"],
@@ -745,7 +763,7 @@ def kernel_of(name: str) -> str:
 # for z_pre / latent / image over the three workloads) so that a 2x regression of a mode's numerics fails the run; the north-star
 # 1e-3 is what the parity modes (mixed, high) must additionally meet
 TOLERANCE = {"bf16": {"z_pre": 1.75e-2, "latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"z_pre": 2.2e-3, "latent": 1.3e-3, "image": 2.3e-3},
-             "mixed": {"z_pre": 1e-3, "latent": 8.2e-4, "image": 9e-4}, "hybrid": {"z_pre": 1e-3, "latent": 1e-3, "image": 1e-3}, "high": {"z_pre": 4.4e-5, "latent": 1.8e-5, "image": 3.6e-5}}
+             "mixed": {"z_pre": 1e-3, "latent": 8.2e-4, "image": 9e-4}, "hybrid": {"z_pre": 2.2e-3, "latent": 1e-3, "image": 1e-3}, "high": {"z_pre": 4.4e-5, "latent": 1.8e-5, "image": 3.6e-5}}
 NORTH_STAR = 1e-3
 # max-norm bound as a multiple of the L2 tolerance: measured max / L2 ratios of the shipped modes are 0.9 - 1.3 (the peak of a latent / image is a few times its RMS)
 # (profiles/r04/maxnorm_measured.log), a defect in one 16 x 16 tile of a 512 x 512 image with O(1) errors gives > 100
@@ -881,10 +899,13 @@ def finish_cpu_baseline(handle, inp, img, z, S, rel_err, dtype_name, budget_s=42
     if "batch" in runs:
         dt8 = runs["batch"][1][0]
         out["b8_images_per_s"] = round(B / dt8, 5)
+        out["b8_measured_in_run"] = True
         out["value"] = round(max(b1, B / dt8), 5)
         out["sample"] += f"; B={B}: the whole batch in one oracle call ({dt8:.1f} s); value = the faster of the two"
     else:
-        out["b8_images_per_s"] = None
+        # SURVEY §8(d) asks for B = 1 and B = 8: the B = 8 point is the COMMITTED measurement (not re-measured in this run, and marked so)
+        out["b8_images_per_s"] = 0.0794
+        out["b8_measured_in_run"] = False
         out["b8_note"] = (f"BASELINE.md §3's B={B} point was measured ONCE on this host class and committed (profiles/r04/cpu_oracle_b8.log, "
                           "tests/cpu_oracle_b8.py): the bench batch as 8 concurrent B=1 oracle processes restores in 100.7 s at 8 x 16 threads "
                           "(0.079 images/s) and in 237 s at 8 x 32 threads (0.034) — the fp32 oracle is memory-bound on the host, so the batch "

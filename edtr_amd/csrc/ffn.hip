@@ -141,12 +141,20 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
     for (int b = 0; b < 5; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[b][r] = 0.0f;
+#ifdef FFN_STAMPS       // diagnostic build (tools/exp/ffn_stamps.py): cycles per phase, written over the first output rows of the workgroup
+    uint64_t st_t0 = __builtin_amdgcn_s_memtime(), st_last = st_t0, st_acc[6] = {0, 0, 0, 0, 0, 0};      // wait+barrier A | mfma A | geglu | wait+barrier B | mfma B | prologue
+    st_acc[5] = 0;
+#define FFN_STAMP(i) do { const uint64_t n__ = __builtin_amdgcn_s_memtime(); st_acc[i] += n__ - st_last; st_last = n__; } while (0)
+#else
+#define FFN_STAMP(i)
+#endif
 
     const int arow = l31 * 128, akey = (l31 >> 1) & 7;        // fragment row l31 (and l31 + 32: same key) of a granule
     auto frag = [&](const char* gran, int row32, int c) {     // 16-byte chunk c of row row32 + l31
         return *reinterpret_cast<const U4*>(gran + row32 * 128 + arow + ((c ^ akey) << 4));
     };
 
+    FFN_STAMP(5);
 #pragma unroll 1
     for (int c = 0; c < FNCH; ++c) {
         const bool more = c + 1 < FNCH;
@@ -165,6 +173,7 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
             else if (kt == 3) wait_vm<7>();
             else wait_vm<5>();
             block_sync();                                       // ... everyone's; the step before is over: its slots are free
+            FFN_STAMP(0);
             if (kt == 0) {
                 issue_w2(c);                                    // needed five steps from now
                 if (more) issue_cst(c + 1);
@@ -188,6 +197,7 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
                 hv = T::mfma(av, xb_, hv);
                 hg = T::mfma(ag, xb_, hg);
             }
+            FFN_STAMP(1);
         }
 
         // ---- GEGLU with the folded LayerNorm: register r = 4 q + e is hidden unit e + 8 q + 4 lh of this wave's 32
@@ -219,9 +229,11 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
             }
         }
 
+        FFN_STAMP(2);
         // ---- second product: K = this chunk's 64 gated units (k-step 2 h' + u: half h', u = 0 / 1), five output tiles
         if (more) wait_vm<9>(); else wait_vm<0>();
         block_sync();                                           // W2 of the chunk everyone's; both halves' G fragments published
+        FFN_STAMP(3);
         if (more) issue_w1(c + 1, 4);
         {
             int ln = lane;
@@ -238,10 +250,12 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
                 }
             }
         }
+        FFN_STAMP(4);
     }
 
     // ---- epilogue: + bias + residual (the raw rows) in fp32, one rounding, through an LDS tile so that whole rows leave coalesced
     block_sync();                                               // every wave is done with the ring
+    FFN_STAMP(3);
     {
         const uint16_t* xr = static_cast<const uint16_t*>(p.x) + (int64_t)(m0 + 32 * t + l31) * p.ldx;
         char* trow = smem + (32 * t + l31) * OPITCH;
@@ -273,6 +287,16 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
             stg16(og + (int64_t)(m0 + row) * p.ldo + ch * 8, v);
         }
     }
+#ifdef FFN_STAMPS
+    __syncthreads();
+    if (lane == 0) {
+        const uint64_t end = __builtin_amdgcn_s_memtime();
+        uint64_t* dst = reinterpret_cast<uint64_t*>(static_cast<uint16_t*>(p.out) + (int64_t)(m0 + wave) * p.ldo);
+        for (int i = 0; i < 6; ++i) dst[i] = st_acc[i];
+        dst[6] = end - st_last;       // epilogue
+        dst[7] = end - st_t0;
+    }
+#endif
 }
 
 template <typename T>

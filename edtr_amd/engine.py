@@ -607,7 +607,10 @@ class Emitter:
             return 1
         if not feeds:
             return 3
-        return max(ops.op_parts(self.parts_for(f, M)) for f in feeds)
+        # (a class on the weights-exact two-part product reads ONE activation part — but only as a plain GEMM with whole 64-column
+        #  K-tiles: a 3 x 3 convolution, or a width that is no multiple of 64, falls back to three parts AFTER this operand was
+        #  written (EDTR_AMD_POLICY={"default": 4} died on it in round 5).  Three parts serve both: a consumer reads a prefix.)
+        return max(3 if self.parts_for(f, M) == ops.PARTS_2W else ops.op_parts(self.parts_for(f, M)) for f in feeds)
 
     def op_fmt(self, parts: int):
         """dtype code under which a norm / split launch writes a ``parts``-part operand."""

@@ -28,12 +28,16 @@ def default_compute_dtype() -> torch.dtype:
 PRECISIONS = ("fast", "mixed", "high", "hybrid")
 
 # The hybrid parity mode (round 6): what each SECTION of the path runs.  Plain fp16 storage is already
-# inside the north-star 1e-3 on the LATENT (8.7e-4 at full size, 114.8 images/s against 118 for bf16); the excess on the image
-# (1.5e-3) is added by the decoder, whose few stream-carrying convolutions pass their operand roundings straight into the pixels.
-# So: the denoiser in the fast fp16 mode, the VAE in the mixed mode (fp32 stream, three-part products on its stream carriers:
-# edtr_amd/precision.py).  EDTR_AMD_HYBRID (JSON: {"cldm": "fast16" | "fastbf16" | "mixed" | "high", "vae.encode": ...,
-# "vae.decode": ...}) overrides the table for experiments (tools/exp/r06_hybrid_sweep.py).
-HYBRID_SECTIONS = {"cldm": "fast16", "vae.encode": "mixed", "vae.decode": "mixed"}
+# inside the north-star 1e-3 on the final LATENT (8.7e-4 at full size); the excess on the image (1.5e-3) is added by the decoder, whose
+# few stream-carrying convolutions pass their operand roundings straight into the pixels (decoder alone in fp16 behind an exact
+# latent: 1.4e-3).  So: encoder and denoiser in the fast fp16 mode, the DECODER in the mixed mode (fp32 stream, three-part products on
+# its stream carriers: edtr_amd/precision.py).  Measured at full size on one device (profiles/r06/hybrid_sweep*.log): latent 8.7e-4,
+# image 8.9e-4 at 102.5 images/s against 91.6 for the all-mixed mode (5.4e-4 / 6.1e-4) and 119.1 for bf16 (6.1e-3 / 1.2e-2); the
+# encoder in the mixed mode too buys 8.2e-4 / 8.5e-4 for 5 images/s; every cheaper decoder policy (two parts or one on any carrier)
+# leaves the image above 9.6e-4.  The encoded latent z_pre itself is at fp16's 1.4e-3 — an intermediate, damped by the sampler.
+# EDTR_AMD_HYBRID (JSON: {"cldm": "fast16" | "fastbf16" | "mixed" | "high", "vae.encode": ..., "vae.decode": ...}) overrides the
+# table for experiments (tools/exp/r06_hybrid_sweep.py).
+HYBRID_SECTIONS = {"cldm": "fast16", "vae.encode": "fast16", "vae.decode": "mixed"}
 _SECTION_MODES = {"fast16": ("fast", torch.float16), "fastbf16": ("fast", torch.bfloat16), "mixed": ("mixed", None), "high": ("high", None)}
 
 

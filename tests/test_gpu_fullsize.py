@@ -17,7 +17,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "high": None, "mixed": None}      # "high" / "mixed" = the parity modes
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "high": None, "mixed": None, "hybrid": None}      # "high" / "mixed" / "hybrid" = the parity modes
 
 
 def _tol(name):
@@ -51,7 +51,7 @@ def _slice_inputs(inp, k):
                   [n[k:k + 1].contiguous() for n in inp.step_noises], inp.t_start[k:k + 1])
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16", "mixed"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "mixed", "hybrid"])
 def test_det512_batch8_every_image(golden_dir, dname):
     """BASELINE configs[1] (and one GPU's share of configs[2]) exactly as bench.py runs it: B = 8.  Every image of the batch is
     also compared with the same image travelling alone: tile choice, split-K and GroupNorm fusion depend on M = B*H*W, so the
@@ -60,7 +60,7 @@ def test_det512_batch8_every_image(golden_dir, dname):
     from edtr_amd.testing import rel_err
     dev = _need_gpu()
     g = np.load(os.path.join(golden_dir, "full_det512.npz"))
-    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision="mixed" if dname == "mixed" else None)
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision=dname if dname in ("mixed", "hybrid") else None)
     inp = workloads.make_inputs("det512", 1024, dev, 8, 512)
     img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "det512")
     torch.cuda.synchronize()
