@@ -50,7 +50,7 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="sd21", choices=["sd21", "tiny"])
-    ap.add_argument("--precision", default="fast", choices=["fast", "mixed", "high", "hybrid"],
+    ap.add_argument("--precision", default="fast", choices=["fast", "mixed", "high", "hybrid", "robust"],
                     help="fast = 16-bit activation storage in --dtype (headline); mixed = the fast parity mode (fp32 stream, fp16 "
                          "operands, 1-3 products per layer class: edtr_amd/precision.py); high = the robust parity mode (fp32 stream, "
                          "bf16 split-3 products everywhere).  Both parity modes meet the 1e-3 north-star tolerance")
@@ -282,7 +282,8 @@ def main() -> None:
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"high": "bf16 split-3 products over an fp32 stream (precision=high)",
                   "mixed": "fp16 1-3-part products over an fp32 stream (precision=mixed)",
-                  "hybrid": "fp16 storage in the denoiser, fp16 1-3-part products over an fp32 stream in the VAE (precision=hybrid)"}.get(args.precision, args.dtype),
+                  "hybrid": "fp16 storage in the encoder and the denoiser, fp16 1-3-part products over an fp32 stream in the decoder (precision=hybrid)",
+                  "robust": "fp16 three-part products over an fp32 stream in the denoiser, the mixed allocation in the VAE (precision=robust)"}.get(args.precision, args.dtype),
         "data": "synthetic",
         "config": {"workload": (f"EDTR-seg s4 ({args.config}), configs[3]: tiled vae_encode (256-px tiles) + q_sample(t=200) + 4 x latent-tiled "
                                 f"(64/32) ControlNet+UNet + untiled vae_decode, batch {B}/GPU of {S}x{S}") if tiled else
@@ -300,7 +301,7 @@ def main() -> None:
         "mfma_frac_whole_path": round(value * FLOP_PER_IMAGE_BY_WORKLOAD[args.workload] / (world * PEAK_TFLOPS * 1e12), 4)
         if (args.config == "sd21" and std_shape) else None,
     }
-    if args.precision in ("mixed", "hybrid") and cldm._policy() is not None:
+    if args.precision in ("mixed", "hybrid", "robust") and cldm._policy() is not None:
         result["config"]["precision_policy"] = cldm._policy().describe()
     if args.precision == "hybrid":
         from edtr_amd.model.cldm import hybrid_sections
@@ -333,31 +334,35 @@ def main() -> None:
     if (rank == 0 and world == 1 and args.parity_steps > 0 and args.precision == "fast" and args.workload == "det512"
             and args.config == "sd21" and std_shape and not args.dup):
         # ---- the modes that meet the north-star tolerance, timed in the SAME run (the headline above is the fast bf16 mode):
-        #      "hybrid" = the fastest one on well-conditioned weights (round 6), "mixed" = the all-sections form of rounds 3-5 (kept on the
-        #      record for continuity), "high" = the one that holds 1e-3 on outlier-bearing weights too (a short leg: it is 3 x the MFMA work)
+        #      "hybrid" = the fastest one on well-conditioned weights (round 6: fp16 encoder + denoiser, mixed decoder); "robust" = the
+        #      cheapest one that holds 1e-3 on OUTLIER-BEARING weights too (round 6: three parts on every denoiser class, mixed VAE, q / k
+        #      split; pinned against 1e-3 on the moderate set by tests/test_gpu_heavy.py); "high" = bf16 split-3 everywhere (a short leg).
+        #      The all-sections "mixed" mode of rounds 3 - 5 is `--precision mixed` (89.9 images/s, 5.4e-4 / 6.1e-4 beside this run's figures).
         try:
             result["parity_mode"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="hybrid")
-            result["parity_mode_mixed"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="mixed")
+            result["parity_mode_robust"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="robust",
+                                                           steps=max(4, args.parity_steps // 2))
             result["parity_mode_high"] = parity_mode_leg(cldm, args, one_pass, capture_all, run_steps, B, rel_err, mode="high",
                                                          steps=max(4, args.parity_steps // 3))
-            pm = max((result[k] for k in ("parity_mode", "parity_mode_mixed") if result[k].get("meets_north_star")),
-                     key=lambda r: r["images_per_s"], default=result["parity_mode"])
-            ph = result["parity_mode_high"]
+            pm = result["parity_mode"]
+            pr = max((result[k] for k in ("parity_mode_robust", "parity_mode_high") if result[k].get("meets_north_star")),
+                     key=lambda r: r["images_per_s"], default=result["parity_mode_high"])
             # how to read `value` against BASELINE.json's north star: `value` is the bf16-storage mode that
             # configs[1] names — its own image error is 1.2e-2 — and the throughput at which "parity within 1e-3" HOLDS is the figure below
             result["north_star"] = {
                 "parity_tolerance": NORTH_STAR,
                 "images_per_s_at_parity": pm.get("images_per_s") if pm.get("meets_north_star") else None,
                 "ratio_to_value": round(pm["images_per_s"] / value, 3) if pm.get("meets_north_star") and value else None,
-                "mode": f"precision=\"{pm.get('precision')}\" (see parity_mode / parity_mode_mixed), same model / inputs / run",
+                "mode": f"precision=\"{pm.get('precision')}\" (parity_mode), same model / inputs / run",
                 "value_mode_image_error": result.get("parity_vs_reference_golden", {}).get("rel_err_image_samples"),
-                "images_per_s_at_parity_outlier_weights": ph.get("images_per_s") if ph.get("meets_north_star") else None,
-                "ratio_to_value_outlier_weights": round(ph["images_per_s"] / value, 3) if ph.get("meets_north_star") and value else None,
-                "scope": "hybrid / mixed hold 1e-3 on well-conditioned weights (synthetic smooth set, tests/golden/full_det512.npz).  With outlier "
-                         "channels in the weights (moderate set: tests/golden/moderate.npz) NO mode faster than precision=\"high\" holds 1e-3: "
-                         "every part-count allocation short of three parts everywhere leaves 1.2 - 1.9e-3 on the denoiser's output "
-                         "(profiles/r05/moderate_policies.log, profiles/r06/moderate_policies.log, tests/test_gpu_heavy.py) — `high` "
-                         "(parity_mode_high, timed above) is the figure to quote for such weights"}
+                "images_per_s_at_parity_outlier_weights": pr.get("images_per_s") if pr.get("meets_north_star") else None,
+                "ratio_to_value_outlier_weights": round(pr["images_per_s"] / value, 3) if pr.get("meets_north_star") and value else None,
+                "mode_outlier_weights": f"precision=\"{pr.get('precision')}\"",
+                "scope": "hybrid holds 1e-3 on well-conditioned weights (synthetic smooth set, tests/golden/full_det512.npz: the parity figures on this "
+                         "line).  With outlier channels in the weights (moderate set: tests/golden/moderate.npz, the reference's outputs) hybrid / mixed "
+                         "leave 1.6 - 3.4e-3 and the modes that hold 1e-3 on EVERY figure are precision=\"robust\" (6.3 - 7.8e-4) and \"high\" (<= 1.3e-4), "
+                         "both asserted against 1e-3 itself in tests/test_gpu_heavy.py; their throughput on this workload is timed above "
+                         "(profiles/r06/moderate_policies*.log)"}
         except Exception as e:       # never take the headline down
             result["parity_mode"] = {"error": repr(e)}
     if dist is not None:
@@ -763,7 +768,8 @@ def kernel_of(name: str) -> str:
 # for z_pre / latent / image over the three workloads) so that a 2x regression of a mode's numerics fails the run; the north-star
 # 1e-3 is what the parity modes (mixed, high) must additionally meet
 TOLERANCE = {"bf16": {"z_pre": 1.75e-2, "latent": 9.3e-3, "image": 1.8e-2}, "fp16": {"z_pre": 2.2e-3, "latent": 1.3e-3, "image": 2.3e-3},
-             "mixed": {"z_pre": 1e-3, "latent": 8.2e-4, "image": 9e-4}, "hybrid": {"z_pre": 2.2e-3, "latent": 1e-3, "image": 1e-3}, "high": {"z_pre": 4.4e-5, "latent": 1.8e-5, "image": 3.6e-5}}
+             "mixed": {"z_pre": 1e-3, "latent": 8.2e-4, "image": 9e-4}, "hybrid": {"z_pre": 2.2e-3, "latent": 1e-3, "image": 1e-3},
+             "robust": {"z_pre": 1e-3, "latent": 3.8e-4, "image": 5.7e-4}, "high": {"z_pre": 4.4e-5, "latent": 1.8e-5, "image": 3.6e-5}}
 NORTH_STAR = 1e-3
 # max-norm bound as a multiple of the L2 tolerance: measured max / L2 ratios of the shipped modes are 0.9 - 1.3 (the peak of a latent / image is a few times its RMS)
 # (profiles/r04/maxnorm_measured.log), a defect in one 16 x 16 tile of a 512 x 512 image with O(1) errors gives > 100

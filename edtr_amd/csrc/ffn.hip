@@ -36,9 +36,9 @@ constexpr int XCH_OFF = RING;              // G fragments: [wave][k-step u] x 1 
 constexpr int XCH = 8 * 2048;              //  barrier of its last k-tile, which every wave reaches after reading the previous chunk's)
 constexpr int XFL = 2;                     // token fragments 20 - XFL .. 19 live in LDS, not in registers (the register file is full)
 constexpr int XF_OFF = XCH_OFF + XCH;      // [wave][XFL] x 1 KiB
-constexpr int CST_OFF = XF_OFF + 8 * XFL * 1024;     // folded-LayerNorm constants of a chunk: [chunk parity][half][128 floats]
-constexpr int CST = 2 * 2 * 512;
-constexpr int FLDS = CST_OFF + CST;        // 157696 bytes
+constexpr int CST_OFF = XF_OFF + 8 * XFL * 1024;     // per-unit constants of a chunk: [chunk parity][half][64 floats]
+constexpr int CST = 2 * 2 * 256;
+constexpr int FLDS = CST_OFF + CST;        // 156672 bytes
 constexpr int OPITCH = 656;                // output tile row pitch in bytes (640 + 16: the 8-byte column writes of 32 rows spread over the banks)
 static_assert(FLDS <= 160 * 1024 && FBM * OPITCH <= RING, "LDS budget");
 
@@ -81,23 +81,21 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
     const uint32_t voff2 = (uint32_t)((grow * FH + 8 * gchunk) * 2);             // W2 [FD][FH]
     const u32x4 srd1 = make_srd(p.w1), srd2 = make_srd(p.w2);
     const uint32_t my_slot = lds0 + wave * 1024;
-    auto issue_w1 = [&](int c, int kt) {          // both halves of k-tile kt of chunk c
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-            dma16_buf(voff1, srd1, (uint32_t)(((128 * c + 64 * hh) * FD + 64 * kt) * 2), my_slot + (2 * kt + hh) * GRAN);
+    auto issue_w1h = [&](int c, int kt, int hh) {          // half hh of k-tile kt of chunk c
+        dma16_buf(voff1, srd1, (uint32_t)(((128 * c + 64 * hh) * FD + 64 * kt) * 2), my_slot + (2 * kt + hh) * GRAN);
     };
-    auto issue_w2 = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) dma16_buf(voff2, srd2, (uint32_t)((64 * j * FH + 64 * c) * 2), my_slot + (10 + j) * GRAN);
+    auto issue_w1 = [&](int c, int kt) {
+        issue_w1h(c, kt, 0);
+        issue_w1h(c, kt, 1);
     };
-    // constants of chunk c: 2 halves x 128 floats; wave (t, hw) brings floats 64 (t & 1) .. of half hw (waves t and t + 2 bring the
-    // same 256 bytes: every wave issues ONE dma per chunk, which keeps the counted waits uniform)
+    auto issue_w2j = [&](int c, int j) { dma16_buf(voff2, srd2, (uint32_t)((64 * j * FH + 64 * c) * 2), my_slot + (10 + j) * GRAN); };
+    // constants of chunk c: 2 halves x 64 floats; every wave of half hw brings that half's 256 bytes (four waves bring the same
+    // bytes: every wave issues ONE dma per chunk, which keeps the counted waits uniform)
     const u32x4 srdc = make_srd(p.cst);
     auto issue_cst = [&](int c) {
         int ln = lane;
         asm volatile("" : "+v"(ln));            // (re-derived per use: see the GEGLU section)
-        dma4_buf((uint32_t)(ln * 4 + c * 1024 + ((wave >> 2) * 128 + (t & 1) * 64) * 4), srdc, 0u,
-                 lds0 + CST_OFF + (c & 1) * 1024 + (wave >> 2) * 512 + (t & 1) * 256);
+        dma4_buf((uint32_t)(ln * 4 + c * 512 + (wave >> 2) * 256), srdc, 0u, lds0 + CST_OFF + (c & 1) * 512 + (wave >> 2) * 256);
     };
 
     // ---- prologue: the token rows into registers (B fragments: lane = token l31, k = 16 s + 8 lh ..), first weights in flight
@@ -114,26 +112,49 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
 #pragma unroll
     for (int kt = 0; kt < 5; ++kt) issue_w1(0, kt);
 
-    // LayerNorm statistics of this lane's token over the stored 16-bit values (model/attention.py:224 norm3, eps 1e-5)
-    float k0, k1, k0h;
+    // LayerNorm of this lane's token IN the registers (model/attention.py:224 norm3, eps 1e-5): two-pass statistics over the stored
+    // 16-bit values, x <- (x - mean) rstd rounded to 16 bits — what the LayerNorm launch of the two-GEMM form hands its GEMM, minus
+    // the affine part: gamma is folded into w1's columns, beta into the per-unit constants (edtr_hip.h).  The raw rows are read
+    // again for the residual at the end.
     {
-        float s = 0.0f, q = 0.0f;
+        float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
             float f[8];
             unpack8<T>(i < 20 - XFL ? xf[i < 20 - XFL ? i : 0] : xtail[i < 20 - XFL ? 0 : i - (20 - XFL)], f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s += f[j]; q = __builtin_fmaf(f[j], f[j], q); }
+            for (int j = 0; j < 8; ++j) s += f[j];
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / FD);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            float f[8];
+            unpack8<T>(i < 20 - XFL ? xf[i < 20 - XFL ? i : 0] : xtail[i < 20 - XFL ? 0 : i - (20 - XFL)], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = f[j] - mean; q = __builtin_fmaf(dlt, dlt, q); }
+        }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / FD) + p.eps);
+        const float shift = -mean * rstd;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            float f[8];
+            if (i < 20 - XFL) {
+                unpack8<T>(xf[i < 20 - XFL ? i : 0], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], rstd, shift);
+                xf[i < 20 - XFL ? i : 0] = pack8<T>(f);
+            } else {
+                unpack8<T>(xtail[i < 20 - XFL ? 0 : i - (20 - XFL)], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = __builtin_fmaf(f[j], rstd, shift);
+                xtail[i < 20 - XFL ? 0 : i - (20 - XFL)] = pack8<T>(f);
+            }
         }
 #pragma unroll
         for (int i = 0; i < XFL; ++i) *reinterpret_cast<U4*>(smem + XF_OFF + (wave * XFL + i) * 1024 + lane * 16) = xtail[i];      // (own lanes only: no barrier needed)
-        s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 32, 64);
-        const float mean = s * (1.0f / FD);
-        const float var = fmaxf(q * (1.0f / FD) - mean * mean, 0.0f);
-        k0 = __builtin_amdgcn_rsqf(var + p.eps);
-        k1 = -k0 * mean;
-        k0h = 0.5f * k0;
     }
 
     f32x16 oacc[5];
@@ -174,12 +195,6 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
             else wait_vm<5>();
             block_sync();                                       // ... everyone's; the step before is over: its slots are free
             FFN_STAMP(0);
-            if (kt == 0) {
-                issue_w2(c);                                    // needed five steps from now
-                if (more) issue_cst(c + 1);
-            } else if (more) {
-                issue_w1(c + 1, kt - 1);
-            }
             const char* gran = smem + (2 * kt + h) * GRAN;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -196,15 +211,24 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
                 }
                 hv = T::mfma(av, xb_, hv);
                 hg = T::mfma(ag, xb_, hg);
+                // refills, spread between the MFMAs (a DMA issued behind queued matrix work costs the wave ~60 cycles of issue, six
+                // in a row right behind the barrier held the matrix pipe empty): at k-tile 0 the chunk's W2 (needed five steps from now:
+                // its slots are free since the barrier above) and the next chunk's constants, later the next chunk's W1 k-tile kt - 1
+                if (kt == 0) {
+                    if (ks < 2) { issue_w2j(c, 2 * ks); issue_w2j(c, 2 * ks + 1); }
+                    else if (ks == 2) { issue_w2j(c, 4); if (more) issue_cst(c + 1); }
+                } else if (more && ks < 2) {
+                    issue_w1h(c + 1, kt - 1, ks);
+                }
             }
             FFN_STAMP(1);
         }
 
-        // ---- GEGLU with the folded LayerNorm: register r = 4 q + e is hidden unit e + 8 q + 4 lh of this wave's 32
+        // ---- GEGLU: register r = 4 q + e is hidden unit e + 8 q + 4 lh of this wave's 32; + (W1 beta + b1), the gate's halved
         {
             int ln = lane;
             asm volatile("" : "+v"(ln));        // (addresses re-derived here: carried through the loop they spill, and a scratch reload drains the DMA queue)
-            const float* cst = reinterpret_cast<const float*>(smem + CST_OFF + (c & 1) * 1024 + h * 512) + 4 * (ln >> 5);
+            const float* cst = reinterpret_cast<const float*>(smem + CST_OFF + (c & 1) * 512 + h * 256) + 4 * (ln >> 5);
             char* mine = smem + XCH_OFF + wave * 2048 + ln * 16;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -212,14 +236,12 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int q = 2 * u + qq;
-                    const f32x4 c1v = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 0) * 2 + 0) * 8);
-                    const f32x4 c2v = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 0) * 2 + 1) * 8);
-                    const f32x4 c1g = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 1) * 2 + 0) * 8);
-                    const f32x4 c2g = *reinterpret_cast<const f32x4*>(cst + ((q * 2 + 1) * 2 + 1) * 8);
+                    const f32x4 c2v = *reinterpret_cast<const f32x4*>(cst + (q * 2 + 0) * 8);
+                    const f32x4 c2g = *reinterpret_cast<const f32x4*>(cst + (q * 2 + 1) * 8);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        val[4 * qq + e] = __builtin_fmaf(k0, hv[4 * q + e], __builtin_fmaf(k1, c1v[e], c2v[e]));
-                        gate[4 * qq + e] = __builtin_fmaf(k0h, hg[4 * q + e], __builtin_fmaf(k1, c1g[e], c2g[e]));      // gate / 2 (constants halved on the host)
+                        val[4 * qq + e] = hv[4 * q + e] + c2v[e];
+                        gate[4 * qq + e] = __builtin_fmaf(0.5f, hg[4 * q + e], c2g[e]);      // gate / 2 (its constant is halved on the host)
                     }
                 }
                 gelu_erf_lockstep<true>(gate);
@@ -234,7 +256,6 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
         if (more) wait_vm<9>(); else wait_vm<0>();
         block_sync();                                           // W2 of the chunk everyone's; both halves' G fragments published
         FFN_STAMP(3);
-        if (more) issue_w1(c + 1, 4);
         {
             int ln = lane;
             asm volatile("" : "+v"(ln));
@@ -248,6 +269,7 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
                     const U4 a = frag(smem + (10 + (gb >> 1)) * GRAN, 32 * (gb & 1), 2 * ks + lh);
                     oacc[b] = T::mfma(a, g, oacc[b]);
                 }
+                if (more && ks < 2) issue_w1h(c + 1, 4, ks);
             }
         }
         FFN_STAMP(4);

@@ -303,7 +303,7 @@ class WeightStore:
         key = ("ffn", w1name, w2name, ln_prefix)
         if key not in self.cache:
             w1p, b1p, c1, c2 = self.ln_fold("geglu", [w1name], [b1name], ln_prefix)
-            cst = ops.pack_ffn_constants(c1, c2 + b1p)
+            cst = ops.pack_ffn_constants(c2 + b1p)
             w2p = ops.pack_ffn_w2(self._p(w2name).reshape(self.params[w2name].shape[0], -1), self.dtype)
             self.cache[key] = (w1p, w2p, cst, self._p(b2name).reshape(-1).contiguous())
         return self.cache[key]
@@ -592,7 +592,8 @@ class Emitter:
         # p / v split, fp32 output.  The fp16 rounding of q and k alone cost 2.7e-3 of a denoiser evaluation on the heavy-tailed
         # weight set (tests/heavy_attention_budget.py); the mixed mode's projections write fp16 directly (no low part exists).
         # EDTR_AMD_ATTN_SPLIT overrides (the mixed mode then keeps its attention projections in fp32 and pays the split launches).
-        self.attn_split = int(os.environ.get("EDTR_AMD_ATTN_SPLIT", "2" if precision == "high" else "0")) if self.hp else 0
+        pol_split = getattr(self.policy, "attn_split", None)
+        self.attn_split = int(os.environ.get("EDTR_AMD_ATTN_SPLIT", "2" if precision == "high" else str(pol_split or 0))) if self.hp else 0
         self._mirrors: List[Tuple[torch.Tensor, torch.Tensor]] = []
         self.last_gnp = None
         self.last_row_stats = None

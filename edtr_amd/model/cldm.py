@@ -25,7 +25,7 @@ def default_compute_dtype() -> torch.dtype:
     return _DTYPES[os.environ.get("EDTR_AMD_DTYPE", "bf16").lower()]
 
 
-PRECISIONS = ("fast", "mixed", "high", "hybrid")
+PRECISIONS = ("fast", "mixed", "high", "hybrid", "robust")
 
 # The hybrid parity mode (round 6): what each SECTION of the path runs.  Plain fp16 storage is already
 # inside the north-star 1e-3 on the final LATENT (8.7e-4 at full size); the excess on the image (1.5e-3) is added by the decoder, whose
@@ -57,6 +57,8 @@ def section_mode(precision: str, compute_dtype, section: str):
     """(precision mode, compute dtype) that ``section`` ("cldm" | "vae.encode" | "vae.decode") runs under ``precision``."""
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+    if precision == "robust":          # the mixed mode's machinery under the robust allocation (edtr_amd/precision.py: robust_policy)
+        return "mixed", compute_dtype
     if precision != "hybrid":
         return precision, compute_dtype
     mode, dt = _SECTION_MODES[hybrid_sections()[section]]
@@ -64,7 +66,8 @@ def section_mode(precision: str, compute_dtype, section: str):
 
 
 def default_precision() -> str:
-    """"fast": 16-bit activation storage in `compute_dtype` (the throughput modes).  "high": the robust parity mode — fp32
+    """"hybrid" / "robust": the two round-6 parity modes (see HYBRID_SECTIONS below and precision.robust_policy).
+    "fast": 16-bit activation storage in `compute_dtype` (the throughput modes).  "high": the robust parity mode — fp32
     activation stream, every convolution / linear as a bf16 split-3 product with fp32 accumulation (~16 mantissa bits per
     operand), fp16 attention operands.  "mixed": the fast parity mode — the same fp32 stream, fp16 operands and a per-layer
     number of products (edtr_amd/precision.py).  `compute_dtype` is ignored by the two parity modes.  EDTR_AMD_PRECISION
@@ -82,9 +85,11 @@ def _store_dtype(precision: str, compute_dtype, section: str = "cldm"):
 
 def _policy_for(owner, section: str = "cldm"):
     """The mixed-mode precision policy of ``section`` (None where the section does not run the mixed mode)."""
-    from ..precision import mixed_policy
+    from ..precision import mixed_policy, robust_policy
     mode, _ = section_mode(owner.precision, owner.compute_dtype, section)
-    return (owner.precision_policy or mixed_policy()) if mode == "mixed" else None
+    if mode != "mixed":
+        return None
+    return owner.precision_policy or (robust_policy() if owner.precision == "robust" else mixed_policy())
 
 
 def _require_gpu(t: torch.Tensor, what: str) -> None:

@@ -314,19 +314,17 @@ def pack_ffn_w2(w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return w2[:, perm].to(dtype).contiguous()
 
 
-def pack_ffn_constants(c1: torch.Tensor, c2b: torch.Tensor) -> torch.Tensor:
-    """The folded-LayerNorm constants in edtr_ffn's per-chunk order (edtr_hip.h: edtr_ffn_params.cst).  ``c1`` / ``c2b`` are indexed
-    by the PACKED (value / gate interleaved) w1 row; gate entries are stored halved."""
-    n = c1.numel()
-    assert n % 128 == 0 and c2b.numel() == n
-    dev = c1.device
-    c, hh, q, vg, kind, lh, e = torch.meshgrid(torch.arange(n // 128, device=dev), torch.arange(2, device=dev), torch.arange(4, device=dev),
-                                               torch.arange(2, device=dev), torch.arange(2, device=dev), torch.arange(2, device=dev),
-                                               torch.arange(4, device=dev), indexing="ij")
+def pack_ffn_constants(c2b: torch.Tensor) -> torch.Tensor:
+    """The per-unit constants W1 beta + b1 in edtr_ffn's per-chunk order (edtr_hip.h: edtr_ffn_params.cst).  ``c2b`` is indexed by the
+    PACKED (value / gate interleaved) w1 row; gate entries are stored halved."""
+    n = c2b.numel()
+    assert n % 128 == 0
+    dev = c2b.device
+    c, hh, q, vg, lh, e = torch.meshgrid(torch.arange(n // 128, device=dev), torch.arange(2, device=dev), torch.arange(4, device=dev),
+                                         torch.arange(2, device=dev), torch.arange(2, device=dev), torch.arange(4, device=dev), indexing="ij")
     R = 128 * c + 64 * hh + 32 * vg + e + 8 * q + 4 * lh
-    both = torch.stack([c1.float(), c2b.float()])            # [kind][R]
-    out = both[kind, R] * torch.where(vg == 1, 0.5, 1.0)
-    return out.reshape(-1).contiguous()                      # [chunk][half][q][vg][kind][lh][e]
+    out = c2b.float()[R] * torch.where(vg == 1, 0.5, 1.0)
+    return out.reshape(-1).contiguous()                      # [chunk][half][q][vg][lh][e]
 
 
 def make_ffn(*, dtype, x, ldx, M, w1, w2, cst, b2, out, ldo, eps=1e-5, name="ff.fused") -> Rec:

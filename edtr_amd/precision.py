@@ -28,10 +28,13 @@ from typing import Dict, Optional
 
 
 class PrecisionPolicy:
-    def __init__(self, default: int = 2, table: Optional[Dict[str, int]] = None, label: str = "custom"):
+    def __init__(self, default: int = 2, table: Optional[Dict[str, int]] = None, label: str = "custom", attn_split: Optional[int] = None):
         self.default = int(default)
         self.table = dict(table or {})
         self.label = label
+        # attention operands: None = the mode's default (one fp16 part in the mixed mode); 1 = q / k as hi + lo pairs (three QK^T products),
+        # 2 = q / k and p / v (Emitter.attn_split; EDTR_AMD_ATTN_SPLIT overrides)
+        self.attn_split = attn_split
         for k, v in list(self.table.items()) + [("default", self.default)]:
             if v not in (1, 2, 3, 4):
                 raise ValueError(f"precision policy: {k} -> {v!r} (parts must be 1, 2, 3 or 4 = the weights-exact two-part product)")
@@ -43,10 +46,10 @@ class PrecisionPolicy:
         return self.default if hit is None else hit
 
     def key(self):
-        return (self.default, tuple(sorted(self.table.items())))
+        return (self.default, tuple(sorted(self.table.items())), self.attn_split)
 
     def describe(self) -> dict:
-        return {"label": self.label, "default": self.default, "table": dict(sorted(self.table.items()))}
+        return {"label": self.label, "default": self.default, "table": dict(sorted(self.table.items())), "attn_split": self.attn_split}
 
 
 class ConstPolicy(PrecisionPolicy):
@@ -86,3 +89,22 @@ def mixed_policy() -> PrecisionPolicy:
         table.update({k: int(v) for k, v in spec.items()})
         return PrecisionPolicy(default, table, "env")
     return PrecisionPolicy(MIXED_DEFAULT, MIXED_TABLE, "mixed-r04")
+
+
+# The ROBUST allocation (round 6, precision="robust"): what holds the north-star 1e-3 on OUTLIER-BEARING weights at the least cost.
+# On the moderate-outlier weight set (edtr_amd.synth.synth_param_moderate; reference outputs in tests/golden/moderate.npz) the shipped
+# table above leaves 1.6 - 1.9e-3 on the denoiser's output, and no re-allocation short of three parts on EVERY denoiser class closes it
+# (profiles/r05/moderate_policies.log; profiles/r06/moderate_policies.log: the weights-exact two-part product on every linear still
+# leaves eps at 1.2e-3 — with outlier rows in the weights the ACTIVATION rounding of the products they amplify matters too).  The VAE,
+# on the other hand, is inside 1e-3 on the shipped allocation (encoder 6.4e-4, decoder 3.0e-4).  So: three parts on every denoiser
+# class, the shipped table in the VAE, q / k of the attention as hi + lo pairs.  Measured (profiles/r06/moderate_policies2.log):
+# moderate set z_pre 6.4e-4, latent 6.5e-4, image 6.3e-4, eps 7.8e-4, VAE 6.4e-4 / 3.0e-4 (without the q / k split: eps 9.6e-4) — every
+# figure inside 1e-3, asserted against 1e-3 itself in tests/test_gpu_heavy.py; smooth set at full size 2.5e-4 / 3.8e-4.  Against
+# precision="high" (bf16 split-3 everywhere, 40.9 images/s) it keeps the FLOP-heavy VAE convolutions at one product.
+ROBUST_VAE_ONE_PART = ("vae.conv1", "vae.conv2", "vae.attn.qk", "vae.attn.vT", "vae.attn.proj_out", "vae.attn.flash")
+
+
+def robust_policy() -> PrecisionPolicy:
+    table = dict(MIXED_TABLE)
+    table.update({k: 1 for k in ROBUST_VAE_ONE_PART})
+    return PrecisionPolicy(3, table, "robust-r06", attn_split=1)

@@ -419,17 +419,17 @@ int edtr_swin_layer(const edtr_swin_attn_params* attn, const edtr_swin_mlp_param
  *           launches `ff.geglu` / `ff.out` of the two-launch form; the (rows, 4 d) hidden tensor never reaches memory.
  * Built for the 64 x 64-latent level of the SD-2.1 UNet / ControlNet: D = 320, H = 4 D = 1280, M % 128 == 0; anything else is
  * EDTR_E_UNSUPPORTED (edtr_ffn_plan answers without a launch) and the caller issues the two edtr_igemm launches.
- *   x   : [M][ldx] 16-bit RAW rows (before the LayerNorm): the kernel takes the row statistics from the stored values it holds
+ *   x   : [M][ldx] 16-bit RAW rows (before the LayerNorm): the kernel normalises them in registers (two-pass statistics over the
+ *         stored values, (x - mean) rstd rounded to 16 bits) and reads them again for the residual
  *   w1  : [2 H][D] 16-bit, the GEGLU projection pre-multiplied by the LayerNorm gamma, value / gate rows interleaved in blocks of
  *         32 exactly as edtr_igemm's EDTR_ACT_GEGLU operand (rows 64 J .. 64 J + 31 = values of gated units 32 J .., the next 32
  *         rows their gates)
  *   w2  : [D][H] 16-bit, the output projection with its COLUMNS permuted inside every aligned group of 16:
  *         stored column 16 g + i = original column 16 g + {0,1,2,3, 8,9,10,11, 4,5,6,7, 12,13,14,15}[i]
  *         (the accumulator registers of the first product are then the operand of the second without a shuffle)
- *   cst : fp32 [H / 64][2][128]: the folded-LayerNorm constants of chunk c, half hh, at ((q*2 + vg)*2 + kind)*8 + lh*4 + e  for the
- *         packed w1 row R = 128 c + 64 hh + 32 vg + (e + 8 q + 4 lh)   (q, e < 4; vg = 0 value / 1 gate; lh < 2):
- *         kind 0 = c1[R] = row sum of the PACKED 16-bit w1 row, kind 1 = (W1 beta)[R] + b1[R]; the GATE entries (vg = 1) of both kinds
- *         are stored HALVED (the kernel evaluates gelu from gate / 2):   pre[R] = rstd (acc[R] - mean c1[R]) + c2b[R]
+ *   cst : fp32 [H / 64][2][64]: the per-unit constant (W1 beta + b1)[R] of chunk c, half hh, at (q*2 + vg)*8 + lh*4 + e  for the
+ *         packed w1 row R = 128 c + 64 hh + 32 vg + (e + 8 q + 4 lh)   (q, e < 4; vg = 0 value / 1 gate; lh < 2); the GATE
+ *         entries (vg = 1) are stored HALVED (the kernel evaluates gelu from gate / 2)
  *   b2  : fp32 [D]
  *   out : [M][ldo] 16-bit, must not alias x (rows are re-read as the residual)
  * ldx % 8 == 0, ldo % 8 == 0, all pointers 16-byte aligned. */

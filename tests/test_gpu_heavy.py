@@ -176,6 +176,11 @@ NORTH_STAR = 1e-3
 # Every figure is held to <= 1.5 x its measurement.
 MODERATE = {"mixed": (None, "mixed", dict(z_pre=9.6e-4, z=2.8e-3, img=2.45e-3, eps=2.55e-3, vae=9.7e-4)),
             "high": (None, "high", dict(z_pre=1.9e-4, z=1.25e-4, img=1.6e-4, eps=4.3e-5, vae=1.5e-4)),
+            # robust (round 6: three parts on every denoiser class, the shipped allocation in the VAE, q / k split): every figure is asserted
+            # against the north-star 1e-3 ITSELF below (measured 6.4e-4 6.5e-4 6.3e-4 | 7.8e-4 6.4e-4 3.0e-4)
+            "robust": (None, "robust", dict(z_pre=1e-3, z=1e-3, img=1e-3, eps=1e-3, vae=1e-3)),
+            # hybrid (round 6: fp16 encoder + denoiser, mixed decoder) is fp16 on everything but the decoder: like `mixed`, scoped to well-conditioned weights
+            "hybrid": (None, "hybrid", dict(z_pre=1.9e-3, z=5.1e-3, img=4.2e-3, eps=3.7e-3, vae=2.2e-3)),
             "fp16": (torch.float16, "fast", dict(z_pre=1.9e-3, z=5.1e-3, img=4.2e-3, eps=3.7e-3, vae=2.2e-3)),
             "bf16": (torch.bfloat16, "fast", dict(z_pre=1.55e-2, z=4.2e-2, img=3.6e-2, eps=2.95e-2, vae=1.7e-2))}
 
@@ -221,5 +226,7 @@ def test_moderate_outlier_weights_pipeline_and_sd21_widths(golden_dir, mode):
           + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     lim = dict(tol, vae_z=tol["vae"], vae_dec=tol["vae"])
     assert all(v < lim[k] for k, v in errs.items()), errs
-    if mode == "high":          # the robust parity mode meets the north star on outlier-bearing weights with a 4 x margin
+    if mode == "high":          # the bf16 split-3 mode meets the north star on outlier-bearing weights with a 4 x margin
         assert max(errs.values()) < 0.25 * NORTH_STAR, errs
+    if mode == "robust":        # ... and the cheapest allocation that holds it at all holds it on every figure
+        assert max(errs.values()) < NORTH_STAR, errs

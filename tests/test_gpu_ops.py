@@ -1688,7 +1688,8 @@ def test_flash_attn512_vs_fp32_softmax(dtype, B, N, sharp, out_f32):
             assert torch.isfinite(got).all()
             worst = max(worst, rel(got, ref))
     MEASURED[f"flash_attn512[{dtype}-{B}-{N}-{sharp}]"] = worst
-    assert worst < (4e-3 if dtype == torch.float16 else 2.5e-2) * (1.0 if sharp < 20 else 2.0), worst
+    # measured (round 6, profiles/r06/per_kernel_errors.json): bf16 <= 2.36e-3, fp16 <= 2.95e-4 over these shapes — the file's envelope (<= 1.5 x)
+    assert worst < TOL[dtype], worst
 
 
 def test_flash_attn512_rejects_what_it_cannot_run():
@@ -1721,7 +1722,7 @@ def _ffn_operands(ops, dtype, seed=0):
     w1p = ops.pack_linear_weight(w1[perm] * gamma[None, :], dtype)
     c1 = w1p.float().sum(1)
     c2b = w1[perm] @ beta + b1[perm]
-    return dict(gamma=gamma, beta=beta, w1=w1, b1=b1, w2=w2, b2=b2, w1p=w1p, w2p=ops.pack_ffn_w2(w2, dtype), cst=ops.pack_ffn_constants(c1, c2b))
+    return dict(gamma=gamma, beta=beta, w1=w1, b1=b1, w2=w2, b2=b2, w1p=w1p, w2p=ops.pack_ffn_w2(w2, dtype), cst=ops.pack_ffn_constants(c2b))
 
 
 def _ffn_reference(x16, o):
@@ -1751,8 +1752,10 @@ def test_ffn_fused_vs_fp32_reference(dtype, M, ldx, shift):
     assert torch.isfinite(got).all()
     ref = _ffn_reference(xs[:, :D], o)
     # the branch alone (residual removed): the sum is dominated by x, which would hide an error of the feed-forward part
-    e_all, e_branch = rel(got, ref), rel(got - xs[:, :D].float(), ref - xs[:, :D].float())
-    MEASURED[f"ffn_branch[{dtype}-{M}]"] = e_branch
+    xb = xs[:, :D].float()
+    e_all = rel(got, ref)
+    e_branch = float(((got - xb) - (ref - xb)).double().norm() / (ref - xb).double().norm())      # (not through rel(): the envelope is about stored tensors)
+    MEASURED[f"ffn_branch_only[{'b16' if dtype == torch.bfloat16 else 'h16'}-{M}]"] = e_branch
     assert e_all < TOL[dtype], (e_all, e_branch)
     assert e_branch < (1.2e-2 if dtype == torch.bfloat16 else 1.6e-3), (e_all, e_branch)      # (the branch is a rounded 16-bit sum with x: its own error is ~ 2^-9 / 2^-12 of |x| / |branch|)
     if ldx > D:

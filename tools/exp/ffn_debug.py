@@ -22,7 +22,7 @@ def run(x16, gamma, beta, w1, b1, w2, b2, dtype, d):
     c2b = w1[perm] @ beta + b1[perm]
     out = torch.full(x16.shape, float("nan"), dtype=dtype, device=d)
     ops.launch(ops.make_ffn(dtype=dtype, x=x16.to(d), ldx=D, M=x16.shape[0], w1=w1p.to(d), w2=ops.pack_ffn_w2(w2, dtype).to(d),
-                            cst=ops.pack_ffn_constants(c1, c2b).to(d), b2=b2.to(d), out=out, ldo=D))
+                            cst=ops.pack_ffn_constants(c2b).to(d), b2=b2.to(d), out=out, ldo=D))
     torch.cuda.synchronize()
     xf = x16.float()
     ln = F.layer_norm(xf, (D,), gamma, beta, 1e-5)

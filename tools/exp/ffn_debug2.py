@@ -23,7 +23,7 @@ def main():
         c1 = w1p.float().sum(1)
         out = torch.full((M, D), float("nan"), dtype=dtype, device=d)
         ops.launch(ops.make_ffn(dtype=dtype, x=x.to(d), ldx=D, M=M, w1=w1p.to(d), w2=ops.pack_ffn_w2(w2, dtype).to(d),
-                                cst=ops.pack_ffn_constants(c1, b1[perm]).to(d), b2=torch.zeros(D, device=d), out=out, ldo=D))
+                                cst=ops.pack_ffn_constants(b1[perm]).to(d), b2=torch.zeros(D, device=d), out=out, ldo=D))
         torch.cuda.synchronize()
         o = out.float().cpu() / 6.0
         vals, counts = torch.unique(o.round(), return_counts=True)
