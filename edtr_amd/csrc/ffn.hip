@@ -65,6 +65,54 @@ __device__ __forceinline__ void block_sync() {
     asm volatile("" ::: "memory");
 }
 
+// gelu from x / 2 over eight values as four PACKED fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32: two values per instruction and lane): the
+// GEGLU of a chunk is ~250 vector instructions per wave between two runs of MFMAs, with both waves of a SIMD in it at the same time —
+// in the stamps it is as long as the chunk's matrix work.  Same arithmetic and order of operations as gelu_erf_lockstep<true>
+// (common.h); v_exp / v_rcp stay per value.
+__device__ __forceinline__ void pin4(f32x2 (&v)[4]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
+__device__ __forceinline__ void gelu_half_in_pk(f32x2 (&h)[4]) {
+    f32x2 d[4], u[4], poly[4], a[4];
+    const f32x2 one = {1.0f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = f32x2{fabsf(h[i][0]), fabsf(h[i][1])};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = a[i] * f32x2{0.3275911f * 1.41421356237309504880f, 0.3275911f * 1.41421356237309504880f} + one;
+    pin4(d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = f32x2{__builtin_amdgcn_rcpf(d[i][0]), __builtin_amdgcn_rcpf(d[i][1])};
+    pin4(d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = h[i] * h[i];
+    pin4(u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = u[i] * f32x2{-2.0f * 1.4426950408889634f, -2.0f * 1.4426950408889634f};
+    pin4(u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = f32x2{__builtin_amdgcn_exp2f(u[i][0]), __builtin_amdgcn_exp2f(u[i][1])};
+    pin4(u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = d[i] * f32x2{1.061405429f, 1.061405429f} + f32x2{-1.453152027f, -1.453152027f};
+    pin4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = poly[i] * d[i] + f32x2{1.421413741f, 1.421413741f};
+    pin4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = poly[i] * d[i] + f32x2{-0.284496736f, -0.284496736f};
+    pin4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = poly[i] * d[i] + f32x2{0.254829592f, 0.254829592f};
+    pin4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = u[i] * d[i];
+    pin4(u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = one - poly[i] * u[i];
+    pin4(u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = a[i] * u[i] + h[i];
+    pin4(h);
+}
+
 template <typename T, int HALF>
 __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -232,22 +280,27 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
             char* mine = smem + XCH_OFF + wave * 2048 + ln * 16;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                float val[8], gate[8];
+                f32x2 val[4], gate[4];
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int q = 2 * u + qq;
                     const f32x4 c2v = *reinterpret_cast<const f32x4*>(cst + (q * 2 + 0) * 8);
                     const f32x4 c2g = *reinterpret_cast<const f32x4*>(cst + (q * 2 + 1) * 8);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        val[4 * qq + e] = hv[4 * q + e] + c2v[e];
-                        gate[4 * qq + e] = __builtin_fmaf(0.5f, hg[4 * q + e], c2g[e]);      // gate / 2 (its constant is halved on the host)
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        val[2 * qq + e2] = f32x2{hv[4 * q + 2 * e2], hv[4 * q + 2 * e2 + 1]} + f32x2{c2v[2 * e2], c2v[2 * e2 + 1]};
+                        gate[2 * qq + e2] = f32x2{hg[4 * q + 2 * e2], hg[4 * q + 2 * e2 + 1]} * f32x2{0.5f, 0.5f} + f32x2{c2g[2 * e2], c2g[2 * e2 + 1]};      // gate / 2
                     }
                 }
-                gelu_erf_lockstep<true>(gate);
+                gelu_half_in_pk(gate);
+                float out8[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] *= gate[e];
-                *reinterpret_cast<U4*>(mine + u * 1024) = pack8<T>(val);
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 pr = val[e] * gate[e];
+                    out8[2 * e] = pr[0];
+                    out8[2 * e + 1] = pr[1];
+                }
+                *reinterpret_cast<U4*>(mine + u * 1024) = pack8<T>(out8);
             }
         }
 
