@@ -774,7 +774,7 @@ NORTH_STAR = 1e-3
 # max-norm bound as a multiple of the L2 tolerance: measured max / L2 ratios of the shipped modes are 0.9 - 1.3 (the peak of a latent / image is a few times its RMS)
 # (profiles/r04/maxnorm_measured.log), a defect in one 16 x 16 tile of a 512 x 512 image with O(1) errors gives > 100
 MAX_OVER_L2 = 3.0
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r05", "pmc_hbm_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r06", "pmc_hbm_traffic.json")
 
 
 def _cpu_worker(q_in, q_out, cfg_name, S, threads):

@@ -2646,7 +2646,10 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
         halo512 = e5 ? atoi(e5) : 1;
     }
     const bool h512_ok = spatial && (p.C1 & 31) == 0 && edtr_halo512_ok(p) && igemm_fast_addressable(p, spatial);
-    if (p.tile == 0 && tile == 16 && halo512 > 0 && h512_ok && (int64_t)(p.M >> 9) * (p.N >> 7) >= 256 * halo512) tile = 17;
+    // (whole-round rules below count the CUs of the device the launch goes to; the HIP-free edtr_igemm_plan has no device and answers
+    //  for the 256 CUs of an MI355X — ADVICE r05)
+    const int cus = dry ? 256 : edtr_cu_count();
+    if (p.tile == 0 && tile == 16 && halo512 > 0 && h512_ok && (int64_t)(p.M >> 9) * (p.N >> 7) >= (int64_t)cus * halo512) tile = 17;
     // Halo tile of 160 columns (tile 20): N % 160 == 0 convolutions whose 16 x 16-pixel x 160-channel units fill whole rounds of the
     // chip (the 64 x 64-latent ResBlock convolutions at batch 8: 256 units = one per CU), where the 128 x 160 implicit-GEMM tile would run.
     // EDTR_IGEMM_HALO160=0 switches the automatic choice off (A/B on one device).
@@ -2656,8 +2659,8 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
         halo160 = (e10 && e10[0] == '0') ? 0 : 1;
     }
     if (p.tile == 0 && tile == 8 && halo160 && spatial && edtr_halo160_ok(p) && igemm_fast_addressable(p, spatial)) {
-        const int64_t units = (int64_t)(p.M >> 8) * (p.N / 160), tail = units % 256;
-        if (units >= 192 && (tail == 0 || tail >= 192)) tile = 20;       // whole rounds of one unit per CU (the last one >= 3/4 full)
+        const int64_t units = (int64_t)(p.M >> 8) * (p.N / 160), tail = units % cus, most = (int64_t)cus * 3 / 4;
+        if (units >= most && (tail == 0 || tail >= most)) tile = 20;       // whole rounds of one unit per CU (the last one >= 3/4 full)
     }
     if (p.a_gn) {           // GroupNorm (+ SiLU) of the input fused into the halo tiles' patch staging: 16 x 16 / 32 x 16-patch geometries only
         if (p.tile == 17 || (p.tile == 0 && tile == 17)) {

@@ -369,8 +369,9 @@ def _g_vae_resblock(em: Emitter, p: str, l: VaeLayer, x: Act):
 
 
 def _g_vae_attn(em: Emitter, p: str, x: Act):
-    """model/vae.py:279-308: single-head attention with d = C (512): too wide for the fused kernel's register
-    budget, and only 2 calls per image, so it runs as QK^T GEMM (fp32 scores) -> row softmax -> PV GEMM.
+    """model/vae.py:279-308: single-head attention with d = C (512): ONE launch of edtr_flash_attn512 (round 5: eight waves share
+    128 queries, the scores never leave the CU) wherever N is whole 32-key tiles; otherwise — and behind EDTR_ATTN512=0 — the
+    QK^T GEMM (fp32 scores) -> row softmax -> PV GEMM form of rounds 1 - 4.
     In the tiled VAE the same code runs per tile (tile-local attention, utils/tilevae/attn.py:85-115)."""
     B, N, C = x.B, x.H * x.W, x.C
     rows = B * N

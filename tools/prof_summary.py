@@ -9,7 +9,7 @@
                                                                         # [start, end] intervals (in-situ busy time: overlapping
                                                                         # lanes / batches counted once) next to the plain sum
 
-Kernel families: igemm (main loops + split-K reducers), flash_attn (v1 / v2 / v3), gn_apply, gn_stats, layernorm, other.
+Kernel families: igemm (main loops + split-K reducers + the fused feed-forward launch), flash_attn (v1 / v2 / v3), gn_apply, gn_stats, layernorm, other.
 PMC conventions (MI355X_MICROARCH.md): FETCH_SIZE is in KiB and counts wide coalesced reads at HALF their bytes on gfx950
 (x2 applied here), WRITE_SIZE is KiB exact; SQ_*_CYCLES are summed over the chip's SIMDs/XCDs as rocprofv3 reports them."""
 import csv
@@ -29,7 +29,7 @@ def family(name: str) -> str:
         if "split" in n:
             return "flash_attn_split"
         return "flash_attn_v3" if "v3" in n else ("flash_attn_v2" if "v2" in n else "flash_attn_v1")
-    if "igemm" in n or "splitk_reduce" in n:
+    if "igemm" in n or "splitk_reduce" in n or "ffn320" in n:      # (edtr_ffn: two linears of the same family in one launch)
         return "igemm"
     for k in ("gn_apply", "gn_stats", "gn_finalize", "layernorm", "softmax_rows", "window_attn"):
         if k in n:

@@ -6,7 +6,7 @@
 #      stamped with the kernel source hash bench.py checks before it quotes roofline.traffic
 #   3. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -> pmc_mfma_busy_bench.json
 # (counters are never combined with a trace domain: gpurun refuses that; the program itself follows `--`.)
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$R/prof
 mkdir -p $OUT
