@@ -301,9 +301,14 @@ FFN_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
 
 def ffn_ok(M: int, D: int, H: int) -> bool:
-    """Does edtr_ffn (the feed-forward half of a transformer block in one launch) take this shape?  EDTR_FFN=0 keeps the two-GEMM
-    form for A/B runs."""
-    return os.environ.get("EDTR_FFN", "1") != "0" and D == FFN_D and H == FFN_H and M > 0 and M % FFN_ROWS == 0
+    """Does edtr_ffn (the feed-forward half of a transformer block in one launch) take this shape — and is it the faster form?  A
+    workgroup owns 128 tokens for the WHOLE hidden dimension, so the launch lasts ~95 us however few rows there are: it pays where the
+    rows fill at least half the chip (batch 8: 256 workgroups, + 1.4 % on the whole path; batch 4: 128 workgroups beside the other lane's
+    launches, + 0.7 %), not on the 4096 rows of a latent tile of the tiled sampler (32 workgroups against two ~20-us GEMMs).
+    EDTR_FFN=0 keeps the two-GEMM form everywhere (A/B runs); EDTR_FFN_MIN_ROWS overrides the threshold."""
+    if os.environ.get("EDTR_FFN", "1") == "0" or D != FFN_D or H != FFN_H or M <= 0 or M % FFN_ROWS:
+        return False
+    return M >= int(os.environ.get("EDTR_FFN_MIN_ROWS", "16384"))
 
 
 def pack_ffn_w2(w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
