@@ -86,8 +86,22 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+    // block -> (image, head, 128-query block).  The query blocks of ONE (image, head) read the same K / V^T: dealt round-robin over
+    // the eight XCDs (blocks b and b + 8 share one) they made every L2 fetch every head's keys and values — 102 MB per launch at
+    // N = 1024 for 42 MB of operands (profiles/r05/pmc_hbm_traffic.json).  With B H a multiple of 8 the heads are dealt to the XCDs
+    // instead and a head's query blocks follow each other on its XCD (the mapping of the v3 kernel below).
+    const int nqb = (p.Nq + 127) / 128, BH = p.B * p.H;
+    int bh, qblk;
+    if ((BH & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = xcd + 8 * (j / nqb);
+        qblk = j % nqb;
+    } else {
+        bh = blockIdx.x / nqb;
+        qblk = blockIdx.x % nqb;
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q_row = qblk * 128 + wave * 32 + l31;
     const bool q_ok = q_row < p.Nq;
 
     const uint16_t* qp = static_cast<const uint16_t*>(p.q) + b * p.q_bs + h * 64;
@@ -175,7 +189,7 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
                     if (key >= p.Nk) s[kb][r] = -1e30f;
                 }
         }
-        if (p.causal && (t + 1) * KV > blockIdx.x * 128 + wave * 32) {   // this tile reaches past some query of the wave
+        if (p.causal && (t + 1) * KV > qblk * 128 + wave * 32) {   // this tile reaches past some query of the wave
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -236,7 +250,7 @@ __global__ void __launch_bounds__(kThreads, 2) flash_attn64_kernel(const edtr_at
     // wave-private slab of the (now dead: the loop's last barrier has passed) K / V^T buffers to whole-row stores
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
     store_o_tile<T>(smem + wave * OSLAB, o[0], o[1], inv, static_cast<uint16_t*>(p.out) + b * p.o_bs + (int64_t)q0 * p.o_ld + h * 64,
                     p.o_ld, q0, p.Nq, lane);
 }
@@ -802,7 +816,7 @@ extern "C" int edtr_flash_attn64(const edtr_attn_params* pp, edtr_stream_t strea
         EDTR_LAUNCH_CHECK();
         return EDTR_OK;
     }
-    dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+    dim3 grid(((p.Nq + 127) / 128) * p.H * p.B);        // one dimension: the kernel deals heads, not query blocks, to the XCDs
     if (p.dtype == EDTR_BF16) hipLaunchKernelGGL((flash_attn64_kernel<BF16>), grid, dim3(kThreads), 0, s, p);
     else hipLaunchKernelGGL((flash_attn64_kernel<F16>), grid, dim3(kThreads), 0, s, p);
     EDTR_LAUNCH_CHECK();
