@@ -7,8 +7,9 @@
 //
 // Everything is computed TRANSPOSED so that the accumulator layout of one product is the operand layout of the next (the trick of
 // attention.hip / swin.hip) and the token rows live in REGISTERS:
-//   H^T[hidden][token] = W1 . X^T      A = W1 rows from LDS, B = this wave's 32 token rows (20 fragments = 80 registers, loaded once)
-//   G = value * gelu(gate)              in the accumulators: lane = token, registers = hidden units; LayerNorm folded in per lane
+//   H^T[hidden][token] = W1 . X^T      A = W1 rows from LDS, B = this wave's 32 token rows (20 fragments, loaded once, normalised in place:
+//                                       18 stay in registers, 2 are parked in LDS — the register file is full)
+//   G = value * gelu(gate)              in the accumulators: lane = token, registers = hidden units; + the per-unit constant W1 beta + b1
 //   O^T[out][token] += W2 . G^T        A = W2 rows from LDS, B = G packed to 16 bits — the accumulator registers 8 u .. 8 u + 7 of a
 //                                       32 x 32 tile ARE the B fragment of k-step u once W2's columns are permuted inside every group
 //                                       of 16 ([0-3, 8-11, 4-7, 12-15], done on the host: edtr_hip.h)
@@ -18,8 +19,15 @@
 // LDS holds only weights: 15 granules of 8 KiB (64 rows x 64 k, the XOR-swizzled tile of common.h) per 64-unit chunk — ten of
 // W1 (k-tile kt, half h) and five of W2 (64 output rows each) — every granule type has a FIXED slot, refilled by LDS-DMA for the
 // next chunk as soon as the step that read it is over (one dma per wave and granule: the counted vmcnt waits are uniform).
+//
+// Schedule of a chunk c (six steps, one barrier each; every wave issues the SAME sequence of DMAs, 16 per chunk):
+//   step kt = 0 .. 4  first product, k-tile kt.  Refills issued between its MFMAs (their slots were freed by the barrier that opens the step):
+//                       kt = 0: W2(c) x 5 (read five steps from now) + the constants of chunk c + 1;   kt >= 1: W1(c + 1, k-tile kt - 1) x 2
+//   GEGLU             on the accumulators, G fragments to the exchange buffer
+//   step B            second product (K = the chunk's 64 gated units); refill W1(c + 1, k-tile 4) x 2
+// A step waits for the pieces it reads by counting what was issued AFTER them (loads complete in order):  kt = 0: vmcnt(8);
+// kt = 1 .. 4: vmcnt(12);  B: vmcnt(9);  in the last chunk, where nothing is refilled: 8, 11, 9, 7, 5, 0.
 #include "common.h"
-#include <type_traits>
 
 namespace {
 
@@ -27,7 +35,7 @@ constexpr int FD = 320;                    // model width d
 constexpr int FH = 1280;                   // gated hidden width 4 d
 constexpr int FBM = 128;                   // tokens per workgroup
 constexpr int FTHREADS = 512;
-constexpr int FCH = 64;                    // gated hidden units per chunk
+constexpr int FCH = 64;                    // gated hidden units per chunk (two halves of 32: a value tile + its gate tile per wave)
 constexpr int FNCH = FH / FCH;             // 20 chunks
 constexpr int GRAN = 8192;                 // one granule: 64 rows x 128 bytes
 constexpr int NGRAN = 15;                  // per chunk: W1 (kt, h) at slot 2 kt + h, W2 rows 64 j .. at slot 10 + j
@@ -234,7 +242,7 @@ __device__ __forceinline__ void ffn_body(const edtr_ffn_params& p, char* smem) {
         // ---- first product: five k-tiles of 64
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt) {
-            // this wave's pieces of k-tile kt have landed (counts: DMAs issued after them, see the schedule in the header comment)
+            // this wave's pieces of k-tile kt have landed (counts: the DMAs issued after them — the schedule in the header comment)
             if (kt == 0) wait_vm<8>();
             else if (more) wait_vm<12>();
             else if (kt == 1) wait_vm<11>();

@@ -592,3 +592,72 @@ def test_demo_padding_helpers_vs_reference_golden(golden_dir):
     y = evalutil.pad_to_multiples_of(x, 64)
     assert torch.equal(y, x) and y.data_ptr() != x.data_ptr()
     assert tuple(evalutil.pad_if_smaller(torch.zeros(1, 3, 600, 40), 512).shape) == (1, 3, 600, 512)
+
+
+def test_weight_store_sibling_formats_share_the_freeze_and_the_tensor_list():
+    """The hybrid precision mode packs the same parameters in two storage formats (WeightStore.for_dtype): everything that walks "the"
+    store — the packed broadcast, its checksum, the freeze of a receiving rank — must see the sibling formats too."""
+    from edtr_amd import ops
+    from edtr_amd.engine import WeightStore
+    params = {"a.weight": torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 4096.0, "a.bias": torch.ones(64)}
+    root = WeightStore(params, torch.float16, torch.device("cpu"))
+    sib = root.for_dtype(ops.MIXED)
+    assert root.for_dtype(torch.float16) is root and sib.for_dtype(torch.float16) is root and root.for_dtype(ops.MIXED) is sib
+    w16, _ = root.linear(["a.weight"], ["a.bias"])
+    wmx, _ = sib.linear(["a.weight"], ["a.bias"])
+    t1, t3 = w16.get(1), wmx.get(3)
+    assert t1.shape[1] == 64 and t3.shape[1] == 3 * 64
+    ptrs = {t.data_ptr() for t in root.tensors()}
+    assert t1.data_ptr() in ptrs and t3.data_ptr() in ptrs, "a root lists its sibling formats' tensors"
+    root.frozen = "received from rank 0"
+    assert sib.frozen == "received from rank 0"
+    with pytest.raises(RuntimeError, match="frozen"):
+        sib.vec("a.bias", 128)
+    sib.frozen = None
+    assert root.frozen is None
+    root.invalidate()
+    assert not sib.cache and not root.cache
+
+
+def test_precision_sections_and_policies():
+    """precision="hybrid" / "robust" resolve to per-section modes and policies (edtr_amd/model/cldm.py, edtr_amd/precision.py)."""
+    import json
+    from edtr_amd import ops
+    from edtr_amd.model import cldm as M
+    from edtr_amd.precision import mixed_policy, robust_policy
+    assert M.section_mode("hybrid", torch.bfloat16, "cldm") == ("fast", torch.float16)
+    assert M.section_mode("hybrid", torch.bfloat16, "vae.encode") == ("fast", torch.float16)
+    assert M.section_mode("hybrid", torch.bfloat16, "vae.decode")[0] == "mixed"
+    assert M.section_mode("robust", torch.bfloat16, "cldm")[0] == "mixed" and M.section_mode("mixed", torch.bfloat16, "vae.decode")[0] == "mixed"
+    assert M._store_dtype("hybrid", torch.bfloat16) == torch.float16 and M._store_dtype("hybrid", torch.bfloat16, "vae.decode") == ops.MIXED
+    os.environ["EDTR_AMD_HYBRID"] = json.dumps({"vae.encode": "mixed"})
+    try:
+        assert M.section_mode("hybrid", torch.bfloat16, "vae.encode")[0] == "mixed"
+        os.environ["EDTR_AMD_HYBRID"] = json.dumps({"vae.encode": "nonsense"})
+        with pytest.raises(ValueError):
+            M.hybrid_sections()
+    finally:
+        del os.environ["EDTR_AMD_HYBRID"]
+    rp, mp = robust_policy(), mixed_policy()
+    assert rp.attn_split == 1 and mp.attn_split is None and rp.key() != mp.key()
+    assert rp.parts("res.conv1") == 3 and rp.parts("ff.geglu") == 3 and rp.parts("vae.conv1") == 1 and rp.parts("vae.upsample.conv") == 3
+    assert mp.parts("res.conv1") == 1
+
+
+def test_ffn_host_packing_matches_the_header():
+    """ops.pack_ffn_w2 / pack_ffn_constants write what include/edtr_hip.h documents for edtr_ffn (column permutation inside groups of 16;
+    per-chunk constant order with halved gate entries); ffn_ok is the host's launch rule."""
+    from edtr_amd import ops
+    w2 = torch.arange(320 * 1280, dtype=torch.float32).reshape(320, 1280)
+    p2 = ops.pack_ffn_w2(w2, torch.float32)
+    perm = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
+    for g in (0, 5, 79):
+        for i in range(16):
+            assert float(p2[7, 16 * g + i]) == float(w2[7, 16 * g + perm[i]])
+    c2b = torch.arange(2560, dtype=torch.float32)
+    cst = ops.pack_ffn_constants(c2b).reshape(20, 2, 4, 2, 2, 4)
+    for (c, hh, q, vg, lh, e) in [(0, 0, 0, 0, 0, 0), (3, 1, 2, 1, 1, 3), (19, 1, 3, 0, 1, 2)]:
+        R = 128 * c + 64 * hh + 32 * vg + e + 8 * q + 4 * lh
+        assert float(cst[c, hh, q, vg, lh, e]) == (0.5 if vg else 1.0) * R
+    assert ops.ffn_ok(32768, 320, 1280) and ops.ffn_ok(16384, 320, 1280)
+    assert not ops.ffn_ok(4096, 320, 1280) and not ops.ffn_ok(32768, 640, 2560) and not ops.ffn_ok(16400, 320, 1280)
