@@ -198,7 +198,14 @@ def transformer_block(sd: SD, p: str, x: torch.Tensor, ctx: torch.Tensor, heads:
 
     x = attention(sd, p + "attn1.", ln("norm1", x), None, heads) + x
     x = attention(sd, p + "attn2.", ln("norm2", x), ctx, heads) + x
-    h = F.linear(ln("norm3", x), sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"])
+    return feed_forward(sd, p, x)
+
+
+def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """x + ff(norm3(x)): LayerNorm (eps 1e-5), the GEGLU projection (value * gelu(gate), exact GELU), the output projection.
+    model/attention.py:233 with FeedForward :30-47 and GEGLU :20-27 — what edtr_ffn computes in one launch."""
+    c = x.shape[-1]
+    h = F.linear(F.layer_norm(x, (c,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5), sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"])
     val, gate = h.chunk(2, dim=-1)
     h = val * F.gelu(gate)
     return F.linear(h, sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"]) + x

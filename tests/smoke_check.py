@@ -61,7 +61,41 @@ def smoke(verbose: bool = True) -> dict:
         # while the default may miss 1e-3 on heavier-tailed ones)
         if mode != "fast" and not (e_img < 0.8e-3 and e_z < 0.8e-3):
             raise AssertionError(f"smoke: {tag} is within its own tolerance but closer than 20 % to the 1e-3 north star: latent {e_z:.3e}, image {e_img:.3e}")
+    out["edtr_ffn"] = smoke_ffn(dev, verbose)
     return out
+
+
+def smoke_ffn(dev, verbose: bool = True):
+    """The fused feed-forward launch (edtr_ffn: the 64 x 64-latent level's transformer blocks; the tiny configuration above has no layer of
+    its width) on one workgroup's worth of rows against the oracle's feed_forward, through the product's own weight packing."""
+    from edtr_amd import ops, synth
+    from edtr_amd.engine import WeightStore
+    from edtr_amd.testing import rel_err
+    from oracle import edtr_oracle as O   # checker only
+    D, M = ops.FFN_D, 2 * ops.FFN_ROWS
+    tb = "smoke.ffn."
+    shapes = {"norm3.weight": (D,), "norm3.bias": (D,), "ff.net.0.proj.weight": (8 * D, D), "ff.net.0.proj.bias": (8 * D,),
+              "ff.net.2.weight": (D, 4 * D), "ff.net.2.bias": (D,)}
+    sd = {tb + k: synth.synth_param(tb + k, shp) for k, shp in shapes.items()}
+    x = synth.synth_normal("smoke:ffn_x", (M, D)) + 0.3
+    res = {}
+    for dtype, tol in ((torch.float16, 4.4e-4), (torch.bfloat16, 3.5e-3)):
+        x16 = x.to(dtype)
+        store = WeightStore(sd, dtype, dev)
+        w1, w2, cst, b2 = store.ffn(tb + "ff.net.0.proj.weight", tb + "ff.net.0.proj.bias", tb + "ff.net.2.weight", tb + "ff.net.2.bias", tb + "norm3.")
+        xd = x16.to(dev)
+        out = torch.empty_like(xd)
+        ops.launch(ops.make_ffn(dtype=dtype, x=xd, ldx=D, M=M, w1=w1, w2=w2, cst=cst, b2=b2, out=out, ldo=D))
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = O.feed_forward(sd, tb, x16.float())
+        e = rel_err(out.float(), ref)
+        res[str(dtype)] = e
+        if verbose:
+            print(f"smoke[edtr_ffn {dtype}]: rel err {e:.2e} (tolerance {tol:.2e})")
+        if not e < tol:
+            raise AssertionError(f"smoke: edtr_ffn {dtype} is {e:.3e} from the oracle (tolerance {tol:.1e})")
+    return res
 
 
 if __name__ == "__main__":
