@@ -1,4 +1,6 @@
-"""edtr_ffn diagnostics: where (which tokens / output columns / hidden chunks) does the fused kernel differ from the fp32 reference?"""
+"""edtr_ffn diagnostics (used while bringing the kernel up): where — which tokens / output columns / hidden chunks — does the fused launch
+differ from the fp32 reference?  Selection matrices as W2 expose G itself; W1 = 0 isolates the second product; `-DFFN_DRAIN` (every counted
+wait drains the DMA queue; build as in tools/exp/ffn_stamps.py, load through EDTR_AMD_LIB) tells a timing bug from a data-path bug."""
 import math
 import sys
 

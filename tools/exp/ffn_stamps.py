@@ -1,5 +1,12 @@
-"""In-kernel phase stamps of edtr_ffn (diagnostic build -DFFN_STAMPS, linked into tools/exp/_build/libedtr_hip_ffnstamps.so by
-tools/exp/ffn_stamps.sh; run with EDTR_AMD_LIB pointing at it).  Prints median cycles per phase over the workgroups, waves 0 and 4."""
+"""In-kernel phase stamps of edtr_ffn.  Needs a DIAGNOSTIC build of the library (the product library contains no stamp code; the stamps
+overwrite the first output rows of every workgroup), kept out of edtr_amd/csrc/build:
+
+    mkdir -p tools/exp/_build && cd tools/exp/_build
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFFN_STAMPS -c ../../../edtr_amd/csrc/ffn.hip -o ffn_stamps.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o libedtr_hip_ffnstamps.so ../../../edtr_amd/csrc/build/{igemm,halo512,attention,attn512,norm,elementwise,swin}.o ffn_stamps.o
+    EDTR_AMD_LIB=$PWD/libedtr_hip_ffnstamps.so python tools/exp/ffn_stamps.py          # from the repo root, on the GPU box
+
+Prints median cycles per phase over the workgroups for waves 0 and 4 (the two waves of SIMD 0).  profiles/r06/ffn_stamps.log."""
 import math
 import sys
 import time
