@@ -85,14 +85,14 @@ def test_det512_batch8_every_image(golden_dir, dname):
     print(f"[det512 B=8 {dname}] worst batch-8 vs batch-1 deviation over the 8 images: {worst:.2e}")
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16", "high", "mixed"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "high", "mixed", "hybrid"])
 def test_seg1024tiled_vs_reference_golden(golden_dir, dname):
     """BASELINE configs[3]: --vae-encoder-tiled --cldm-tiled at 1024x1024 (demo.py:96-124)."""
     from edtr_amd import workloads
     from edtr_amd.testing import rel_err
     dev = _need_gpu()
     g = np.load(os.path.join(golden_dir, "full_seg1024.npz"))
-    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision=dname if dname in ("high", "mixed") else None)
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision=dname if dname in ("high", "mixed", "hybrid") else None)
     inp = workloads.make_inputs("seg1024tiled", 1024, dev, 1, 1024)
     fwd = cldm.forward
     img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "seg1024tiled", fwd)
@@ -106,7 +106,7 @@ def test_seg1024tiled_vs_reference_golden(golden_dir, dname):
     np.testing.assert_allclose(float(img.mean()), g["img_stats"][0], atol=5e-3)
 
 
-@pytest.mark.parametrize("dname", ["bf16", "fp16", "high", "mixed"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16", "high", "mixed", "hybrid"])
 def test_det512s50_vs_reference_golden(golden_dir, dname):
     """BASELINE configs[4] per GPU (batch 4, 50 spaced steps from pure noise, every step the same program): image 0 vs the
     reference's `SpacedSampler.sample(steps=50)` with the same injected per-step noise.  50 sequential network evaluations
@@ -116,7 +116,7 @@ def test_det512s50_vs_reference_golden(golden_dir, dname):
     from edtr_amd.testing import rel_err
     dev = _need_gpu()
     g = np.load(os.path.join(golden_dir, "full_s50.npz"))
-    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision=dname if dname in ("high", "mixed") else None)
+    cldm, diffusion, sampler = _build(dev, DTYPES[dname], precision=dname if dname in ("high", "mixed", "hybrid") else None)
     inp = workloads.make_inputs("det512s50", 1024, dev, 4, 512, with_step_noises=True)
     img, z, tr = workloads.restore_pass(cldm, diffusion, sampler, inp, "det512s50")
     torch.cuda.synchronize()
@@ -125,7 +125,7 @@ def test_det512s50_vs_reference_golden(golden_dir, dname):
     e_img = rel_err(_samples(img[:1]), g["img_samples"].astype(np.float32))
     print(f"\n[det512s50 {dname}] image 0 vs reference after 50 steps: latent {e_z:.2e} image {e_img:.2e}")
     assert torch.isfinite(img).all()
-    if dname in ("high", "mixed"):
+    if dname in ("high", "mixed", "hybrid"):
         tol = {"latent": 1e-3, "image": 1e-3}   # the parity modes hold the north-star 1e-3 even after 50 steps
     assert e_z < tol["latent"] and e_img < tol["image"]
 
