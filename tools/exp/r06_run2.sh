@@ -1,4 +1,6 @@
-# Round 6, second set (one device): the v1 attention kernel's XCD-aware block mapping (old build = tools/exp/_build/libedtr_hip_attnold.so),
+# Round 6, second set (one device).  The OLD v1 mapping is a build of commit b36e86e's attention.hip linked against the other current objects
+# (git show b36e86e:edtr_amd/csrc/attention.hip > tools/exp/_build/attention_old.hip; hipcc -c ...; hipcc -shared -o tools/exp/_build/libedtr_hip_attnold.so ...).
+# Round 6, second set: the v1 attention kernel's XCD-aware block mapping (old build = tools/exp/_build/libedtr_hip_attnold.so),
 # the fused feed-forward's row threshold on the tiled workload, the driver-form bench against the committed PMC file.
 mkdir -p gpurun_out/r06
 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "attn or flash or clip" 2>&1 | tail -3
