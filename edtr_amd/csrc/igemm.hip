@@ -198,6 +198,67 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const edtr_igemm_par
     }
 }
 
+// Split-K second stage WITH the fused GroupNorm statistics of the output (round 6): the split convolutions / linears of the 16 x 16 and
+// 8 x 8 latent levels could not hand their consumer's GroupNorm its statistics (the main loops only write slabs), so an edtr_gn_stats
+// launch re-read every such tensor — 100 of a batch-8 pass's 204 statistics launches, 2000 of 3250 on the 50-step workload, each one more
+// dependent launch between a convolution and the normalisation behind it.  Here a block owns ONE statistics slot (SR = 64 or 128 rows,
+// never across an image) x 32 columns: thread (row lane, column group) reduces the slabs of its 8-column vectors in split order like the
+// plain reducer, finishes them, and the per-column sums of the FINISHED fp32 values (what the main-loop epilogues sum) meet in LDS.
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_reduce_stats_kernel(const edtr_igemm_params p, int SR) {
+    __shared__ float red[64][4][16];                           // [row lane][column group][8 sums | 8 sums of squares]
+    const int tid = threadIdx.x, g = tid & 3, rl = tid >> 2;    // 4 column groups of 8 columns x 64 row lanes
+    const int n = blockIdx.x * 32 + g * 8, m_base = blockIdx.y * SR;
+    const float* ws = static_cast<const float*>(p.workspace);
+    const int64_t slab = (int64_t)p.M * p.N;
+    float cs[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cs[j] = 0.0f; cq[j] = 0.0f; }
+    if (n < p.N) {
+        for (int m = m_base + rl; m < m_base + SR; m += 64) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.0f;
+            const float* src = ws + (int64_t)m * p.N + n;
+            for (int sidx = 0; sidx < p.splitk; ++sidx) {      // split order: the result does not depend on the launch geometry
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src + sidx * slab), b = *reinterpret_cast<const f32x4*>(src + sidx * slab + 4);
+                f[0] += a[0]; f[1] += a[1]; f[2] += a[2]; f[3] += a[3];
+                f[4] += b[0]; f[5] += b[1]; f[6] += b[2]; f[7] += b[3];
+            }
+            finish_vector<T>(p, f, m, n, true, 0);              // (f holds the finished values afterwards)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cs[j] += f[j]; cq[j] += f[j] * f[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[rl][g][j] = cs[j]; red[rl][g][8 + j] = cq[j]; }
+    __syncthreads();
+    if (tid < 32 && blockIdx.x * 32 + tid < p.N) {              // one thread per column: the 64 row lanes in lane order
+        const int gg = tid >> 3, j = tid & 7;
+        float a = 0.0f, q = 0.0f;
+        for (int r = 0; r < 64; ++r) { a += red[r][gg][j]; q += red[r][gg][8 + j]; }
+        float* dst = p.gn_partial + ((int64_t)blockIdx.y * p.N + blockIdx.x * 32 + tid) * 2;
+        dst[0] = a;
+        dst[1] = q;
+    }
+}
+
+// the second launch of a split-K edtr_igemm: the plain reducer, or the one that also writes the output's GroupNorm statistics
+template <typename T>
+static int launch_splitk_reducer(const edtr_igemm_params& p, hipStream_t stream) {
+    if (p.gn_partial) {
+        const int SR = p.gn_slot_rows > 0 ? p.gn_slot_rows : 128;
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel<T>, dim3((unsigned)((p.N + 31) / 32), (unsigned)(p.M / SR)), dim3(256), 0, stream, p, SR);
+    } else {
+        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
+        int64_t blocks = (nvec + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    }
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 // Second half of the tile epilogue: the staged fp32 tile [BM][BNO] -> 8-column row vectors -> bias / time-embedding
 // row / SiLU / residual -> 16-byte stores.  A thread owns ONE 8-column group for all of its ITER rows (256 threads,
 // BNO/8 groups), so the per-column operands (bias, and the time-embedding row when the tile lies inside one image) are
@@ -1282,13 +1343,7 @@ int launch_dma(const edtr_igemm_params& p, hipStream_t stream) {
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
     hipLaunchKernelGGL((igemm_dma_kernel<T, SPATIAL, FAST>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
-        int64_t blocks = (nvec + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
-        EDTR_LAUNCH_CHECK();
-    }
+    if (p.splitk > 1) return launch_splitk_reducer<T>(p, stream);
     return EDTR_OK;
 }
 
@@ -1550,7 +1605,7 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
 
     // ---- epilogue: rows of A half `h` (128 x 256 fp32 = the whole 128 KiB) per pass
     float* stage = reinterpret_cast<float*>(smem);
-    const bool gn_acc = p.gn_partial != nullptr;
+    const bool gn_acc = p.gn_partial != nullptr && p.splitk <= 1;      // (split-K: the reducer writes the statistics)
     // (two passes written as two calls of one generic lambda with a compile-time pass index: as a `#pragma unroll` loop the body —
     //  rows_phase and its specialised row loops — outgrew the unroller in round 4, the loop stayed rolled, `acc[h]` became a
     //  dynamically indexed array and the 128 accumulators went through 528 bytes of scratch per lane)
@@ -1895,13 +1950,7 @@ int launch_n160(const edtr_igemm_params& p, hipStream_t stream) {
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
     hipLaunchKernelGGL((igemm_n160_kernel<T, SPATIAL, MB, NB>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
-        int64_t blocks = (nvec + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
-        EDTR_LAUNCH_CHECK();
-    }
+    if (p.splitk > 1) return launch_splitk_reducer<T>(p, stream);
     return EDTR_OK;
 }
 
@@ -1916,13 +1965,7 @@ int launch(const edtr_igemm_params& p, hipStream_t stream) {
     dim3 grid(nbm * nbn, p.splitk > 1 ? p.splitk : 1, p.Z);
     hipLaunchKernelGGL((igemm_kernel<T, MI, NI, SPATIAL>), grid, dim3(kThreads), lds, stream, p);
     EDTR_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
-        int64_t blocks = (nvec + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
-        EDTR_LAUNCH_CHECK();
-    }
+    if (p.splitk > 1) return launch_splitk_reducer<T>(p, stream);
     return EDTR_OK;
 }
 
@@ -2272,7 +2315,7 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
                 }
         }
     };
-    const bool gn_acc = p.gn_partial != nullptr;
+    const bool gn_acc = p.gn_partial != nullptr && p.splitk <= 1;      // (split-K: the reducer writes the statistics)
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.0f; gq[j] = 0.0f; }
@@ -2318,13 +2361,7 @@ int launch_halo(const edtr_igemm_params& p, hipStream_t stream) {
     const int nbm = GEO == 2 ? p.M >> 8 : (p.M / (p.OH * p.OW)) * (p.OH >> 4) * (p.OW >> 4), nbn = (p.N + 127) / 128;
     hipLaunchKernelGGL((igemm_halo_kernel<T, GEO>), dim3(nbm * nbn, p.splitk > 1 ? p.splitk : 1, 1), dim3(512), lds, stream, p);
     EDTR_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        const int64_t nvec = (int64_t)p.M * (p.N >> 3);
-        int64_t blocks = (nvec + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
-        EDTR_LAUNCH_CHECK();
-    }
+    if (p.splitk > 1) return launch_splitk_reducer<T>(p, stream);
     return EDTR_OK;
 }
 
@@ -2707,8 +2744,15 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
     if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 17 || tile == 20)) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
     if (tile >= 3 && !dma_ok && !((tile == 17 || tile == 20) && p.C2 == 0 && (p.C1 & 31) == 0)) return EDTR_E_UNSUPPORTED;      // (tiles 17 / 20 walk 32-channel chunks)
-    if (p.gn_partial && (tile == 2 || p.Z != 1 || p.act == EDTR_ACT_GEGLU || p.splitk > 1 || (p.M & 127)))
-        return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
+    if (p.gn_partial) {
+        const int sr = p.gn_slot_rows > 0 ? p.gn_slot_rows : 128;
+        if (p.Z != 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
+        if (p.splitk > 1) {          // the split-K reducer writes the statistics: slots of 128 rows, or of 64 (the 8 x 8 images)
+            if ((sr != 64 && sr != 128) || p.M % sr || (p.N & 31)) return EDTR_E_UNSUPPORTED;
+        } else if (tile == 2 || sr != 128 || (p.M & 127)) {
+            return EDTR_E_UNSUPPORTED;   // fused GroupNorm statistics need whole 128-row tiles of the 128x128 kernels
+        }
+    }
     // live tiles: 1, 2 (register-staged), 3 (LDS-DMA 128x128), 6 (256x256 ping-pong), 8 (128x160), 14 (256x32), 16 (halo), 17 (halo, 512-pixel units).
     // 4, 5, 7, 9 - 13, 15, 18 (and a round-2 "17") were experiments, measured (profiles/r01 - r03) and removed (15 = the 8-wave ping-pong 128x128 tile
     // for small grids and 18 = the persistent halo tile were faster in isolation and neutral on the whole path: round 4 took them out)

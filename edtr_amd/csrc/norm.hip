@@ -413,7 +413,9 @@ extern "C" int edtr_gn_apply(const edtr_gn_params* pp, edtr_stream_t stream) {
     if (int e = check_gn(p, true)) return e;
     if (p.partial) {      // fused finalize: few tiles; a chunk extended to whole groups must fit the LDS arrays
         const int cpg = p.C / p.groups;
-        if (p.tiles_per_image <= 0 || p.tiles_per_image > 64 || (int64_t)p.tiles_per_image * 128 != p.HW) return EDTR_E_SHAPE;
+        // slots of 128 rows (the main-loop epilogues) or of 64 (the split-K reducer's statistics of 8 x 8 images: edtr_igemm gn_slot_rows)
+        if (p.tiles_per_image <= 0 || p.tiles_per_image > 64 || ((int64_t)p.tiles_per_image * 128 != p.HW && (int64_t)p.tiles_per_image * 64 != p.HW))
+            return EDTR_E_SHAPE;
         if (cpg > 64) return EDTR_E_UNSUPPORTED;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);

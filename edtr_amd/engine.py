@@ -523,7 +523,7 @@ class Act:
     H: int
     W: int
     C: int
-    gnp: Optional[torch.Tensor] = None    # fused GroupNorm partials written by the producing igemm ([rows/128][C][2] fp32)
+    gnp: Optional[torch.Tensor] = None    # fused GroupNorm partials written by the producing igemm ([rows / gn_slot][C][2] fp32)
     # a GroupNorm (+ SiLU) that has NOT been applied: ``t`` is the raw tensor and ``gn_in`` the (scale, shift) table [B][C][2] the
     # consuming 3x3 convolution applies while it stages its operand (edtr_hip.h: a_gn).  ``owns``: False = ``t`` still belongs to
     # the Act it was derived from (Emitter.free releases the table only)
@@ -533,6 +533,12 @@ class Act:
     # emits the ordinary apply launch of that GroupNorm and returns the normalised Act: what Emitter.conv falls back to when the
     # convolution that receives the deferred Act turns out not to be one the halo tiles take (the decision is conv()'s)
     gn_apply: Optional[object] = None
+    gn_slot: int = 128                    # rows per slot of ``gnp`` (64: the split-K reducer's statistics of 8 x 8 images, ops.gn_slot_rows)
+
+    @property
+    def gn_tiles(self) -> int:
+        """slots of ``gnp`` per image"""
+        return (self.H * self.W) // self.gn_slot
 
     @property
     def ld(self) -> int:
@@ -596,6 +602,7 @@ class Emitter:
         self.attn_split = int(os.environ.get("EDTR_AMD_ATTN_SPLIT", "2" if precision == "high" else str(pol_split or 0))) if self.hp else 0
         self._mirrors: List[Tuple[torch.Tensor, torch.Tensor]] = []
         self.last_gnp = None
+        self.last_gn_slot = 128
         self.last_row_stats = None
 
     # -- precision plumbing ---------------------------------------------------------------------
@@ -753,6 +760,7 @@ class Emitter:
         operand, mixed mode only) or ``feeds`` names a GEMM class that takes it as a one-part operand."""
         n_out = N // 2 if act == L.ACT_GEGLU else N
         self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
+        self.last_gn_slot = 128  # ... and the rows each of their slots covers
         self.last_row_stats = None   # per-row statistics of this output for a LayerNorm folded into the next GEMMs (row_stats=True)
         parts = self.parts_for(name, M, N, K)
         if parts == ops.PARTS_2W and (K % 64 or "Z" in kw or isinstance(a, LNRef) or kw.get("C2", 0)):
@@ -794,8 +802,10 @@ class Emitter:
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
         if (stats_hw and act == 0 and (self.hp or not out_f32) and out.stride(0) == N and "Z" not in kw
                 and ops.gn_fusable(M, N, Ke, stats_hw, splitk=splitk, C2=kw.get("C2", 0), invariant=self.invariant)):
-            self.last_gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
+            self.last_gn_slot = ops.gn_slot_rows(stats_hw) if splitk > 1 else 128
+            self.last_gnp = self.arena.alloc((M // self.last_gn_slot, N, 2), torch.float32)
             kw["gn_partial"] = self.last_gnp
+            kw["gn_slot_rows"] = self.last_gn_slot if splitk > 1 else 0
         res32 = residual is not None and residual.dtype == torch.float32
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=a, w=wt, out=out, M=M, N=N, C1=Ke, ld1=a.stride(0), ldw=wt.stride(0), ldc=out.stride(0),
@@ -905,20 +915,22 @@ class Emitter:
                 raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")      # (checked above)
             tile = 0             # (edtr_igemm picks the halo geometry itself: tile 17 from 256 units of 512 pixels, tile 16 below)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
-        gnp = None
+        gnp, gn_slot = None, 128
         if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk, invariant=self.invariant):
-            gnp = self.arena.alloc((M // 128, N, 2), torch.float32)
+            gn_slot = ops.gn_slot_rows(OH * OW) if splitk > 1 else 128
+            gnp = self.arena.alloc((M // gn_slot, N, 2), torch.float32)
         res32 = residual is not None and residual.dtype == torch.float32
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=a, w=wt, out=out, taps=taps, M=M, N=N, C1=Ce, ld1=a.stride(0), ldw=wt.stride(0),
             ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
             ldr=residual.stride(0) if residual is not None else 0, residual_f32=res32, out_f32=out_f32, alpha=alpha, tile=tile,
-            splitk=splitk, workspace=ws, gn_partial=gnp, name=name, w_phase_stride=(N * wt.stride(0)) if subpix else 0,
+            splitk=splitk, workspace=ws, gn_partial=gnp, gn_slot_rows=gn_slot if splitk > 1 else 0, name=name,
+            w_phase_stride=(N * wt.stride(0)) if subpix else 0,
             out16=m16, a_wrap=x.C if parts == ops.PARTS_2W else 0, a_gn=x.gn_in, a_gn_silu=x.gn_silu))
         self.arena.free(ws)
         self.arena.free(tmp)
-        return Act(out, x.B, OH, OW, N, gnp)
+        return Act(out, x.B, OH, OW, N, gnp, gn_slot=gn_slot)
 
     def conv128_out(self, x: Act, prefix: str, out_nchw: torch.Tensor, n_valid: int, alpha: float = 1.0, name="vae.conv_out") -> None:
         """The VAE decoder's conv_out on edtr_conv128_out: ``x`` carries its deferred GroupNorm (group_norm / gn_stats_into with
@@ -941,7 +953,7 @@ class Emitter:
         in32 = x.t.dtype == torch.float32
         return ops.make_gn(dtype=(self.op_fmt(parts) if in32 else self.dtype) if self.hp else self.io, x=x.t, ldx=x.ld, B=x.B, HW=x.H * x.W, C=x.C,
                            sums=sums, gamma=gamma, beta=beta, eps=eps, silu=silu, y=y, ldy=y.stride(0), sums_zeroed=sums_zeroed,
-                           partial=partial)
+                           partial=partial, tiles_per_image=x.gn_tiles)
 
     def _norm_out(self, rows: int, C: int, parts: int):
         """(buffer the apply launch writes, what the caller carries): fp32-stream modes = the multi-part operand itself."""
@@ -983,7 +995,7 @@ class Emitter:
             table = self.arena.alloc((x.B, x.C, 2), torch.float32)
             hw = x.H * x.W
             if x.gnp is not None:
-                self.prog.add(ops.make_gn_table(partial=x.gnp, tiles_per_image=hw // 128, sums=None, B=x.B, C=x.C, HW=hw, gamma=gamma,
+                self.prog.add(ops.make_gn_table(partial=x.gnp, tiles_per_image=x.gn_tiles, sums=None, B=x.B, C=x.C, HW=hw, gamma=gamma,
                                                 beta=beta, eps=eps, table=table))
             else:
                 sums = self.prog.sums_slot(self.arena, x.B)
@@ -991,18 +1003,18 @@ class Emitter:
                 self.prog.add(st)
                 self.prog.add(ops.make_gn_table(partial=None, tiles_per_image=0, sums=sums, B=x.B, C=x.C, HW=hw, gamma=gamma, beta=beta,
                                                 eps=eps, table=table))
-            raw, gnp, geo = x.t, x.gnp, (x.B, x.H, x.W, x.C)
+            raw, gnp, geo, slot = x.t, x.gnp, (x.B, x.H, x.W, x.C), x.gn_slot
             stat_sums = None if x.gnp is not None else sums
 
             def apply_now() -> Act:          # the launch(es) group_norm would have emitted without the deferral, on the same statistics
-                xr = Act(raw, *geo, gnp)
+                xr = Act(raw, *geo, gnp, gn_slot=slot)
                 y, carried = self._norm_out(xr.rows, xr.C, 1)
-                if gnp is not None and ops.gn_foldable(xr.H * xr.W, xr.C):
+                if gnp is not None and ops.gn_foldable(xr.H * xr.W, xr.C, tiles=xr.gn_tiles):
                     _, ap = self._gn_recs(xr, prefix, eps, silu, None, y, partial=gnp)
                 elif gnp is not None:
                     fs = self.arena.alloc((xr.B, 32, 2), torch.float64)
                     _, ap = self._gn_recs(xr, prefix, eps, silu, fs, y)
-                    self.prog.add(ops.make_gn_finalize(partial=gnp, tiles_per_image=(xr.H * xr.W) // 128, B=xr.B, C=xr.C, sums=fs))
+                    self.prog.add(ops.make_gn_finalize(partial=gnp, tiles_per_image=xr.gn_tiles, B=xr.B, C=xr.C, sums=fs))
                     self.arena.free(fs)
                 else:
                     _, ap = self._gn_recs(xr, prefix, eps, silu, stat_sums, y, sums_zeroed=True)
@@ -1017,7 +1029,7 @@ class Emitter:
         else:
             y, carried = self._norm_out(x.rows, x.C, parts)
         sums = None
-        if x.gnp is not None and ops.gn_foldable(x.H * x.W, x.C):
+        if x.gnp is not None and ops.gn_foldable(x.H * x.W, x.C, tiles=x.gn_tiles):
             # the producer's epilogue already reduced this tensor per 128-row tile, and the tiles are few: the apply launch folds
             # them itself (one launch per GroupNorm instead of two)
             _, ap = self._gn_recs(x, prefix, eps, silu, None, y, parts=parts, partial=x.gnp)
@@ -1025,7 +1037,7 @@ class Emitter:
         elif x.gnp is not None:  # many tiles (the VAE's large levels): a finalize launch folds them once for all workgroups
             sums = self.arena.alloc((x.B, 32, 2), torch.float64)
             _, ap = self._gn_recs(x, prefix, eps, silu, sums, y, parts=parts)
-            st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
+            st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=x.gn_tiles, B=x.B, C=x.C, sums=sums)
         else:                    # atomically accumulated statistics: a pre-zeroed pool slot, never reused in this program
             sums = self.prog.sums_slot(self.arena, x.B)
             st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=True, parts=parts)
@@ -1043,7 +1055,7 @@ class Emitter:
         the apply half is then the (scale, shift) table launch and the activation stays raw."""
         if self.gn_deferrable(x, conv_n, feeds):
             if x.gnp is not None:
-                self.prog.add(ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums))
+                self.prog.add(ops.make_gn_finalize(partial=x.gnp, tiles_per_image=x.gn_tiles, B=x.B, C=x.C, sums=sums))
             else:
                 st, _ = self._gn_recs(x, prefix, eps, silu, sums, x.t, sums_zeroed=sums_zeroed)
                 self.prog.add(st)
@@ -1069,7 +1081,7 @@ class Emitter:
         y, carried = self._norm_out(x.rows, x.C, parts)
         st, ap = self._gn_recs(x, prefix, eps, silu, sums, y, sums_zeroed=sums_zeroed, parts=parts)
         if x.gnp is not None:
-            st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=(x.H * x.W) // 128, B=x.B, C=x.C, sums=sums)
+            st = ops.make_gn_finalize(partial=x.gnp, tiles_per_image=x.gn_tiles, B=x.B, C=x.C, sums=sums)
         self.prog.add(st)
 
         def apply() -> Act:

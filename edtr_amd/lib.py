@@ -55,6 +55,7 @@ class IgemmParams(C.Structure):
         ("out16", C.c_void_p), ("ld16", C.c_int32),
         ("a_wrap", C.c_int32),
         ("a_gn", C.c_void_p), ("a_gn_silu", C.c_int32),
+        ("gn_slot_rows", C.c_int32),
     ]
 
 

@@ -218,7 +218,7 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
     y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out", stats_hw=0 if out is not None else N, mirror=mirror)
     em.free(t3)
-    return Act(y, x.B, x.H, x.W, C, em.last_gnp)
+    return Act(y, x.B, x.H, x.W, C, em.last_gnp, gn_slot=em.last_gn_slot)
 
 
 def mirror_for(em: Emitter, nxt: Optional[Layer]) -> bool:
@@ -414,7 +414,7 @@ def _g_vae_attn(em: Emitter, p: str, x: Act):
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
     y = em.gemm(o, wo, rows, C, C, bias=bo, residual=x.t, name="vae.attn.proj_out", stats_hw=N)
     em.free(o)
-    return Act(y, x.B, x.H, x.W, C, em.last_gnp)
+    return Act(y, x.B, x.H, x.W, C, em.last_gnp, gn_slot=em.last_gn_slot)
 
 
 def gen_vae_net(em: Emitter, P: str, layers: List[VaeLayer], x: Act, final_f32: bool, final_nchw: Optional[torch.Tensor] = None):

@@ -72,7 +72,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0, ln_valid: int = 0,
                ln_eps: float = 1e-5, ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None,
                w_phase_stride: int = 0, out16: Optional[torch.Tensor] = None, a_wrap: int = 0, a_gn: Optional[torch.Tensor] = None,
-               a_gn_silu: bool = True, name: str = "igemm") -> Rec:
+               a_gn_silu: bool = True, gn_slot_rows: int = 0, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -86,6 +86,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
         p.out16, p.ld16 = ptr(out16), out16.stride(0)
     p.a_wrap = a_wrap                     # weights-exact two-part product: A columns read twice against [Wh | Wl]
     p.a_gn, p.a_gn_silu = ptr(a_gn), int(a_gn_silu)     # GroupNorm apply (+ SiLU) of the input fused into the halo tile's staging
+    p.gn_slot_rows = int(gn_slot_rows)
     p.w_zs_outer, p.w_zs_inner = w_zs
     p.alpha = alpha
     p.bias_n, p.bias_m, p.rowvec = ptr(bias_n), ptr(bias_m), ptr(rowvec)
@@ -432,13 +433,18 @@ def make_zero(t: torch.Tensor, name: str = "zero") -> Rec:
 GN_FOLD_MAX_TILES = int(__import__("os").environ.get("EDTR_GN_FOLD_MAX", "8"))
 
 
-def gn_foldable(HW: int, C: int, groups: int = 32) -> bool:
-    """Can edtr_gn_apply fold the producing igemm's partials itself (no edtr_gn_finalize launch)?"""
-    return HW % 128 == 0 and HW // 128 <= GN_FOLD_MAX_TILES and C // groups <= 64
+def gn_foldable(HW: int, C: int, groups: int = 32, tiles: int = 0) -> bool:
+    """Can edtr_gn_apply fold the producing igemm's partials itself (no edtr_gn_finalize launch)?  ``tiles``: slots per image of the
+    partials (0 = HW / 128: the main-loop epilogues' 128-row slots)."""
+    if tiles <= 0:
+        if HW % 128:
+            return False
+        tiles = HW // 128
+    return tiles <= GN_FOLD_MAX_TILES and C // groups <= 64
 
 
 def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, groups: int = 32, name="gn",
-            sums_zeroed: bool = False, partial=None):
+            sums_zeroed: bool = False, partial=None, tiles_per_image: int = 0):
     """Returns (stats_rec, apply_rec).  ``partial``: the producing igemm's gn_partial tensor — the apply launch folds it
     itself (gn_foldable) and ``sums`` may be None."""
     p = L.GnParams()
@@ -448,7 +454,7 @@ def make_gn(*, dtype, x, ldx, B, HW, C, sums, gamma, beta, eps, silu, y, ldy, gr
     p.y, p.ldy = ptr(y), ldy
     p.sums_zeroed = int(sums_zeroed)
     if partial is not None:
-        p.partial, p.tiles_per_image = ptr(partial), HW // 128
+        p.partial, p.tiles_per_image = ptr(partial), tiles_per_image or HW // 128
     keep = (p, x, sums, gamma, beta, y, partial)
     lib = L.load()
     nb = 2.0 * B * HW * C
@@ -492,13 +498,33 @@ def gn_in_conv_ok(B: int, H: int, W: int, C: int, N: int, splitk: int = 1, ld: i
     return (B * H * W // 256) * (N // 128) * max(splitk, 1) >= 48
 
 
+def gn_slot_rows(hw: int) -> int:
+    """Rows per slot of the fused GroupNorm partials for images of ``hw`` pixels (0 = no fused statistics): 128-row slots wherever an
+    image is whole slots; 64-row slots for the 8 x 8 images of the deepest latent level (the split-K reducer writes those)."""
+    if hw > 0 and hw % 128 == 0:
+        return 128
+    return 64 if hw == 64 else 0
+
+
 def gn_fusable(M: int, N: int, C1: int, hw: int, taps: int = 1, C2: int = 0, splitk: int = 1, invariant: bool = False) -> bool:
-    """Can the producing edtr_igemm also emit GroupNorm partials?  (whole 128-row tiles inside one image, 128x128 kernel)"""
-    if splitk > 1 or C2 or hw % 128 or M % 128 or N % 32:
+    """Can the producing edtr_igemm also emit GroupNorm partials?  Without split-K: whole 128-row tiles inside one image on the
+    128x128 kernels.  With split-K (round 6) the REDUCER writes them: any slot size gn_slot_rows() knows, N % 32 == 0.
+    EDTR_GN_SPLITK_STATS=0 keeps the edtr_gn_stats launch behind split-K producers (A/B runs)."""
+    if C2 or N % 32:
+        return False
+    if splitk > 1:
+        sr = gn_slot_rows(hw)
+        return os.environ.get("EDTR_GN_SPLITK_STATS", "1") != "0" and sr > 0 and M % sr == 0
+    if hw % 128 or M % 128:
         return False
     dma_ok = C1 % 64 == 0
     big = ((M + 127) // 128) * ((N + 127) // 128)
     return dma_ok or invariant or big >= 200      # (register-staged shapes: the 128x128 tile 1, which the invariant mode always takes)
+
+
+def gn_tiles(hw: int, splitk: int = 1) -> int:
+    """Slots per image of a fused-partials buffer written by a producer with this split-K count."""
+    return hw // (gn_slot_rows(hw) if splitk > 1 else 128)
 
 
 def make_layernorm(*, dtype, x, rows, C, ldx, gamma, beta, eps, y, ldy, c_valid: int = 0, name="layernorm") -> Rec:

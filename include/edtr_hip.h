@@ -146,7 +146,10 @@ typedef struct edtr_igemm_params {
      * kernel's business — the halo tile fills slot 2k with a 256-pixel patch and zeroes slot 2k+1 — only the per-image
      * totals over an image's H*W/128 consecutive slots are defined).  edtr_gn_finalize folds them into
      * the fp64 sums edtr_gn_apply consumes, so the separate statistics pass over the tensor (edtr_gn_stats) disappears.
-     * Needs M % 128 == 0, no GEGLU / split-K / z-batching, tile 0/1/3/6/8/16 (16-bit or fp32 output). */
+     * Needs M % 128 == 0, no GEGLU / z-batching, tile 0/1/3/6/8/16 (16-bit or fp32 output).
+     * With split-K (ABI 10) the REDUCER writes them (the main loops only write slabs): slots of gn_slot_rows rows (0 = 128; 64 for the
+     * 8 x 8 images of the deepest latent level, where a 128-row slot would straddle two images), gn_partial[M / gn_slot_rows][N][2];
+     * needs M % gn_slot_rows == 0 and N % 32 == 0.  Without split-K gn_slot_rows must be 0 or 128. */
     float* gn_partial;
     float act_slope;        /* negative-side slope of EDTR_ACT_LRELU (0 <= slope <= 1) */
     int32_t residual_f32;   /* nonzero: `residual` is fp32 (ldr in floats, multiple of 4): the fp32 activation stream of the
@@ -210,6 +213,7 @@ typedef struct edtr_igemm_params {
      * replaces: `F.silu(self.norm1(x))` / `in_layers[:2]` in front of the 3 x 3 convolutions of the ResBlocks, reference
      * model/vae.py:103-114, model/unet.py:203-218 (GroupNorm32 + SiLU, model/util.py:146-163). */
     const float* a_gn; int32_t a_gn_silu;
+    int32_t gn_slot_rows;   /* rows per gn_partial slot when the split-K reducer writes the statistics (ABI 10; see gn_partial): 0 / 128 / 64 */
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -284,7 +288,7 @@ typedef struct edtr_gn_params {
     int32_t sums_zeroed;            /* edtr_gn_stats only: nonzero = the caller has already zeroed `sums` (e.g. one edtr_zero_bytes
                                        over a pool of them), so no per-call memset node is enqueued */
     /* edtr_gn_apply only (optional): fold the per-tile column partials of the producing edtr_igemm (gn_partial,
-     * tiles_per_image = H*W/128 <= 64 tiles per image) inside the apply launch itself — `sums` is then ignored and the
+     * tiles_per_image = H*W/128 — or H*W/64 where the split-K reducer wrote 64-row slots — <= 64 tiles per image) inside the apply launch itself — `sums` is then ignored and the
      * edtr_gn_finalize launch disappears (one launch less per GroupNorm of the UNet / ControlNet levels). */
     const float* partial; int32_t tiles_per_image;
 } edtr_gn_params;

@@ -577,6 +577,61 @@ def test_fused_groupnorm_partials(dtype, cin, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,cin,cout,sk,res", [(4, 8, 8, 128, 160, 2, True), (8, 8, 8, 1280, 1280, 10, True), (2, 16, 16, 192, 128, 3, False),
+                                                   (2, 16, 16, 1280, 1280, 3, True), (1, 16, 24, 64, 96, 2, False)])
+def test_split_k_reducer_writes_the_groupnorm_partials(dtype, B, H, W, cin, cout, sk, res):
+    """Round 6: with split-K the REDUCER writes the output's GroupNorm statistics (gn_slot_rows: 128-row slots, 64-row slots for the
+    8 x 8 images of the deepest latent level) — the finalize of its slots reproduces edtr_gn_stats on the stored tensor, the tensor
+    itself is the one the plain reducer writes (bit for bit), and the apply launch folds the slots itself where they are few."""
+    ops = _ops()
+    d = dev()
+    hw = H * W
+    sr = ops.gn_slot_rows(hw)
+    assert sr in (64, 128)
+    x = rnd((B, cin, H, W), 190)
+    w = rnd((cout, cin, 3, 3), 191, 1 / math.sqrt(9 * cin))
+    x16, _ = nhwc16(x, dtype)
+    wp = ops.pack_conv_weight(w, dtype).to(d)
+    bias = rnd((cout,), 192).to(d)
+    M = B * hw
+    r16 = rnd((M, cout), 193).to(dtype).to(d) if res else None
+    ws = torch.empty((sk * M * cout,), dtype=torch.float32, device=d)
+    kw = dict(dtype=dtype, a1=x16, w=wp, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout, spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bias,
+              residual=r16, ldr=cout, splitk=sk, workspace=ws, rows_per_image=hw)
+    plain = torch.empty((M, cout), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(out=plain, **kw))
+    out = torch.empty((M, cout), dtype=dtype, device=d)
+    gnp = torch.full((M // sr, cout, 2), 123.0, dtype=torch.float32, device=d)
+    assert ops.gn_fusable(M, cout, cin, hw, splitk=sk)
+    ops.launch(ops.make_igemm(out=out, gn_partial=gnp, gn_slot_rows=sr, **kw))
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain), "the statistics reducer must store what the plain reducer stores"
+    s_fused = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    ops.launch(ops.make_gn_finalize(partial=gnp, tiles_per_image=hw // sr, B=B, C=cout, sums=s_fused))
+    s_ref = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    g1 = (1 + 0.1 * rnd((cout,), 194)).to(d)
+    b1 = (0.1 * rnd((cout,), 195)).to(d)
+    y_ref = torch.empty_like(out)
+    st, ap = ops.make_gn(dtype=dtype, x=out, ldx=cout, B=B, HW=hw, C=cout, sums=s_ref, gamma=g1, beta=b1, eps=1e-5, silu=True, y=y_ref, ldy=cout)
+    ops.launch(st)
+    ops.launch(ap)
+    torch.cuda.synchronize()
+    # the fused sums use the values BEFORE the 16-bit rounding of the store: agreement to rounding noise
+    assert rel(s_fused[..., 1], s_ref[..., 1]) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    assert float((s_fused[..., 0] - s_ref[..., 0]).abs().max()) < (0.5 if dtype == torch.bfloat16 else 0.06) * max(1.0, hw * (cout // 32) / 1152.0)
+    if ops.gn_foldable(hw, cout, tiles=hw // sr):      # the apply launch folds the slots itself
+        y = torch.empty_like(out)
+        _, ap2 = ops.make_gn(dtype=dtype, x=out, ldx=cout, B=B, HW=hw, C=cout, sums=None, gamma=g1, beta=b1, eps=1e-5, silu=True, y=y, ldy=cout,
+                             partial=gnp, tiles_per_image=hw // sr)
+        ops.launch(ap2)
+        torch.cuda.synchronize()
+        assert rel(y.float(), y_ref.float()) < TOL[dtype]
+    # slot sizes the library does not know, or a main-loop launch asked for 64-row slots: refused, not mis-indexed
+    with pytest.raises(RuntimeError):
+        ops.launch(ops.make_igemm(out=out, gn_partial=gnp, gn_slot_rows=32, **kw))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,C,tile", [(2, 1024, 320, 0), (2, 256, 640, 0), (3, 64, 1280, 0), (1, 4096, 320, 8), (2, 64, 128, 3), (2, 200, 128, 1),
                                         (1, 72, 64, 0)])
 def test_fused_qkv_projection_with_transposed_v(dtype, B, N, C, tile):
