@@ -211,6 +211,10 @@ __device__ __forceinline__ void dma16_buf(uint32_t voff, const u32x4& srd, uint3
                  : "memory");   // M0 is free here: hipcc keeps no value in it across statements on gfx950
 }
 
+// slot stride (in channels) of edtr_igemm's fused GroupNorm partials: N, or the caller's wider buffer (gn_ld: the two halves of a
+// concatenation share one buffer of slots)
+__device__ __forceinline__ int gn_ld_of(const edtr_igemm_params& p) { return p.gn_ld > 0 ? p.gn_ld : p.N; }
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // tile 17 of edtr_igemm lives in its own translation unit (halo512.hip)

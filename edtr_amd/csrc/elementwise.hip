@@ -75,6 +75,49 @@ __global__ void __launch_bounds__(256) add_kernel(const uint16_t* a, int lda, co
     }
 }
 
+// a (+ b) -> out with the per-slot column statistics of the result in edtr_igemm's gn_partial format (edtr_hip.h: edtr_add_stats): a block
+// owns one slot of SR rows x 32 columns — thread (row lane, column group of 8) like the split-K reducer that writes statistics.
+template <typename T>
+__global__ void __launch_bounds__(256) add_stats_kernel(const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* out, int ldo, int C,
+                                                       float* gn_partial, int gn_ld, int SR) {
+    __shared__ float red[64][4][16];
+    const int tid = threadIdx.x, g = tid & 3, rl = tid >> 2;
+    const int n = blockIdx.x * 32 + g * 8;
+    const int64_t m_base = (int64_t)blockIdx.y * SR;
+    float cs[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cs[j] = 0.0f; cq[j] = 0.0f; }
+    if (n < C) {
+        for (int64_t m = m_base + rl; m < m_base + SR; m += 64) {
+            float fa[8];
+            const U4 va = ldg16(a + m * lda + n);
+            unpack8<T>(va, fa);
+            if (b) {
+                float fb[8];
+                unpack8<T>(ldg16(b + m * ldb + n), fb);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+                stg16(out + m * ldo + n, pack8<T>(fa));
+            } else {
+                stg16(out + m * ldo + n, va);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cs[j] += fa[j]; cq[j] += fa[j] * fa[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[rl][g][j] = cs[j]; red[rl][g][8 + j] = cq[j]; }
+    __syncthreads();
+    if (tid < 32 && blockIdx.x * 32 + tid < C) {
+        const int gg = tid >> 3, j = tid & 7;
+        float s = 0.0f, q = 0.0f;
+        for (int r = 0; r < 64; ++r) { s += red[r][gg][j]; q += red[r][gg][8 + j]; }
+        float* dst = gn_partial + ((int64_t)blockIdx.y * gn_ld + blockIdx.x * 32 + tid) * 2;
+        dst[0] = s;
+        dst[1] = q;
+    }
+}
+
 // fp32 a (+ b) -> fp32 out, row-strided (high-precision activation stream)
 __global__ void __launch_bounds__(256) add_f32_kernel(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
                                                      int64_t rows, int CV4) {
@@ -385,6 +428,25 @@ extern "C" int edtr_add_mirror(const float* a, int lda, const float* b, int ldb,
         return EDTR_E_ALIGN;
     hipLaunchKernelGGL(add_f32_mirror_kernel, dim3(blocks_for(rows * (C >> 3))), dim3(256), 0, static_cast<hipStream_t>(stream), a, lda,
                        b, ldb, out, ldo, static_cast<uint16_t*>(out16), ld16, rows, C >> 3);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
+extern "C" int edtr_add_stats(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C,
+                              float* gn_partial, int gn_ld, int slot_rows, edtr_stream_t stream) {
+    if (!a || !out || !gn_partial) return EDTR_E_NULL;
+    if (dtype != EDTR_BF16 && dtype != EDTR_F16) return EDTR_E_DTYPE;
+    if (rows <= 0 || C <= 0 || (slot_rows != 64 && slot_rows != 128) || rows % slot_rows || gn_ld < C) return EDTR_E_SHAPE;
+    if ((C & 31) || (lda & 7) || (ldo & 7) || (b && (ldb & 7)) || !aligned16(a) || (b && !aligned16(b)) || !aligned16(out) || (reinterpret_cast<uintptr_t>(gn_partial) & 7))
+        return EDTR_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(C / 32), (unsigned)(rows / slot_rows));
+    if (dtype == EDTR_BF16)
+        hipLaunchKernelGGL(add_stats_kernel<BF16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(b), ldb,
+                           static_cast<uint16_t*>(out), ldo, C, gn_partial, gn_ld, slot_rows);
+    else
+        hipLaunchKernelGGL(add_stats_kernel<F16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(a), lda, static_cast<const uint16_t*>(b), ldb,
+                           static_cast<uint16_t*>(out), ldo, C, gn_partial, gn_ld, slot_rows);
     EDTR_LAUNCH_CHECK();
     return EDTR_OK;
 }

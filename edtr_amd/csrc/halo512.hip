@@ -363,11 +363,11 @@ __device__ __forceinline__ void direct_epilogue(const edtr_igemm_params& p, f32x
             float a = 0.0f, s = 0.0f;
 #pragma unroll
             for (int k = 0; k < NW / 2; ++k) { a += red[((2 * k + wcc) * 64 + cl) * 2]; s += red[((2 * k + wcc) * 64 + cl) * 2 + 1]; }
-            float* dst = p.gn_partial + ((int64_t)(NW / 2 * tm) * p.N + n0 + tid) * 2;  // NW / 2 slots of 128 rows per unit: the first takes the sums
+            float* dst = p.gn_partial + ((int64_t)(NW / 2 * tm) * gn_ld_of(p) + n0 + tid) * 2;  // NW / 2 slots of 128 rows per unit: the first takes the sums
             dst[0] = a;
             dst[1] = s;
 #pragma unroll
-            for (int k = 1; k < NW / 2; ++k) { dst[2 * k * (int64_t)p.N] = 0.0f; dst[2 * k * (int64_t)p.N + 1] = 0.0f; }
+            for (int k = 1; k < NW / 2; ++k) { dst[2 * k * (int64_t)gn_ld_of(p)] = 0.0f; dst[2 * k * (int64_t)gn_ld_of(p) + 1] = 0.0f; }
         }
     }
 }
@@ -829,11 +829,11 @@ __global__ void __launch_bounds__(512, 1) igemm_halo160_kernel(const edtr_igemm_
             float a = 0.0f, sq = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) { a += red[(w * 160 + tid) * 2]; sq += red[(w * 160 + tid) * 2 + 1]; }
-            float* dst = p.gn_partial + ((int64_t)(2 * tm) * p.N + n0 + tid) * 2;      // two 128-row slots per 256-pixel unit
+            float* dst = p.gn_partial + ((int64_t)(2 * tm) * gn_ld_of(p) + n0 + tid) * 2;      // two 128-row slots per 256-pixel unit
             dst[0] = a;
             dst[1] = sq;
-            dst[2 * (int64_t)p.N] = 0.0f;
-            dst[2 * (int64_t)p.N + 1] = 0.0f;
+            dst[2 * (int64_t)gn_ld_of(p)] = 0.0f;
+            dst[2 * (int64_t)gn_ld_of(p) + 1] = 0.0f;
         }
     }
 }

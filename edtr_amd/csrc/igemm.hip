@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_stats_kernel(const edtr_ige
         const int gg = tid >> 3, j = tid & 7;
         float a = 0.0f, q = 0.0f;
         for (int r = 0; r < 64; ++r) { a += red[r][gg][j]; q += red[r][gg][8 + j]; }
-        float* dst = p.gn_partial + ((int64_t)blockIdx.y * p.N + blockIdx.x * 32 + tid) * 2;
+        float* dst = p.gn_partial + ((int64_t)blockIdx.y * gn_ld_of(p) + blockIdx.x * 32 + tid) * 2;
         dst[0] = a;
         dst[1] = q;
     }
@@ -852,7 +852,7 @@ __device__ __forceinline__ void tile_epilogue(const edtr_igemm_params& p, f32x16
             float a = 0.0f, q = 0.0f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { a += stage[(w * 128 + tid) * 2]; q += stage[(w * 128 + tid) * 2 + 1]; }
-            float* dst = p.gn_partial + ((int64_t)(m0 / BM) * p.N + n0 + tid) * 2;
+            float* dst = p.gn_partial + ((int64_t)(m0 / BM) * gn_ld_of(p) + n0 + tid) * 2;
             dst[0] = a;
             dst[1] = q;
         }
@@ -1639,7 +1639,7 @@ __global__ void __launch_bounds__(512, 1) igemm_256_kernel(const edtr_igemm_para
                 float a = 0.0f, q = 0.0f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) { a += stage[(w * 256 + tid) * 2]; q += stage[(w * 256 + tid) * 2 + 1]; }
-                float* dst = p.gn_partial + ((int64_t)((m0 >> 7) + h) * p.N + n0 + tid) * 2;
+                float* dst = p.gn_partial + ((int64_t)((m0 >> 7) + h) * gn_ld_of(p) + n0 + tid) * 2;
                 dst[0] = a;
                 dst[1] = q;
             }
@@ -1930,7 +1930,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_n160_kernel(const edtr_igem
             float a = 0.0f, q = 0.0f;
 #pragma unroll
             for (int g = 0; g < RG; ++g) { a += stage[(g * BN + tid) * 2]; q += stage[(g * BN + tid) * 2 + 1]; }
-            float* dst = p.gn_partial + ((int64_t)(m0 >> 7) * p.N + n0 + tid) * 2;
+            float* dst = p.gn_partial + ((int64_t)(m0 >> 7) * gn_ld_of(p) + n0 + tid) * 2;
             dst[0] = a;
             dst[1] = q;
         }
@@ -2341,11 +2341,11 @@ __global__ void __launch_bounds__(512, 1) igemm_halo_kernel(const edtr_igemm_par
             float a = 0.0f, q = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) { a += stage[(w * 128 + tid) * 2]; q += stage[(w * 128 + tid) * 2 + 1]; }
-            float* dst = p.gn_partial + ((int64_t)(2 * tm) * p.N + n0 + tid) * 2;     // two 128-row slots per 256-pixel patch
+            float* dst = p.gn_partial + ((int64_t)(2 * tm) * gn_ld_of(p) + n0 + tid) * 2;     // two 128-row slots per 256-pixel patch
             dst[0] = a;
             dst[1] = q;
-            dst[2 * p.N] = 0.0f;
-            dst[2 * p.N + 1] = 0.0f;
+            dst[2 * gn_ld_of(p)] = 0.0f;
+            dst[2 * gn_ld_of(p) + 1] = 0.0f;
         }
     }
     EDTR_STAMP(4); EDTR_STAMP(7);
@@ -2746,6 +2746,7 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
     if (tile >= 3 && !dma_ok && !((tile == 17 || tile == 20) && p.C2 == 0 && (p.C1 & 31) == 0)) return EDTR_E_UNSUPPORTED;      // (tiles 17 / 20 walk 32-channel chunks)
     if (p.gn_partial) {
         const int sr = p.gn_slot_rows > 0 ? p.gn_slot_rows : 128;
+        if (p.gn_ld < 0 || (p.gn_ld > 0 && p.gn_ld < p.N)) return EDTR_E_SHAPE;
         if (p.Z != 1 || p.act == EDTR_ACT_GEGLU) return EDTR_E_UNSUPPORTED;
         if (p.splitk > 1) {          // the split-K reducer writes the statistics: slots of 128 rows, or of 64 (the 8 x 8 images)
             if ((sr != 64 && sr != 128) || p.M % sr || (p.N & 31)) return EDTR_E_UNSUPPORTED;

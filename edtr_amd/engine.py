@@ -604,6 +604,8 @@ class Emitter:
         self.last_gnp = None
         self.last_gn_slot = 128
         self.last_row_stats = None
+        self.gnp_into_done = False       # did the last gemm / conv write its GroupNorm partials into the caller's shared slot buffer?
+        self.add_stats_done = False      # ... and the last add()
 
     # -- precision plumbing ---------------------------------------------------------------------
     def parts_for(self, name: str, M: int = 0, N: int = 0, K: int = 0) -> int:
@@ -752,15 +754,29 @@ class Emitter:
         self.last_row_stats = None
         return out
 
+    def _gnp_into_args(self, gnp_into, M: int, N: int, K: int, hw: int, splitk: int, C2: int = 0):
+        """A producer that writes a COLUMN SLICE of a concatenation can still hand the concatenation's GroupNorm its statistics: the
+        two halves share one buffer of slots (``gnp_into`` = (buffer [slots][Ctot][2], first column, rows per slot); edtr_hip.h:
+        gn_ld).  Returns the extra edtr_igemm arguments, or None where this launch cannot write them (the caller then keeps the
+        edtr_gn_stats pass over the concatenated tensor).  Fast modes only."""
+        if gnp_into is None or self.hp:
+            return None
+        buf, col, slot = gnp_into
+        want = ops.gn_slot_rows(hw) if splitk > 1 else 128
+        if want != slot or not ops.gn_fusable(M, N, K, hw, splitk=splitk, C2=C2, invariant=self.invariant):
+            return None
+        return dict(gn_partial=buf.reshape(-1)[2 * col:], gn_ld=buf.shape[1], gn_slot_rows=slot if splitk > 1 else 0)
+
     def gemm(self, a, w, M: int, N: int, K: int, *, bias=None, out=None, act=0,
              residual=None, rowvec=None, rows_per_image=0, out_f32=False, alpha=1.0, name="linear", stats_hw=0,
-             out16=False, feeds=None, row_stats=False, ln_vec=None, mirror=False, **kw) -> torch.Tensor:
+             out16=False, feeds=None, row_stats=False, ln_vec=None, mirror=False, gnp_into=None, **kw) -> torch.Tensor:
         """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  ``a``/``out``/``residual`` are 2-D views (row stride = ld); ``w`` is a
         WRef of the store (or a ready packed tensor).  fp32-stream modes: the output is fp32 unless ``out16`` (an attention
         operand, mixed mode only) or ``feeds`` names a GEMM class that takes it as a one-part operand."""
         n_out = N // 2 if act == L.ACT_GEGLU else N
         self.last_gnp = None     # fused GroupNorm partials of this output (stats_hw = pixels per image), if eligible
         self.last_gn_slot = 128  # ... and the rows each of their slots covers
+        self.gnp_into_done = False   # ... or whether they went into the caller's shared buffer (gnp_into)
         self.last_row_stats = None   # per-row statistics of this output for a LayerNorm folded into the next GEMMs (row_stats=True)
         parts = self.parts_for(name, M, N, K)
         if parts == ops.PARTS_2W and (K % 64 or "Z" in kw or isinstance(a, LNRef) or kw.get("C2", 0)):
@@ -806,6 +822,11 @@ class Emitter:
             self.last_gnp = self.arena.alloc((M // self.last_gn_slot, N, 2), torch.float32)
             kw["gn_partial"] = self.last_gnp
             kw["gn_slot_rows"] = self.last_gn_slot if splitk > 1 else 0
+        elif gnp_into is not None and stats_hw and act == 0 and not out_f32 and "Z" not in kw:
+            into = self._gnp_into_args(gnp_into, M, N, Ke, stats_hw, splitk, kw.get("C2", 0))
+            if into is not None:
+                kw.update(into)
+                self.gnp_into_done = True
         res32 = residual is not None and residual.dtype == torch.float32
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=a, w=wt, out=out, M=M, N=N, C1=Ke, ld1=a.stride(0), ldw=wt.stride(0), ldc=out.stride(0),
@@ -847,7 +868,7 @@ class Emitter:
         return qk, vt, N
 
     def conv(self, x: Act, prefix: str, *, taps=9, stride=1, pad_tl=1, ups=False, rowvec=None, residual=None,
-             out=None, out_f32=False, alpha=1.0, name=None, stats=False, feeds=None, mirror=False) -> Act:
+             out=None, out_f32=False, alpha=1.0, name=None, stats=False, feeds=None, mirror=False, gnp_into=None) -> Act:
         """3x3 (or 1x1) convolution of an NHWC activation with the packed weight ``prefix``.  ``feeds`` (mixed mode): the output is
         BRANCH-INTERNAL — its only consumer is a normalisation that feeds the named one-part GEMM classes, which round it to fp16
         anyway — so it is stored as fp16 instead of joining the fp32 stream (Emitter.branch16)."""
@@ -878,7 +899,7 @@ class Emitter:
                     raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")
                 xn = x.gn_apply()
                 y = self.conv(xn, prefix, taps=taps, stride=stride, pad_tl=pad_tl, ups=ups, rowvec=rowvec, residual=residual, out=out,
-                              out_f32=out_f32, alpha=alpha, name=name, stats=stats, feeds=feeds, mirror=mirror)
+                              out_f32=out_f32, alpha=alpha, name=name, stats=stats, feeds=feeds, mirror=mirror, gnp_into=gnp_into)
                 self.free(xn)
                 return y
         a, tmp = x.t, None
@@ -915,17 +936,22 @@ class Emitter:
                 raise RuntimeError(f"{name}: a deferred GroupNorm reached a convolution that cannot apply it")      # (checked above)
             tile = 0             # (edtr_igemm picks the halo geometry itself: tile 17 from 256 units of 512 pixels, tile 16 below)
         ws = self.arena.alloc((splitk * M * N,), torch.float32) if splitk > 1 else None
-        gnp, gn_slot = None, 128
+        gnp, gn_slot, into = None, 128, None
+        self.gnp_into_done = False
         if stats and (self.hp or not out_f32) and out.stride(0) == N and ops.gn_fusable(M, N, Ce, OH * OW, splitk=splitk, invariant=self.invariant):
             gn_slot = ops.gn_slot_rows(OH * OW) if splitk > 1 else 128
             gnp = self.arena.alloc((M // gn_slot, N, 2), torch.float32)
+        elif gnp_into is not None and not out_f32:
+            into = self._gnp_into_args(gnp_into, M, N, Ce, OH * OW, splitk)
+            self.gnp_into_done = into is not None
         res32 = residual is not None and residual.dtype == torch.float32
         self.prog.add(ops.make_igemm(
             dtype=self.dtype, a1=a, w=wt, out=out, taps=taps, M=M, N=N, C1=Ce, ld1=a.stride(0), ldw=wt.stride(0),
             ldc=out.stride(0), spatial=spatial, bias_n=bias, rowvec=rowvec,
             rowvec_ld=rowvec.stride(0) if rowvec is not None else 0, rows_per_image=OH * OW, residual=residual,
             ldr=residual.stride(0) if residual is not None else 0, residual_f32=res32, out_f32=out_f32, alpha=alpha, tile=tile,
-            splitk=splitk, workspace=ws, gn_partial=gnp, gn_slot_rows=gn_slot if splitk > 1 else 0, name=name,
+            splitk=splitk, workspace=ws, name=name,
+            **(into if into is not None else dict(gn_partial=gnp, gn_slot_rows=gn_slot if splitk > 1 else 0)),
             w_phase_stride=(N * wt.stride(0)) if subpix else 0,
             out16=m16, a_wrap=x.C if parts == ops.PARTS_2W else 0, a_gn=x.gn_in, a_gn_silu=x.gn_silu))
         self.arena.free(ws)
@@ -1102,9 +1128,19 @@ class Emitter:
         return carried
 
     # -- elementwise --------------------------------------------------------------------------
-    def add(self, a: torch.Tensor, b: Optional[torch.Tensor], rows: int, C: int, out=None) -> torch.Tensor:
+    def add(self, a: torch.Tensor, b: Optional[torch.Tensor], rows: int, C: int, out=None, stats_into=None) -> torch.Tensor:
+        """``stats_into`` = (buffer [slots][Ctot][2], first column, rows per slot): the launch also writes the result's GroupNorm partials
+        into the shared slot buffer of the concatenation it fills a column slice of (fast modes; Emitter._gnp_into_args)."""
         if out is None:
             out = self.new(rows, C)
+        if stats_into is not None and not self.hp and C % 32 == 0 and rows % stats_into[2] == 0:
+            buf, col, slot = stats_into
+            self.prog.add(ops.make_add_stats(dtype=self.io, a=a, lda=a.stride(0), b=b, ldb=b.stride(0) if b is not None else 0, out=out,
+                                             ldo=out.stride(0), rows=rows, C=C, gn_partial=buf.reshape(-1)[2 * col:], gn_ld=buf.shape[1],
+                                             slot_rows=slot))
+            self.add_stats_done = True
+            return out
+        self.add_stats_done = False
         m16 = self.mirror_view(out) if self.mirrors_on else None
         if m16 is not None and C % 8:
             raise ValueError(f"add into a mirrored stream buffer needs C % 8 == 0 (got {C}): its fp16 mirror would go stale")

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = [
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp", "edtr_swin_attn", "edtr_swin_layer", "edtr_conv64", "edtr_conv128_out",
     "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror", "edtr_igemm_plan", "edtr_flash_attn512",
-    "edtr_ffn", "edtr_ffn_plan",
+    "edtr_ffn", "edtr_ffn_plan", "edtr_add_stats",
 ]
 
 
@@ -55,7 +55,7 @@ class IgemmParams(C.Structure):
         ("out16", C.c_void_p), ("ld16", C.c_int32),
         ("a_wrap", C.c_int32),
         ("a_gn", C.c_void_p), ("a_gn_silu", C.c_int32),
-        ("gn_slot_rows", C.c_int32),
+        ("gn_slot_rows", C.c_int32), ("gn_ld", C.c_int32),
     ]
 
 
@@ -223,6 +223,7 @@ def load() -> C.CDLL:
     lib.edtr_conv64.argtypes = [C.POINTER(Conv64Params), vp]
     lib.edtr_conv128_out.argtypes = [C.POINTER(Conv128OutParams), vp]
     lib.edtr_swin_layer.argtypes = [C.POINTER(SwinAttnParams), C.POINTER(SwinMlpParams), vp]
+    lib.edtr_add_stats.argtypes = [i32, vp, i32, vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]
     lib.edtr_ffn.argtypes = [C.POINTER(FfnParams), vp]
     lib.edtr_ffn_plan.argtypes = [C.POINTER(FfnParams)]
     if lib.edtr_abi_version() != 10:

@@ -13,6 +13,7 @@ Fusions relative to the reference's op-by-op execution:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -98,7 +99,7 @@ def emit_context_kv(em: Emitter, P: str, a: UNetArch, ctx16: torch.Tensor, B: in
 # ----------------------------------------------------------------------------------------------
 # UNet / ControlNet blocks
 # ----------------------------------------------------------------------------------------------
-def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, offs: Dict[str, int], out=None, mirror=False) -> Act:
+def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, offs: Dict[str, int], out=None, mirror=False, gnp_into=None) -> Act:
     """model/unet.py:203-223: GN-SiLU-conv (+bias +emb row) ; GN-SiLU-conv (+bias) + skip(x)."""
     p = P + l.prefix
     # (conv_n: where the halo tile takes the convolution, the GroupNorm is applied inside its operand staging — no apply launch)
@@ -111,10 +112,12 @@ def emit_resblock(em: Emitter, P: str, l: Layer, x: Act, table: torch.Tensor, of
         skip = em.conv(x, p + "skip_connection.", taps=1, name="res.skip1x1").t
     else:
         skip = x.t
-    y = em.conv(n2, p + "out_layers.3.", residual=skip, out=out, name="res.conv2", stats=out is None, mirror=mirror)
+    y = em.conv(n2, p + "out_layers.3.", residual=skip, out=out, name="res.conv2", stats=out is None, mirror=mirror, gnp_into=gnp_into)
+    into_done = em.gnp_into_done
     em.free(n2)
     if l.cin != l.cout:
         em.free(skip)
+    em.gnp_into_done = into_done
     return y
 
 
@@ -167,7 +170,7 @@ def emit_attention_core(em: Emitter, p: str, x, B: int, N: int, C: int, heads: i
     return y
 
 
-def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextKV, out=None, mirror=False) -> Act:
+def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextKV, out=None, mirror=False, gnp_into=None) -> Act:
     """model/attention.py:283-302 + :230-234 + :20-47 (use_linear, depth 1, gated FF)."""
     p = P + l.prefix
     B, N, C = x.B, x.H * x.W, x.C
@@ -216,8 +219,11 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
         t3 = em.gemm(g, wf, rows, C, 4 * C, bias=bf, residual=t2, name="ff.out", feeds="st.proj_out" if em.branch16 else None)
         em.free(g, t2)
     wo, bo = em.store.linear([p + "proj_out.weight"], [p + "proj_out.bias"])
-    y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out", stats_hw=0 if out is not None else N, mirror=mirror)
+    y = em.gemm(t3, wo, rows, C, C, bias=bo, residual=x.t, out=out, name="st.proj_out", stats_hw=N if (out is None or gnp_into is not None) else 0,
+                mirror=mirror, gnp_into=gnp_into if out is not None else None)
+    into_done = em.gnp_into_done
     em.free(t3)
+    em.gnp_into_done = into_done
     return Act(y, x.B, x.H, x.W, C, em.last_gnp, gn_slot=em.last_gn_slot)
 
 
@@ -236,7 +242,8 @@ def mirror_for(em: Emitter, nxt: Optional[Layer]) -> bool:
     return False
 
 
-def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv, out=None, keep_input=True, mirror_out=False) -> Act:
+def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv, out=None, keep_input=True, mirror_out=False,
+               gnp_into=None) -> Act:
     """TimestepEmbedSequential dispatch (model/unet.py:40-48).  ``out`` (a 2-D view) receives the LAST layer's
     result; the block input is freed unless ``keep_input``.  ``mirror_out``: a consumer of the block's result reads it as a
     one-part operand (mirror_for / the ControlNet's zero convolutions)."""
@@ -244,22 +251,25 @@ def emit_block(em: Emitter, P: str, layers: List[Layer], x: Act, table, offs, kv
     for i, l in enumerate(layers):
         last = i == len(layers) - 1
         tgt = out if last else None
+        into = gnp_into if last else None          # (the block's LAST layer fills the caller's slice: it can write that slice's GroupNorm partials)
         mir = mirror_out if last else mirror_for(em, layers[i + 1])
         if l.kind == "conv":
             y = em.conv(h, P + l.prefix, out=tgt, name="conv_in", stats=tgt is None, mirror=mir)
         elif l.kind == "res":
-            y = emit_resblock(em, P, l, h, table, offs, out=tgt, mirror=mir)
+            y = emit_resblock(em, P, l, h, table, offs, out=tgt, mirror=mir, gnp_into=into)
         elif l.kind == "attn":
-            y = emit_spatial_transformer(em, P, l, h, kv, out=tgt, mirror=mir)
+            y = emit_spatial_transformer(em, P, l, h, kv, out=tgt, mirror=mir, gnp_into=into)
         elif l.kind == "down":
             y = em.conv(h, P + l.prefix + "op.", stride=2, out=tgt, name="downsample", stats=tgt is None, mirror=mir)  # unet.py:99-108
         elif l.kind == "up":
-            y = em.conv(h, P + l.prefix + "conv.", ups=True, out=tgt, name="upsample.conv", stats=tgt is None, mirror=mir)  # unet.py:70-79
+            y = em.conv(h, P + l.prefix + "conv.", ups=True, out=tgt, name="upsample.conv", stats=tgt is None, mirror=mir, gnp_into=into)  # unet.py:70-79
         else:
             raise ValueError(l.kind)
+        into_done = em.gnp_into_done if last else False
         if h is not x or not keep_input:
             em.free(h)
         h = y
+    em.gnp_into_done = bool(gnp_into is not None and into_done)
     return h
 
 
@@ -298,13 +308,25 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
     # first decoder input: cat([mid + control_mid, hs[-1] + control[-2]])
     skip = hs.pop()
     # the decoder's concat buffers: every output block starts with a ResBlock whose 1x1 skip convolution reads the concat raw
+
+    def concat_slots(rows: int, hw: int, ctot: int):
+        """The GroupNorm of a concatenation needs no pass over it (edtr_gn_stats) when BOTH halves' producers write their columns'
+        partials into one buffer of slots (round 6: edtr_igemm gn_ld, edtr_add_stats): (buffer, rows per slot) or (None, 0).  Fast
+        modes; EDTR_GN_CONCAT_STATS=0 keeps the statistics launch (A/B runs)."""
+        slot = ops.gn_slot_rows(hw)
+        if em.hp or em.invariant or not slot or rows % slot or os.environ.get("EDTR_GN_CONCAT_STATS", "1") == "0":
+            return None, 0
+        return em.arena.alloc((rows // slot, ctot, 2), torch.float32), slot
+
     cat = em.new_stream(skip.rows, mid.C + skip.C, mirror=em.want_mirror("res.skip1x1"))
+    cg, cslot = concat_slots(skip.rows, skip.H * skip.W, mid.C + skip.C)
     c = control.pop() if control is not None else None      # a None entry = no control at that tap (only_mid_control)
+    em.add(mid.t, c.t if c is not None else None, mid.rows, mid.C, out=cat[:, :mid.C], stats_into=(cg, 0, cslot) if cg is not None else None)
+    if cg is not None and not em.add_stats_done:
+        em.arena.free(cg)
+        cg = None
     if c is not None:
-        em.add(mid.t, c.t, mid.rows, mid.C, out=cat[:, :mid.C])
         em.free(c)
-    else:
-        em.add(mid.t, None, mid.rows, mid.C, out=cat[:, :mid.C])
     em.free(mid)
     cur_C = mid.C
     B, H, W = skip.B, skip.H, skip.W
@@ -312,24 +334,35 @@ def emit_unet(em: Emitter, P: str, a: UNetArch, x8: Act, table, offs, kv, contro
     for j, layers in enumerate(a.output_blocks):
         # right half of the concat: skip (+ control)
         c = control.pop() if control is not None else None
+        em.add(skip.t, c.t if c is not None else None, skip.rows, skip.C, out=cat[:, cur_C:],
+               stats_into=(cg, cur_C, cslot) if cg is not None else None)
+        if cg is not None and not em.add_stats_done:
+            em.arena.free(cg)
+            cg = None
         if c is not None:
-            em.add(skip.t, c.t, skip.rows, skip.C, out=cat[:, cur_C:])
             em.free(c)
-        else:
-            em.add(skip.t, None, skip.rows, skip.C, out=cat[:, cur_C:])
         em.free(skip)
-        xin = Act(cat, B, H, W, cur_C + skip.C)
+        xin = Act(cat, B, H, W, cur_C + skip.C, cg, gn_slot=cslot or 128)      # (cg: both halves' partials, None = a statistics launch)
         if j + 1 < nblk:
             nskip = hs.pop()
             out_C = layers[-1].cout
             ncat = em.new_stream(nskip.rows, out_C + nskip.C, mirror=em.want_mirror("res.skip1x1"))
-            y = emit_block(em, P, layers, xin, table, offs, kv, out=ncat[:, :out_C], keep_input=True)
+            ncg, nslot = concat_slots(nskip.rows, nskip.H * nskip.W, out_C + nskip.C)
+            y = emit_block(em, P, layers, xin, table, offs, kv, out=ncat[:, :out_C], keep_input=True,
+                           gnp_into=(ncg, 0, nslot) if ncg is not None else None)
+            if ncg is not None and not em.gnp_into_done:      # the block's last layer could not write its half: keep the statistics launch
+                em.arena.free(ncg)
+                ncg = None
             em.free(cat)
-            cat, skip, cur_C = ncat, nskip, out_C
+            if cg is not None:
+                em.arena.free(cg)
+            cat, skip, cur_C, cg, cslot = ncat, nskip, out_C, ncg, nslot
             B, H, W = nskip.B, nskip.H, nskip.W
         else:
             y = emit_block(em, P, layers, xin, table, offs, kv, keep_input=True)
             em.free(cat)
+            if cg is not None:
+                em.arena.free(cg)
     n = em.group_norm(y, P + "out.0.", 1e-5, True, feeds=("unet.out_conv",))
     em.free(y)
     eps = em.conv(n, P + "out.2.", out_f32=True, name="unet.out_conv")

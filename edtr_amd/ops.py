@@ -72,7 +72,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
                row_stats: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None, ln_C: int = 0, ln_valid: int = 0,
                ln_eps: float = 1e-5, ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None,
                w_phase_stride: int = 0, out16: Optional[torch.Tensor] = None, a_wrap: int = 0, a_gn: Optional[torch.Tensor] = None,
-               a_gn_silu: bool = True, gn_slot_rows: int = 0, name: str = "igemm") -> Rec:
+               a_gn_silu: bool = True, gn_slot_rows: int = 0, gn_ld: int = 0, name: str = "igemm") -> Rec:
     p = L.IgemmParams()
     p.dtype, p.taps, p.M, p.N, p.K = dt_code(dtype), taps, M, N, taps * (C1 + C2)
     p.n_valid, p.Z, p.zdiv = n_valid, Z, zdiv
@@ -86,7 +86,7 @@ def make_igemm(*, dtype: torch.dtype, a1: torch.Tensor, w: torch.Tensor, out: to
         p.out16, p.ld16 = ptr(out16), out16.stride(0)
     p.a_wrap = a_wrap                     # weights-exact two-part product: A columns read twice against [Wh | Wl]
     p.a_gn, p.a_gn_silu = ptr(a_gn), int(a_gn_silu)     # GroupNorm apply (+ SiLU) of the input fused into the halo tile's staging
-    p.gn_slot_rows = int(gn_slot_rows)
+    p.gn_slot_rows, p.gn_ld = int(gn_slot_rows), int(gn_ld)
     p.w_zs_outer, p.w_zs_inner = w_zs
     p.alpha = alpha
     p.bias_n, p.bias_m, p.rowvec = ptr(bias_n), ptr(bias_m), ptr(rowvec)
@@ -561,6 +561,13 @@ def make_nhwc_to_nchw(*, dtype, src, src_f32, B, C, HW, ld, dst, scale=1.0, name
 def make_add(*, dtype, a, lda, b, ldb, out, ldo, rows, C, name="add") -> Rec:
     args = (dt_code(dtype), ptr(a), lda, ptr(b), ldb, ptr(out), ldo, rows, C)
     return Rec(L.load().edtr_add, args, (a, b, out), name, 0.0, (6.0 if b is not None else 4.0) * rows * C)
+
+
+def make_add_stats(*, dtype, a, lda, b, ldb, out, ldo, rows, C, gn_partial, gn_ld, slot_rows, name="add") -> Rec:
+    """a (+ b) -> out and the result's per-slot column statistics in edtr_igemm's gn_partial format (edtr_hip.h: edtr_add_stats);
+    ``gn_partial`` is a 1-D view that starts at this tensor's first column inside slot 0."""
+    args = (dt_code(dtype), ptr(a), lda, ptr(b), ldb, ptr(out), ldo, rows, C, ptr(gn_partial), gn_ld, slot_rows)
+    return Rec(L.load().edtr_add_stats, args, (a, b, out, gn_partial), name, 0.0, (6.0 if b is not None else 4.0) * rows * C)
 
 
 def make_add_mirror(*, a, lda, b, ldb, out, ldo, out16, rows, C, name="add") -> Rec:

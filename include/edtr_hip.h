@@ -214,6 +214,9 @@ typedef struct edtr_igemm_params {
      * model/vae.py:103-114, model/unet.py:203-218 (GroupNorm32 + SiLU, model/util.py:146-163). */
     const float* a_gn; int32_t a_gn_silu;
     int32_t gn_slot_rows;   /* rows per gn_partial slot when the split-K reducer writes the statistics (ABI 10; see gn_partial): 0 / 128 / 64 */
+    int32_t gn_ld;          /* channels per gn_partial slot (ABI 10): 0 = N; > N when the output is a column slice of a concatenation whose
+                               halves share one buffer of slots — gn_partial then points at this launch's first column inside a slot
+                               (slot s, column n of this launch at gn_partial[(s * gn_ld + n) * 2]); edtr_add_stats writes the other half */
 } edtr_igemm_params;
 
 int edtr_igemm(const edtr_igemm_params* p, edtr_stream_t stream);
@@ -537,6 +540,13 @@ int edtr_nhwc_to_nchw(int dtype, const void* src, int src_f32, int B, int C, int
  * replaces: `hs.pop() + control.pop()`, `h += control.pop()` and the torch.cat of model/controlnet.py:31,35,37. */
 int edtr_add(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C,
              edtr_stream_t stream);
+/* edtr_add on 16-bit tensors that also writes the per-slot column statistics of its result in edtr_igemm's gn_partial format (ABI 10):
+ * gn_partial[(s * gn_ld + c) * 2 + {0, 1}] = sum / sum of squares over the slot's slot_rows rows (128, or 64 for 8 x 8 images) of column c,
+ * of the fp32 sums before the 16-bit store — the skip + control half of the UNet decoder's concatenations (reference
+ * model/controlnet.py:35-37), whose GroupNorm then needs no pass over the concatenated tensor (edtr_gn_stats).  rows % slot_rows == 0,
+ * C % 32 == 0, gn_ld >= C; otherwise as edtr_add (b may be NULL: a copy). */
+int edtr_add_stats(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C,
+                   float* gn_partial, int gn_ld, int slot_rows, edtr_stream_t stream);
 /* The fp32-stream form of edtr_add that also writes the result's fp16 MIRROR out16[r * ld16 + c] (ABI 7; see edtr_igemm_params.out16):
  * the `hs.pop() + control.pop()` half of a decoder concat whose 1x1 skip convolution reads the mirror (model/controlnet.py:35-37,
  * model/unet.py:189).  C % 8 == 0. */

@@ -632,6 +632,56 @@ def test_split_k_reducer_writes_the_groupnorm_partials(dtype, B, H, W, cin, cout
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C1,C2,sk", [(2, 16, 16, 128, 64, 1), (4, 8, 8, 1280, 1280, 10), (2, 32, 32, 320, 640, 1), (2, 16, 16, 1280, 640, 3)])
+def test_concat_halves_share_one_buffer_of_groupnorm_slots(dtype, B, H, W, C1, C2, sk):
+    """Round 6: the two halves of torch.cat([h, skip + control]) (reference model/controlnet.py:35-37) are written by different launches — a
+    convolution into the left column slice (edtr_igemm gn_ld: its partials go to ITS columns of a shared slot buffer; with split-K the
+    reducer writes them) and edtr_add_stats into the right one — and the GroupNorm of the concatenation reads the statistics from that
+    buffer: finalize(shared slots) == edtr_gn_stats on the concatenated tensor."""
+    ops = _ops()
+    d = dev()
+    hw, Ct = H * W, C1 + C2
+    M = B * hw
+    slot = ops.gn_slot_rows(hw) if sk > 1 else 128
+    if hw % slot:
+        pytest.skip("main-loop statistics need whole 128-row slots per image")
+    cat = torch.full((M, Ct), float("nan"), dtype=dtype, device=d)
+    slots = torch.full((M // slot, Ct, 2), 321.0, dtype=torch.float32, device=d)
+    # left half: a 3 x 3 convolution writing columns [0, C1)
+    cin = 128
+    x16, _ = nhwc16(rnd((B, cin, H, W), 210), dtype)
+    wp = ops.pack_conv_weight(rnd((C1, cin, 3, 3), 211, 1 / math.sqrt(9 * cin)), dtype).to(d)
+    ws = torch.empty((sk * M * C1,), dtype=torch.float32, device=d) if sk > 1 else None
+    ops.launch(ops.make_igemm(dtype=dtype, a1=x16, w=wp, out=cat[:, :C1], taps=9, M=M, N=C1, C1=cin, ld1=cin, ldw=9 * cin, ldc=Ct,
+                              spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=rnd((C1,), 212).to(d), splitk=sk, workspace=ws, rows_per_image=hw,
+                              gn_partial=slots.reshape(-1), gn_ld=Ct, gn_slot_rows=slot if sk > 1 else 0))
+    # right half: skip + control into columns [C1, Ct)
+    a = rnd((M, C2), 213).to(dtype).to(d)
+    b = rnd((M, C2), 214).to(dtype).to(d)
+    ops.launch(ops.make_add_stats(dtype=dtype, a=a, lda=C2, b=b, ldb=C2, out=cat[:, C1:], ldo=Ct, rows=M, C=C2,
+                                  gn_partial=slots.reshape(-1)[2 * C1:], gn_ld=Ct, slot_rows=slot))
+    torch.cuda.synchronize()
+    assert torch.isfinite(cat.float()).all()
+    assert rel(cat[:, C1:].float(), (a.float() + b.float())) < TOL[dtype]
+    s_fused = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    ops.launch(ops.make_gn_finalize(partial=slots, tiles_per_image=hw // slot, B=B, C=Ct, sums=s_fused))
+    s_ref = torch.empty((B, 32, 2), dtype=torch.float64, device=d)
+    g = torch.ones(Ct, device=d)
+    st, _ = ops.make_gn(dtype=dtype, x=cat, ldx=Ct, B=B, HW=hw, C=Ct, sums=s_ref, gamma=g, beta=g, eps=1e-5, silu=False, y=torch.empty_like(cat), ldy=Ct)
+    ops.launch(st)
+    torch.cuda.synchronize()
+    assert rel(s_fused[..., 1], s_ref[..., 1]) < (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    assert float((s_fused[..., 0] - s_ref[..., 0]).abs().max()) < (0.5 if dtype == torch.bfloat16 else 0.06) * max(1.0, hw * (Ct // 32) / 1152.0)
+    with pytest.raises(RuntimeError):          # a slot stride narrower than the launch's own columns
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x16, w=wp, out=cat[:, :C1], taps=9, M=M, N=C1, C1=cin, ld1=cin, ldw=9 * cin, ldc=Ct,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), splitk=sk, workspace=ws, rows_per_image=hw, gn_partial=slots.reshape(-1),
+                                  gn_ld=C1 - 32, gn_slot_rows=slot if sk > 1 else 0))
+    with pytest.raises(RuntimeError):          # rows that are not whole slots
+        ops.launch(ops.make_add_stats(dtype=dtype, a=a, lda=C2, b=None, ldb=0, out=cat[:, C1:], ldo=Ct, rows=M - 8, C=C2,
+                                      gn_partial=slots.reshape(-1)[2 * C1:], gn_ld=Ct, slot_rows=slot))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,C,tile", [(2, 1024, 320, 0), (2, 256, 640, 0), (3, 64, 1280, 0), (1, 4096, 320, 8), (2, 64, 128, 3), (2, 200, 128, 1),
                                         (1, 72, 64, 0)])
 def test_fused_qkv_projection_with_transposed_v(dtype, B, N, C, tile):
