@@ -220,6 +220,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // tile 17 of edtr_igemm lives in its own translation unit (halo512.hip)
 bool edtr_halo512_ok(const edtr_igemm_params& p);
 int edtr_launch_halo512(const edtr_igemm_params& p, hipStream_t stream);
+bool edtr_halo512p_ok(const edtr_igemm_params& p);           // tile 21
+int edtr_launch_halo512p(const edtr_igemm_params& p, hipStream_t stream);
 bool edtr_halo160_ok(const edtr_igemm_params& p);            // tile 20
 int edtr_launch_halo160(const edtr_igemm_params& p, hipStream_t stream);
 

@@ -574,6 +574,412 @@ __global__ void __launch_bounds__(512, 1) igemm_halo512_kernel(const edtr_igemm_
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Tile 21 (round 6): tile 17 as a PERSISTENT kernel whose store phase runs under the next unit's multiply loop.
+// A workgroup walks its units (its XCD's range, strided by the workgroups of that XCD) as ONE sequence of chunks: the last chunk
+// of unit i stages the first patch and the first two weight slices of unit i + 1 exactly as a chunk stages its successor's, so
+// there is no set-up / first-load phase between units.  After the last tap the 128 accumulators become the unit's FINISHED
+// 16-bit output in 64 registers (bias added, GroupNorm sums taken, lanes P / P + 8 swapped so that a store instruction moves
+// eight whole 128-byte lines: the arithmetic and the rounding of tile 17's finish16), the accumulators restart from zero (the
+// first tap of the next unit multiplies into C = 0), and the 16 store instructions of the wave are issued ONE PER PHASE of the
+// next unit's first chunk, next to that phase's DMA requests (loads, stores and LDS-DMA retire in issue order: the counted
+// waits of those phases leave the stores in flight too).  The statistics of unit i meet in LDS behind the first phase of unit
+// i + 1.  16-bit output without a residual or a time-embedding row only (bias rows live in LDS); the last unit of a workgroup
+// flushes its stores at once.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace h1p {
+using namespace h1;
+constexpr int BIASL = RED + 4096;               // the launch's bias row (fp32, N <= 512)
+constexpr int LDS_BYTES_P = BIASL + 2048;
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_n() {
+    static_assert(N >= 1 && N <= 12, "wait_vm_n");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512, 1) igemm_halo512p_kernel(const edtr_igemm_params p) {
+    using namespace h1p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    H5_STAMP(0); H5_STAMP(14);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, q = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int tw = p.OW >> 5, tpi = tw * (p.OH >> 4);
+    const int nbn = p.N >> 7, nblk = (p.M / (p.OH * p.OW)) * tpi * nbn;
+    // the units of this workgroup: XCD x (blockIdx mod 8) owns a contiguous range of units, its workgroups walk it with stride per
+    const int per = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+    const int qq = nblk >> 3, rr = nblk & 7;
+    const int xs = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq, xc = qq + (xcd < rr ? 1 : 0);
+    if (jx >= xc) return;
+    const int nmine = (xc - jx + per - 1) / per;
+
+    const uint16_t* a1 = static_cast<const uint16_t*>(p.a1);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const u32x4 srd_a = srd_of(a1);
+    const u32x4 srd_w = srd_of(p.w);
+    const int Cin = p.C1, nchunk = Cin / CK;
+    const bool gnf = p.a_gn != nullptr;
+    const u32x4 srd_t = srd_of(gnf ? p.a_gn : reinterpret_cast<const float*>(a1));
+    const bool gn_acc = p.gn_partial != nullptr;
+
+    // unit geometry (wave-uniform): cur = the unit whose taps run, nxt = the unit whose first operands the last chunk stages
+    struct Unit { int tm, n0, img, m0, sy0, sx0; };
+    auto decode = [&](int k) {
+        const int bid = xs + jx + k * per;
+        Unit u;
+        u.tm = bid / nbn;
+        const int tn = bid - u.tm * nbn;
+        u.img = u.tm / tpi;
+        const int tr = u.tm - u.img * tpi, ty = tr / tw, tx = tr - ty * tw;
+        u.n0 = tn * 128;
+        u.sy0 = ty * 16 - 1;
+        u.sx0 = tx * 32 - 1;
+        u.m0 = (u.img * p.OH + ty * 16) * p.OW + tx * 32;
+        return u;
+    };
+
+    // weight piece = wave (tile 17's permuted rows); the unit's n0 rides in the scalar offset
+    uint32_t voff_w;
+    {
+        const int R = wave * 16 + (lane >> 2), slot = lane & 3;
+        const int r = R & 15, nb = (R >> 4) & 3;
+        const int n = (R & 64) + 32 * (nb >> 1) + 8 * (r >> 2) + 4 * (nb & 1) + (r & 3);
+        const int c = slot ^ key8(R);
+        voff_w = (uint32_t)(((int64_t)n * p.ldw + c * 8) * 2);
+    }
+    auto stage_w = [&](int n0, int chunk, int tap, int buf, bool valid) {
+        dma(valid ? voff_w : kOob, srd_w, (uint32_t)(((int64_t)n0 * p.ldw + tap * Cin + chunk * CK) * 2), smem_base + W_BASE + buf * WTAP + wave * 1024);
+    };
+    uint32_t voff_p[NPP];
+    uint32_t gn_bits = 0;
+    auto set_patch = [&](const Unit& u, bool valid) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));           // (an opaque lane index: the unit-independent parts are recomputed per unit, not carried through the loop)
+        gn_bits = 0;
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) {
+            const int uu = (wave + 8 * j) * 64 + ln, pp = uu >> 2, slot = uu & 3;
+            const int py = pp / PW, px = pp - py * PW;
+            const int iy = u.sy0 + py, ix = u.sx0 + px;
+            const bool ok = valid && pp < PPIX && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const int c = slot ^ key8(px);
+            voff_p[j] = ok ? (uint32_t)(((((int64_t)u.img * p.IH + iy) * p.IW + ix) * p.ld1 + c * 8) * 2) : kOob;
+            if (ok) gn_bits |= (uint32_t)(8 | c) << (4 * j);
+        }
+    };
+    auto stage_p = [&](int chunk, int j, int par) {
+        dma(voff_p[j], srd_a, (uint32_t)(chunk * CK * 2), smem_base + par * PATCHB + (wave + 8 * j) * 1024);
+    };
+    auto stage_t = [&](int img, int chunk, int par, bool valid) {
+        const uint32_t vo = (valid && lane < 16) ? (uint32_t)(lane * 16) : kOob;
+        dma(vo, srd_t, (uint32_t)((img * Cin * 2 + chunk * CK * 2) * 4), smem_base + TBL + par * 1024);
+    };
+    auto gn_piece = [&](int j, int par) {
+        const uint32_t bits = gn_bits >> (4 * j);
+        if (bits & 8) {
+            char* qp = smem + par * PATCHB + (wave + 8 * j) * 1024 + lane * 16;
+            const float* tb = reinterpret_cast<const float*>(smem + TBL + par * 1024) + (bits & 3) * 16;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(tb + 8), t3 = *reinterpret_cast<const f32x4*>(tb + 12);
+            float f[8];
+            unpack8<T>(*reinterpret_cast<const U4*>(qp), f);
+            f[0] = f[0] * t0[0] + t0[1]; f[1] = f[1] * t0[2] + t0[3];
+            f[2] = f[2] * t1[0] + t1[1]; f[3] = f[3] * t1[2] + t1[3];
+            f[4] = f[4] * t2[0] + t2[1]; f[5] = f[5] * t2[2] + t2[3];
+            f[6] = f[6] * t3[0] + t3[1]; f[7] = f[7] * t3[2] + t3[3];
+            if (p.a_gn_silu) {
+                float e[8];
+                pin8(f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = f[i] * -1.4426950408889634f;
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = 1.0f + e[i];
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+                pin8(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = f[i] * e[i];
+            }
+            *reinterpret_cast<U4*>(qp) = pack8<T>(f);
+        }
+    };
+
+    int a_rd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = l15 + kx;
+        a_rd[kx] = (4 * q * PW + px) * 64 + ((lq ^ key8(px)) << 4);
+    }
+    const int b_rd = (wc * 64 + l15) * 64 + ((lq ^ key8(l15)) << 4);
+
+    f32x4 acc[8][4];                               // (the first tap of every unit multiplies into C = 0)
+    U4 afr[4], bfr[4];
+    U4 pk[8][2];                                   // the previous unit's finished output, as its store instructions take it
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pk[i][0] = zero16(); pk[i][1] = zero16(); }
+
+    Unit cur = decode(0), nxt = cur, prv = cur;
+    bool has_next = false, have_prev = false;
+
+    // ---- prologue (first unit only): bias row -> LDS, weight slices of taps 0 / 1, patch of chunk 0 (+ its table)
+    stage_w(cur.n0, 0, 0, 0, true);
+    stage_w(cur.n0, 0, 1, 1, true);
+    set_patch(cur, true);
+    H5_STAMP(1);
+    if (gnf) stage_t(cur.img, 0, 0, true);
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) stage_p(0, j, 0);
+    if (tid < (p.N >> 2)) {
+        f32x4 b = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.bias_n) b = *reinterpret_cast<const f32x4*>(p.bias_n + 4 * tid);
+        *reinterpret_cast<f32x4*>(smem + BIASL + 16 * tid) = b;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (gnf) {
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) gn_piece(j, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run half a phase behind their SIMD partners
+    asm volatile("" ::: "memory");
+    H5_STAMP(2);
+
+    // The stores are buffer-addressed: lane offset + a wave-uniform scalar offset, and an out-of-range lane offset DROPS the lane — the first
+    // unit of a workgroup has no predecessor, but its first chunk must issue the same 16 instructions (the counted waits count them).
+    const u32x4 srd_o = srd_of(p.out);
+    uint32_t so1 = kOob, so2 = kOob;
+    auto store_piece = [&](const Unit& u, int k) {            // store instruction k of the wave: pixel block k >> 1, lanes' pixels pa (+ 8)
+        const int mb = k >> 1;
+        const int64_t mu = (int64_t)u.m0 + (4 * q + (mb & 3)) * p.OW + 16 * (mb >> 2);
+        const uint32_t soff = (uint32_t)((mu * p.ldc + u.n0 + wc * 64) * 2);
+        const u32x4 v = u32x4{pk[mb][k & 1].x, pk[mb][k & 1].y, pk[mb][k & 1].z, pk[mb][k & 1].w};
+#ifdef H5P_NOSTORE     // (diagnostic builds only: what do the stores cost the loop?)
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(v), "v"(kOob), "s"(srd_o), "s"(soff) : "memory");
+#else
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(v), "v"((k & 1) ? so2 : so1), "s"(srd_o), "s"(soff) : "memory");
+#endif
+    };
+    float* const red = reinterpret_cast<float*>(smem + RED);
+    auto ror8 = [&](const U4& v) {
+        U4 r;
+        r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x128, 0xF, 0xF, false);
+        r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x128, 0xF, 0xF, false);
+        r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x128, 0xF, 0xF, false);
+        r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x128, 0xF, 0xF, false);
+        return r;
+    };
+    auto sel = [&](bool c, const U4& a, const U4& b) {
+        U4 r;
+        r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; r.z = c ? a.z : b.z; r.w = c ? a.w : b.w;
+        return r;
+    };
+    // accumulators -> pk (bias, GroupNorm sums, one rounding); the wave's partial sums go to its own rows of `red`
+    auto pack_unit = [&](const Unit& u) {
+        // epilogue lane geometry (tile 17, finish16): instruction 1 writes pixel pa of a block, instruction 2 pixel pa + 8 — from an
+        // opaque copy of the lane index, so that nothing of it is carried through the multiply loop
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int l15e = lane_e & 15, lqe = lane_e >> 4;
+        const bool lo8 = l15e < 8;
+        so1 = (uint32_t)((l15e & 7) * p.ldc + (lo8 ? 0 : 32) + 8 * lqe) * 2u;
+        so2 = so1 + 16u * (uint32_t)p.ldc;
+        const float alpha = p.alpha;
+        const int nu = u.n0 + wc * 64;
+        float cb[2][8], gs[2][8], gq[2][8];
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const float* bl = reinterpret_cast<const float*>(smem + BIASL) + nu + 32 * hp + 8 * lqe;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cb[hp][j] = b0[j]; cb[hp][j + 4] = b1[j]; gs[hp][j] = 0.0f; gs[hp][j + 4] = 0.0f; gq[hp][j] = 0.0f; gq[hp][j + 4] = 0.0f; }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            float f[2][8];
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f[hp][i] = __builtin_fmaf(acc[mb][2 * hp][i], alpha, cb[hp][i]);
+                    f[hp][i + 4] = __builtin_fmaf(acc[mb][2 * hp + 1][i], alpha, cb[hp][i + 4]);
+                }
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { gs[hp][i] += f[hp][i]; gq[hp][i] += f[hp][i] * f[hp][i]; }
+                pin8(gs[hp]);
+                pin8(gq[hp]);
+            }
+            const U4 h0 = pack8<T>(f[0]), h1 = pack8<T>(f[1]);
+            const U4 got = ror8(sel(lo8, h1, h0));
+            pk[mb][0] = sel(lo8, h0, got);
+            pk[mb][1] = sel(lo8, got, h1);
+        }
+        if (gn_acc) {
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gs[hp][j] = row16_sum(gs[hp][j]); gq[hp][j] = row16_sum(gq[hp][j]); }
+                if (l15e == 0) {
+                    float* dst = red + (wave * 64 + 32 * hp + 8 * lqe) * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { dst[2 * j] = gs[hp][j]; dst[2 * j + 1] = gq[hp][j]; }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    auto gn_publish = [&](const Unit& u) {                    // per-channel sums of the unit's 512 pixels -> its four 128-row slots (the first takes them)
+        if (tid < 128) {
+            const int wcc = tid >> 6, cl = tid & 63;
+            float a = 0.0f, s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a += red[((2 * k + wcc) * 64 + cl) * 2]; s += red[((2 * k + wcc) * 64 + cl) * 2 + 1]; }
+            float* dst = p.gn_partial + ((int64_t)(4 * u.tm) * gn_ld_of(p) + u.n0 + tid) * 2;
+            dst[0] = a;
+            dst[1] = s;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { dst[2 * k * (int64_t)gn_ld_of(p)] = 0.0f; dst[2 * k * (int64_t)gn_ld_of(p) + 1] = 0.0f; }
+        }
+    };
+
+    constexpr int PP0 = 2;                               // phases PP0 .. PP0 + NPP - 1 of a chunk stage a piece of the next patch
+    // the previous unit's 16 store instructions: the first STB at once behind the pack (their registers never enter the loop, whose first
+    // phases hold the most: old output + new accumulators + fragments), the others one per phase ST0 .. of the unit's first chunk
+#ifndef H5P_STB
+#define H5P_STB 4
+#endif
+#ifndef H5P_ST0
+#define H5P_ST0 1
+#endif
+    constexpr int STB = H5P_STB, ST0 = H5P_ST0, STN = 16 - STB;
+    static_assert(ST0 + STN <= 18, "the stores of a unit leave within the next unit's first chunk");
+    // PAR = LDS parity of the chunk's patch; LAST = last chunk of its unit (the "next chunk" is the next unit's first);
+    // ST = first chunk of a unit that follows another: the first tap multiplies into C = 0 and the previous unit's stores are issued
+    auto chunk_body = [&](int c, auto PARc, auto LASTc, auto STc) {
+        constexpr int par = decltype(PARc)::value;
+        constexpr bool LAST = decltype(LASTc)::value, ST = decltype(STc)::value;
+        const char* pa = smem + par * PATCHB;
+        auto phase = [&](auto TAPc, auto SUBc) {
+            constexpr int TAP = decltype(TAPc)::value, SUB = decltype(SUBc)::value, KY = TAP / 3, KX = TAP % 3;
+            constexpr int TAP2 = (TAP + 2) % 9, PH = 2 * TAP + SUB, BUF = TAP % 3, BUF2 = TAP2 % 3;
+            if constexpr (SUB == 0) {
+                const char* pb = smem + W_BASE + BUF * WTAP + b_rd;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const U4*>(pb + nb * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) afr[j] = *reinterpret_cast<const U4*>(pa + a_rd[KX] + (j + KY) * PROWB + SUB * 1024);
+            if constexpr (SUB == 0) {
+                if constexpr (TAP + 2 >= 9) {
+                    if constexpr (LAST) stage_w(nxt.n0, 0, TAP2, BUF2, has_next);
+                    else stage_w(cur.n0, c + 1, TAP2, BUF2, true);
+                } else {
+                    stage_w(cur.n0, c, TAP2, BUF2, true);
+                }
+            }
+            if constexpr (PH >= PP0 && PH < PP0 + NPP) stage_p(LAST ? 0 : c + 1, PH - PP0, par ^ 1);      // (LAST: voff_p is the next unit's already)
+            if constexpr (PH == 0) {
+                if (gnf) {
+                    if constexpr (LAST) stage_t(nxt.img, 0, par ^ 1, has_next);
+                    else stage_t(cur.img, c + 1, par ^ 1, true);
+                }
+            }
+            constexpr bool STH = ST && PH >= ST0 && PH < ST0 + STN, STP = ST && PH - 1 >= ST0 && PH - 1 < ST0 + STN;
+            if constexpr (STH) store_piece(prv, STB + PH - ST0);
+            if constexpr (SUB == 1) {
+                // in flight by design: what this and the previous phase issued (one weight piece, up to two patch pieces, the table, up to two stores)
+                // (+ in phase 1 the STB stores issued between the units: younger than everything phase 2 reads)
+                constexpr int INFLIGHT = 1 + (PH >= PP0 && PH < PP0 + NPP ? 1 : 0) + (PH - 1 >= PP0 && PH - 1 < PP0 + NPP ? 1 : 0) + (STH ? 1 : 0) + (STP ? 1 : 0) +
+                                         (ST && PH == 1 ? STB : 0);
+                if (PH == 1 && gnf) wait_vm_n<INFLIGHT + 1>();
+                else wait_vm_n<INFLIGHT>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    if constexpr (ST && TAP == 0) acc[SUB * 4 + j][nb] = T::mfma16(bfr[nb], afr[j], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+                    else acc[SUB * 4 + j][nb] = T::mfma16(bfr[nb], afr[j], acc[SUB * 4 + j][nb]);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PH >= 6 && PH < 6 + NPP) {
+                if (gnf) gn_piece(PH - 6, par ^ 1);         // (no next unit: gn_bits == 0)
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (ST && PH == 0) {
+                // every wave's partial sums of the previous unit are in `red` (each waited for its LDS writes before it came here)
+                if (gn_acc && have_prev) gn_publish(prv);
+            }
+        };
+        auto tap_body = [&](auto TAPc) { phase(TAPc, IC<0>{}); phase(TAPc, IC<1>{}); };
+        tap_body(IC<0>{}); tap_body(IC<1>{}); tap_body(IC<2>{}); tap_body(IC<3>{}); tap_body(IC<4>{});
+        tap_body(IC<5>{}); tap_body(IC<6>{}); tap_body(IC<7>{}); tap_body(IC<8>{});
+    };
+
+    using std::true_type;
+    using std::false_type;
+    for (int k = 0; k < nmine; ++k) {
+        chunk_body(0, IC<0>{}, false_type{}, true_type{});
+        for (int c = 1; c + 1 < nchunk; c += 2) {
+            chunk_body(c, IC<1>{}, false_type{}, false_type{});
+            chunk_body(c + 1, IC<0>{}, false_type{}, false_type{});
+        }
+        has_next = k + 1 < nmine;
+        if (has_next) nxt = decode(k + 1);
+        set_patch(nxt, has_next);                        // (the current unit's staging offsets are dead: its last patch is in LDS)
+        chunk_body(nchunk - 1, IC<1>{}, true_type{}, false_type{});
+#ifdef EDTR_STAMPS
+        if (k < 6) H5_STAMP(8 + k);
+#endif
+        pack_unit(cur);
+        prv = cur;
+        cur = nxt;
+        have_prev = true;
+        if (has_next) {
+#pragma unroll
+            for (int i = 0; i < STB; ++i) store_piece(prv, i);
+        }
+    }
+    H5_STAMP(3);
+    // the last unit: its stores at once, its statistics behind a workgroup barrier
+#pragma unroll
+    for (int i = 0; i < 16; ++i) store_piece(prv, i);
+    H5_STAMP(4);
+    if (g == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave groups
+    if (gn_acc) {
+        __syncthreads();
+        gn_publish(prv);
+    }
+    H5_STAMP(5); H5_STAMP(15);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Tile 20 (round 5): the halo tile for N % 160 == 0 — the UNet / ControlNet ResBlock convolutions of the 64 x 64 latent level
 // (N = 320, M = 32768 at batch 8; reference model/unet.py:152,178).  The 128-column halo tiles pad N = 320 to three column tiles and
 // 1.5 rounds of units, which is why these convolutions stayed on the 128 x 160 implicit-GEMM tile (tile 8: every input element staged
@@ -859,7 +1265,30 @@ int launch_halo512(const edtr_igemm_params& p, hipStream_t stream) {
     return EDTR_OK;
 }
 
+template <typename T>
+int launch_halo512p(const edtr_igemm_params& p, hipStream_t stream) {
+    using namespace h1p;
+    static EdtrLdsOnce attr_set;
+    if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(&igemm_halo512p_kernel<T>), LDS_BYTES_P, attr_set)) return rc_;
+    const int64_t units = (int64_t)(p.M >> 9) * (p.N >> 7);
+    int grid = edtr_cu_count() & ~7;                     // one workgroup per CU, a multiple of the eight XCDs
+    if (grid > units) grid = (int)((units + 7) & ~7);
+    hipLaunchKernelGGL((igemm_halo512p_kernel<T>), dim3(grid), dim3(512), LDS_BYTES_P, stream, p);
+    EDTR_LAUNCH_CHECK();
+    return EDTR_OK;
+}
+
 }  // namespace
+
+// tile 21 = tile 17's shapes with a 16-bit output, no residual, no time-embedding row, an even number of 32-channel chunks
+bool edtr_halo512p_ok(const edtr_igemm_params& p) {
+    return edtr_halo512_ok(p) && !p.out_f32 && !p.out16 && !p.residual && !p.rowvec && p.N <= 512 && ((p.C1 / CK) & 1) == 0 &&
+           (int64_t)p.M * p.ldc * 2 < 0xF0000000LL;      // (the output is written by buffer-addressed stores)
+}
+
+int edtr_launch_halo512p(const edtr_igemm_params& p, hipStream_t stream) {
+    return p.dtype == EDTR_BF16 ? launch_halo512p<BF16>(p, stream) : launch_halo512p<F16>(p, stream);
+}
 
 // shape / option requirements of tile 17 (the caller has validated the generic edtr_igemm rules and buffer addressability)
 bool edtr_halo512_ok(const edtr_igemm_params& p) {
@@ -889,6 +1318,7 @@ int edtr_launch_halo160(const edtr_igemm_params& p, hipStream_t stream) {
 #ifdef EDTR_STAMPS
 extern "C" int edtr_halo512_stamped(const edtr_igemm_params* p, void* stream) {      // stand-alone diagnostic build: no edtr_igemm in front
     if (p->tile == 20) return edtr_halo160_ok(*p) ? edtr_launch_halo160(*p, static_cast<hipStream_t>(stream)) : EDTR_E_UNSUPPORTED;
+    if (p->tile == 21) return edtr_halo512p_ok(*p) ? edtr_launch_halo512p(*p, static_cast<hipStream_t>(stream)) : EDTR_E_UNSUPPORTED;
     if (!edtr_halo512_ok(*p)) return EDTR_E_UNSUPPORTED;
     return edtr_launch_halo512(*p, static_cast<hipStream_t>(stream));
 }

@@ -2406,6 +2406,11 @@ int dispatch(const edtr_igemm_params& p, int tile, bool spatial, hipStream_t s, 
         if (dry) return tile;
         return edtr_launch_halo160(p, s);
     }
+    if (tile == 21) {      // tile 17 as a persistent kernel with deferred stores (halo512.hip)
+        if (!spatial || !edtr_halo512p_ok(p) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
+        if (dry) return tile;
+        return edtr_launch_halo512p(p, s);
+    }
     if (tile == 17) {      // halo tile, 512-pixel units (halo512.hip)
         if (!spatial || !edtr_halo512_ok(p) || !igemm_fast_addressable(p, spatial)) return EDTR_E_UNSUPPORTED;
         if (dry) return tile;
@@ -2687,6 +2692,12 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
     //  for the 256 CUs of an MI355X — ADVICE r05)
     const int cus = dry ? 256 : edtr_cu_count();
     if (p.tile == 0 && tile == 16 && halo512 > 0 && h512_ok && (int64_t)(p.M >> 9) * (p.N >> 7) >= (int64_t)cus * halo512) tile = 17;
+    static int halo512p = -1;
+    if (halo512p < 0) {
+        const char* e13 = getenv("EDTR_IGEMM_HALO512P");
+        halo512p = e13 ? atoi(e13) : 0;
+    }
+    if (p.tile == 0 && tile == 17 && halo512p > 0 && edtr_halo512p_ok(p) && (int64_t)(p.M >> 9) * (p.N >> 7) >= (int64_t)cus * halo512p) tile = 21;
     // Halo tile of 160 columns (tile 20): N % 160 == 0 convolutions whose 16 x 16-pixel x 160-channel units fill whole rounds of the
     // chip (the 64 x 64-latent ResBlock convolutions at batch 8: 256 units = one per CU), where the 128 x 160 implicit-GEMM tile would run.
     // EDTR_IGEMM_HALO160=0 switches the automatic choice off (A/B on one device).
@@ -2700,7 +2711,10 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
         if (units >= most && (tail == 0 || tail >= most)) tile = 20;       // whole rounds of one unit per CU (the last one >= 3/4 full)
     }
     if (p.a_gn) {           // GroupNorm (+ SiLU) of the input fused into the halo tiles' patch staging: 16 x 16 / 32 x 16-patch geometries only
-        if (p.tile == 17 || (p.tile == 0 && tile == 17)) {
+        if (p.tile == 21 || (p.tile == 0 && tile == 21)) {
+            if (!h512_ok || !edtr_halo512p_ok(p)) return EDTR_E_UNSUPPORTED;
+            tile = 21;
+        } else if (p.tile == 17 || (p.tile == 0 && tile == 17)) {
             if (!h512_ok) return EDTR_E_UNSUPPORTED;
             tile = 17;
         } else {
@@ -2741,9 +2755,9 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
         if (p.tile != 0) return EDTR_E_UNSUPPORTED;
         tile = dma_ok ? 3 : 1;
     }
-    if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 17 || tile == 20)) return EDTR_E_UNSUPPORTED;
+    if ((p.row_stats || p.vt_out) && (tile == 16 || tile == 17 || tile == 20 || tile == 21)) return EDTR_E_UNSUPPORTED;
     if (p.act == EDTR_ACT_GEGLU && tile == 2) tile = 1;  // value/gate pairing needs two 32-column MFMA tiles per wave
-    if (tile >= 3 && !dma_ok && !((tile == 17 || tile == 20) && p.C2 == 0 && (p.C1 & 31) == 0)) return EDTR_E_UNSUPPORTED;      // (tiles 17 / 20 walk 32-channel chunks)
+    if (tile >= 3 && !dma_ok && !((tile == 17 || tile == 20 || tile == 21) && p.C2 == 0 && (p.C1 & 31) == 0)) return EDTR_E_UNSUPPORTED;      // (tiles 17 / 20 walk 32-channel chunks)
     if (p.gn_partial) {
         const int sr = p.gn_slot_rows > 0 ? p.gn_slot_rows : 128;
         if (p.gn_ld < 0 || (p.gn_ld > 0 && p.gn_ld < p.N)) return EDTR_E_SHAPE;
@@ -2757,7 +2771,7 @@ static int igemm_run(const edtr_igemm_params* pp, edtr_stream_t stream, bool dry
     // live tiles: 1, 2 (register-staged), 3 (LDS-DMA 128x128), 6 (256x256 ping-pong), 8 (128x160), 14 (256x32), 16 (halo), 17 (halo, 512-pixel units).
     // 4, 5, 7, 9 - 13, 15, 18 (and a round-2 "17") were experiments, measured (profiles/r01 - r03) and removed (15 = the 8-wave ping-pong 128x128 tile
     // for small grids and 18 = the persistent halo tile were faster in isolation and neutral on the whole path: round 4 took them out)
-    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || tile == 14 || tile == 16 || tile == 17 || tile == 20)) return EDTR_E_DTYPE;
+    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || tile == 14 || tile == 16 || tile == 17 || tile == 20 || tile == 21)) return EDTR_E_DTYPE;
     // lockstep breaker of the two-workgroups-per-CU kernels (stagger_second_slot): only when the grid has more than one round
     // (>= 768 workgroups: below that the second slot's blocks are the tail anyway) and the tile is short enough for the epilogue
     // to matter.  EDTR_IGEMM_STAGGER = percent of the estimated half life (default 100; 0 = off).

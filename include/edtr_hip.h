@@ -132,7 +132,11 @@ typedef struct edtr_igemm_params {
                                1.10 - 1.13 x over tile 16 on the VAE's convolutions); 20 = the halo tile on 16 x 16 pixels x 160 channels
                                (ABI 9, halo512.hip: N % 160 == 0, otherwise tile 17's rules with OW % 16 == 0 and no a_gn; automatic
                                where the 128x160 tile would run and the units fill one round of the chip, 192 .. 256: the 64 x 64-latent
-                               ResBlock convolutions at batch 8).  4, 5, 7, 9 - 13, 15, 18, 19 were experiments (3-stage BK32, 256x128 tiles, 64x128,
+                               ResBlock convolutions at batch 8); 21 = tile 17 as a persistent kernel (ABI 10, halo512.hip: one workgroup per
+                               CU walks its units, the finished 16-bit output of a unit leaves under the next unit's multiply loop; bit-identical
+                               to tile 17; 16-bit output, no residual / rowvec, N <= 512, C1 % 64 == 0; never automatic — 1.00 - 1.05 x in
+                               isolation, neutral on the whole path: profiles/r06/halo512p_*.log; EDTR_IGEMM_HALO512P=N picks it from N units
+                               per CU for A/B runs).  4, 5, 7, 9 - 13, 15, 18, 19 were experiments (3-stage BK32, 256x128 tiles, 64x128,
                                16x16x32 at 128x128, deeper LDS rings, bank-swizzled epilogue staging, an 8-wave ping-pong 128x128 tile
                                for small grids, two-workgroup and persistent halo variants), measured without a whole-path gain
                                (profiles/r01 - r03) and removed: EDTR_E_DTYPE */

@@ -1368,6 +1368,39 @@ def test_halo_conv_tile17_with_groupnorm_of_its_input(dtype, B, H, W, cin, cout,
     assert rel(outs[True].float(), outs[False].float()) < 0.1 * TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,cin,cout,gnin,bias", [(1, 512, 512, 64, 128, False, True),       # 512 units: two per workgroup, two chunks
+                                                      (3, 256, 256, 128, 256, True, True),       # 768 units in two column tiles: three per workgroup, GroupNorm + SiLU of the input
+                                                      (1, 272, 512, 64, 128, True, False),       # 272 units: 16 workgroups walk two, the others one
+                                                      (1, 32, 64, 64, 128, False, True)])        # four units: a grid of eight, half of it without work
+def test_halo_conv_tile21_persistent_form_is_bit_identical_to_tile17(dtype, B, H, W, cin, cout, gnin, bias):
+    """Tile 21 (round 6, opt-in): tile 17's units walked by a persistent grid, the finished 16-bit output of unit i held in registers and
+    stored under unit i + 1's multiply loop, its GroupNorm sums published behind that unit's first phase.  Same products in the same
+    order, same single rounding: the stored tensor and the statistics must EQUAL tile 17's."""
+    ops = _ops()
+    d = dev()
+    M = B * H * W
+    g = torch.Generator().manual_seed(2100 + cin + H)
+    x = (torch.randn((M, cin), generator=g) * 1.2 + 0.3).to(dtype).to(d)
+    w = (torch.randn((cout, 9 * cin), generator=g) / math.sqrt(9 * cin)).to(dtype).to(d)
+    bv = torch.randn((cout,), generator=g).to(d) if bias else None
+    table = None
+    if gnin:
+        table = torch.stack([1 + 0.3 * torch.randn((B, cin), generator=g), 0.2 * torch.randn((B, cin), generator=g)], dim=-1).contiguous().to(d)
+    outs = {}
+    for t in (17, 21):
+        out = torch.full((M, cout), float("nan"), dtype=dtype, device=d)
+        gn = torch.full((M // 128, cout, 2), float("nan"), dtype=torch.float32, device=d)
+        ops.launch(ops.make_igemm(dtype=dtype, a1=x, w=w, out=out, taps=9, M=M, N=cout, C1=cin, ld1=cin, ldw=9 * cin, ldc=cout,
+                                  spatial=(H, W, H, W, 1, 1, 1, 0), bias_n=bv, rows_per_image=H * W, tile=t, gn_partial=gn,
+                                  a_gn=table, a_gn_silu=gnin))
+        outs[t] = (out, gn)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[21][0].float()).all()
+    assert torch.equal(outs[21][0], outs[17][0])
+    assert torch.equal(outs[21][1], outs[17][1])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Tile 20 (halo512.hip, round 5): the halo tile on 16 x 16 pixels x 160 channels for N % 160 == 0 (the 64 x 64-latent ResBlock
 # convolutions of the UNet / ControlNet: N = 320).  One / three / ten chunks, one / two / four column tiles, time-embedding row,

@@ -661,3 +661,32 @@ def test_ffn_host_packing_matches_the_header():
         assert float(cst[c, hh, q, vg, lh, e]) == (0.5 if vg else 1.0) * R
     assert ops.ffn_ok(32768, 320, 1280) and ops.ffn_ok(16384, 320, 1280)
     assert not ops.ffn_ok(4096, 320, 1280) and not ops.ffn_ok(32768, 640, 2560) and not ops.ffn_ok(16400, 320, 1280)
+
+
+def test_tile21_is_opt_in_and_refuses_what_it_cannot_hold():
+    """Tile 21 (the persistent form of tile 17 with deferred stores, round 6) runs only when asked for: 16-bit output, no residual, no
+    time-embedding row, an even number of 32-channel chunks (edtr_igemm_plan: every check of the launch, no HIP call)."""
+    import ctypes as C
+    from edtr_amd import lib as L
+    lib = L.load()
+    buf = (C.c_char * 4096)()
+    base = C.addressof(buf) & ~15
+
+    def plan(tile, cin=64, N=128, residual=False, out_f32=False, rowvec=False, H=512, W=512):
+        p = L.IgemmParams()
+        p.dtype, p.taps, p.M, p.N, p.K, p.Z, p.zdiv = 0, 9, H * W, N, 9 * cin, 1, 1
+        p.a1, p.C1, p.ld1, p.w, p.ldw = base, cin, cin, base, 9 * cin
+        p.IH, p.IW, p.OH, p.OW, p.stride, p.pad_t, p.pad_l = H, W, H, W, 1, 1, 1
+        p.alpha, p.out, p.ldc, p.tile, p.splitk, p.out_f32 = 1.0, base, N, tile, 1, int(out_f32)
+        if residual:
+            p.residual, p.ldr = base, N
+        if rowvec:
+            p.rowvec, p.rowvec_ld, p.rows_per_image = base, N, H * W
+        return lib.edtr_igemm_plan(C.byref(p))
+
+    assert plan(21) == 21 and plan(21, cin=128, N=256) == 21
+    assert plan(0) == 17                                            # the automatic choice stays tile 17 (EDTR_IGEMM_HALO512P is the A/B switch)
+    assert plan(21, residual=True) < 0 and plan(21, out_f32=True) < 0 and plan(21, rowvec=True) < 0
+    assert plan(21, cin=96) < 0                                     # three chunks
+    assert plan(21, W=528) < 0 and plan(17, W=528) < 0              # tile 17's own shape rules apply
+

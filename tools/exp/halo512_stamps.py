@@ -62,6 +62,29 @@ def run():
             p.a_gn, p.a_gn_silu = tbl.p, 1
         ms = H.time_launches([lambda s: H.chk(lib.edtr_halo512_stamped(C.byref(p), s), "halo512")], iters=10, warm=3)
         st = stamps.get(np.int64, (nb, 16))
+        if tile == 21:      # the persistent form: bit-identical to tile 17?  per-unit spans of a workgroup
+            got = out.get(np.uint16, (M, N)).copy()
+            gg = g.get(np.float32, ((M // 128), N, 2)).copy() if gnp else None
+            out2 = H.Dev(nbytes=M * N * 2, fill=0)
+            g2 = H.Dev(nbytes=(M // 128) * N * 8, fill=0) if gnp else None
+            p.tile, p.out = 17, out2.p
+            if gnp:
+                p.gn_partial = g2.p
+            ms17 = H.time_launches([lambda s: H.chk(lib.edtr_halo512_stamped(C.byref(p), s), "halo512")], iters=10, warm=3)
+            ref = out2.get(np.uint16, (M, N))
+            same = bool((got == ref).all())
+            gsame = bool((gg == g2.get(np.float32, ((M // 128), N, 2))).all()) if gnp else True
+            p.tile, p.out = 21, out.p
+            if gnp:
+                p.gn_partial = g.p
+            G = min(256, nb)
+            sw = st[:G]
+            dd = lambda i, j: int(np.median(sw[:, j] - sw[:, i]))
+            per = [dd(2, 8)] + [dd(8 + k - 1, 8 + k) for k in range(1, min(6, nb // G))]
+            flops = 2.0 * M * N * K
+            print(f"{label:30s} tile21 {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF | tile17 {ms17 * 1e3:7.1f} us {flops / ms17 / 1e9:6.0f} TF | x{ms17 / ms:5.3f} | "
+                  f"bit-identical out {same} gn {gsame} | cycles: setup+first {dd(0, 2)} units(loop+pack) {per} tail {dd(3, 5)} total {dd(0, 5)}", flush=True)
+            return
         d = lambda i, j: int(np.median(st[:, j] - st[:, i]))
         nchunk = Cin // 32
         life = np.median(st[:, 15] - st[:, 14]) / 100.0
@@ -85,6 +108,16 @@ def run():
         for (b, hh, ww) in [(1, 64, 128), (1, 128, 256), (1, 256, 256), (1, 256, 512), (2, 512, 512)]:
             case(f"{b}x{hh}x{ww} 128->128 res gnp", b, hh, ww, 128, 128)
             case(f"{b}x{hh}x{ww} 128->128 plain", b, hh, ww, 128, 128, residual=False, gnp=False)
+        return
+    if tile == 21:
+        case("512^2 128->128 gnp", 8, 512, 512, 128, 128, residual=False)
+        case("512^2 128->128 plain", 8, 512, 512, 128, 128, residual=False, gnp=False)
+        case("512^2 128->128 gnin gnp", 8, 512, 512, 128, 128, residual=False, gnin=True)
+        case("256^2 256->256 gnp", 8, 256, 256, 256, 256, residual=False)
+        case("256^2 256->256 gnin gnp", 8, 256, 256, 256, 256, residual=False, gnin=True)
+        case("128^2 512->512 gnp", 8, 128, 128, 512, 512, residual=False)
+        case("3x256x512 128->256 gnin gnp", 3, 256, 512, 128, 256, residual=False, gnin=True)
+        case("1x64x96 256->128 gnp", 1, 64, 96, 256, 128, residual=False)
         return
     case("512^2 128->128 res gnp", 8, 512, 512, 128, 128)
     case("512^2 128->128 plain", 8, 512, 512, 128, 128, residual=False, gnp=False)
