@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libedtr_hip.so")
-SOURCES = ["igemm.hip", "halo512.hip", "attention.hip", "attn512.hip", "norm.hip", "elementwise.hip", "swin.hip", "ffn.hip"]
+SOURCES = ["igemm.hip", "halo512.hip", "attention.hip", "attn512.hip", "norm.hip", "elementwise.hip", "swin.hip", "ffn.hip", "lin320.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "edtr_hip.h")]
 # files #include'd by one source only (generated code): a regenerated .inc must rebuild its object
 EXTRA_DEPS = {"attention.hip": [os.path.join(CSRC, "attn_v3_loop.inc")]}

@@ -308,6 +308,25 @@ class WeightStore:
             self.cache[key] = (w1p, w2p, cst, self._p(b2name).reshape(-1).contiguous())
         return self.cache[key]
 
+    def lin320(self, names: Sequence[str], biases, ln_prefix: Optional[str], alpha: float):
+        """Operands of edtr_lin320 (include/edtr_hip.h) for one K = 320 projection: (the matrix in fragment order — with the LayerNorm's
+        gamma folded into its columns when ``ln_prefix`` is given — and the additive row bias + alpha W beta, or None).  Fast modes only."""
+        names = tuple(names)
+        key = ("lin320", names, tuple(biases) if biases else None, ln_prefix, float(alpha))
+        if key not in self.cache:
+            w = torch.cat([self._p(n).reshape(self.params[n].shape[0], -1) for n in names], dim=0)
+            cvec = None
+            if biases:
+                cvec = torch.cat([self._p(bn).reshape(-1) if bn else torch.zeros(self.params[n].shape[0], device=self.device)
+                                  for n, bn in zip(names, biases)]).float()
+            if ln_prefix is not None:
+                gamma, beta = self._p(ln_prefix + "weight").reshape(-1), self._p(ln_prefix + "bias").reshape(-1)
+                shift = float(alpha) * (w @ beta)
+                cvec = shift if cvec is None else cvec + shift
+                w = w * gamma[None, :]
+            self.cache[key] = (ops.pack_lin320_w(w, self.dtype), cvec.contiguous() if cvec is not None else None)
+        return self.cache[key]
+
     def raw(self, name: str) -> torch.Tensor:
         """The fp32 parameter itself on the device (embedding tables)."""
         key = ("raw", name)
@@ -506,6 +525,14 @@ class OpN:
         return self.t.stride(dim)
 
 
+class LNReg:
+    """A LayerNorm that is not launched: its raw input rows ``x`` [rows, C]; the consuming projection is an edtr_lin320 launch that
+    normalises the rows in its registers (gamma / beta folded into its weights and additive row by the weight store)."""
+
+    def __init__(self, x: torch.Tensor, C: int, prefix: str):
+        self.x, self.C, self.prefix = x, C, prefix
+
+
 class LNRef:
     """A LayerNorm that is not launched: its raw input rows ``x`` [rows, C] and the per-row statistics ``stats`` [rows, C / 32, 2]
     the producing GEMM wrote; the consuming GEMMs fold the normalisation into their weights and epilogue (edtr_hip.h ln_stats)."""
@@ -641,6 +668,8 @@ class Emitter:
                 t = t.t
             if isinstance(t, OpN):
                 t = t.t
+            if isinstance(t, LNReg):
+                continue             # (owns nothing: the raw rows belong to the residual stream)
             if isinstance(t, LNRef):
                 t = t.stats          # (the raw rows belong to the residual stream: their owner frees them)
             self._drop_mirror(t)
@@ -742,6 +771,22 @@ class Emitter:
     def ffn_ok(self, rows: int, C: int) -> bool:
         """May x + ff(norm3(x)) of a transformer block run as ONE edtr_ffn launch?  (fast modes; the shapes edtr_ffn is built for)"""
         return not self.hp and not self.invariant and ops.ffn_ok(rows, C, 4 * C)
+
+    def lin320_ok(self, rows: int, N: int, K: int) -> bool:
+        """May a K = 320 projection (optionally behind its LayerNorm) run as ONE edtr_lin320 launch?  (fast modes; the shapes it is built for)"""
+        return not self.hp and not self.invariant and ops.lin320_ok(rows, N, K)
+
+    def lin320(self, x: torch.Tensor, rows: int, N: int, names, biases=None, *, ln_prefix: Optional[str] = None, alpha: float = 1.0,
+               residual: Optional[torch.Tensor] = None, name: str = "lin320") -> torch.Tensor:
+        """out = alpha LayerNorm?(x) W^T + bias (+ residual) on raw 16-bit rows (edtr_lin320: the rows live in registers, the LayerNorm is
+        applied there — no normalisation launch, no normalised tensor)."""
+        self.last_gnp, self.last_row_stats, self.gnp_into_done = None, None, False
+        w, cvec = self.store.lin320(names, biases, ln_prefix, alpha)
+        out = self.new(rows, N)
+        self.prog.add(ops.make_lin320(dtype=self.dtype, x=x, ldx=x.stride(0), M=rows, N=N, w=w, cvec=cvec, alpha=alpha, ln=ln_prefix is not None,
+                                      eps=1e-5, residual=residual, ldr=residual.stride(0) if residual is not None else 0, out=out,
+                                      ldo=out.stride(0), name=name))
+        return out
 
     def ffn(self, x: torch.Tensor, rows: int, C: int, tb: str, name: str = "ff.fused") -> torch.Tensor:
         """out = x + W2 GEGLU(W1 LayerNorm(x) + b1) + b2 on the RAW rows x (model/attention.py:233) as one launch."""

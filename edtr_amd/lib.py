@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = [
     "edtr_tile_accumulate", "edtr_divide", "edtr_wavelet_level", "edtr_gn_pool", "edtr_copy3d_f32", "edtr_graph_begin", "edtr_graph_end", "edtr_graph_launch",
     "edtr_graph_destroy", "edtr_zero_bytes", "edtr_embed_tokens", "edtr_window_attn", "edtr_pixel_unshuffle", "edtr_swin_mlp", "edtr_swin_attn", "edtr_swin_layer", "edtr_conv64", "edtr_conv128_out",
     "edtr_split_operand", "edtr_sampler_update_indexed", "edtr_gaussian_sample", "edtr_add_mirror", "edtr_igemm_plan", "edtr_flash_attn512",
-    "edtr_ffn", "edtr_ffn_plan", "edtr_add_stats",
+    "edtr_ffn", "edtr_ffn_plan", "edtr_add_stats", "edtr_lin320", "edtr_lin320_plan",
 ]
 
 
@@ -104,6 +104,17 @@ class FfnParams(C.Structure):
         ("x", C.c_void_p), ("ldx", C.c_int32),
         ("w1", C.c_void_p), ("w2", C.c_void_p),
         ("cst", C.c_void_p), ("b2", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
+class Lin320Params(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("ln", C.c_int32), ("eps", C.c_float), ("alpha", C.c_float),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("w", C.c_void_p), ("cvec", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int32),
     ]
 
@@ -226,6 +237,8 @@ def load() -> C.CDLL:
     lib.edtr_add_stats.argtypes = [i32, vp, i32, vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]
     lib.edtr_ffn.argtypes = [C.POINTER(FfnParams), vp]
     lib.edtr_ffn_plan.argtypes = [C.POINTER(FfnParams)]
+    lib.edtr_lin320.argtypes = [C.POINTER(Lin320Params), vp]
+    lib.edtr_lin320_plan.argtypes = [C.POINTER(Lin320Params)]
     if lib.edtr_abi_version() != 10:
         raise RuntimeError("libedtr_hip.so ABI version mismatch")
     _lib = lib

@@ -21,7 +21,7 @@ import torch
 from . import lib as L
 from . import ops
 from .arch import Layer, UNetArch, VaeLayer
-from .engine import Act, Emitter, LNRef
+from .engine import Act, Emitter, LNRef, LNReg
 from .ops import round_up
 
 
@@ -156,7 +156,9 @@ def emit_attention_core(em: Emitter, p: str, x, B: int, N: int, C: int, heads: i
         em.free(qk, vt)
     else:
         k, vt, k_bs, vt_bs, ldv, nctx, k_lo, vt_lo = ctx
-        if fold:
+        if isinstance(x, LNReg):    # norm2 + to_q as ONE launch on the raw rows (edtr_lin320: the rows are normalised in registers)
+            q = em.lin320(x.x, B * N, C, [p + "to_q.weight"], None, ln_prefix=x.prefix, alpha=c, name="attn2.q")
+        elif fold:
             wq, _, c1, c2 = em.store.ln_fold("linear", [p + "to_q.weight"], None, fold)
             q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=True, ln_vec=(c1, c2))
         else:
@@ -164,8 +166,11 @@ def emit_attention_core(em: Emitter, p: str, x, B: int, N: int, C: int, heads: i
             q = em.gemm(x, wq, B * N, C, C, alpha=c, name="attn2.q", out16=em.attn_split < 1)
         o = em.flash(q, k, vt, B=B, H=heads, Nq=N, Nk=nctx, k_bs=k_bs, vt_bs=vt_bs, vt_ld=ldv, prescaled=True, k_lo=k_lo, vt_lo=vt_lo)
         em.free(q)
-    wo, bo = em.store.linear([p + "to_out.0.weight"], [p + "to_out.0.bias"])
-    y = em.gemm(o, wo, B * N, C, C, bias=bo, residual=residual, name="attn.out", row_stats=row_stats)
+    if not row_stats and em.lin320_ok(B * N, C, C) and o.dtype == residual.dtype:
+        y = em.lin320(o, B * N, C, [p + "to_out.0.weight"], [p + "to_out.0.bias"], residual=residual, name="attn.out")
+    else:
+        wo, bo = em.store.linear([p + "to_out.0.weight"], [p + "to_out.0.bias"])
+        y = em.gemm(o, wo, B * N, C, C, bias=bo, residual=residual, name="attn.out", row_stats=row_stats)
     em.free(o)
     return y
 
@@ -181,7 +186,11 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     # per-row statistics, the GEMMs that read them run on the raw rows with gamma folded into the weights (Emitter.layer_norm).
     fold = em.ln_fold_ok(C, B)
     fold1 = fold and em.fused_qkv_ok(N, C)        # (the operand-swapped V^T product would need per-COLUMN scalars)
-    t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in", row_stats=fold1)
+    lin = em.lin320_ok(rows, C, C)           # the K = 320 projections of the block as row-resident launches (edtr_lin320)
+    if lin and not fold1 and os.environ.get("EDTR_LIN320_PROJ_IN", "1") != "0":
+        t = em.lin320(n.t, rows, C, [p + "proj_in.weight"], [p + "proj_in.bias"], name="st.proj_in")
+    else:
+        t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in", row_stats=fold1)
     st = em.last_row_stats
     em.free(n)
     tb = p + "transformer_blocks.0."
@@ -189,7 +198,7 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     t1 = emit_attention_core(em, tb + "attn1.", l1, B, N, C, l.heads, None, t, row_stats=fold)
     st = em.last_row_stats
     em.free(l1, t)
-    l2 = em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",), stats=st)
+    l2 = LNReg(t1, C, tb + "norm2.") if (lin and st is None) else em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",), stats=st)
     off = kv.offs[l.prefix]
     k_view = kv.k_all[:, off:off + C]
     k_lo = kv.k_all[:, kv.sumC + off:kv.sumC + off + C] if kv.split >= 1 else None

@@ -346,6 +346,39 @@ def make_ffn(*, dtype, x, ldx, M, w1, w2, cst, b2, out, ldo, eps=1e-5, name="ff.
     return rec
 
 
+LIN320_K, LIN320_ROWS = 320, 128              # what edtr_lin320 is built for (include/edtr_hip.h)
+
+
+def lin320_ok(M: int, N: int, K: int) -> bool:
+    """Does edtr_lin320 (a K = 320 linear layer as a row-resident product, optionally behind its LayerNorm) take this shape — and is it
+    the faster form?  EDTR_LIN320=0 keeps the edtr_igemm form everywhere (A/B runs); EDTR_LIN320_MIN_ROWS overrides the threshold."""
+    if os.environ.get("EDTR_LIN320", "1") == "0" or K != LIN320_K or M <= 0 or M % LIN320_ROWS or N % 64 or N > 1024:
+        return False
+    return M >= int(os.environ.get("EDTR_LIN320_MIN_ROWS", "16384"))
+
+
+def pack_lin320_w(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[N, 320] fp32 -> 16-bit in edtr_lin320's fragment order (edtr_hip.h: edtr_lin320_params.w): 16 bytes per (chunk of 32 rows, k-step of
+    16, lane) = w[32 c + (lane & 31)][16 s + 8 (lane >> 5) .. + 7]."""
+    n, k = w.shape
+    assert k == LIN320_K and n % 32 == 0
+    w16 = w.to(dtype).reshape(n // 32, 32, k // 16, 2, 8)            # [c][l31][s][lh][8]
+    return w16.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)         # [c][s][lh][l31][8]: lane = 32 lh + l31
+
+
+def make_lin320(*, dtype, x, ldx, M, N, w, cvec=None, alpha=1.0, ln=False, eps=1e-5, residual=None, ldr=0, out, ldo, name="lin320") -> Rec:
+    """out = alpha * (LayerNorm?)(x) w^T + cvec (+ residual) in one launch (edtr_hip.h: edtr_lin320)."""
+    p = L.Lin320Params()
+    p.dtype, p.M, p.N, p.K, p.ln, p.eps, p.alpha = dt_code(dtype), M, N, LIN320_K, int(ln), eps, alpha
+    p.x, p.ldx, p.w, p.cvec = ptr(x), ldx, ptr(w), ptr(cvec)
+    p.residual, p.ldr, p.out, p.ldo = ptr(residual), ldr, ptr(out), ldo
+    flops = 2.0 * M * N * LIN320_K
+    nbytes = 2.0 * M * (LIN320_K + N * (2 if residual is not None else 1)) + 2.0 * N * LIN320_K
+    rec = Rec(L.load().edtr_lin320, (ct.byref(p),), (p, x, w, cvec, residual, out), name, flops, nbytes)
+    rec.tag = f"lin320 M{M} N{N}" + (" ln" if ln else "") + (" res" if residual is not None else "")
+    return rec
+
+
 def make_swin_layer(attn: Rec, mlp: Rec, name="swin.layer") -> Rec:
     """A whole Swin layer in one launch from the two half-layer records (edtr_hip.h: edtr_swin_layer): the attention record's x / out
     are the layer's input / output, the MLP record contributes its weights and constants."""

@@ -457,6 +457,34 @@ typedef struct edtr_ffn_params {
 int edtr_ffn(const edtr_ffn_params* p, edtr_stream_t stream);
 int edtr_ffn_plan(const edtr_ffn_params* p);      /* no HIP call: EDTR_OK or the error edtr_ffn would return */
 
+/* The K = 320 linear layers of the 64 x 64-latent transformer blocks as a row-resident product, optionally with the LayerNorm in front
+ * (ABI 10, lin320.hip):
+ *     out[m][n] = alpha * sum_k xhat[m][k] w[n][k] + cvec[n] (+ residual[m][n]),   xhat = x, or (x - mean_m) rstd_m rounded to 16 bits
+ * replaces: `attn2.to_q(norm2(x))` (model/attention.py:171, 224-232: ln = 1, alpha = the softmax prescale), `to_out[0](o) + x`
+ * (:195), `proj_in` / `proj_out(x) + x_in` (:283-302) — an edtr_layernorm launch + an edtr_igemm launch, or one edtr_igemm launch.
+ * A wave keeps 32 token rows in registers (loaded once, normalised in place), LDS holds only the weight stream.
+ *   x        [M][ldx] 16-bit rows, K = 320 valid columns
+ *   w        the [N][320] weight matrix in FRAGMENT order: 16 bytes per (chunk c of 32 output columns, k-step s of 16, lane l) at
+ *            ((c * 20 + s) * 64 + l) * 16 = w[32 c + (l & 31)][16 s + 8 (l >> 5) .. + 7] (ops.pack_lin320_w); with ln != 0 the caller
+ *            has folded the LayerNorm's gamma into the columns and put alpha * (W beta) (+ bias) into cvec
+ *   cvec     fp32 [N] or NULL; residual: 16-bit [M][ldr] or NULL; out: 16-bit [M][ldo], != x
+ * Needs K == 320, M % 128 == 0, N % 64 == 0, N <= 1024; anything else is EDTR_E_UNSUPPORTED (edtr_lin320_plan answers without a
+ * launch) and the caller issues the edtr_igemm form. */
+typedef struct edtr_lin320_params {
+    int32_t dtype;
+    int32_t M, N, K;
+    int32_t ln; float eps;
+    float alpha;
+    const void* x; int32_t ldx;
+    const void* w;
+    const float* cvec;
+    const void* residual; int32_t ldr;
+    void* out; int32_t ldo;
+} edtr_lin320_params;
+
+int edtr_lin320(const edtr_lin320_params* p, edtr_stream_t stream);
+int edtr_lin320_plan(const edtr_lin320_params* p);      /* no HIP call: EDTR_OK or the error edtr_lin320 would return */
+
 /* 3 x 3 / stride 1 / pad 1 convolution of a 64-channel NHWC image into <= 64 channels, persistent workgroups with the nine tap
  * matrices resident in LDS (ABI 8) — SwinIR's reconstruction tail at the pixel levels, where edtr_igemm's 128-column tiles are
  * half padding.  replaces: conv_up1 / conv_up2 / conv_up3 (behind `F.interpolate(scale_factor=2, mode="nearest")`), conv_hr and

@@ -1942,6 +1942,95 @@ def test_ffn_rejects_what_it_cannot_run():
     assert not ops.ffn_ok(192, 320, 1280) and not ops.ffn_ok(8192, 640, 2560) and ops.ffn_ok(16384, 320, 1280)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# edtr_lin320 (lin320.hip, round 6): the K = 320 linear layers of the 64 x 64-latent transformer blocks as a row-resident product — a wave
+# keeps 32 token rows in registers (normalised in place where a LayerNorm is asked for), the weights stream through LDS in fragment
+# order, the 64-column groups leave row-major through a wave-private fp32 tile.  Reference: model/attention.py:171, 195, 224-232, 283-302.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,ln,res,pad", [(128, 320, False, False, 0), (384, 320, True, False, 0), (256, 320, False, True, 64), (128, 960, True, False, 0),
+                                            (640, 64, True, True, 8), (128, 1024, False, True, 0)])
+def test_lin320_vs_fp32_reference(dtype, M, N, ln, res, pad):
+    ops = _ops()
+    d = dev()
+    K = ops.LIN320_K
+    x = torch.full((M, K + pad), float("nan"), dtype=dtype)
+    x[:, :K] = (rnd((M, K), 801, 1.4) + 0.3).to(dtype)
+    w = rnd((N, K), 802, 1 / math.sqrt(K))
+    gamma, beta = 1 + 0.2 * rnd((K,), 803), 0.2 * rnd((K,), 804)
+    bias = rnd((N,), 805)
+    alpha = 0.31
+    r = rnd((M, N), 806).to(dtype) if res else None
+    if ln:        # gamma into the columns, alpha * W beta (+ bias) into the additive row: what the engine's weight store hands the kernel
+        wp = ops.pack_lin320_w(w * gamma[None, :], dtype)
+        cvec = alpha * (w @ beta) + bias
+    else:
+        wp = ops.pack_lin320_w(w, dtype)
+        cvec = bias
+    out = torch.full((M, N + pad), float("nan"), dtype=dtype, device=d)
+    xd = x.to(d)
+    ops.launch(ops.make_lin320(dtype=dtype, x=xd[:, :K], ldx=K + pad, M=M, N=N, w=wp.to(d), cvec=cvec.to(d), alpha=alpha, ln=ln, eps=1e-5,
+                               residual=None if r is None else r.to(d), ldr=N, out=out[:, :N], ldo=N + pad))
+    torch.cuda.synchronize()
+    xf = x[:, :K].float()
+    if ln:
+        xn = F.layer_norm(xf, (K,), None, None, 1e-5)
+        # the kernel rounds the normalised rows to 16 bits (what the LayerNorm launch hands its GEMM) and multiplies 16-bit weights
+        ref = alpha * (xn @ (w * gamma[None, :]).T) + cvec
+    else:
+        ref = alpha * (xf @ w.T) + cvec
+    if res:
+        ref = ref + r.float()
+    got = out[:, :N].float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel(got, ref) < TOL[dtype]
+    if pad:
+        assert bool(torch.isnan(out[:, N:].float()).all())      # pad columns untouched
+
+
+def test_lin320_matches_the_layernorm_plus_igemm_form():
+    """Against the product path it replaces on the same operands (edtr_layernorm -> edtr_igemm with alpha / bias / residual): both round
+    the normalised rows to 16 bits and accumulate in fp32; only the summation order differs."""
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    M, N, K = 2048, 320, ops.LIN320_K
+    x = (rnd((M, K), 811, 1.4) + 0.3).to(dtype).to(d)
+    w = rnd((N, K), 812, 1 / math.sqrt(K))
+    gamma, beta = (1 + 0.2 * rnd((K,), 813)).to(d), (0.2 * rnd((K,), 814)).to(d)
+    r = rnd((M, N), 815).to(dtype).to(d)
+    alpha = 0.5
+    xn = torch.empty_like(x)
+    ops.launch(ops.make_layernorm(dtype=dtype, x=x, rows=M, C=K, ldx=K, gamma=gamma, beta=beta, eps=1e-5, y=xn, ldy=K))
+    two = torch.empty((M, N), dtype=dtype, device=d)
+    ops.launch(ops.make_igemm(dtype=dtype, a1=xn, w=ops.pack_linear_weight(w, dtype).to(d), out=two, M=M, N=N, C1=K, ld1=K, ldw=K, ldc=N, alpha=alpha,
+                              residual=r, ldr=N))
+    one = torch.empty((M, N), dtype=dtype, device=d)
+    cvec = (alpha * (w @ beta.cpu())).to(d)
+    ops.launch(ops.make_lin320(dtype=dtype, x=x, ldx=K, M=M, N=N, w=ops.pack_lin320_w(w * gamma.cpu()[None, :], dtype).to(d), cvec=cvec, alpha=alpha, ln=True,
+                               eps=1e-5, residual=r, ldr=N, out=one, ldo=N))
+    torch.cuda.synchronize()
+    ref = alpha * (F.layer_norm(x.float().cpu(), (K,), gamma.cpu(), beta.cpu(), 1e-5) @ w.T) + r.float().cpu()
+    e1, e2 = rel(one.float().cpu(), ref), rel(two.float().cpu(), ref)
+    assert e1 < TOL[dtype] and e1 < 1.3 * e2 + 1e-4, (e1, e2)
+
+
+def test_lin320_rejects_what_it_cannot_run():
+    ops = _ops()
+    d = dev()
+    dtype = torch.bfloat16
+    x = torch.zeros((256, 320), dtype=dtype, device=d)
+    w = torch.zeros((320 * 320,), dtype=dtype, device=d)
+    out = torch.zeros((256, 320), dtype=dtype, device=d)
+    with pytest.raises(RuntimeError):                        # 192 rows: not whole 128-row workgroups
+        ops.launch(ops.make_lin320(dtype=dtype, x=x, ldx=320, M=192, N=320, w=w, out=out, ldo=320))
+    with pytest.raises(RuntimeError):                        # N = 96: not whole 64-column groups
+        ops.launch(ops.make_lin320(dtype=dtype, x=x, ldx=320, M=256, N=96, w=w, out=out, ldo=320))
+    with pytest.raises(RuntimeError):                        # in place
+        ops.launch(ops.make_lin320(dtype=dtype, x=x, ldx=320, M=256, N=320, w=w, out=x, ldo=320))
+    assert not ops.lin320_ok(32768, 320, 640) and not ops.lin320_ok(192, 320, 320) and ops.lin320_ok(32768, 320, 320) and ops.lin320_ok(32768, 960, 320)
+
+
 def test_zz_measured_error_envelope():
     """Bookkeeping (runs last in this file): the largest error each dtype's kernels measured against their torch references —
     TOL above is held to <= 1.5 x these."""
