@@ -27,9 +27,12 @@ constexpr int LBM = 128;                       // tokens per workgroup (4 waves 
 constexpr int LCH = 32;                        // output columns per chunk
 constexpr int LCHB = LCH * LK * 2;             // 20 KiB: one chunk of W as 20 fragments
 constexpr int LPITCH = 272;                    // bytes per token row of the fp32 staging tile (64 columns + 16 bytes)
-constexpr int L_STG = 2 * LCHB;                // staging tiles: 4 waves x 32 rows x LPITCH
-constexpr int L_CV = L_STG + 4 * 32 * LPITCH;  // the additive row (fp32, N <= 1024)
-constexpr int L_LDS = L_CV + 4096;
+constexpr int LVPITCH = 144;                   // ... and per CHANNEL row (32 tokens + 16 bytes) where a group is stored transposed (V^T)
+constexpr int LSTGB = 64 * LVPITCH;            // 9 KiB per wave (>= 32 x LPITCH)
+constexpr int L_STG = 2 * LCHB;                // staging tiles: 4 waves x LSTGB
+constexpr int L_CV = L_STG + 4 * LSTGB;        // the additive row (fp32, N <= 1024)
+constexpr int L_LDS = L_CV + 4096;             // 80 KiB: two workgroups per CU
+static_assert(LSTGB >= 32 * LPITCH && 2 * L_LDS <= 160 * 1024, "LDS budget");
 
 template <int N> __device__ __forceinline__ void lwait() {
     static_assert(N == 0 || N == 4 || N == 5 || N == 9, "lwait");
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) lin320_kernel(const edtr_lin320_params
         }
     }
 
-    char* const stg = smem + L_STG + wave * (32 * LPITCH);     // this wave's staging tile: [32 tokens][64 columns] fp32
+    char* const stg = smem + L_STG + wave * LSTGB;             // this wave's staging tile: [32 tokens][64 columns] fp32 (or [64 channels][32 tokens])
     const float alpha = p.alpha;
     // epilogue geometry: lane -> rows (lane >> 3) + 8 i, columns 8 (lane & 7) .. + 7 of the group
     const int erow = lane >> 3, ecol = 8 * (lane & 7);
@@ -114,6 +117,7 @@ __global__ void __launch_bounds__(256, 2) lin320_kernel(const edtr_lin320_params
 #pragma unroll 1
     for (int g = 0; g < (nchunk >> 1); ++g) {
         U4 rv[4];
+        const bool tgroup = p.vt_out != nullptr && 64 * g >= p.vt_col0;      // (wave-uniform; RES launches have no transposed part)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int c = 2 * g + hh;
@@ -140,13 +144,41 @@ __global__ void __launch_bounds__(256, 2) lin320_kernel(const edtr_lin320_params
                 a1 = T::mfma(w1, xf[s + 1], a1);
             }
             // D[col][token]: register 4 j + e = column 8 j + 4 lh + e of the chunk, token l31 -> four consecutive fp32 of the token's row
+            // (a transposed group: one fp32 per register into the column's own row of 32 tokens)
+            if (!tgroup) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 v;
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = a0[4 * j + e] + a1[4 * j + e];
-                *reinterpret_cast<f32x4*>(stg + l31 * LPITCH + (32 * hh + 8 * j + 4 * lh) * 4) = v;
+                    for (int e = 0; e < 4; ++e) v[e] = a0[4 * j + e] + a1[4 * j + e];
+                    *reinterpret_cast<f32x4*>(stg + l31 * LPITCH + (32 * hh + 8 * j + 4 * lh) * 4) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *reinterpret_cast<float*>(stg + (32 * hh + 8 * j + 4 * lh + e) * LVPITCH + l31 * 4) = a0[4 * j + e] + a1[4 * j + e];
             }
+        }
+        if (tgroup) {
+            // ---- a group of V: channel rows of this wave's 32 tokens -> vt_out[(image) * (N - vt_col0) + channel][token], 16 bytes
+            // (8 tokens) per lane, four lanes per channel row (edtr_igemm's vt_out layout: what edtr_flash_attn64 reads)
+            const int img = m0 / p.rows_per_image, tok0 = m0 - img * p.rows_per_image;
+            uint16_t* const vb = static_cast<uint16_t*>(p.vt_out) + ((int64_t)img * (p.N - p.vt_col0) + (64 * g - p.vt_col0)) * p.vt_ld + tok0;
+            const float va = p.vt_alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = (lane >> 2) + 16 * i, oct = lane & 3;
+                const char* sp = stg + ch * LVPITCH + oct * 32;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 16);
+                const float cc = reinterpret_cast<const float*>(smem + L_CV)[64 * g + ch];
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f[e] = __builtin_fmaf(v0[e], va, cc); f[e + 4] = __builtin_fmaf(v1[e], va, cc); }
+                stg16(vb + (int64_t)ch * p.vt_ld + 8 * oct, pack8<T>(f));
+            }
+            continue;
         }
         // ---- the group's 64 columns, row-major: alpha, additive row, residual, one rounding, whole-line stores
         const float* cv = reinterpret_cast<const float*>(smem + L_CV) + 64 * g + ecol;
@@ -193,10 +225,19 @@ int check_lin320(const edtr_lin320_params& p) {
     if (p.dtype != EDTR_BF16 && p.dtype != EDTR_F16) return EDTR_E_DTYPE;
     if (p.K != LK || p.M <= 0 || p.N <= 0) return EDTR_E_SHAPE;
     if ((p.M % LBM) || (p.N % 64) || p.N > 1024) return EDTR_E_UNSUPPORTED;
-    if (p.ldx < LK || p.ldo < p.N || (p.residual && p.ldr < p.N)) return EDTR_E_SHAPE;
+    if (p.ldx < LK || (p.residual && p.ldr < p.N)) return EDTR_E_SHAPE;
     if ((p.ldx & 7) || (p.ldo & 7) || (p.residual && (p.ldr & 7))) return EDTR_E_ALIGN;
     if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.out) || (p.residual && !aligned16(p.residual)) || (p.cvec && !aligned16(p.cvec))) return EDTR_E_ALIGN;
     if (p.x == p.out) return EDTR_E_UNSUPPORTED;               // (another workgroup may still read the rows this one writes)
+    if (p.vt_out) {      // the columns from vt_col0 on leave transposed: whole 64-column groups, a wave's 32 rows inside one image
+        if (p.residual || p.vt_col0 <= 0 || p.vt_col0 >= p.N || (p.vt_col0 & 63) || p.rows_per_image <= 0 || (p.rows_per_image & 31) ||
+            (p.M % p.rows_per_image) || p.vt_ld < p.rows_per_image)
+            return EDTR_E_UNSUPPORTED;
+        if ((p.vt_ld & 7) || !aligned16(p.vt_out)) return EDTR_E_ALIGN;
+        if (p.ldo < p.vt_col0) return EDTR_E_SHAPE;
+    } else if (p.ldo < p.N) {
+        return EDTR_E_SHAPE;
+    }
     if ((int64_t)p.N * LK * 2 >= 0xF0000000LL) return EDTR_E_UNSUPPORTED;
     return EDTR_OK;
 }

@@ -308,11 +308,12 @@ class WeightStore:
             self.cache[key] = (w1p, w2p, cst, self._p(b2name).reshape(-1).contiguous())
         return self.cache[key]
 
-    def lin320(self, names: Sequence[str], biases, ln_prefix: Optional[str], alpha: float):
+    def lin320(self, names: Sequence[str], biases, ln_prefix: Optional[str], alpha: float, vt_col0: Optional[int] = None, vt_alpha: float = 1.0):
         """Operands of edtr_lin320 (include/edtr_hip.h) for one K = 320 projection: (the matrix in fragment order — with the LayerNorm's
-        gamma folded into its columns when ``ln_prefix`` is given — and the additive row bias + alpha W beta, or None).  Fast modes only."""
+        gamma folded into its columns when ``ln_prefix`` is given — and the additive row bias + alpha W beta, or None; the rows from
+        ``vt_col0`` on carry ``vt_alpha`` instead of ``alpha``: the V part of a fused [Wq; Wk; Wv]).  Fast modes only."""
         names = tuple(names)
-        key = ("lin320", names, tuple(biases) if biases else None, ln_prefix, float(alpha))
+        key = ("lin320", names, tuple(biases) if biases else None, ln_prefix, float(alpha), vt_col0, float(vt_alpha))
         if key not in self.cache:
             w = torch.cat([self._p(n).reshape(self.params[n].shape[0], -1) for n in names], dim=0)
             cvec = None
@@ -322,6 +323,8 @@ class WeightStore:
             if ln_prefix is not None:
                 gamma, beta = self._p(ln_prefix + "weight").reshape(-1), self._p(ln_prefix + "bias").reshape(-1)
                 shift = float(alpha) * (w @ beta)
+                if vt_col0 is not None:
+                    shift[vt_col0:] *= float(vt_alpha) / float(alpha)
                 cvec = shift if cvec is None else cvec + shift
                 w = w * gamma[None, :]
             self.cache[key] = (ops.pack_lin320_w(w, self.dtype), cvec.contiguous() if cvec is not None else None)
@@ -772,9 +775,9 @@ class Emitter:
         """May x + ff(norm3(x)) of a transformer block run as ONE edtr_ffn launch?  (fast modes; the shapes edtr_ffn is built for)"""
         return not self.hp and not self.invariant and ops.ffn_ok(rows, C, 4 * C)
 
-    def lin320_ok(self, rows: int, N: int, K: int) -> bool:
+    def lin320_ok(self, rows: int, N: int, K: int, ln: bool = False) -> bool:
         """May a K = 320 projection (optionally behind its LayerNorm) run as ONE edtr_lin320 launch?  (fast modes; the shapes it is built for)"""
-        return not self.hp and not self.invariant and ops.lin320_ok(rows, N, K)
+        return not self.hp and not self.invariant and ops.lin320_ok(rows, N, K, ln)
 
     def lin320(self, x: torch.Tensor, rows: int, N: int, names, biases=None, *, ln_prefix: Optional[str] = None, alpha: float = 1.0,
                residual: Optional[torch.Tensor] = None, name: str = "lin320") -> torch.Tensor:
@@ -787,6 +790,17 @@ class Emitter:
                                       eps=1e-5, residual=residual, ldr=residual.stride(0) if residual is not None else 0, out=out,
                                       ldo=out.stride(0), name=name))
         return out
+
+    def qkv_lin320(self, x: torch.Tensor, names, *, B: int, N: int, C: int, ln_prefix: str, alpha: float, name: str = "attn1.qkv"):
+        """qkv_gemm on the RAW rows with norm1 applied in the launch's registers (edtr_lin320 with its transposed V part): (qk [B*N, 2C]
+        row-major with ``alpha`` applied, v^T [B*C, N], its row stride)."""
+        M = B * N
+        w, cvec = self.store.lin320(names, None, ln_prefix, alpha, vt_col0=2 * C, vt_alpha=1.0)
+        qk = self.arena.alloc((M, 2 * C), self.attn_dtype)
+        vt = self.arena.alloc((B * C, N), self.attn_dtype)
+        self.prog.add(ops.make_lin320(dtype=self.dtype, x=x, ldx=x.stride(0), M=M, N=3 * C, w=w, cvec=cvec, alpha=alpha, ln=True, eps=1e-5, out=qk,
+                                      ldo=2 * C, vt_out=vt, vt_col0=2 * C, vt_ld=N, vt_alpha=1.0, rows_per_image=N, name=name))
+        return qk, vt, N
 
     def ffn(self, x: torch.Tensor, rows: int, C: int, tb: str, name: str = "ff.fused") -> torch.Tensor:
         """out = x + W2 GEGLU(W1 LayerNorm(x) + b1) + b2 on the RAW rows x (model/attention.py:233) as one launch."""

@@ -137,7 +137,9 @@ def emit_attention_core(em: Emitter, p: str, x, B: int, N: int, C: int, heads: i
     if ctx is None and em.fused_qkv_ok(N, C):
         # self attention: ONE launch for [Wq; Wk; Wv] — q / k row-major (scaled), v^T written transposed by the epilogue
         names = [p + "to_q.weight", p + "to_k.weight", p + "to_v.weight"]
-        if fold:
+        if isinstance(x, LNReg):    # norm1 + [Wq; Wk; Wv] as ONE launch on the raw rows (edtr_lin320, transposed V part)
+            qk, vt, ldv = em.qkv_lin320(x.x, names, B=B, N=N, C=C, ln_prefix=x.prefix, alpha=math.sqrt(c))
+        elif fold:
             wqkv, _, c1, c2 = em.store.ln_fold("linear", names, None, fold)
             qk, vt, ldv = em.qkv_gemm(x, wqkv, B=B, N=N, C=C, alpha=math.sqrt(c), ln_vec=(c1, c2))
         else:
@@ -187,18 +189,23 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     fold = em.ln_fold_ok(C, B)
     fold1 = fold and em.fused_qkv_ok(N, C)        # (the operand-swapped V^T product would need per-COLUMN scalars)
     lin = em.lin320_ok(rows, C, C)           # the K = 320 projections of the block as row-resident launches (edtr_lin320)
-    if lin and not fold1 and os.environ.get("EDTR_LIN320_PROJ_IN", "1") != "0":
+    if lin and not fold1:
         t = em.lin320(n.t, rows, C, [p + "proj_in.weight"], [p + "proj_in.bias"], name="st.proj_in")
     else:
         t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in", row_stats=fold1)
     st = em.last_row_stats
     em.free(n)
     tb = p + "transformer_blocks.0."
-    l1 = em.layer_norm(t, rows, C, tb + "norm1.", feeds=("attn1.qkv",) if em.fused_qkv_ok(N, C) else ("attn1.qk", "attn1.vT"), stats=st)
+    if (st is None and em.fused_qkv_ok(N, C) and em.lin320_ok(rows, 3 * C, C, ln=True) and N % 32 == 0 and em.attn_dtype == em.dtype
+            and os.environ.get("EDTR_LIN320_QKV", "1") != "0"):
+        l1 = LNReg(t, C, tb + "norm1.")
+    else:
+        l1 = em.layer_norm(t, rows, C, tb + "norm1.", feeds=("attn1.qkv",) if em.fused_qkv_ok(N, C) else ("attn1.qk", "attn1.vT"), stats=st)
     t1 = emit_attention_core(em, tb + "attn1.", l1, B, N, C, l.heads, None, t, row_stats=fold)
     st = em.last_row_stats
     em.free(l1, t)
-    l2 = LNReg(t1, C, tb + "norm2.") if (lin and st is None) else em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",), stats=st)
+    l2 = (LNReg(t1, C, tb + "norm2.") if (st is None and em.lin320_ok(rows, C, C, ln=True))
+          else em.layer_norm(t1, rows, C, tb + "norm2.", feeds=("attn2.q",), stats=st))
     off = kv.offs[l.prefix]
     k_view = kv.k_all[:, off:off + C]
     k_lo = kv.k_all[:, kv.sumC + off:kv.sumC + off + C] if kv.split >= 1 else None

@@ -349,12 +349,16 @@ def make_ffn(*, dtype, x, ldx, M, w1, w2, cst, b2, out, ldo, eps=1e-5, name="ff.
 LIN320_K, LIN320_ROWS = 320, 128              # what edtr_lin320 is built for (include/edtr_hip.h)
 
 
-def lin320_ok(M: int, N: int, K: int) -> bool:
+def lin320_ok(M: int, N: int, K: int, ln: bool = False) -> bool:
     """Does edtr_lin320 (a K = 320 linear layer as a row-resident product, optionally behind its LayerNorm) take this shape — and is it
-    the faster form?  EDTR_LIN320=0 keeps the edtr_igemm form everywhere (A/B runs); EDTR_LIN320_MIN_ROWS overrides the threshold."""
+    the faster form?  Measured against the launches it replaces (profiles/r06/lin320_time.log): with a LayerNorm in front and N = 320 it
+    wins from half a chip of 128-row workgroups (16384 rows: 15 against 20 us), everything else from a full one (32768 rows; at 16384 the
+    plain forms and the N = 960 projection are 4 - 17 % slower than edtr_igemm's tiles).  EDTR_LIN320=0 keeps the edtr_igemm form
+    everywhere (A/B runs); EDTR_LIN320_MIN_ROWS overrides the thresholds."""
     if os.environ.get("EDTR_LIN320", "1") == "0" or K != LIN320_K or M <= 0 or M % LIN320_ROWS or N % 64 or N > 1024:
         return False
-    return M >= int(os.environ.get("EDTR_LIN320_MIN_ROWS", "16384"))
+    env = os.environ.get("EDTR_LIN320_MIN_ROWS")
+    return M >= (int(env) if env else (16384 if (ln and N <= 320) else 32768))
 
 
 def pack_lin320_w(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -366,16 +370,19 @@ def pack_lin320_w(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return w16.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)         # [c][s][lh][l31][8]: lane = 32 lh + l31
 
 
-def make_lin320(*, dtype, x, ldx, M, N, w, cvec=None, alpha=1.0, ln=False, eps=1e-5, residual=None, ldr=0, out, ldo, name="lin320") -> Rec:
-    """out = alpha * (LayerNorm?)(x) w^T + cvec (+ residual) in one launch (edtr_hip.h: edtr_lin320)."""
+def make_lin320(*, dtype, x, ldx, M, N, w, cvec=None, alpha=1.0, ln=False, eps=1e-5, residual=None, ldr=0, out, ldo, vt_out=None, vt_col0=0,
+                vt_ld=0, vt_alpha=1.0, rows_per_image=0, name="lin320") -> Rec:
+    """out = alpha * (LayerNorm?)(x) w^T + cvec (+ residual) in one launch; the columns from ``vt_col0`` on transposed into ``vt_out`` (the V^T
+    operand of a fused [Wq; Wk; Wv] projection) where given (edtr_hip.h: edtr_lin320)."""
     p = L.Lin320Params()
     p.dtype, p.M, p.N, p.K, p.ln, p.eps, p.alpha = dt_code(dtype), M, N, LIN320_K, int(ln), eps, alpha
     p.x, p.ldx, p.w, p.cvec = ptr(x), ldx, ptr(w), ptr(cvec)
     p.residual, p.ldr, p.out, p.ldo = ptr(residual), ldr, ptr(out), ldo
+    p.vt_out, p.vt_col0, p.vt_ld, p.vt_alpha, p.rows_per_image = ptr(vt_out), vt_col0, vt_ld, vt_alpha, rows_per_image
     flops = 2.0 * M * N * LIN320_K
     nbytes = 2.0 * M * (LIN320_K + N * (2 if residual is not None else 1)) + 2.0 * N * LIN320_K
-    rec = Rec(L.load().edtr_lin320, (ct.byref(p),), (p, x, w, cvec, residual, out), name, flops, nbytes)
-    rec.tag = f"lin320 M{M} N{N}" + (" ln" if ln else "") + (" res" if residual is not None else "")
+    rec = Rec(L.load().edtr_lin320, (ct.byref(p),), (p, x, w, cvec, residual, out, vt_out), name, flops, nbytes)
+    rec.tag = f"lin320 M{M} N{N}" + (" ln" if ln else "") + (" res" if residual is not None else "") + (" vT" if vt_out is not None else "")
     return rec
 
 

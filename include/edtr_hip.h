@@ -468,6 +468,10 @@ int edtr_ffn_plan(const edtr_ffn_params* p);      /* no HIP call: EDTR_OK or the
  *            ((c * 20 + s) * 64 + l) * 16 = w[32 c + (l & 31)][16 s + 8 (l >> 5) .. + 7] (ops.pack_lin320_w); with ln != 0 the caller
  *            has folded the LayerNorm's gamma into the columns and put alpha * (W beta) (+ bias) into cvec
  *   cvec     fp32 [N] or NULL; residual: 16-bit [M][ldr] or NULL; out: 16-bit [M][ldo], != x
+ *   vt_out   optional (the fused [Wq; Wk; Wv] projection of a self-attention, model/attention.py:170-178): the columns n >= vt_col0 are
+ *            not stored at out[m][n] but TRANSPOSED and scaled by vt_alpha instead of alpha, exactly as edtr_igemm's vt_out:
+ *            vt_out[(m / rows_per_image) * (N - vt_col0) + (n - vt_col0)][m % rows_per_image], row stride vt_ld, 16-bit (cvec applies to
+ *            all columns).  Needs vt_col0 % 64 == 0, rows_per_image % 32 == 0, M % rows_per_image == 0, no residual; ldo >= vt_col0.
  * Needs K == 320, M % 128 == 0, N % 64 == 0, N <= 1024; anything else is EDTR_E_UNSUPPORTED (edtr_lin320_plan answers without a
  * launch) and the caller issues the edtr_igemm form. */
 typedef struct edtr_lin320_params {
@@ -480,6 +484,7 @@ typedef struct edtr_lin320_params {
     const float* cvec;
     const void* residual; int32_t ldr;
     void* out; int32_t ldo;
+    void* vt_out; int32_t vt_col0; int32_t vt_ld; float vt_alpha; int32_t rows_per_image;
 } edtr_lin320_params;
 
 int edtr_lin320(const edtr_lin320_params* p, edtr_stream_t stream);

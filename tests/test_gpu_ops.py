@@ -1988,6 +1988,32 @@ def test_lin320_vs_fp32_reference(dtype, M, N, ln, res, pad):
         assert bool(torch.isnan(out[:, N:].float()).all())      # pad columns untouched
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lin320_fused_qkv_with_transposed_v(dtype):
+    """The [Wq; Wk; Wv] projection behind norm1: q / k row-major with alpha, v^T transposed per image with vt_alpha (edtr_igemm's vt_out layout)."""
+    ops = _ops()
+    d = dev()
+    K, C, B, Ntok = ops.LIN320_K, 320, 3, 128
+    M, N = B * Ntok, 3 * C
+    x = (rnd((M, K), 821, 1.4) + 0.3).to(dtype)
+    w = rnd((N, K), 822, 1 / math.sqrt(K))
+    gamma, beta = 1 + 0.2 * rnd((K,), 823), 0.2 * rnd((K,), 824)
+    alpha = 0.6
+    acol = torch.full((N,), alpha)
+    acol[2 * C:] = 1.0
+    cvec = acol * (w @ beta)
+    qk = torch.full((M, 2 * C), float("nan"), dtype=dtype, device=d)
+    vt = torch.full((B * C, Ntok + 8), float("nan"), dtype=dtype, device=d)
+    ops.launch(ops.make_lin320(dtype=dtype, x=x.to(d), ldx=K, M=M, N=N, w=ops.pack_lin320_w(w * gamma[None, :], dtype).to(d), cvec=cvec.to(d), alpha=alpha,
+                               ln=True, eps=1e-5, out=qk, ldo=2 * C, vt_out=vt, vt_col0=2 * C, vt_ld=Ntok + 8, vt_alpha=1.0, rows_per_image=Ntok))
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.T            # [M, 3C]
+    assert rel(qk.float().cpu(), alpha * ref[:, :2 * C]) < TOL[dtype]
+    vref = ref[:, 2 * C:].reshape(B, Ntok, C).permute(0, 2, 1).reshape(B * C, Ntok)
+    assert rel(vt[:, :Ntok].float().cpu(), vref) < TOL[dtype]
+    assert bool(torch.isnan(vt[:, Ntok:].float()).all())                     # pad columns untouched
+
+
 def test_lin320_matches_the_layernorm_plus_igemm_form():
     """Against the product path it replaces on the same operands (edtr_layernorm -> edtr_igemm with alpha / bias / residual): both round
     the normalised rows to 16 bits and accumulate in fp32; only the summation order differs."""
@@ -2029,6 +2055,7 @@ def test_lin320_rejects_what_it_cannot_run():
     with pytest.raises(RuntimeError):                        # in place
         ops.launch(ops.make_lin320(dtype=dtype, x=x, ldx=320, M=256, N=320, w=w, out=x, ldo=320))
     assert not ops.lin320_ok(32768, 320, 640) and not ops.lin320_ok(192, 320, 320) and ops.lin320_ok(32768, 320, 320) and ops.lin320_ok(32768, 960, 320)
+    assert ops.lin320_ok(16384, 320, 320, ln=True) and not ops.lin320_ok(16384, 320, 320) and not ops.lin320_ok(16384, 960, 320, ln=True)
 
 
 def test_zz_measured_error_envelope():
