@@ -695,7 +695,7 @@ def roofline_pass(cldm, args, ms_per_step=None) -> dict:
             pass
         except ValueError as e:
             traffic_src = str(e)
-        out["roofline"] = {"kernel": "edtr_igemm family (implicit-GEMM conv / linear, MFMA 32x32x16 and 16x16x32 tiles; incl. the fused feed-forward launch edtr_ffn)", "bound": "mfma",
+        out["roofline"] = {"kernel": "edtr_igemm family (implicit-GEMM conv / linear, MFMA 32x32x16 and 16x16x32 tiles; incl. the fused feed-forward launch edtr_ffn and the row-resident K = 320 projections edtr_lin320)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_TFLOPS, 4),
                            "achieved_executed": round(ach_x, 2), "frac_executed": round(ach_x / PEAK_TFLOPS, 4),

@@ -10,8 +10,8 @@ for f in files:
     kn,cn,cv,gs=h.index("Kernel_Name"),h.index("Counter_Name"),h.index("Counter_Value"),h.index("Grid_Size")
     for r in rd:
         n=r[kn]
-        if "igemm" not in n and "splitk" not in n and "ffn320" not in n: continue
-        short=n.replace("void (anonymous namespace)::","").replace("(edtr_igemm_params)","").replace("(edtr_ffn_params)","").replace("(anonymous namespace)::","")[:60]
+        if "igemm" not in n and "splitk" not in n and "ffn320" not in n and "lin320" not in n: continue
+        short=n.replace("void (anonymous namespace)::","").replace("(edtr_igemm_params)","").replace("(edtr_ffn_params)","").replace("(edtr_lin320_params)","").replace("(anonymous namespace)::","")[:60]
         key=(short,r[gs])
         agg[key][0]+=1; agg[key][1]+=float(r[cv])
 rows=sorted(agg.items(),key=lambda kv:-kv[1][1])

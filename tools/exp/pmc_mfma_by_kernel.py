@@ -18,9 +18,9 @@ for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
     seen = set()
     for r in rd:
         n = r[kn]
-        if not any(k in n for k in ("igemm", "flash_attn", "conv128", "conv64", "swin", "ffn320")):
+        if not any(k in n for k in ("igemm", "flash_attn", "conv128", "conv64", "swin", "ffn320", "lin320")):
             continue
-        short = n.replace("void (anonymous namespace)::", "").replace("(edtr_igemm_params)", "").replace("(edtr_attn_params)", "").replace("(edtr_ffn_params)", "").replace("(anonymous namespace)::", "")[:56]
+        short = n.replace("void (anonymous namespace)::", "").replace("(edtr_igemm_params)", "").replace("(edtr_attn_params)", "").replace("(edtr_ffn_params)", "").replace("(edtr_lin320_params)", "").replace("(anonymous namespace)::", "")[:56]
         key = (short, r[gs] if "halo" in n else "")
         agg[key][r[cn]] += float(r[cv])
         if (r[di], key) not in seen:

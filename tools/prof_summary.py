@@ -29,7 +29,7 @@ def family(name: str) -> str:
         if "split" in n:
             return "flash_attn_split"
         return "flash_attn_v3" if "v3" in n else ("flash_attn_v2" if "v2" in n else "flash_attn_v1")
-    if "igemm" in n or "splitk_reduce" in n or "ffn320" in n:      # (edtr_ffn: two linears of the same family in one launch)
+    if "igemm" in n or "splitk_reduce" in n or "ffn320" in n or "lin320" in n:      # (edtr_ffn / edtr_lin320: linears of the same family)
         return "igemm"
     for k in ("gn_apply", "gn_stats", "gn_finalize", "layernorm", "softmax_rows", "window_attn"):
         if k in n:
