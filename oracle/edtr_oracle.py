@@ -211,6 +211,15 @@ def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return F.linear(h, sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"]) + x
 
 
+def norm_linear(sd: SD, ln: Optional[str], w: str, b: Optional[str], x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Linear(LayerNorm(x)) (+ residual): the pairs `to_q(norm2(x))` (model/attention.py:171 behind :231), `to_out[0](o) + x` (:195 behind
+    :230-231), `proj_in` / `proj_out` (:283-302) taken on their own — what one edtr_lin320 launch computes."""
+    if ln is not None:
+        x = F.layer_norm(x, (x.shape[-1],), sd[ln + "weight"], sd[ln + "bias"], 1e-5)
+    y = F.linear(x, sd[w], sd[b] if b else None)
+    return y if residual is None else y + residual
+
+
 def spatial_transformer(sd: SD, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int) -> torch.Tensor:
     """GN(1e-6) -> tokens -> proj_in -> block -> proj_out -> image, + input.
     model/attention.py:283-302 (use_linear=True, depth 1)."""

@@ -62,6 +62,7 @@ def smoke(verbose: bool = True) -> dict:
         if mode != "fast" and not (e_img < 0.8e-3 and e_z < 0.8e-3):
             raise AssertionError(f"smoke: {tag} is within its own tolerance but closer than 20 % to the 1e-3 north star: latent {e_z:.3e}, image {e_img:.3e}")
     out["edtr_ffn"] = smoke_ffn(dev, verbose)
+    out["edtr_lin320"] = smoke_lin320(dev, verbose)
     return out
 
 
@@ -95,6 +96,46 @@ def smoke_ffn(dev, verbose: bool = True):
             print(f"smoke[edtr_ffn {dtype}]: rel err {e:.2e} (tolerance {tol:.2e})")
         if not e < tol:
             raise AssertionError(f"smoke: edtr_ffn {dtype} is {e:.3e} from the oracle (tolerance {tol:.1e})")
+    return res
+
+
+def smoke_lin320(dev, verbose: bool = True):
+    """The row-resident K = 320 projection (edtr_lin320: the 64 x 64-latent level's transformer blocks; the tiny configuration above has no
+    layer of its width): `alpha to_q(norm2(x))` and `to_out(o) + x` on one workgroup's worth of rows against the oracle's norm_linear, through
+    the product's own weight packing."""
+    from edtr_amd import ops, synth
+    from edtr_amd.engine import WeightStore
+    from edtr_amd.testing import rel_err
+    from oracle import edtr_oracle as O   # checker only
+    K, M = ops.LIN320_K, 2 * ops.LIN320_ROWS
+    tb = "smoke.lin320."
+    shapes = {"norm2.weight": (K,), "norm2.bias": (K,), "to_q.weight": (K, K), "to_out.0.weight": (K, K), "to_out.0.bias": (K,)}
+    sd = {tb + k: synth.synth_param(tb + k, shp) for k, shp in shapes.items()}
+    x = synth.synth_normal("smoke:lin320_x", (M, K)) + 0.3
+    r = synth.synth_normal("smoke:lin320_r", (M, K))
+    alpha = 0.42
+    res = {}
+    for dtype, tol in ((torch.float16, 4.4e-4), (torch.bfloat16, 3.5e-3)):
+        x16, r16 = x.to(dtype), r.to(dtype)
+        store = WeightStore(sd, dtype, dev)
+        worst = 0.0
+        for ln, names, biases, resid in ((tb + "norm2.", [tb + "to_q.weight"], None, None), (None, [tb + "to_out.0.weight"], [tb + "to_out.0.bias"], r16)):
+            a = alpha if ln else 1.0
+            w, cvec = store.lin320(names, biases, ln, a)
+            out = torch.empty((M, K), dtype=dtype, device=dev)
+            rd = resid.to(dev) if resid is not None else None
+            ops.launch(ops.make_lin320(dtype=dtype, x=x16.to(dev), ldx=K, M=M, N=K, w=w, cvec=cvec, alpha=a, ln=ln is not None, eps=1e-5, residual=rd,
+                                       ldr=K, out=out, ldo=K))
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                ref = O.norm_linear(sd, ln, names[0], biases[0] if biases else None, x16.float())
+                ref = a * ref if resid is None else ref + resid.float()
+            worst = max(worst, rel_err(out.float(), ref))
+        res[str(dtype)] = worst
+        if verbose:
+            print(f"smoke[edtr_lin320 {dtype}]: rel err {worst:.2e} (tolerance {tol:.2e})")
+        if not worst < tol:
+            raise AssertionError(f"smoke: edtr_lin320 {dtype} is {worst:.3e} from the oracle (tolerance {tol:.1e})")
     return res
 
 
