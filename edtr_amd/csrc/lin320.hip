@@ -42,7 +42,7 @@ template <int N> __device__ __forceinline__ void lwait() {
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 }
 
-template <typename T, bool LN, bool RES>
+template <typename T, bool LN, bool RES, bool GN>
 __global__ void __launch_bounds__(256, 2) lin320_kernel(const edtr_lin320_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,6 +71,34 @@ __global__ void __launch_bounds__(256, 2) lin320_kernel(const edtr_lin320_params
         f32x4 v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (p.cvec) v = *reinterpret_cast<const f32x4*>(p.cvec + 4 * i);
         *reinterpret_cast<f32x4*>(smem + L_CV + 16 * i) = v;
+    }
+    if constexpr (GN) {
+        // GroupNorm of the rows in the registers: x <- x scale[image][k] + shift[image][k] rounded to 16 bits — the (scale, shift) table
+        // edtr_gn_table writes and edtr_igemm's a_gn applies, i.e. what the edtr_gn_apply launch in front of this projection stored.
+        // The workgroup's 128 rows lie in one image: its table row (2.5 KiB) crosses LDS (the staging tiles are idle until the first group).
+        const int img = (blockIdx.x * LBM) / p.rows_per_image;
+        if (tid < LK / 2) *reinterpret_cast<f32x4*>(smem + L_STG + 16 * tid) = *reinterpret_cast<const f32x4*>(p.gn_table + (int64_t)img * LK * 2 + 4 * tid);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int tbo = L_STG + 64 * lh;
+#pragma unroll
+        for (int i = 0; i < LKS; ++i) {
+            // (the fragment and its table offset are made to depend on the previous fragment's result: left alone, hipcc reads all 80
+            //  table vectors and unpacks all 160 values up front and spills 88 - 156 registers)
+            if (i > 0) asm volatile("" : "+v"(tbo), "+v"(xf[i].x), "+v"(xf[i].y), "+v"(xf[i].z), "+v"(xf[i].w) : "v"(xf[i - 1].x));
+            const char* tb = smem + tbo + 128 * i;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 16);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(tb + 32), t3 = *reinterpret_cast<const f32x4*>(tb + 48);
+            float f[8];
+            unpack8<T>(xf[i], f);
+            f[0] = f[0] * t0[0] + t0[1]; f[1] = f[1] * t0[2] + t0[3];
+            f[2] = f[2] * t1[0] + t1[1]; f[3] = f[3] * t1[2] + t1[3];
+            f[4] = f[4] * t2[0] + t2[1]; f[5] = f[5] * t2[2] + t2[3];
+            f[6] = f[6] * t3[0] + t3[1]; f[7] = f[7] * t3[2] + t3[3];
+            xf[i] = pack8<T>(f);
+            asm volatile("" : "+v"(xf[i].x), "+v"(xf[i].y), "+v"(xf[i].z), "+v"(xf[i].w));      // (finished HERE, not sunk into the loop preheader)
+        }
     }
     if constexpr (LN) {
         // LayerNorm of this lane's token in the registers: two-pass statistics over the stored 16-bit values (reference nn.LayerNorm,
@@ -203,8 +231,8 @@ __global__ void __launch_bounds__(256, 2) lin320_kernel(const edtr_lin320_params
 
 template <typename T>
 int launch_lin320(const edtr_lin320_params& p, hipStream_t stream) {
-    static EdtrLdsOnce once[4];
-    const int v = (p.ln ? 2 : 0) | (p.residual ? 1 : 0);
+    static EdtrLdsOnce once[6];
+    const int v = p.gn_table ? 4 + (p.residual ? 1 : 0) : (p.ln ? 2 : 0) | (p.residual ? 1 : 0);
     const dim3 grid((unsigned)(p.M / LBM)), block(256);
     auto go = [&](auto kern) -> int {
         if (int rc_ = edtr_lds_attr(reinterpret_cast<const void*>(kern), L_LDS, once[v])) return rc_;
@@ -213,10 +241,12 @@ int launch_lin320(const edtr_lin320_params& p, hipStream_t stream) {
         return EDTR_OK;
     };
     switch (v) {
-        case 0: return go(&lin320_kernel<T, false, false>);
-        case 1: return go(&lin320_kernel<T, false, true>);
-        case 2: return go(&lin320_kernel<T, true, false>);
-        default: return go(&lin320_kernel<T, true, true>);
+        case 0: return go(&lin320_kernel<T, false, false, false>);
+        case 1: return go(&lin320_kernel<T, false, true, false>);
+        case 2: return go(&lin320_kernel<T, true, false, false>);
+        case 3: return go(&lin320_kernel<T, true, true, false>);
+        case 4: return go(&lin320_kernel<T, false, false, true>);
+        default: return go(&lin320_kernel<T, false, true, true>);
     }
 }
 
@@ -229,6 +259,10 @@ int check_lin320(const edtr_lin320_params& p) {
     if ((p.ldx & 7) || (p.ldo & 7) || (p.residual && (p.ldr & 7))) return EDTR_E_ALIGN;
     if (!aligned16(p.x) || !aligned16(p.w) || !aligned16(p.out) || (p.residual && !aligned16(p.residual)) || (p.cvec && !aligned16(p.cvec))) return EDTR_E_ALIGN;
     if (p.x == p.out) return EDTR_E_UNSUPPORTED;               // (another workgroup may still read the rows this one writes)
+    if (p.gn_table) {    // a GroupNorm of the rows applied in registers: one image per wave, not together with the LayerNorm
+        if (p.ln || p.rows_per_image <= 0 || (p.rows_per_image % LBM) || (p.M % p.rows_per_image)) return EDTR_E_UNSUPPORTED;
+        if (!aligned16(p.gn_table)) return EDTR_E_ALIGN;
+    }
     if (p.vt_out) {      // the columns from vt_col0 on leave transposed: whole 64-column groups, a wave's 32 rows inside one image
         if (p.residual || p.vt_col0 <= 0 || p.vt_col0 >= p.N || (p.vt_col0 & 63) || p.rows_per_image <= 0 || (p.rows_per_image & 31) ||
             (p.M % p.rows_per_image) || p.vt_ld < p.rows_per_image)

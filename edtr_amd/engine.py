@@ -780,7 +780,8 @@ class Emitter:
         return not self.hp and not self.invariant and ops.lin320_ok(rows, N, K, ln)
 
     def lin320(self, x: torch.Tensor, rows: int, N: int, names, biases=None, *, ln_prefix: Optional[str] = None, alpha: float = 1.0,
-               residual: Optional[torch.Tensor] = None, name: str = "lin320") -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, gn_table: Optional[torch.Tensor] = None, rows_per_image: int = 0,
+               name: str = "lin320") -> torch.Tensor:
         """out = alpha LayerNorm?(x) W^T + bias (+ residual) on raw 16-bit rows (edtr_lin320: the rows live in registers, the LayerNorm is
         applied there — no normalisation launch, no normalised tensor)."""
         self.last_gnp, self.last_row_stats, self.gnp_into_done = None, None, False
@@ -788,7 +789,7 @@ class Emitter:
         out = self.new(rows, N)
         self.prog.add(ops.make_lin320(dtype=self.dtype, x=x, ldx=x.stride(0), M=rows, N=N, w=w, cvec=cvec, alpha=alpha, ln=ln_prefix is not None,
                                       eps=1e-5, residual=residual, ldr=residual.stride(0) if residual is not None else 0, out=out,
-                                      ldo=out.stride(0), name=name))
+                                      ldo=out.stride(0), gn_table=gn_table, rows_per_image=rows_per_image, name=name))
         return out
 
     def qkv_lin320(self, x: torch.Tensor, names, *, B: int, N: int, C: int, ln_prefix: str, alpha: float, name: str = "attn1.qkv"):
@@ -1069,13 +1070,18 @@ class Emitter:
             x.t, x.gnp = None, None
         return y
 
-    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None, feeds=None, conv_n: int = 0, take: bool = False) -> Act:
+    def group_norm(self, x: Act, prefix: str, eps: float, silu: bool, out=None, feeds=None, conv_n: int = 0, take: bool = False,
+                   lin_ok: bool = False) -> Act:
         """``feeds``: the GEMM classes that consume the result (their precision policy decides how many operand parts the
         apply launch writes in the fp32-stream modes).  ``conv_n``: the result's ONLY consumer is a 3x3 / stride 1 / pad 1
         convolution with that many output channels — where the halo tile takes it, no apply launch is emitted: one small launch
         turns the statistics into a (scale, shift) table and the convolution normalises its operand while staging it (the returned
-        Act carries the RAW tensor; ``take``: it takes over x's storage, i.e. the caller is done with x)."""
-        if out is None and self.gn_deferrable(x, conv_n, feeds):
+        Act carries the RAW tensor; ``take``: it takes over x's storage, i.e. the caller is done with x).  ``lin_ok``: the ONLY consumer
+        is an edtr_lin320 projection (proj_in of a SpatialTransformer at the 64 x 64-latent level), which applies the table to the rows
+        it holds in registers (no SiLU) — deferred the same way."""
+        lin_defer = (lin_ok and not silu and not self.hp and not self.invariant and x.t.dtype != torch.float32 and (x.H * x.W) % ops.LIN320_ROWS == 0
+                     and os.environ.get("EDTR_LIN320_GN", "1") != "0")
+        if out is None and (self.gn_deferrable(x, conv_n, feeds) or lin_defer):
             gamma, beta = self.store.vec(prefix + "weight", x.C), self.store.vec(prefix + "bias", x.C)
             table = self.arena.alloc((x.B, x.C, 2), torch.float32)
             hw = x.H * x.W

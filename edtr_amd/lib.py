@@ -117,6 +117,7 @@ class Lin320Params(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int32),
         ("vt_out", C.c_void_p), ("vt_col0", C.c_int32), ("vt_ld", C.c_int32), ("vt_alpha", C.c_float), ("rows_per_image", C.c_int32),
+        ("gn_table", C.c_void_p),
     ]
 
 

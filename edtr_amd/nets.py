@@ -182,15 +182,16 @@ def emit_spatial_transformer(em: Emitter, P: str, l: Layer, x: Act, kv: ContextK
     p = P + l.prefix
     B, N, C = x.B, x.H * x.W, x.C
     rows = B * N
-    n = em.group_norm(x, p + "norm.", 1e-6, False, feeds=("st.proj_in",))
-    wi, bi = em.store.linear([p + "proj_in.weight"], [p + "proj_in.bias"])
-    # The three LayerNorms of the block are not launched in the fast modes: the GEMM that writes their input also writes
-    # per-row statistics, the GEMMs that read them run on the raw rows with gamma folded into the weights (Emitter.layer_norm).
     fold = em.ln_fold_ok(C, B)
     fold1 = fold and em.fused_qkv_ok(N, C)        # (the operand-swapped V^T product would need per-COLUMN scalars)
     lin = em.lin320_ok(rows, C, C)           # the K = 320 projections of the block as row-resident launches (edtr_lin320)
+    # (proj_in on edtr_lin320 applies the GroupNorm to the rows it holds: a (scale, shift) table launch instead of the apply launch)
+    n = em.group_norm(x, p + "norm.", 1e-6, False, feeds=("st.proj_in",), lin_ok=lin and not fold1)
+    wi, bi = em.store.linear([p + "proj_in.weight"], [p + "proj_in.bias"])
+    # The three LayerNorms of the block are not launched in the fast modes: the GEMM that writes their input also writes
+    # per-row statistics, the GEMMs that read them run on the raw rows with gamma folded into the weights (Emitter.layer_norm).
     if lin and not fold1:
-        t = em.lin320(n.t, rows, C, [p + "proj_in.weight"], [p + "proj_in.bias"], name="st.proj_in")
+        t = em.lin320(n.t, rows, C, [p + "proj_in.weight"], [p + "proj_in.bias"], gn_table=n.gn_in, rows_per_image=N, name="st.proj_in")
     else:
         t = em.gemm(n.t, wi, rows, C, C, bias=bi, name="st.proj_in", row_stats=fold1)
     st = em.last_row_stats

@@ -371,7 +371,7 @@ def pack_lin320_w(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def make_lin320(*, dtype, x, ldx, M, N, w, cvec=None, alpha=1.0, ln=False, eps=1e-5, residual=None, ldr=0, out, ldo, vt_out=None, vt_col0=0,
-                vt_ld=0, vt_alpha=1.0, rows_per_image=0, name="lin320") -> Rec:
+                vt_ld=0, vt_alpha=1.0, rows_per_image=0, gn_table=None, name="lin320") -> Rec:
     """out = alpha * (LayerNorm?)(x) w^T + cvec (+ residual) in one launch; the columns from ``vt_col0`` on transposed into ``vt_out`` (the V^T
     operand of a fused [Wq; Wk; Wv] projection) where given (edtr_hip.h: edtr_lin320)."""
     p = L.Lin320Params()
@@ -379,10 +379,12 @@ def make_lin320(*, dtype, x, ldx, M, N, w, cvec=None, alpha=1.0, ln=False, eps=1
     p.x, p.ldx, p.w, p.cvec = ptr(x), ldx, ptr(w), ptr(cvec)
     p.residual, p.ldr, p.out, p.ldo = ptr(residual), ldr, ptr(out), ldo
     p.vt_out, p.vt_col0, p.vt_ld, p.vt_alpha, p.rows_per_image = ptr(vt_out), vt_col0, vt_ld, vt_alpha, rows_per_image
+    p.gn_table = ptr(gn_table)
     flops = 2.0 * M * N * LIN320_K
     nbytes = 2.0 * M * (LIN320_K + N * (2 if residual is not None else 1)) + 2.0 * N * LIN320_K
-    rec = Rec(L.load().edtr_lin320, (ct.byref(p),), (p, x, w, cvec, residual, out, vt_out), name, flops, nbytes)
-    rec.tag = f"lin320 M{M} N{N}" + (" ln" if ln else "") + (" res" if residual is not None else "") + (" vT" if vt_out is not None else "")
+    rec = Rec(L.load().edtr_lin320, (ct.byref(p),), (p, x, w, cvec, residual, out, vt_out, gn_table), name, flops, nbytes)
+    rec.tag = (f"lin320 M{M} N{N}" + (" ln" if ln else "") + (" gnin" if gn_table is not None else "") + (" res" if residual is not None else "")
+               + (" vT" if vt_out is not None else ""))
     return rec
 
 

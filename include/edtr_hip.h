@@ -472,6 +472,9 @@ int edtr_ffn_plan(const edtr_ffn_params* p);      /* no HIP call: EDTR_OK or the
  *            not stored at out[m][n] but TRANSPOSED and scaled by vt_alpha instead of alpha, exactly as edtr_igemm's vt_out:
  *            vt_out[(m / rows_per_image) * (N - vt_col0) + (n - vt_col0)][m % rows_per_image], row stride vt_ld, 16-bit (cvec applies to
  *            all columns).  Needs vt_col0 % 64 == 0, rows_per_image % 32 == 0, M % rows_per_image == 0, no residual; ldo >= vt_col0.
+ *   gn_table optional (`proj_in(norm(x))`, model/attention.py:283-296): fp32 [M / rows_per_image][320][2] = (scale, shift) per image and
+ *            channel, as edtr_gn_table writes it; the rows become x * scale + shift rounded to 16 bits in registers — the edtr_gn_apply launch
+ *            in front of the projection is gone.  Not together with ln; rows_per_image % 128 == 0, M % rows_per_image == 0.
  * Needs K == 320, M % 128 == 0, N % 64 == 0, N <= 1024; anything else is EDTR_E_UNSUPPORTED (edtr_lin320_plan answers without a
  * launch) and the caller issues the edtr_igemm form. */
 typedef struct edtr_lin320_params {
@@ -485,6 +488,7 @@ typedef struct edtr_lin320_params {
     const void* residual; int32_t ldr;
     void* out; int32_t ldo;
     void* vt_out; int32_t vt_col0; int32_t vt_ld; float vt_alpha; int32_t rows_per_image;
+    const float* gn_table;
 } edtr_lin320_params;
 
 int edtr_lin320(const edtr_lin320_params* p, edtr_stream_t stream);

@@ -2014,6 +2014,33 @@ def test_lin320_fused_qkv_with_transposed_v(dtype):
     assert bool(torch.isnan(vt[:, Ntok:].float()).all())                     # pad columns untouched
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("res", [False, True])
+def test_lin320_applies_a_groupnorm_table_to_its_rows(dtype, res):
+    """proj_in(norm(x)): the (scale, shift) table of edtr_gn_table applied to the rows in registers, per image (two images of 256 rows, a
+    workgroup never leaves its image), against x * scale + shift rounded to 16 bits (what edtr_gn_apply stores) and torch fp32."""
+    ops = _ops()
+    d = dev()
+    K, N, B, HW = ops.LIN320_K, 320, 2, 256
+    M = B * HW
+    x = (rnd((M, K), 831, 1.4) + 0.3).to(dtype)
+    w = rnd((N, K), 832, 1 / math.sqrt(K))
+    bias = rnd((N,), 833)
+    table = torch.stack([1 + 0.3 * rnd((B, K), 834), 0.3 * rnd((B, K), 835)], dim=-1).contiguous()      # [B][K][2]
+    r = rnd((M, N), 836).to(dtype) if res else None
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=d)
+    ops.launch(ops.make_lin320(dtype=dtype, x=x.to(d), ldx=K, M=M, N=N, w=ops.pack_lin320_w(w, dtype).to(d), cvec=bias.to(d), gn_table=table.to(d),
+                               rows_per_image=HW, residual=None if r is None else r.to(d), ldr=N, out=out, ldo=N))
+    torch.cuda.synchronize()
+    xn = (x.float().reshape(B, HW, K) * table[:, None, :, 0] + table[:, None, :, 1]).reshape(M, K)
+    ref = xn.to(dtype).float() @ w.to(dtype).float().T + bias + (r.float() if res else 0)
+    assert rel(out.float().cpu(), ref.to(dtype).float()) < 0.3 * TOL[dtype]      # same roundings as the reference composition: only the fp32 summation order differs
+    assert rel(out.float().cpu(), xn @ w.T + bias + (r.float() if res else 0)) < TOL[dtype]
+    with pytest.raises(RuntimeError):                               # 192 rows per image: a workgroup would straddle two images
+        ops.launch(ops.make_lin320(dtype=dtype, x=x.to(d), ldx=K, M=384, N=N, w=ops.pack_lin320_w(w, dtype).to(d), gn_table=table.to(d), rows_per_image=192,
+                                   out=out, ldo=N))
+
+
 def test_lin320_matches_the_layernorm_plus_igemm_form():
     """Against the product path it replaces on the same operands (edtr_layernorm -> edtr_igemm with alpha / bias / residual): both round
     the normalised rows to 16 bits and accumulate in fp32; only the summation order differs."""
