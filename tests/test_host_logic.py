@@ -690,3 +690,50 @@ def test_tile21_is_opt_in_and_refuses_what_it_cannot_hold():
     assert plan(21, cin=96) < 0                                     # three chunks
     assert plan(21, W=528) < 0 and plan(17, W=528) < 0              # tile 17's own shape rules apply
 
+
+
+def test_lin320_host_packing_and_launch_rules():
+    """ops.pack_lin320_w writes the fragment order include/edtr_hip.h documents for edtr_lin320; WeightStore.lin320 folds the LayerNorm (gamma into
+    the columns, alpha W beta + bias into the additive row, vt_alpha on the V rows); edtr_lin320_plan answers every launch check without HIP."""
+    import ctypes as C
+    from edtr_amd import lib as L
+    from edtr_amd import ops
+    from edtr_amd.engine import WeightStore
+    w = torch.arange(96 * 320, dtype=torch.float32).reshape(96, 320)
+    pk = ops.pack_lin320_w(w, torch.float32).reshape(3, 20, 64, 8)
+    for (c, s, lane, j) in [(0, 0, 0, 0), (1, 7, 37, 5), (2, 19, 63, 7), (0, 3, 31, 2)]:
+        assert float(pk[c, s, lane, j]) == float(w[32 * c + (lane & 31), 16 * s + 8 * (lane >> 5) + j])
+    g = torch.Generator().manual_seed(5)
+    params = {"n.weight": 1 + 0.1 * torch.randn(320, generator=g), "n.bias": 0.1 * torch.randn(320, generator=g),
+              "q.weight": torch.randn(320, 320, generator=g) / 18, "k.weight": torch.randn(320, 320, generator=g) / 18,
+              "v.weight": torch.randn(320, 320, generator=g) / 18, "o.weight": torch.randn(320, 320, generator=g) / 18, "o.bias": torch.randn(320, generator=g)}
+    store = WeightStore(params, torch.float32, torch.device("cpu"))      # (fp32 "storage": the packing is exact, the fold can be checked to rounding)
+    wq, cq = store.lin320(["q.weight", "k.weight", "v.weight"], None, "n.", 0.5, vt_col0=640, vt_alpha=1.0)
+    wcat = torch.cat([params["q.weight"], params["k.weight"], params["v.weight"]])
+    assert torch.equal(wq, ops.pack_lin320_w(wcat * params["n.weight"][None, :], torch.float32))
+    shift = wcat @ params["n.bias"]
+    assert torch.allclose(cq[:640], 0.5 * shift[:640], atol=1e-6) and torch.allclose(cq[640:], shift[640:], atol=1e-6)
+    wo, co = store.lin320(["o.weight"], ["o.bias"], None, 1.0)
+    assert torch.equal(wo, ops.pack_lin320_w(params["o.weight"], torch.float32)) and torch.equal(co, params["o.bias"])
+    assert store.lin320(["o.weight"], None, None, 1.0)[1] is None
+
+    lib = L.load()
+    buf = (C.c_char * 4096)()
+    base = C.addressof(buf) & ~15
+
+    def plan(M=256, N=320, K=320, ln=0, res=False, vt=False, gn=False, rpi=0, same=False, ldo=None):
+        p = L.Lin320Params()
+        p.dtype, p.M, p.N, p.K, p.ln, p.eps, p.alpha = 0, M, N, K, ln, 1e-5, 1.0
+        p.x, p.ldx, p.w, p.out, p.ldo = base, 320, base + 1024, base if same else base + 2048, ldo or (640 if vt else N)
+        if res:
+            p.residual, p.ldr = base + 512, N
+        if vt:
+            p.vt_out, p.vt_col0, p.vt_ld, p.vt_alpha, p.rows_per_image = base + 3072, 640, rpi or 128, 1.0, rpi or 128
+        if gn:
+            p.gn_table, p.rows_per_image = base + 3584, rpi or 128
+        return lib.edtr_lin320_plan(C.byref(p))
+
+    assert plan() == 0 and plan(ln=1, res=True) == 0 and plan(N=960, ln=1, vt=True) == 0 and plan(gn=True) == 0 and plan(gn=True, res=True) == 0
+    assert plan(M=192) < 0 and plan(N=96) < 0 and plan(K=640) < 0 and plan(same=True) < 0 and plan(N=2048) < 0
+    assert plan(N=960, vt=True, res=True) < 0 and plan(N=960, vt=True, rpi=48) < 0 and plan(N=960, vt=True, ldo=320) < 0
+    assert plan(gn=True, ln=1) < 0 and plan(gn=True, rpi=192) < 0 and plan(M=384, gn=True, rpi=256) < 0
