@@ -761,7 +761,7 @@ def kernel_of(name: str) -> str:
         return "flash_attn64_kernel"
     if name.endswith(".stats"):
         return "gn_stats_kernel"
-    if name.endswith(".finalize"):
+    if name.endswith(".finalize") or name.endswith(".table"):     # (gn.table: the finalize that writes a (scale, shift) table for a fused GroupNorm input)
         return "gn_finalize_kernel"
     if name.startswith("gn_pool") or name.startswith("copy3d") or name.startswith("wavelet"):
         return name.split(".")[0] + "_kernel"
